@@ -1,0 +1,182 @@
+"""oracle.py -- TEST INFRASTRUCTURE ONLY: ctypes front-end of oracle/_build/librt_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+See rt_oracle.h for the parity status ("parity unpinned" for the arithmetic).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, '_build', 'librt_oracle.so')
+
+NODE = np.dtype([('data', '<u4', 4), ('lo', '<f4', 4), ('hi', '<f4', 4)])        # 48 B  BVHData.h:70-74
+CONTACT = np.dtype([('pixelIndex', '<u4'), ('materialIndex', '<u4'), ('pad', '<u4', 2),
+                    ('normal_t', '<f4', 4)])                                      # 32 B  CLStructs.h:112-118
+RAY = np.dtype([('idx', '<u4'), ('pad', '<u4', 3), ('origin', '<f4', 4), ('direction', '<f4', 4)])  # 48 B
+PAIR = np.dtype([('key', '<u4'), ('value', '<u4')])
+CAMERA = np.dtype([('FOVDistance', '<f4'), ('resX', '<u4'), ('resY', '<u4'), ('supersampling', '<u4'),
+                   ('m', '<f4', 12)])                                             # 64 B  CLStructs.h:44-51
+
+
+class Stats(C.Structure):
+    _fields_ = [('inner_visits', C.c_uint64), ('leaf_tests', C.c_uint64), ('hits', C.c_uint64),
+                ('max_stack', C.c_uint32), ('pad_', C.c_uint32), ('sum_t', C.c_double)]
+
+    def as_dict(self):
+        return dict(inner_visits=self.inner_visits, leaf_tests=self.leaf_tests, hits=self.hits,
+                    max_stack=self.max_stack, sum_t=self.sum_t)
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(HERE, f) for f in ('rt_oracle.c', 'tlg_oracle.c', 'rt_oracle.h') if
+           os.path.exists(os.path.join(HERE, f))]
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
+    if stale:
+        subprocess.check_call(['make', '-s', '-C', HERE])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        L.orc_sizeof.restype = C.c_size_t
+        L.orc_sizeof.argtypes = [C.c_char_p]
+        L.orc_demo_camera.argtypes = [vp, u32, u32, vp]
+        L.orc_generate_ray.argtypes = [vp, u32, vp]
+        L.orc_scene_triangle_count.restype = C.c_uint64
+        L.orc_scene_triangle_count.argtypes = [vp]
+        L.orc_scene_triangle.argtypes = [vp, u32, vp, vp, vp]
+        L.orc_morton_buffer_items.restype = u32
+        L.orc_morton_buffer_items.argtypes = [u32]
+        L.orc_bitonic_sort.argtypes = [vp, u32]
+        L.orc_build_bvh.argtypes = [vp, i32, vp, vp]
+        L.orc_check_hierarchy.argtypes = [vp, u32, vp]
+        L.orc_trace_primary.argtypes = [vp, vp, u32, vp, vp, vp, i32]
+        L.orc_trace_primary_range.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, i32]
+        L.orc_trace_rays.argtypes = [vp, u32, vp, u32, vp, vp, vp, i32]
+        L.orc_brute_primary.argtypes = [vp, vp, vp, i32]
+        L.orc_shade_frame.argtypes = [vp, vp, u32, vp, vp, i32]
+        L.orc_scan_inclusive_u32.argtypes = [vp, vp, u32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ncpu() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+class Scene:
+    """A packed scene buffer (bytes, reference format) held for the C oracle."""
+
+    def __init__(self, buf: bytes):
+        self.bytes = bytes(buf)
+        self.arr = np.frombuffer(self.bytes, dtype=np.uint8)
+        self.n_tris = int(lib().orc_scene_triangle_count(_p(self.arr)))
+
+    def demo_camera(self, resx: int, resy: int) -> np.ndarray:
+        cam = np.zeros(1, dtype=CAMERA)
+        lib().orc_demo_camera(_p(self.arr), resx, resy, _p(cam))
+        return cam
+
+    def triangles(self):
+        """(verts[n,3,4] f32, refs[n,3] u32, material[n] u32) through the reference's index walkers."""
+        n = self.n_tris
+        v = np.zeros((n, 3, 4), dtype=np.float32)
+        r = np.zeros((n, 3), dtype=np.uint32)
+        m = np.zeros(n, dtype=np.uint32)
+        L = lib()
+        for t in range(n):
+            L.orc_scene_triangle(_p(self.arr), t, C.c_void_p(v.ctypes.data + t * 48),
+                                 C.c_void_p(r.ctypes.data + t * 12), C.c_void_p(m.ctypes.data + t * 4))
+        return v, r, m
+
+
+class BVH:
+    def __init__(self, scene: Scene, mode: int = 0):
+        self.scene = scene
+        self.n = scene.n_tris
+        self.N = int(lib().orc_morton_buffer_items(self.n))
+        self.nodes = np.zeros(2 * self.n - 1, dtype=NODE)
+        self.pairs = np.zeros(self.N, dtype=PAIR)
+        rc = lib().orc_build_bvh(_p(scene.arr), mode, _p(self.nodes), _p(self.pairs))
+        if rc:
+            raise RuntimeError('orc_build_bvh failed: %d' % rc)
+
+    def check_hierarchy(self):
+        d = C.c_uint32(0)
+        rc = lib().orc_check_hierarchy(_p(self.nodes), self.n, C.byref(d))
+        return rc, d.value
+
+    def trace_primary(self, cam: np.ndarray, nthreads: int = 0, first: int = 0, count: int | None = None):
+        npx = int(cam['resX'][0]) * int(cam['resY'][0])
+        if count is None:
+            count = npx - first
+        out = np.zeros(count, dtype=CONTACT)
+        st = Stats()
+        lib().orc_trace_primary_range(_p(cam), _p(self.nodes), self.n, _p(self.scene.arr), first, count,
+                                      _p(out), C.byref(st), nthreads or ncpu())
+        return out, st
+
+    def trace_rays(self, rays: np.ndarray, nthreads: int = 0):
+        out = np.zeros(len(rays), dtype=CONTACT)
+        st = Stats()
+        lib().orc_trace_rays(_p(rays), len(rays), _p(self.nodes), self.n, _p(self.scene.arr), _p(out),
+                             C.byref(st), nthreads or ncpu())
+        return out, st
+
+
+def brute_primary(scene: Scene, cam: np.ndarray, nthreads: int = 0) -> np.ndarray:
+    npx = int(cam['resX'][0]) * int(cam['resY'][0])
+    out = np.zeros(npx, dtype=CONTACT)
+    lib().orc_brute_primary(_p(cam), _p(scene.arr), _p(out), nthreads or ncpu())
+    return out
+
+
+def generate_rays(cam: np.ndarray, first: int = 0, count: int | None = None) -> np.ndarray:
+    npx = int(cam['resX'][0]) * int(cam['resY'][0])
+    if count is None:
+        count = npx - first
+    rays = np.zeros(count, dtype=RAY)
+    L = lib()
+    for k in range(count):
+        L.orc_generate_ray(_p(cam), first + k, C.c_void_p(rays.ctypes.data + 48 * k))
+    return rays
+
+
+def shade_frame(scene: Scene, cam: np.ndarray, contacts: np.ndarray, nthreads: int = 0) -> np.ndarray:
+    npx = int(cam['resX'][0]) * int(cam['resY'][0])
+    rgba = np.zeros((npx, 4), dtype=np.float32)
+    lib().orc_shade_frame(_p(cam), _p(contacts), len(contacts), _p(scene.arr), _p(rgba), nthreads or ncpu())
+    return rgba
+
+
+def bitonic_sort(pairs: np.ndarray) -> np.ndarray:
+    out = np.ascontiguousarray(pairs.copy())
+    lib().orc_bitonic_sort(_p(out), len(out))
+    return out
+
+
+def scan_inclusive(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    out = np.zeros_like(a)
+    lib().orc_scan_inclusive_u32(_p(a), _p(out), len(a))
+    return out
