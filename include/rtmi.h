@@ -1,0 +1,153 @@
+/*
+ * rtmi.h -- C ABI of librtmi.so, the MI355X (gfx950) ray-intersection engine that
+ * replaces the OpenCL back end of kotturtech/OpenCLRayTracer for ONE path:
+ * BVH build + BVH traversal + ray/AABB + ray/triangle + primary-ray Blinn-Phong shading
+ * (SURVEY.md section 8).
+ *
+ * Conventions (mirroring the reference's error convention, Include/Common/Errata.h:47-51):
+ *   - every call returns int: 0 = Success, 1 = Error; nothing throws across the boundary;
+ *   - the message of the last error on a context is returned by rt_last_error();
+ *   - plain pointers and sizes only; `d_` parameters are DEVICE pointers (hipMalloc'd or
+ *     any allocation visible to the GPU, e.g. a torch tensor's data_ptr()), `h_` are host;
+ *   - all work is enqueued on the context's HIP stream (rt_ctx_set_stream); calls that hand
+ *     data back to the host synchronise that stream, everything else is asynchronous;
+ *   - one host thread per context (the reference is single-threaded and synchronous:
+ *     every enqueue is followed by clFlush + clWaitForEvents, BVHManager.cpp:184-192).
+ *
+ * Reference paths below are relative to OpenCLRayTracer/ in the reference tree.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_ABI_VERSION 1
+
+/* ---- POD types shared with the reference (byte-identical) ------------------------------ */
+
+/* struct Camera, Include/CLData/CLStructs.h:44-51 (Matrix4 = 12 floats, Transform.h:150-154) */
+typedef struct rt_camera {
+    float    FOVDistance;
+    uint32_t resX;
+    uint32_t resY;
+    uint32_t supersamplingFactor;
+    float    viewTransform[12];
+} rt_camera;                                        /* 64 bytes */
+
+/* struct Ray, CLStructs.h:82-87 (CL_FLOAT3 is 16 bytes) */
+typedef struct rt_ray {
+    uint32_t idx; uint32_t pad_[3];
+    float    origin[4];
+    float    direction[4];
+} rt_ray;                                           /* 48 bytes */
+
+/* struct Contact, CLStructs.h:112-118; miss <=> normalAndDistance[3] == 0 */
+typedef struct rt_contact {
+    uint32_t pixelIndex;
+    uint32_t materialIndex;
+    uint32_t pad[2];
+    float    normalAndDistance[4];
+} rt_contact;                                       /* 32 bytes */
+
+/* struct BVHNode, Include/CLData/AccelerationStructs/BVHData.h:70-74 */
+typedef struct rt_bvh_node {
+    uint32_t data[4];
+    float    boundsMin[4];   /* .w = node type: 0 inner, 1 leaf (BVHData.h:65) */
+    float    boundsMax[4];
+} rt_bvh_node;                                      /* 48 bytes */
+
+typedef struct rt_ctx   rt_ctx;     /* replaces OpenCLUtils::CLExecutionContext (CLExecutionContext.h:297-456) */
+typedef struct rt_scene rt_scene;   /* device side of CLRayTracer::Scene (Include/Scene/Scene.h:66-106)        */
+typedef struct rt_bvh   rt_bvh;     /* device side of AccelerationStructures::BVHManager (BVHManager.h:59-126) */
+
+enum { RT_SUCCESS = 0, RT_ERROR = 1 };
+/* parity modes, SURVEY.md 8(c): FIXED builds all n-1 inner nodes; LITERAL_ZERO is not implemented
+ * on the device (rt_bvh_create rejects it) because it encodes undefined behaviour.               */
+enum { RT_MODE_FIXED = 0, RT_MODE_LITERAL_ZERO = 1 };
+
+/* ---- context: replaces CLExecutionContext creation (CLExecutionContext.cpp:270-300) ------ */
+int         rt_abi_version(void);
+int         rt_ctx_create(int device_ordinal, rt_ctx** out);
+void        rt_ctx_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);       /* valid until the next failing call on ctx */
+/* stream = hipStream_t (NULL = the context's own stream created by rt_ctx_create) */
+int         rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
+void*       rt_ctx_get_stream(const rt_ctx* ctx);
+int         rt_ctx_synchronize(rt_ctx* ctx);        /* flushQueue + finishQueue, CLExecutionContext.h:436-445 */
+int         rt_ctx_device_info(const rt_ctx* ctx, int* compute_units, int* wave_size, uint64_t* lds_bytes,
+                               char* name, size_t name_len);
+
+/* ---- device buffers: back OpenCLUtils::CLBuffer (CLBuffer.h:39-112, CLBuffer.cpp:40-121) -- */
+int rt_buf_alloc(rt_ctx* ctx, uint64_t bytes, void** d_out);
+int rt_buf_free(rt_ctx* ctx, void* d_ptr);
+int rt_buf_upload(rt_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);            /* enqueueWriteBuffer */
+int rt_buf_download(rt_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);          /* enqueueReadBuffer, blocking (CL_TRUE) */
+int rt_buf_fill_u32(rt_ctx* ctx, void* d_dst, uint32_t pattern, uint64_t count);           /* enqueueFillBuffer */
+
+/* ---- scene: Scene::loadToGPU (Scene.cpp:451-456) ----------------------------------------- */
+/* h_scene_buffer is the reference's packed scene buffer (SceneBufferParser.h:55-160) exactly as
+ * Scene::load builds it.  The library keeps the raw bytes on the device (getDeviceSceneData())
+ * and derives its own SoA triangle table from them with a HIP kernel.                          */
+int         rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_scene** out);
+void        rt_scene_destroy(rt_scene* scene);
+const void* rt_scene_device_ptr(const rt_scene* scene);     /* Scene::getDeviceSceneData */
+uint64_t    rt_scene_bytes(const rt_scene* scene);          /* Scene::getSceneDataSize   */
+uint32_t    rt_scene_triangle_count(const rt_scene* scene); /* SceneHeader.totalNumberOfTriangles */
+
+/* ---- BVH manager: AccelerationStructureManager's six virtuals (AccelerationStructureManager.h:57-74) */
+int  rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** out);  /* ctor + initialize(), BVHManager.cpp:57-115 */
+void rt_bvh_destroy(rt_bvh* bvh);
+int  rt_bvh_initialize_frame(rt_bvh* bvh);   /* initializeFrame(), BVHManager.cpp:122-150: size + clear build buffers */
+int  rt_bvh_construct(rt_bvh* bvh);          /* construct(), BVHManager.cpp:156-228: morton -> sort -> radix tree -> refit (+ relayout) */
+/* generateContacts(Camera&), BVHManager.cpp:234-284 + kernel generateContacts, BVHKernels.cl:84-98.
+ * Writes resX*resY contacts, contacts[p].pixelIndex == p.                                         */
+int  rt_bvh_generate_contacts_primary(rt_bvh* bvh, const rt_camera* cam, void* d_contacts);
+/* generateContacts(CLBuffer& rays, CLBuffer& contacts, n), BVHManager.cpp:292-329 + generateContacts2, BVHKernels.cl:103-117 */
+int  rt_bvh_generate_contacts_rays(rt_bvh* bvh, const void* d_rays, uint32_t ray_count, void* d_contacts);
+/* parity/debug read-backs in the reference's own layouts (blocking) */
+int  rt_bvh_read_nodes(const rt_bvh* bvh, void* h_nodes /* (2n-1) * 48 B */);
+int  rt_bvh_read_morton_pairs(const rt_bvh* bvh, void* h_pairs /* N * 8 B */, uint32_t* n_pow2);
+int  rt_bvh_info(const rt_bvh* bvh, uint32_t* leaves, uint32_t* morton_items, uint32_t* max_depth);
+
+/* ---- shading: the host loop of RTFrame (OpenCLRayTracerDemo.cpp:298-316) calling
+ *      cpuShadeBlinnPhong (Include/CLData/Shading.h:74-166), moved to the device.
+ *      d_rgba holds resX*resY float4; pixels without a hit are written (0,0,0,0).               */
+int  rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
+                          const void* d_contacts, uint32_t contact_count, void* d_rgba);
+
+/* ---- framebuffer tiling for multi-GPU frames (new functionality) ---------
+ * The frame is cut into tile x tile pixel squares (tile = 64), numbered row-major; rank r of
+ * `nranks` owns tiles r, r+nranks, ...  The compact per-rank buffers are ordered by
+ * (owned tile ordinal, pixel within tile) so that one gather of contiguous buffers assembles
+ * the frame; rt_untile_* scatters a gathered buffer back to pixel order on the root.           */
+uint32_t rt_tiles_owned_pixels(const rt_camera* cam, uint32_t rank, uint32_t nranks); /* slots in the compact buffer */
+int  rt_bvh_generate_contacts_primary_tiled(rt_bvh* bvh, const rt_camera* cam, uint32_t rank, uint32_t nranks,
+                                            void* d_contacts_compact);
+int  rt_shade_blinn_phong_tiled(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint32_t rank,
+                                uint32_t nranks, const void* d_contacts_compact, void* d_rgba_compact);
+int  rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgba_gathered,
+                    uint32_t slots_per_rank, void* d_rgba_frame);
+
+/* ---- parallel primitives used by the builders ------------------------------------------- */
+/* BitonicSort::sort (Include/Algorithms/Sorting.h:77, BitonicSort.cpp:118-189): uint2 pairs, key = .x,
+ * same comparator network => same permutation of equal keys.  n_pow2 must be a power of two.     */
+int  rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2);
+/* PrefixSum::computePrefixSum (Include/Algorithms/PrefixSum.h:68): inclusive uint scan          */
+int  rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n);
+
+/* ---- measurement helpers (HIP events on the context's stream) --------------------------- */
+int  rt_timer_create(rt_ctx* ctx, void** timer);
+int  rt_timer_start(rt_ctx* ctx, void* timer);
+int  rt_timer_stop(rt_ctx* ctx, void* timer);
+int  rt_timer_elapsed_ms(rt_ctx* ctx, void* timer, float* ms);   /* synchronises on the stop event */
+void rt_timer_destroy(rt_ctx* ctx, void* timer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

@@ -1,0 +1,335 @@
+"""ctypes binding of librtmi.so -- one Python function/class per entry point of include/rtmi.h.
+
+This is harness plumbing for tests/ and bench.py (the reference's host language is C++; the C++
+mirror of its classes lives in openclraytracer_amd/csrc/host/).  There is NO CPU fallback: if the
+HIP library is missing or no gfx950 device is present, loading / context creation raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, 'librtmi.so')
+
+# byte-identical mirrors of the reference PODs (include/rtmi.h)
+CAMERA = np.dtype([('FOVDistance', '<f4'), ('resX', '<u4'), ('resY', '<u4'), ('supersamplingFactor', '<u4'),
+                   ('viewTransform', '<f4', 12)])
+RAY = np.dtype([('idx', '<u4'), ('pad_', '<u4', 3), ('origin', '<f4', 4), ('direction', '<f4', 4)])
+CONTACT = np.dtype([('pixelIndex', '<u4'), ('materialIndex', '<u4'), ('pad', '<u4', 2),
+                    ('normalAndDistance', '<f4', 4)])
+BVH_NODE = np.dtype([('data', '<u4', 4), ('boundsMin', '<f4', 4), ('boundsMax', '<f4', 4)])
+PAIR = np.dtype([('key', '<u4'), ('value', '<u4')])
+assert CAMERA.itemsize == 64 and RAY.itemsize == 48 and CONTACT.itemsize == 32 and BVH_NODE.itemsize == 48
+
+# every symbol include/rtmi.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    'rt_abi_version', 'rt_ctx_create', 'rt_ctx_destroy', 'rt_last_error', 'rt_ctx_set_stream', 'rt_ctx_get_stream',
+    'rt_ctx_synchronize', 'rt_ctx_device_info', 'rt_buf_alloc', 'rt_buf_free', 'rt_buf_upload', 'rt_buf_download',
+    'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
+    'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
+    'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
+    'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
+    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba',
+    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
+    'rt_timer_elapsed_ms', 'rt_timer_destroy',
+]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads librtmi.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError('librtmi.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                      'or `make -C openclraytracer_amd/csrc`' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    pvp = C.POINTER(C.c_void_p)
+    L.rt_abi_version.restype = i32
+    L.rt_ctx_create.argtypes = [i32, pvp]
+    L.rt_ctx_destroy.argtypes = [vp]; L.rt_ctx_destroy.restype = None
+    L.rt_last_error.argtypes = [vp]; L.rt_last_error.restype = C.c_char_p
+    L.rt_ctx_set_stream.argtypes = [vp, vp]
+    L.rt_ctx_get_stream.argtypes = [vp]; L.rt_ctx_get_stream.restype = vp
+    L.rt_ctx_synchronize.argtypes = [vp]
+    L.rt_ctx_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64), C.c_char_p, C.c_size_t]
+    L.rt_buf_alloc.argtypes = [vp, u64, pvp]
+    L.rt_buf_free.argtypes = [vp, vp]
+    L.rt_buf_upload.argtypes = [vp, vp, vp, u64]
+    L.rt_buf_download.argtypes = [vp, vp, vp, u64]
+    L.rt_buf_fill_u32.argtypes = [vp, vp, u32, u64]
+    L.rt_scene_upload.argtypes = [vp, vp, u64, pvp]
+    L.rt_scene_destroy.argtypes = [vp]; L.rt_scene_destroy.restype = None
+    L.rt_scene_device_ptr.argtypes = [vp]; L.rt_scene_device_ptr.restype = vp
+    L.rt_scene_bytes.argtypes = [vp]; L.rt_scene_bytes.restype = u64
+    L.rt_scene_triangle_count.argtypes = [vp]; L.rt_scene_triangle_count.restype = u32
+    L.rt_bvh_create.argtypes = [vp, vp, i32, pvp]
+    L.rt_bvh_destroy.argtypes = [vp]; L.rt_bvh_destroy.restype = None
+    L.rt_bvh_initialize_frame.argtypes = [vp]
+    L.rt_bvh_construct.argtypes = [vp]
+    L.rt_bvh_generate_contacts_primary.argtypes = [vp, vp, vp]
+    L.rt_bvh_generate_contacts_rays.argtypes = [vp, vp, u32, vp]
+    L.rt_bvh_read_nodes.argtypes = [vp, vp]
+    L.rt_bvh_read_morton_pairs.argtypes = [vp, vp, C.POINTER(u32)]
+    L.rt_bvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.rt_shade_blinn_phong.argtypes = [vp, vp, vp, vp, u32, vp]
+    L.rt_tiles_owned_pixels.argtypes = [vp, u32, u32]; L.rt_tiles_owned_pixels.restype = u32
+    L.rt_bvh_generate_contacts_primary_tiled.argtypes = [vp, vp, u32, u32, vp]
+    L.rt_shade_blinn_phong_tiled.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.rt_untile_rgba.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.rt_sort_pairs_bitonic.argtypes = [vp, vp, u32]
+    L.rt_scan_inclusive_u32.argtypes = [vp, vp, vp, u32]
+    L.rt_timer_create.argtypes = [vp, pvp]
+    L.rt_timer_start.argtypes = [vp, vp]
+    L.rt_timer_stop.argtypes = [vp, vp]
+    L.rt_timer_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.rt_timer_destroy.argtypes = [vp, vp]; L.rt_timer_destroy.restype = None
+    _lib = L
+    return L
+
+
+def _p(a: np.ndarray) -> C.c_void_p:
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """rt_ctx: stands where the reference has OpenCLUtils::CLExecutionContext."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if self.lib.rt_ctx_create(device, C.byref(h)):
+            raise RtError(self.lib.rt_last_error(None).decode())
+        self.h = h
+        if stream is not None:
+            self.check(self.lib.rt_ctx_set_stream(self.h, C.c_void_p(stream)))
+
+    def check(self, rc: int):
+        if rc:
+            raise RtError(self.lib.rt_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.rt_ctx_destroy(self.h)
+            self.h = None
+
+    def synchronize(self):
+        self.check(self.lib.rt_ctx_synchronize(self.h))
+
+    def device_info(self) -> dict:
+        cu, ws, lds = C.c_int(), C.c_int(), C.c_uint64()
+        name = C.create_string_buffer(64)
+        self.check(self.lib.rt_ctx_device_info(self.h, C.byref(cu), C.byref(ws), C.byref(lds), name, 64))
+        return dict(compute_units=cu.value, wave_size=ws.value, lds_bytes=lds.value, name=name.value.decode())
+
+    # ---- CLBuffer-like helpers
+    def alloc(self, nbytes: int) -> int:
+        d = C.c_void_p()
+        self.check(self.lib.rt_buf_alloc(self.h, nbytes, C.byref(d)))
+        return d.value
+
+    def free(self, dptr: int):
+        self.check(self.lib.rt_buf_free(self.h, C.c_void_p(dptr)))
+
+    def upload(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.rt_buf_upload(self.h, C.c_void_p(dptr), _p(arr), arr.nbytes))
+
+    def download(self, dptr: int, count: int, dtype) -> np.ndarray:
+        out = np.zeros(count, dtype=dtype)
+        self.check(self.lib.rt_buf_download(self.h, _p(out), C.c_void_p(dptr), out.nbytes))
+        return out
+
+    def fill_u32(self, dptr: int, pattern: int, count: int):
+        self.check(self.lib.rt_buf_fill_u32(self.h, C.c_void_p(dptr), pattern, count))
+
+    # ---- primitives
+    def sort_pairs_bitonic(self, pairs: np.ndarray) -> np.ndarray:
+        d = self.alloc(pairs.nbytes)
+        try:
+            self.upload(d, pairs)
+            self.check(self.lib.rt_sort_pairs_bitonic(self.h, C.c_void_p(d), len(pairs)))
+            return self.download(d, len(pairs), PAIR)
+        finally:
+            self.free(d)
+
+    def scan_inclusive(self, a: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        di, do = self.alloc(max(a.nbytes, 4)), self.alloc(max(a.nbytes, 4))
+        try:
+            self.upload(di, a)
+            self.check(self.lib.rt_scan_inclusive_u32(self.h, C.c_void_p(di), C.c_void_p(do), len(a)))
+            return self.download(do, len(a), np.uint32)
+        finally:
+            self.free(di); self.free(do)
+
+
+class Timer:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rt_timer_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def start(self):
+        self.ctx.check(self.ctx.lib.rt_timer_start(self.ctx.h, self.h))
+
+    def stop(self):
+        self.ctx.check(self.ctx.lib.rt_timer_stop(self.ctx.h, self.h))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float()
+        self.ctx.check(self.ctx.lib.rt_timer_elapsed_ms(self.ctx.h, self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rt_timer_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class DeviceScene:
+    """rt_scene: Scene::loadToGPU of a packed scene buffer."""
+
+    def __init__(self, ctx: Context, scene_bytes: bytes):
+        self.ctx = ctx
+        self.host = np.frombuffer(bytes(scene_bytes), dtype=np.uint8)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rt_scene_upload(ctx.h, _p(self.host), self.host.nbytes, C.byref(h)))
+        self.h = h
+        self.n_tris = ctx.lib.rt_scene_triangle_count(h)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rt_scene_destroy(self.h)
+            self.h = None
+
+
+class DeviceBVH:
+    """rt_bvh: the device side of BVHManager (create = ctor+initialize)."""
+
+    def __init__(self, ctx: Context, scene: DeviceScene, mode: int = 0):
+        self.ctx, self.scene = ctx, scene
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rt_bvh_create(ctx.h, scene.h, mode, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rt_bvh_destroy(self.h)
+            self.h = None
+
+    def initialize_frame(self):
+        self.ctx.check(self.ctx.lib.rt_bvh_initialize_frame(self.h))
+
+    def construct(self):
+        self.ctx.check(self.ctx.lib.rt_bvh_construct(self.h))
+
+    def build(self):
+        self.initialize_frame()
+        self.construct()
+        return self
+
+    def info(self) -> dict:
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.ctx.check(self.ctx.lib.rt_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(leaves=a.value, morton_items=b.value, max_depth=c.value)
+
+    def read_nodes(self) -> np.ndarray:
+        n = self.info()['leaves']
+        out = np.zeros(2 * n - 1, dtype=BVH_NODE)
+        self.ctx.check(self.ctx.lib.rt_bvh_read_nodes(self.h, _p(out)))
+        return out
+
+    def read_morton_pairs(self) -> np.ndarray:
+        N = self.info()['morton_items']
+        out = np.zeros(N, dtype=PAIR)
+        self.ctx.check(self.ctx.lib.rt_bvh_read_morton_pairs(self.h, _p(out), None))
+        return out
+
+    # ---- device-pointer entry points (used by bench.py with torch tensors)
+    def generate_contacts_primary_d(self, cam: np.ndarray, d_contacts: int):
+        self.ctx.check(self.ctx.lib.rt_bvh_generate_contacts_primary(self.h, _p(cam), C.c_void_p(d_contacts)))
+
+    def generate_contacts_primary_tiled_d(self, cam: np.ndarray, rank: int, nranks: int, d_contacts: int):
+        self.ctx.check(self.ctx.lib.rt_bvh_generate_contacts_primary_tiled(self.h, _p(cam), rank, nranks,
+                                                                           C.c_void_p(d_contacts)))
+
+    def generate_contacts_rays_d(self, d_rays: int, count: int, d_contacts: int):
+        self.ctx.check(self.ctx.lib.rt_bvh_generate_contacts_rays(self.h, C.c_void_p(d_rays), count,
+                                                                  C.c_void_p(d_contacts)))
+
+    # ---- convenience host round trips (tests)
+    def generate_contacts_primary(self, cam: np.ndarray) -> np.ndarray:
+        npx = int(cam['resX'][0]) * int(cam['resY'][0])
+        d = self.ctx.alloc(npx * 32)
+        try:
+            self.ctx.fill_u32(d, 0xDEADBEEF, npx * 8)
+            self.generate_contacts_primary_d(cam, d)
+            return self.ctx.download(d, npx, CONTACT)
+        finally:
+            self.ctx.free(d)
+
+    def generate_contacts_rays(self, rays: np.ndarray) -> np.ndarray:
+        dr, dc = self.ctx.alloc(max(rays.nbytes, 48)), self.ctx.alloc(max(len(rays) * 32, 32))
+        try:
+            self.ctx.upload(dr, rays)
+            self.ctx.fill_u32(dc, 0xDEADBEEF, max(len(rays) * 8, 8))
+            self.generate_contacts_rays_d(dr, len(rays), dc)
+            return self.ctx.download(dc, len(rays), CONTACT)
+        finally:
+            self.ctx.free(dr); self.ctx.free(dc)
+
+
+def shade_blinn_phong_d(ctx: Context, scene: DeviceScene, cam: np.ndarray, d_contacts: int, count: int, d_rgba: int):
+    ctx.check(ctx.lib.rt_shade_blinn_phong(ctx.h, scene.h, _p(cam), C.c_void_p(d_contacts), count, C.c_void_p(d_rgba)))
+
+
+def shade_blinn_phong(ctx: Context, scene: DeviceScene, cam: np.ndarray, contacts: np.ndarray) -> np.ndarray:
+    npx = int(cam['resX'][0]) * int(cam['resY'][0])
+    dc, dr = ctx.alloc(max(contacts.nbytes, 32)), ctx.alloc(npx * 16)
+    try:
+        ctx.upload(dc, contacts)
+        ctx.fill_u32(dr, 0x7FC00000, npx * 4)
+        shade_blinn_phong_d(ctx, scene, cam, dc, len(contacts), dr)
+        return ctx.download(dr, npx * 4, np.float32).reshape(npx, 4)
+    finally:
+        ctx.free(dc); ctx.free(dr)
+
+
+def tiles_owned_pixels(cam: np.ndarray, rank: int, nranks: int) -> int:
+    return int(load_library().rt_tiles_owned_pixels(_p(cam), rank, nranks))
+
+
+def shade_blinn_phong_tiled_d(ctx, scene, cam, rank, nranks, d_contacts, d_rgba):
+    ctx.check(ctx.lib.rt_shade_blinn_phong_tiled(ctx.h, scene.h, _p(cam), rank, nranks, C.c_void_p(d_contacts),
+                                                 C.c_void_p(d_rgba)))
+
+
+def untile_rgba_d(ctx, cam, nranks, d_gathered, slots_per_rank, d_frame):
+    ctx.check(ctx.lib.rt_untile_rgba(ctx.h, _p(cam), nranks, C.c_void_p(d_gathered), slots_per_rank,
+                                     C.c_void_p(d_frame)))
+
+
+def tile_slot_map(resx: int, resy: int, nranks: int):
+    """Host statement of the tiling contract of include/rtmi.h: for every pixel, (rank, slot)."""
+    T = 64
+    tiles_x = (resx + T - 1) // T
+    y, x = np.divmod(np.arange(resx * resy, dtype=np.int64), resx)
+    tx, ty = x // T, y // T
+    tile = ty * tiles_x + tx
+    rank = tile % nranks
+    ordinal = tile // nranks
+    slot = ordinal * (T * T) + (y - ty * T) * T + (x - tx * T)
+    return rank.astype(np.int64), slot.astype(np.int64)

@@ -1,0 +1,317 @@
+// build_kernels.hip -- BVH construction on the device (gfx950).
+//
+// Restates, as hand-written HIP kernels over an SoA triangle table, the reference's build chain
+//   calculateMortonCodes -> BitonicSort -> buildRadixTree -> computeBoundingBoxes
+// (src/CLRayTracerEngine/BVHKernels.cl:46-79, Include/CLData/AccelerationStructs/BVH.h:49-334,
+//  BVHManager.cpp:156-228) and adds the re-layout into 64-byte traversal records.
+// Integer work must be bit-exact with the reference; float work uses device_math.h.
+#include "rtmi_internal.h"
+#include "device_math.h"
+
+#include <limits.h>
+
+// ----------------------------------------------------------------------------------------
+// 1. scene bytes -> SoA triangle table
+//    replaces the per-access pointer chase getModelAtIndex/getMeshAtIndex/getIndexAt/getVertexAt
+//    (SceneBufferParser.h:175-217) and getTriangleRefByIndex (:253-293).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float load_f32_unaligned(const unsigned char* p)
+{
+    // meshes after the first are only 2-byte aligned (mesh size = 48 + 16 nv + 2 ni)
+    const uint16_t* h = reinterpret_cast<const uint16_t*>(p);
+    uint32_t bits = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    return __uint_as_float(bits);
+}
+
+__global__ __launch_bounds__(256) void k_gather_triangles(DeviceScene sc)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sc.n_tris) return;
+    // binary search: last mesh with first_triangle <= t (meshes with 0 triangles never match)
+    uint32_t lo = 0, hi = sc.n_meshes;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sc.meshes[mid].first_triangle <= t) lo = mid; else hi = mid;
+    }
+    while (sc.meshes[lo].triangle_count == 0 || t >= sc.meshes[lo].first_triangle + sc.meshes[lo].triangle_count) lo--;
+    const MeshEntry me = sc.meshes[lo];
+    uint32_t local = t - me.first_triangle;
+    const unsigned char* mesh = sc.bytes + me.byte_offset;
+    const unsigned char* verts = mesh + 48;                                   // MESH_HEADER_SIZE
+    const uint16_t* idx = reinterpret_cast<const uint16_t*>(verts + (uint64_t)me.vertex_count * 16);
+    f3 v[3];
+    for (int k = 0; k < 3; k++) {
+        uint32_t vi = idx[local * 3 + k];                                     // INDEX_TYPE = ushort
+        const unsigned char* p = verts + (uint64_t)vi * 16;                   // VERTEX_SIZE = 16
+        v[k].x = load_f32_unaligned(p);
+        v[k].y = load_f32_unaligned(p + 4);
+        v[k].z = load_f32_unaligned(p + 8);
+    }
+    f3 e1 = f3_sub(v[1], v[0]);                                               // Triangle.h:72-73
+    f3 e2 = f3_sub(v[2], v[0]);
+    f3 n = f3_normalize(f3_cross(e1, e2));                                    // Triangle.h:105
+    sc.v0[t] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(me.material_index));
+    sc.v1[t] = make_float4(v[1].x, v[1].y, v[1].z, 0.0f);
+    sc.v2[t] = make_float4(v[2].x, v[2].y, v[2].z, 0.0f);
+    sc.e1[t] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+    sc.e2[t] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+    sc.nrm[t] = make_float4(n.x, n.y, n.z, 0.0f);
+    sc.ref[t] = make_uint4(local, me.submesh_index, me.model_index, me.material_index);
+}
+
+void launch_gather_triangles(hipStream_t s, const DeviceScene& sc)
+{
+    if (!sc.n_tris) return;
+    hipLaunchKernelGGL(k_gather_triangles, dim3((sc.n_tris + 255) / 256), dim3(256), 0, s, sc);
+}
+
+// ----------------------------------------------------------------------------------------
+// 2. Morton codes + leaf nodes: calculateMorton, BVH.h:83-130 (host branch: centroid per
+//    component (a+b+c)/3.0f), calculateTriangleAABB AABB.h:61-79, normalizeScale
+//    RTKernelUtils.h:63-81 (value/oldLen, oldMin NOT subtracted), morton3D BVH.h:65-73.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3d(float x, float y, float z)
+{
+    x = RMIN(RMAX(x * 1024.0f, 0.0f), 1023.0f);
+    y = RMIN(RMAX(y * 1024.0f, 0.0f), 1023.0f);
+    z = RMIN(RMAX(z * 1024.0f, 0.0f), 1023.0f);
+    return expand_bits((uint32_t)x) * 4 + expand_bits((uint32_t)y) * 2 + expand_bits((uint32_t)z);
+}
+__device__ __forceinline__ float normalize_scale(float oldMin, float oldMax, float value)
+{
+    float oldLen = oldMax - oldMin;
+    float percentage = value / oldLen;
+    float newLen = 1.0f - 0.0f;
+    return percentage * newLen + 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_node* nodes, uint2* pairs)
+{
+    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= sc.n_tris) return;
+    float4 a = sc.v0[leaf], b = sc.v1[leaf], c = sc.v2[leaf];
+    float lo[3] = { RMIN(RMIN(a.x, b.x), c.x), RMIN(RMIN(a.y, b.y), c.y), RMIN(RMIN(a.z, b.z), c.z) };
+    float hi[3] = { RMAX(RMAX(a.x, b.x), c.x), RMAX(RMAX(a.y, b.y), c.y), RMAX(RMAX(a.z, b.z), c.z) };
+    for (int k = 0; k < 3; k++) {
+        uint32_t flat = (hi[k] - lo[k]) < FLT_EPSILON;
+        hi[k] += (float)flat * FLT_EPSILON;
+        lo[k] -= (float)flat * FLT_EPSILON;
+    }
+    float cx = (a.x + b.x + c.x) / 3.0f;
+    float cy = (a.y + b.y + c.y) / 3.0f;
+    float cz = (a.z + b.z + c.z) / 3.0f;
+    float nx = normalize_scale(sc.bb_lo[0], sc.bb_hi[0], cx);
+    float ny = normalize_scale(sc.bb_lo[1], sc.bb_hi[1], cy);
+    float nz = normalize_scale(sc.bb_lo[2], sc.bb_hi[2], cz);
+    uint4 ref = sc.ref[leaf];
+    rt_bvh_node nd;
+    nd.data[0] = 0;            // parent: written by the radix-tree kernel
+    nd.data[1] = ref.x;        // triangleIndex
+    nd.data[2] = ref.y;        // submeshIndex
+    nd.data[3] = ref.z;        // modelIndex
+    nd.boundsMin[0] = lo[0]; nd.boundsMin[1] = lo[1]; nd.boundsMin[2] = lo[2]; nd.boundsMin[3] = 1.0f; // LEAF_NODE
+    nd.boundsMax[0] = hi[0]; nd.boundsMax[1] = hi[1]; nd.boundsMax[2] = hi[2]; nd.boundsMax[3] = 0.0f;
+    nodes[leaf] = nd;
+    pairs[leaf] = make_uint2(morton3d(nx, ny, nz), leaf);
+}
+
+void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs)
+{
+    hipLaunchKernelGGL(k_morton_leaves, dim3((sc.n_tris + 255) / 256), dim3(256), 0, s, sc, nodes, pairs);
+}
+
+// ----------------------------------------------------------------------------------------
+// 3. radix tree: determineRange / findSplit / constructNode, BVH.h:138-321 (the NekoEngine
+//    duplicate-key variant, restated literally).  FIXED mode: all n-1 internal nodes
+//    (the reference kernel's guard idx < leafCount-2, BVHKernels.cl:58, loses node n-2).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t r_clz(uint32_t x) { return x ? (uint32_t)__clz((int)x) : 32u; }  // software_clz: clz(0)=32
+
+__device__ int find_split(const uint2* list, int first, int last)
+{
+    uint32_t firstCode = list[first].x;
+    uint32_t lastCode = list[last].x;
+    if (firstCode == lastCode) return first;
+    int commonPrefix = (int)r_clz(firstCode ^ lastCode);
+    int split = first;
+    int step = last - first;
+    do {
+        step = (step + 1) >> 1;
+        int newSplit = split + step;
+        if (newSplit < last) {
+            uint32_t splitCode = list[newSplit].x;
+            int splitPrefix = (int)r_clz(firstCode ^ splitCode);
+            if (splitPrefix > commonPrefix) split = newSplit;
+        }
+    } while (step > 1);
+    return split;
+}
+
+__device__ uint2 determine_range(const uint2* list, int index, uint32_t size)
+{
+    int lso = (int)size - 1;
+    if (index == 0) return make_uint2(0, (uint32_t)lso);
+    int dir, d_min;
+    int initialindex = index;
+    uint32_t minone = list[index - 1].x;
+    uint32_t precis = list[index].x;
+    uint32_t pluone = list[index + 1].x;
+    if (minone == precis && pluone == precis) {
+        while (index > 0 && index < lso) {
+            index += 1;
+            if (index >= lso || list[index].x != list[index + 1].x) break;
+        }
+        return make_uint2((uint32_t)initialindex, (uint32_t)index);
+    } else {
+        uint32_t lx = r_clz(precis ^ minone);
+        uint32_t ly = r_clz(precis ^ pluone);
+        if (lx > ly) { dir = -1; d_min = (int)ly; }
+        else         { dir = 1;  d_min = (int)lx; }
+    }
+    int l_max = 2;
+    int testindex = index + l_max * dir;
+    while ((testindex <= lso && testindex >= 0) ? (r_clz(precis ^ list[testindex].x) > (uint32_t)d_min) : false) {
+        l_max = l_max << 1;
+        testindex = index + l_max * dir;
+    }
+    int l = 0;
+    for (int div = 2; l_max / div >= 1; div = div << 1) {
+        int t = l_max / div;
+        int newTest = index + (l + t) * dir;
+        if (newTest <= lso && newTest >= 0) {
+            int splitPrefix = (int)r_clz(precis ^ list[newTest].x);
+            if (splitPrefix > d_min) l = l + t;
+        }
+    }
+    int a = index, b = index + l * dir;
+    return make_uint2((uint32_t)(a < b ? a : b), (uint32_t)(a > b ? a : b));
+}
+
+__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* mc, uint32_t numLeaves)
+{
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= numLeaves - 1) return;
+    uint2 range = determine_range(mc, (int)idx, numLeaves);
+    int split = find_split(mc, (int)range.x, (int)range.y);
+    uint32_t internal = idx + numLeaves;
+    uint32_t first = range.x < range.y ? range.x : range.y;
+    uint32_t last = range.x > range.y ? range.x : range.y;
+    bool aIsLeaf = first == (uint32_t)split;
+    bool bIsLeaf = last == (uint32_t)(split + 1);
+    uint32_t child_A = aIsLeaf ? mc[split].y : (uint32_t)split + numLeaves;
+    uint32_t child_B = bIsLeaf ? mc[split + 1].y : (uint32_t)split + 1 + numLeaves;
+    rt_bvh_node* nd = &nodes[internal];
+    // init box (FLT_MAX, FLT_MIN) -- FLT_MIN is the smallest POSITIVE normal, as written (BVH.h:309-310)
+    nd->boundsMin[0] = FLT_MAX; nd->boundsMin[1] = FLT_MAX; nd->boundsMin[2] = FLT_MAX; nd->boundsMin[3] = 0.0f; // INNER_NODE
+    nd->boundsMax[0] = FLT_MIN; nd->boundsMax[1] = FLT_MIN; nd->boundsMax[2] = FLT_MIN; nd->boundsMax[3] = 0.0f;
+    if (internal == numLeaves) nd->data[0] = UINT_MAX;
+    nd->data[1] = child_A;
+    nd->data[2] = child_B;
+    nd->data[3] = 0;
+    nodes[child_A].data[0] = internal;
+    nodes[child_B].data[0] = internal;
+}
+
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n)
+{
+    hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, pairs, n);
+}
+
+// ----------------------------------------------------------------------------------------
+// 4. refit: computeBoundingBoxes, BVHKernels.cl:65-79 + mergeBoundingBox BVH.h:328-334 +
+//    merge3 AABB.h:107-113 (all four lanes).  One walker per leaf; the SECOND arriver at a
+//    node merges (decided by the atomic's return value; the reference re-reads the counter
+//    non-atomically and has no fence).  Boxes written by one CU are handed to another CU
+//    with an agent-scope release before the counter add and an agent-scope acquire after it
+//    (per-CU L1 and per-XCD L2 are not coherent, MI355X_MICROARCH "inter-workgroup visibility").
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n)
+{
+    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    uint32_t current = nodes[leaf].data[0];
+    bool wrote = false;
+    while (current != UINT_MAX) {
+        if (wrote) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        uint32_t old = atomicAdd(&counters[current - n], 1u);
+        if (old == 0) break;                      // first arriver leaves
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rt_bvh_node* nd = &nodes[current];
+        uint32_t ca = nd->data[1], cb = nd->data[2];
+        float4 alo = *reinterpret_cast<const float4*>(nodes[ca].boundsMin);
+        float4 ahi = *reinterpret_cast<const float4*>(nodes[ca].boundsMax);
+        float4 blo = *reinterpret_cast<const float4*>(nodes[cb].boundsMin);
+        float4 bhi = *reinterpret_cast<const float4*>(nodes[cb].boundsMax);
+        float4 slo = *reinterpret_cast<const float4*>(nd->boundsMin);
+        float4 shi = *reinterpret_cast<const float4*>(nd->boundsMax);
+        float4 rlo, rhi, t;
+        t.x = RMIN(alo.x, blo.x); t.y = RMIN(alo.y, blo.y); t.z = RMIN(alo.z, blo.z); t.w = RMIN(alo.w, blo.w);
+        rlo.x = RMIN(t.x, slo.x); rlo.y = RMIN(t.y, slo.y); rlo.z = RMIN(t.z, slo.z); rlo.w = RMIN(t.w, slo.w);
+        t.x = RMAX(ahi.x, bhi.x); t.y = RMAX(ahi.y, bhi.y); t.z = RMAX(ahi.z, bhi.z); t.w = RMAX(ahi.w, bhi.w);
+        rhi.x = RMAX(t.x, shi.x); rhi.y = RMAX(t.y, shi.y); rhi.z = RMAX(t.z, shi.z); rhi.w = RMAX(t.w, shi.w);
+        *reinterpret_cast<float4*>(nd->boundsMin) = rlo;
+        *reinterpret_cast<float4*>(nd->boundsMax) = rhi;
+        wrote = true;
+        current = nd->data[0];
+    }
+}
+
+void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n)
+{
+    hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n);
+}
+
+// ----------------------------------------------------------------------------------------
+// 5. re-layout into 64-byte traversal records + tree depth (sizes the deep-stack spill area)
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relayout(const rt_bvh_node* nodes, TravNode* trav, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const rt_bvh_node* nd = &nodes[n + i];
+    uint32_t ca = nd->data[1], cb = nd->data[2];
+    TravNode t;
+    for (int k = 0; k < 3; k++) {
+        t.a_lo[k] = nodes[ca].boundsMin[k]; t.a_hi[k] = nodes[ca].boundsMax[k];
+        t.b_lo[k] = nodes[cb].boundsMin[k]; t.b_hi[k] = nodes[cb].boundsMax[k];
+    }
+    t.child_a = ca < n ? (RT_LEAF_FLAG | ca) : ca - n;
+    t.child_b = cb < n ? (RT_LEAF_FLAG | cb) : cb - n;
+    t.pad0 = 0; t.pad1 = 0;
+    trav[i] = t;
+}
+
+__global__ __launch_bounds__(256) void k_tree_depth(const rt_bvh_node* nodes, uint32_t n, uint32_t* depth_out)
+{
+    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (leaf < n) {
+        uint32_t cur = nodes[leaf].data[0];
+        while (cur != UINT_MAX && d < 2 * n) { d++; cur = nodes[cur].data[0]; }
+    }
+    // wave max, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_down((int)d, off, 64);
+        d = d > o ? d : o;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(depth_out, d);
+}
+
+void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, TravNode* trav, uint32_t n, uint32_t* depth_out)
+{
+    hipLaunchKernelGGL(k_relayout, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, trav, n);
+    hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_tree_depth, dim3((n + 255) / 256), dim3(256), 0, s, nodes, n, depth_out);
+}

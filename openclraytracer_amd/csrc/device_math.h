@@ -1,0 +1,53 @@
+// device_math.h -- the reference's host-branch arithmetic, restated for gfx950 device code.
+//
+// Everything here must produce the same binary32 results as the x86-64 oracle:
+//  * translation units are compiled with -ffp-contract=off (no FMA formation);
+//  * `/` and sqrtf are the correctly rounded forms (hipcc default
+//    -fhip-fp32-correctly-rounded-divide-sqrt; never -ffast-math);
+//  * min/max are the TERNARY macros of CLData/CLPortability.h:147-148, not v_min/v_max:
+//    they differ for NaN and for signed zeros.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#define RMIN(X, Y) (((X) < (Y)) ? (X) : (Y))
+#define RMAX(X, Y) (((X) > (Y)) ? (X) : (Y))
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 f3_sub(f3 a, f3 b) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+__device__ __forceinline__ f3 f3_add(f3 a, f3 b) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ f3 f3_scale(f3 a, float s) { return f3{ a.x * s, a.y * s, a.z * s }; }
+// cross / dot, CLPortability.h:266-278
+__device__ __forceinline__ f3 f3_cross(f3 a, f3 b)
+{
+    return f3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+__device__ __forceinline__ float f3_dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// cpu_normalize, CLPortability.h:151-159
+__device__ __forceinline__ f3 f3_normalize(f3 v)
+{
+    float l = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return f3{ v.x * l, v.y * l, v.z * l };
+}
+// LENGTH3, CLPortability.h:280
+__device__ __forceinline__ float f3_length(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+
+__device__ __forceinline__ f3 f3_from4(float4 v) { return f3{ v.x, v.y, v.z }; }
+
+// generateRay, CLStructs.h:95-106 with transformVectorByMatrix_const (Transform.h:282-295):
+// the translation column is added to the direction; origin = translation.
+__device__ __forceinline__ void generate_ray(const rt_camera& cam, uint32_t pixelIndex, f3& origin, f3& dir)
+{
+    float dx = -((float)(pixelIndex % cam.resX) - (float)cam.resX * 0.5f);
+    float dy = (float)(pixelIndex / cam.resX) - (float)cam.resY * 0.5f;
+    float dz = cam.FOVDistance;
+    const float* m = cam.viewTransform;
+    f3 v;
+    v.x = dx * m[0] + dy * m[1] + dz * m[2] + m[3];
+    v.y = dx * m[4] + dy * m[5] + dz * m[6] + m[7];
+    v.z = dx * m[8] + dy * m[9] + dz * m[10] + m[11];
+    dir = f3_normalize(v);
+    origin = f3{ m[3], m[7], m[11] };
+}

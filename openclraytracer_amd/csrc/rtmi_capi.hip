@@ -1,0 +1,578 @@
+// rtmi_capi.hip -- the C ABI of librtmi.so (include/rtmi.h): host-side orchestration only.
+// Mirrors the call sequence of the reference managers (BVHManager.cpp, Scene.cpp, CLBuffer.cpp)
+// but enqueues hand-written HIP kernels on one HIP stream instead of JIT-compiled OpenCL.
+#include "rtmi_internal.h"
+
+#include <cstring>
+#include <new>
+#include <sstream>
+
+static thread_local std::string g_null_ctx_error;
+
+int rt_fail(const rt_ctx* ctx, const char* file, int line, const char* func, const std::string& msg)
+{
+    std::ostringstream os;
+    // same fields as Common::Errata (Errata.h:58-110): file(line) function message
+    os << file << '(' << line << ") " << func << ' ' << msg;
+    if (ctx) ctx->last_error = os.str(); else g_null_ctx_error = os.str();
+    return RT_ERROR;
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RTMI_ABI_VERSION; }
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_null_ctx_error.c_str(); }
+
+int rt_ctx_create(int device_ordinal, rt_ctx** out)
+{
+    if (!out) return RT_FAIL(nullptr, "out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return RT_FAIL(nullptr, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= count) return RT_FAIL(nullptr, "device ordinal out of range");
+    rt_ctx* ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return RT_FAIL(nullptr, "out of host memory");
+    ctx->device = device_ordinal;
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void**)&ctx->d_ray_counter, 4096)) != hipSuccess) {
+        RT_FAIL(nullptr, std::string("context creation failed: ") + hipGetErrorString(e));
+        if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return RT_ERROR;
+    }
+    if (std::string(ctx->prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        RT_FAIL(nullptr, std::string("librtmi is built for gfx950 only, device is ") + ctx->prop.gcnArchName);
+        hipFree(ctx->d_ray_counter); hipStreamDestroy(ctx->own_stream); delete ctx;
+        return RT_ERROR;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return RT_SUCCESS;
+}
+
+void rt_ctx_destroy(rt_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->d_ray_counter) hipFree(ctx->d_ray_counter);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RT_SUCCESS;
+}
+
+void* rt_ctx_get_stream(const rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt_ctx_synchronize(rt_ctx* ctx)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_SUCCESS;
+}
+
+int rt_ctx_device_info(const rt_ctx* ctx, int* compute_units, int* wave_size, uint64_t* lds_bytes, char* name,
+                       size_t name_len)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (wave_size) *wave_size = ctx->prop.warpSize;
+    if (lds_bytes) *lds_bytes = ctx->prop.maxSharedMemoryPerMultiProcessor;
+    if (name && name_len) { std::strncpy(name, ctx->prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    return RT_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------
+// buffers
+// ---------------------------------------------------------------------------------------
+int rt_buf_alloc(rt_ctx* ctx, uint64_t bytes, void** d_out)
+{
+    if (!ctx || !d_out) return RT_FAIL(ctx, "null argument");
+    *d_out = nullptr;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
+    return RT_SUCCESS;
+}
+
+int rt_buf_free(rt_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (!d_ptr) return RT_SUCCESS;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipFree(d_ptr));
+    return RT_SUCCESS;
+}
+
+int rt_buf_upload(rt_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !h_src))) return RT_FAIL(ctx, "null argument");
+    if (!bytes) return RT_SUCCESS;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the host buffer may be reused on return
+    return RT_SUCCESS;
+}
+
+int rt_buf_download(rt_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!h_dst || !d_src))) return RT_FAIL(ctx, "null argument");
+    if (!bytes) return RT_SUCCESS;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_SUCCESS;
+}
+
+__global__ void k_fill_u32(uint32_t* dst, uint32_t pattern, uint64_t count)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) dst[i] = pattern;
+}
+
+int rt_buf_fill_u32(rt_ctx* ctx, void* d_dst, uint32_t pattern, uint64_t count)
+{
+    if (!ctx || (count && !d_dst)) return RT_FAIL(ctx, "null argument");
+    if (!count) return RT_SUCCESS;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (uint32_t*)d_dst, pattern, count);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------------------
+static uint64_t rd64(const unsigned char* p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+
+int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_scene** out)
+{
+    if (!ctx || !h_scene_buffer || !out) return RT_FAIL(ctx, "null argument");
+    *out = nullptr;
+    const unsigned char* s = (const unsigned char*)h_scene_buffer;
+    // SceneHeader, SceneBufferParser.h:55-66
+    if (bytes < 96) return RT_FAIL(ctx, "scene buffer smaller than a SceneHeader");
+    uint64_t totalDataSize = rd64(s), nLights = rd64(s + 16), nSpheres = rd64(s + 24), nMaterials = rd64(s + 32),
+             nModels = rd64(s + 48), nTris = rd64(s + 56);
+    if (totalDataSize > bytes) return RT_FAIL(ctx, "SceneHeader.totalDataSize exceeds the buffer");
+    if (nLights > bytes || nSpheres > bytes || nMaterials > bytes) return RT_FAIL(ctx, "corrupt scene header counts");
+    uint64_t off = 96 + 16 * nLights + 16 * nSpheres + 96 * nMaterials;        // MODEL_BUFFER_PTR, :69-74
+    if (off > bytes) return RT_FAIL(ctx, "scene header counts exceed the buffer");
+    if (nTris >= 0x7FFFFFFFull) return RT_FAIL(ctx, "too many triangles");
+
+    rt_scene* sc = new (std::nothrow) rt_scene();
+    if (!sc) return RT_FAIL(ctx, "out of host memory");
+    sc->ctx = ctx;
+    uint64_t tri_acc = 0;
+    for (uint64_t m = 0; m < nModels; m++) {
+        if (off + 64 > bytes) { delete sc; return RT_FAIL(ctx, "model header outside the buffer"); }
+        uint64_t modelSize = rd64(s + off), nSub = rd64(s + off + 8);           // ModelHeader, :129-136
+        if (modelSize < 64 || off + modelSize > bytes) { delete sc; return RT_FAIL(ctx, "model size outside the buffer"); }
+        uint64_t moff = off + 64;
+        for (uint64_t k = 0; k < nSub; k++) {
+            if (moff + 48 > off + modelSize) { delete sc; return RT_FAIL(ctx, "mesh header outside its model"); }
+            uint64_t meshSize = rd64(s + moff), mt = rd64(s + moff + 8), nv = rd64(s + moff + 16), ni = rd64(s + moff + 24),
+                     mat = rd64(s + moff + 32);                                  // MeshHeader, :141-149
+            if (meshSize < 48 + 16 * nv + 2 * ni || moff + meshSize > off + modelSize || mt * 3 > ni) {
+                delete sc; return RT_FAIL(ctx, "mesh sizes inconsistent");
+            }
+            const unsigned char* ib = s + moff + 48 + 16 * nv;
+            for (uint64_t i = 0; i < mt * 3; i++) {
+                uint16_t v; std::memcpy(&v, ib + 2 * i, 2);
+                if (v >= nv) { delete sc; return RT_FAIL(ctx, "vertex index out of range"); }
+            }
+            MeshEntry e{};
+            e.byte_offset = moff; e.first_triangle = (uint32_t)tri_acc; e.triangle_count = (uint32_t)mt;
+            e.vertex_count = (uint32_t)nv; e.material_index = (uint32_t)mat;
+            e.model_index = (uint32_t)m; e.submesh_index = (uint32_t)k;
+            sc->h_meshes.push_back(e);
+            tri_acc += mt;
+            moff += meshSize;
+        }
+        off += modelSize;
+    }
+    if (tri_acc != nTris) { delete sc; return RT_FAIL(ctx, "SceneHeader.totalNumberOfTriangles does not match the meshes"); }
+
+    hipError_t e = hipSetDevice(ctx->device);
+    size_t tri_bytes = (size_t)nTris * (6 * sizeof(float4) + sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc(&sc->d_bytes, bytes);
+    if (e == hipSuccess) e = hipMalloc(&sc->d_meshes, sizeof(MeshEntry) * (sc->h_meshes.size() + 1));
+    if (e == hipSuccess) e = hipMalloc(&sc->d_tri, tri_bytes ? tri_bytes : 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(sc->d_bytes, s, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !sc->h_meshes.empty())
+        e = hipMemcpyAsync(sc->d_meshes, sc->h_meshes.data(), sizeof(MeshEntry) * sc->h_meshes.size(),
+                           hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        RT_FAIL(ctx, std::string("scene upload failed: ") + hipGetErrorString(e));
+        rt_scene_destroy(sc);
+        return RT_ERROR;
+    }
+    DeviceScene& d = sc->d;
+    d.bytes = (const unsigned char*)sc->d_bytes; d.nbytes = bytes;
+    d.n_tris = (uint32_t)nTris; d.n_meshes = (uint32_t)sc->h_meshes.size();
+    d.meshes = (const MeshEntry*)sc->d_meshes;
+    float4* base = (float4*)sc->d_tri;
+    d.v0 = base; d.v1 = base + nTris; d.v2 = base + 2 * nTris; d.e1 = base + 3 * nTris; d.e2 = base + 4 * nTris;
+    d.nrm = base + 5 * nTris; d.ref = (uint4*)(base + 6 * nTris);
+    d.n_lights = (uint32_t)nLights; d.n_spheres = (uint32_t)nSpheres; d.n_materials = (uint32_t)nMaterials;
+    std::memcpy(d.bb_lo, s + 64, 12);
+    std::memcpy(d.bb_hi, s + 80, 12);
+    launch_gather_triangles(ctx->stream, d);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        RT_FAIL(ctx, std::string("triangle gather failed: ") + hipGetErrorString(e));
+        rt_scene_destroy(sc);
+        return RT_ERROR;
+    }
+    *out = sc;
+    return RT_SUCCESS;
+}
+
+void rt_scene_destroy(rt_scene* sc)
+{
+    if (!sc) return;
+    if (sc->ctx) { hipSetDevice(sc->ctx->device); hipStreamSynchronize(sc->ctx->stream); }
+    if (sc->d_bytes) hipFree(sc->d_bytes);
+    if (sc->d_meshes) hipFree(sc->d_meshes);
+    if (sc->d_tri) hipFree(sc->d_tri);
+    delete sc;
+}
+
+const void* rt_scene_device_ptr(const rt_scene* sc) { return sc ? sc->d_bytes : nullptr; }
+uint64_t rt_scene_bytes(const rt_scene* sc) { return sc ? sc->d.nbytes : 0; }
+uint32_t rt_scene_triangle_count(const rt_scene* sc) { return sc ? sc->d.n_tris : 0; }
+
+// ---------------------------------------------------------------------------------------
+// BVH manager
+// ---------------------------------------------------------------------------------------
+static uint32_t morton_buffer_items(uint32_t n)     // BVHManager.cpp:128-131
+{
+    uint32_t p = 1;
+    while ((uint64_t)p * 2 <= n) p *= 2;
+    if (p < n) p *= 2;
+    return p;
+}
+
+int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** out)
+{
+    if (!ctx || !scene || !out) return RT_FAIL(ctx, "null argument");
+    *out = nullptr;
+    if (scene->ctx != ctx) return RT_FAIL(ctx, "scene belongs to another context");
+    if (parity_mode != RT_MODE_FIXED)
+        return RT_FAIL(ctx, "only RT_MODE_FIXED is implemented on the device (LITERAL_ZERO encodes undefined behaviour)");
+    rt_bvh* b = new (std::nothrow) rt_bvh();
+    if (!b) return RT_FAIL(ctx, "out of host memory");
+    b->ctx = ctx; b->scene = scene; b->mode = parity_mode;
+    *out = b;
+    return RT_SUCCESS;
+}
+
+static void free_build_buffers(rt_bvh* b)
+{
+    if (b->d_nodes) hipFree(b->d_nodes);
+    if (b->d_pairs) hipFree(b->d_pairs);
+    if (b->d_counters) hipFree(b->d_counters);
+    if (b->d_trav) hipFree(b->d_trav);
+    if (b->d_depth) hipFree(b->d_depth);
+    if (b->d_overflow) hipFree(b->d_overflow);
+    b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
+    b->d_depth = nullptr; b->d_overflow = nullptr;
+}
+
+void rt_bvh_destroy(rt_bvh* b)
+{
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    free_build_buffers(b);
+    delete b;
+}
+
+int rt_bvh_initialize_frame(rt_bvh* b)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t n = b->scene->d.n_tris;
+    if (n < 2) return RT_FAIL(ctx, "a BVH needs at least two triangles");
+    uint32_t N = morton_buffer_items(n);
+    if (n != b->n) {                                  // grow-only in the reference (CLBuffer::resize); exact here
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        free_build_buffers(b);
+        b->n = n; b->N = N;
+        RT_HIP(ctx, hipMalloc((void**)&b->d_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node)));
+        RT_HIP(ctx, hipMalloc((void**)&b->d_pairs, (size_t)N * sizeof(uint2)));
+        RT_HIP(ctx, hipMalloc((void**)&b->d_counters, (size_t)n * sizeof(uint32_t)));
+        RT_HIP(ctx, hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode)));
+        RT_HIP(ctx, hipMalloc((void**)&b->d_depth, 256));
+    }
+    // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
+    // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
+    RT_HIP(ctx, hipMemsetAsync(b->d_pairs, 0xFF, (size_t)N * sizeof(uint2), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), ctx->stream));
+    b->frame_initialised = true;
+    b->built = false;
+    return RT_SUCCESS;
+}
+
+int rt_bvh_construct(rt_bvh* b)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!b->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const DeviceScene& sc = b->scene->d;
+    launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
+    launch_bitonic_sort(s, b->d_pairs, b->N);                     // 2. :195
+    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n);           // 3. :204
+    launch_refit(s, b->d_nodes, b->d_counters, b->n);             // 4. :217
+    launch_relayout(s, b->d_nodes, b->d_trav, b->n, b->d_depth);  // traversal records + depth
+    RT_HIP(ctx, hipGetLastError());
+    uint32_t depth = 0;
+    RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
+    b->max_depth = depth;
+    uint64_t words = depth >= trace_lds_stack_entries() ? (uint64_t)(depth - trace_lds_stack_entries() + 2) : 0;
+    if (words != b->overflow_words_per_lane) {
+        if (b->d_overflow) { hipFree(b->d_overflow); b->d_overflow = nullptr; }
+        b->overflow_words_per_lane = words;
+        if (words) {
+            uint64_t lanes = trace_max_resident_lanes(ctx->prop.multiProcessorCount);
+            RT_HIP(ctx, hipMalloc((void**)&b->d_overflow, lanes * words * sizeof(uint32_t)));
+        }
+    }
+    b->frame_initialised = false;
+    b->built = true;
+    return RT_SUCCESS;
+}
+
+static TraceLaunch make_launch(rt_bvh* b)
+{
+    TraceLaunch t{};
+    t.trav = b->d_trav; t.scene = &b->scene->d; t.n_leaves = b->n;
+    t.work_counter = b->ctx->d_ray_counter;
+    t.overflow = b->d_overflow; t.overflow_words_per_lane = (uint32_t)b->overflow_words_per_lane;
+    t.compute_units = b->ctx->prop.multiProcessorCount;
+    return t;
+}
+
+static int check_camera(rt_ctx* ctx, const rt_camera* cam)
+{
+    if (!cam) return RT_FAIL(ctx, "camera is null");
+    if (cam->resX == 0 || cam->resY == 0) return RT_FAIL(ctx, "camera resolution is zero");
+    if ((uint64_t)cam->resX * cam->resY > 0x3FFFFFFFull) return RT_FAIL(ctx, "camera resolution too large");
+    return RT_SUCCESS;
+}
+
+int rt_bvh_generate_contacts_primary(rt_bvh* b, const rt_camera* cam, void* d_contacts)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (!d_contacts) return RT_FAIL(ctx, "contacts buffer is null");
+    if (check_camera(ctx, cam)) return RT_ERROR;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_trace_primary(ctx->stream, make_launch(b), *cam, 0, 1, false, (rt_contact*)d_contacts);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks,
+                                           void* d_contacts_compact)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (!d_contacts_compact) return RT_FAIL(ctx, "contacts buffer is null");
+    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_trace_primary(ctx->stream, make_launch(b), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_bvh_generate_contacts_rays(rt_bvh* b, const void* d_rays, uint32_t ray_count, void* d_contacts)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (ray_count == 0) return RT_SUCCESS;
+    if (!d_rays || !d_contacts) return RT_FAIL(ctx, "null buffer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_trace_rays(ctx->stream, make_launch(b), (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_bvh_read_nodes(const rt_bvh* b, void* h_nodes)
+{
+    if (!b || !h_nodes) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
+    if (!b->built) return RT_FAIL(b->ctx, "BVH not built");
+    return rt_buf_download(b->ctx, h_nodes, b->d_nodes, (uint64_t)(2 * b->n - 1) * sizeof(rt_bvh_node));
+}
+
+int rt_bvh_read_morton_pairs(const rt_bvh* b, void* h_pairs, uint32_t* n_pow2)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    if (!b->built) return RT_FAIL(b->ctx, "BVH not built");
+    if (n_pow2) *n_pow2 = b->N;
+    if (!h_pairs) return RT_SUCCESS;
+    return rt_buf_download(b->ctx, h_pairs, b->d_pairs, (uint64_t)b->N * sizeof(uint2));
+}
+
+int rt_bvh_info(const rt_bvh* b, uint32_t* leaves, uint32_t* morton_items, uint32_t* max_depth)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    if (leaves) *leaves = b->n;
+    if (morton_items) *morton_items = b->N;
+    if (max_depth) *max_depth = b->max_depth;
+    return RT_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------
+// shading + tiling
+// ---------------------------------------------------------------------------------------
+int rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const void* d_contacts,
+                         uint32_t contact_count, void* d_rgba)
+{
+    if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
+    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (!d_rgba || (contact_count && !d_contacts)) return RT_FAIL(ctx, "null buffer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (contact_count == 0) {
+        RT_HIP(ctx, hipMemsetAsync(d_rgba, 0, (size_t)cam->resX * cam->resY * sizeof(float4), ctx->stream));
+        return RT_SUCCESS;
+    }
+    launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts, contact_count, (float4*)d_rgba, false, 0, 1);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+uint32_t rt_tiles_owned_pixels(const rt_camera* cam, uint32_t rank, uint32_t nranks)
+{
+    if (!cam || nranks == 0 || rank >= nranks) return 0;
+    uint32_t total = rt_tiles_x(cam->resX) * rt_tiles_y(cam->resY);
+    return rt_owned_tiles(total, rank, nranks) * RT_TILE * RT_TILE;
+}
+
+int rt_shade_blinn_phong_tiled(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks,
+                               const void* d_contacts_compact, void* d_rgba_compact)
+{
+    if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
+    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (!d_contacts_compact || !d_rgba_compact) return RT_FAIL(ctx, "null buffer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t count = rt_tiles_owned_pixels(cam, rank, nranks);
+    launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts_compact, count, (float4*)d_rgba_compact, true,
+                 rank, nranks);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgba_gathered, uint32_t slots_per_rank,
+                   void* d_rgba_frame)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (nranks == 0 || !d_rgba_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
+    if (slots_per_rank < rt_tiles_owned_pixels(cam, 0, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_untile_rgba(ctx->stream, *cam, nranks, (const float4*)d_rgba_gathered, slots_per_rank, (float4*)d_rgba_frame);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------
+// primitives
+// ---------------------------------------------------------------------------------------
+int rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2)
+{
+    if (!ctx || !d_pairs) return RT_FAIL(ctx, "null argument");
+    if (n_pow2 == 0 || (n_pow2 & (n_pow2 - 1))) return RT_FAIL(ctx, "item count must be a power of two");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_bitonic_sort(ctx->stream, (uint2*)d_pairs, n_pow2);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (n == 0) return RT_SUCCESS;
+    if (!d_in || !d_out) return RT_FAIL(ctx, "null buffer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t* scratch = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&scratch, scan_scratch_words(n) * sizeof(uint32_t)));
+    launch_scan_inclusive(ctx->stream, (const uint32_t*)d_in, (uint32_t*)d_out, n, scratch);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // scratch is freed below
+    hipFree(scratch);
+    if (e != hipSuccess) return RT_FAIL(ctx, std::string("scan failed: ") + hipGetErrorString(e));
+    return RT_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------
+// timers
+// ---------------------------------------------------------------------------------------
+struct rt_timer { hipEvent_t start, stop; };
+
+int rt_timer_create(rt_ctx* ctx, void** timer)
+{
+    if (!ctx || !timer) return RT_FAIL(ctx, "null argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rt_timer* t = new (std::nothrow) rt_timer();
+    if (!t) return RT_FAIL(ctx, "out of host memory");
+    if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) {
+        delete t;
+        return RT_FAIL(ctx, "hipEventCreate failed");
+    }
+    *timer = t;
+    return RT_SUCCESS;
+}
+int rt_timer_start(rt_ctx* ctx, void* timer)
+{
+    if (!ctx || !timer) return RT_FAIL(ctx, "null argument");
+    RT_HIP(ctx, hipEventRecord(((rt_timer*)timer)->start, ctx->stream));
+    return RT_SUCCESS;
+}
+int rt_timer_stop(rt_ctx* ctx, void* timer)
+{
+    if (!ctx || !timer) return RT_FAIL(ctx, "null argument");
+    RT_HIP(ctx, hipEventRecord(((rt_timer*)timer)->stop, ctx->stream));
+    return RT_SUCCESS;
+}
+int rt_timer_elapsed_ms(rt_ctx* ctx, void* timer, float* ms)
+{
+    if (!ctx || !timer || !ms) return RT_FAIL(ctx, "null argument");
+    rt_timer* t = (rt_timer*)timer;
+    RT_HIP(ctx, hipEventSynchronize(t->stop));
+    RT_HIP(ctx, hipEventElapsedTime(ms, t->start, t->stop));
+    return RT_SUCCESS;
+}
+void rt_timer_destroy(rt_ctx* ctx, void* timer)
+{
+    if (!timer) return;
+    rt_timer* t = (rt_timer*)timer;
+    hipEventDestroy(t->start); hipEventDestroy(t->stop);
+    delete t;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// rtmi_internal.h -- shared declarations of librtmi.so (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rtmi.h"
+
+// ---------------------------------------------------------------------------------------
+// Device-side data layout (all in HBM, built once per construct(), read-only while tracing)
+// ---------------------------------------------------------------------------------------
+
+// One 64-byte record per INNER node i (reference node index n+i): both child boxes plus the
+// child ids, so one visit = one 64-byte fetch instead of the reference's 48 + 32 + 32 bytes
+// (BVH.h:359-364).  Child id: bit31 set -> leaf (low bits = leaf/global triangle index),
+// else inner record index.  The boxes are bit copies of the reference BVHNode boxes.
+struct __attribute__((aligned(16))) TravNode {
+    float a_lo[3]; uint32_t child_a;
+    float a_hi[3]; uint32_t child_b;
+    float b_lo[3]; uint32_t pad0;
+    float b_hi[3]; uint32_t pad1;
+};
+static_assert(sizeof(TravNode) == 64, "TravNode must be 64 bytes");
+
+#define RT_LEAF_FLAG 0x80000000u
+#define RT_SENTINEL 0xFFFFFFFFu   // stack sentinel, BVH.h:352
+
+// One entry per mesh of the packed scene buffer (host walks the headers once at upload).
+struct MeshEntry {
+    uint64_t byte_offset;     // of the MeshHeader inside the scene buffer
+    uint32_t first_triangle;  // global index of the mesh's first triangle
+    uint32_t triangle_count;
+    uint32_t vertex_count;
+    uint32_t material_index;  // (CL_UINT)MeshHeader.materialIndex, BVH.h:395
+    uint32_t model_index;
+    uint32_t submesh_index;
+};
+
+struct DeviceScene {
+    const unsigned char* bytes;     // raw packed scene buffer (reference format)
+    uint64_t nbytes;
+    uint32_t n_tris;
+    uint32_t n_meshes;
+    const MeshEntry* meshes;
+    // SoA triangle table indexed by global triangle index == BVH leaf index
+    float4* v0;        // xyz = vertex 0, w = material index (bits)
+    float4* v1;
+    float4* v2;
+    float4* e1;        // v1 - v0 (Triangle.h:72)
+    float4* e2;        // v2 - v0 (Triangle.h:73)
+    float4* nrm;       // normalize(cross(e1,e2)) (Triangle.h:105), ray independent
+    uint4*  ref;       // (triangle in mesh, submesh, model, material)
+    // scene header fields needed on the device
+    uint32_t n_lights, n_spheres, n_materials;
+    float bb_lo[3], bb_hi[3];
+};
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipDeviceProp_t prop;
+    mutable std::string last_error;
+    uint32_t* d_ray_counter = nullptr;   // persistent-wave work counters (one 128-B line each)
+};
+
+struct rt_scene {
+    rt_ctx* ctx = nullptr;
+    DeviceScene d{};
+    std::vector<MeshEntry> h_meshes;
+    void* d_bytes = nullptr;
+    void* d_meshes = nullptr;
+    void* d_tri = nullptr;     // one allocation backing the SoA arrays
+};
+
+struct rt_bvh {
+    rt_ctx* ctx = nullptr;
+    const rt_scene* scene = nullptr;
+    int mode = 0;
+    uint32_t n = 0;            // leaves
+    uint32_t N = 0;            // morton buffer items (power of two)
+    rt_bvh_node* d_nodes = nullptr;    // reference layout, 2n-1 entries
+    uint2* d_pairs = nullptr;          // N (morton, leaf)
+    uint32_t* d_counters = nullptr;    // n visit counters (BVHManager.cpp:67)
+    TravNode* d_trav = nullptr;        // n-1 traversal records
+    uint32_t* d_depth = nullptr;       // max depth (1 word)
+    uint32_t* d_overflow = nullptr;    // deep-stack spill area
+    uint64_t overflow_words_per_lane = 0;
+    uint32_t max_depth = 0;
+    bool frame_initialised = false;
+    bool built = false;
+};
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+int rt_fail(const rt_ctx* ctx, const char* file, int line, const char* func, const std::string& msg);
+#define RT_FAIL(ctx, msg) rt_fail((ctx), __FILE__, __LINE__, __func__, (msg))
+#define RT_HIP(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return RT_FAIL((ctx), std::string(#expr) + ": " + hipGetErrorString(e__));         \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// kernel launchers (one translation unit per family)
+// ---------------------------------------------------------------------------------------
+// build_kernels.hip
+void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
+void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs);
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n);
+void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n);
+void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, TravNode* trav, uint32_t n, uint32_t* depth_out);
+// sort_scan_kernels.hip
+void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
+int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch);
+size_t scan_scratch_words(uint32_t n);
+// trace_kernels.hip
+struct TraceLaunch {
+    const TravNode* trav;
+    const DeviceScene* scene;
+    uint32_t n_leaves;
+    uint32_t* work_counter;       // zeroed by the launcher
+    uint32_t* overflow;           // may be null when max_depth fits the LDS stack
+    uint32_t overflow_words_per_lane;
+    int compute_units;
+};
+void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
+                          bool compact, rt_contact* out);
+void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
+uint32_t trace_max_resident_lanes(int compute_units);
+uint32_t trace_lds_stack_entries();
+// shade_kernels.hip
+void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,
+                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks);
+void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,
+                        uint32_t slots_per_rank, float4* frame);
+
+// tiling helpers shared by host and device (64x64-pixel tiles dealt round-robin)
+#define RT_TILE 64u
+__host__ __device__ inline uint32_t rt_tiles_x(uint32_t resX) { return (resX + RT_TILE - 1) / RT_TILE; }
+__host__ __device__ inline uint32_t rt_tiles_y(uint32_t resY) { return (resY + RT_TILE - 1) / RT_TILE; }
+__host__ __device__ inline uint32_t rt_owned_tiles(uint32_t total_tiles, uint32_t rank, uint32_t nranks)
+{
+    return total_tiles > rank ? (total_tiles - rank + nranks - 1) / nranks : 0u;
+}

@@ -1,0 +1,129 @@
+// shade_kernels.hip -- primary-ray Blinn-Phong shading on the device (gfx950).
+//
+// The reference shades on the HOST: RTFrame copies every Contact back and loops over them calling
+// cpuShadeBlinnPhong (src/Demos/OpenCLRayTracerDemo/OpenCLRayTracerDemo.cpp:298-316,
+// Include/CLData/Shading.h:74-166, lightEnergyPercentage Primitives/Light.h:55-58).  This kernel
+// restates that function per contact; pixels without a hit get (0,0,0,0) (the memset at :298).
+// powf comes from the device library, hence the 1e-5 relative tolerance on RGB.
+#include "rtmi_internal.h"
+#include "device_math.h"
+
+struct ShadeArgs {
+    const unsigned char* __restrict__ scene;   // raw packed scene buffer: lights + materials
+    uint32_t n_lights, n_spheres, n_materials;
+    rt_camera cam;
+    const rt_contact* __restrict__ contacts;
+    uint32_t count;
+    float4* __restrict__ rgba;
+    uint32_t tiled, rank, nranks, tiles_x;
+};
+
+__device__ __forceinline__ float light_energy_percentage(float distance, float lightEnergy)
+{
+    return RMAX((1.0f - distance / lightEnergy), 0.0f);
+}
+
+__device__ __forceinline__ float4 shade_one(const ShadeArgs& a, const rt_contact& c)
+{
+    // default material, Shading.h:76-96
+    f3 ambient = { 0.2f, 0.2f, 0.2f }, diffuse = { 1.0f, 1.0f, 1.0f }, specular = { 1.0f, 0.0f, 0.0f };
+    float shininess = 0.4f;
+    const float4* lights = reinterpret_cast<const float4*>(a.scene + 96);                       // LIGHTS_PTR
+    const float4* materials = reinterpret_cast<const float4*>(a.scene + 96 + 16ull * a.n_lights + 16ull * a.n_spheres);
+    f3 o, d;
+    generate_ray(a.cam, c.pixelIndex, o, d);
+    float t = c.normalAndDistance[3];
+    f3 P = f3_add(o, f3_scale(d, t));
+    if (c.materialIndex < a.n_materials) {
+        const float4* m = materials + 6ull * c.materialIndex;     // Material = 96 B
+        ambient = f3_from4(m[0]); diffuse = f3_from4(m[1]); specular = f3_from4(m[2]);
+        shininess = m[5].x;
+    }
+    f3 camPos = { a.cam.viewTransform[3], a.cam.viewTransform[7], a.cam.viewTransform[11] };
+    f3 N = { c.normalAndDistance[0], c.normalAndDistance[1], c.normalAndDistance[2] };
+    f3 V = f3_normalize(f3_sub(camPos, P));
+    float cr = ambient.x, cg = ambient.y, cb = ambient.z;
+    float totalEnergy = 0.0f;
+    uint32_t nl = a.n_lights + 1;          // scene lights, then the camera light (energy 100000)
+    for (uint32_t i = 0; i < nl; i++) {
+        float4 l = (i < a.n_lights) ? lights[i] : make_float4(camPos.x, camPos.y, camPos.z, 100000.0f);
+        float dist = f3_length(f3_sub(f3_from4(l), P));
+        totalEnergy += light_energy_percentage(dist, l.w) * l.w;
+    }
+    for (uint32_t i = 0; i < nl; i++) {
+        float4 l = (i < a.n_lights) ? lights[i] : make_float4(camPos.x, camPos.y, camPos.z, 100000.0f);
+        f3 L = f3_sub(f3_from4(l), P);
+        float dist = f3_length(L);
+        float lightIntensity = light_energy_percentage(dist, l.w);
+        float percentageOfTotal = (lightIntensity * l.w) / totalEnergy;
+        float lsEnergy = lightIntensity * percentageOfTotal;
+        L = f3_normalize(L);
+        float LDotN = f3_dot(L, N);
+        LDotN = LDotN > 0.0f ? LDotN : 0.0f;
+        cr += diffuse.x * LDotN * lsEnergy;
+        cg += diffuse.y * LDotN * lsEnergy;
+        cb += diffuse.z * LDotN * lsEnergy;
+        f3 R = f3_normalize(f3_sub(f3_scale(N, 2.0f * LDotN), L));
+        float nSpecular = powf(f3_dot(R, V), shininess);
+        float px = specular.x * nSpecular * lsEnergy;
+        float py = specular.y * nSpecular * lsEnergy;
+        float pz = specular.z * nSpecular * lsEnergy;
+        cr += RMAX(px, 0.0f);
+        cg += RMAX(py, 0.0f);
+        cb += RMAX(pz, 0.0f);
+    }
+    return make_float4(RMIN(cr, 1.0f), RMIN(cg, 1.0f), RMIN(cb, 1.0f), 1.0f);
+}
+
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.count) return;
+    // contacts are 32 B: two float4 loads
+    const float4* p = reinterpret_cast<const float4*>(a.contacts + i);
+    float4 h = p[0], nt = p[1];
+    rt_contact c;
+    c.pixelIndex = __float_as_uint(h.x); c.materialIndex = __float_as_uint(h.y); c.pad[0] = 0; c.pad[1] = 0;
+    c.normalAndDistance[0] = nt.x; c.normalAndDistance[1] = nt.y; c.normalAndDistance[2] = nt.z; c.normalAndDistance[3] = nt.w;
+    // untiled: exactly RTFrame -- the frame was cleared by the launcher (memset at :298) and only hits are
+    //          stored, at colors[contact.pixelIndex] (:305-311);
+    // tiled  : compact slot i keeps its slot, misses and out-of-frame slots store zeros.
+    if (nt.w > 0.0f) a.rgba[a.tiled ? i : c.pixelIndex] = shade_one(a, c);
+    else if (a.tiled) a.rgba[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,
+                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks)
+{
+    if (!count) return;
+    ShadeArgs a{};
+    a.scene = sc.bytes;
+    a.n_lights = sc.n_lights; a.n_spheres = sc.n_spheres; a.n_materials = sc.n_materials;
+    a.cam = cam;
+    a.contacts = contacts; a.count = count; a.rgba = rgba;
+    a.tiled = tiled ? 1u : 0u; a.rank = rank; a.nranks = nranks; a.tiles_x = rt_tiles_x(cam.resX);
+    if (!tiled) hipMemsetAsync(rgba, 0, (size_t)cam.resX * cam.resY * sizeof(float4), s);   // memset(colors,0), :298
+    hipLaunchKernelGGL(k_shade, dim3((count + 255) / 256), dim3(256), 0, s, a);
+}
+
+// gathered[r * slots_per_rank + ordinal*4096 + ly*64 + lx]  ->  frame[y*resX + x]
+__global__ __launch_bounds__(256) void k_untile_rgba(rt_camera cam, uint32_t nranks, const float4* __restrict__ gathered,
+                                                     uint32_t slots_per_rank, float4* __restrict__ frame)
+{
+    uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixel >= cam.resX * cam.resY) return;
+    uint32_t y = pixel / cam.resX, x = pixel - y * cam.resX;
+    uint32_t tx = x / RT_TILE, ty = y / RT_TILE;
+    uint32_t tile = ty * rt_tiles_x(cam.resX) + tx;
+    uint32_t rank = tile % nranks, ordinal = tile / nranks;
+    uint32_t slot = ordinal * (RT_TILE * RT_TILE) + (y - ty * RT_TILE) * RT_TILE + (x - tx * RT_TILE);
+    frame[pixel] = gathered[(uint64_t)rank * slots_per_rank + slot];
+}
+
+void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,
+                        uint32_t slots_per_rank, float4* frame)
+{
+    uint32_t n = cam.resX * cam.resY;
+    hipLaunchKernelGGL(k_untile_rgba, dim3((n + 255) / 256), dim3(256), 0, s, cam, nranks, gathered, slots_per_rank,
+                       frame);
+}
