@@ -309,9 +309,19 @@ __global__ __launch_bounds__(256) void k_tree_depth(const rt_bvh_node* nodes, ui
     if ((threadIdx.x & 63) == 0) atomicMax(depth_out, d);
 }
 
-void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, TravNode* trav, uint32_t n, uint32_t* depth_out)
+// leaf -> position in the sorted pair array.  The radix tree is built over that array, so this is
+// the leaf's rank in the reference's A-first depth-first order (the tie rule of BVH.h:392).
+__global__ __launch_bounds__(256) void k_leaf_positions(const uint2* pairs, uint32_t* pos, uint32_t n)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) pos[pairs[j].y] = j;
+}
+
+void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
+                     uint32_t n, uint32_t* depth_out)
 {
     hipLaunchKernelGGL(k_relayout, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, trav, n);
-    hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_leaf_positions, dim3((n + 255) / 256), dim3(256), 0, s, pairs, pos, n);
+    (void)hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(k_tree_depth, dim3((n + 255) / 256), dim3(256), 0, s, nodes, n, depth_out);
 }

@@ -38,10 +38,11 @@ __device__ __forceinline__ f3 f3_from4(float4 v) { return f3{ v.x, v.y, v.z }; }
 
 // generateRay, CLStructs.h:95-106 with transformVectorByMatrix_const (Transform.h:282-295):
 // the translation column is added to the direction; origin = translation.
-__device__ __forceinline__ void generate_ray(const rt_camera& cam, uint32_t pixelIndex, f3& origin, f3& dir)
+// x = pixelIndex % resX, y = pixelIndex / resX
+__device__ __forceinline__ void generate_ray_xy(const rt_camera& cam, uint32_t x, uint32_t y, f3& origin, f3& dir)
 {
-    float dx = -((float)(pixelIndex % cam.resX) - (float)cam.resX * 0.5f);
-    float dy = (float)(pixelIndex / cam.resX) - (float)cam.resY * 0.5f;
+    float dx = -((float)x - (float)cam.resX * 0.5f);
+    float dy = (float)y - (float)cam.resY * 0.5f;
     float dz = cam.FOVDistance;
     const float* m = cam.viewTransform;
     f3 v;
@@ -50,4 +51,8 @@ __device__ __forceinline__ void generate_ray(const rt_camera& cam, uint32_t pixe
     v.z = dx * m[8] + dy * m[9] + dz * m[10] + m[11];
     dir = f3_normalize(v);
     origin = f3{ m[3], m[7], m[11] };
+}
+__device__ __forceinline__ void generate_ray(const rt_camera& cam, uint32_t pixelIndex, f3& origin, f3& dir)
+{
+    generate_ray_xy(cam, pixelIndex % cam.resX, pixelIndex / cam.resX, origin, dir);
 }

@@ -3,6 +3,7 @@
 // but enqueues hand-written HIP kernels on one HIP stream instead of JIT-compiled OpenCL.
 #include "rtmi_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <sstream>
@@ -16,6 +17,40 @@ int rt_fail(const rt_ctx* ctx, const char* file, int line, const char* func, con
     os << file << '(' << line << ") " << func << ' ' << msg;
     if (ctx) ctx->last_error = os.str(); else g_null_ctx_error = os.str();
     return RT_ERROR;
+}
+
+static void free_ctx_buffers(rt_ctx* ctx)
+{
+    if (ctx->d_trace_ctrl) (void)hipFree(ctx->d_trace_ctrl);
+    if (ctx->d_long_list) (void)hipFree(ctx->d_long_list);
+    ctx->d_trace_ctrl = nullptr; ctx->d_long_list = nullptr; ctx->long_cap = 0;
+}
+
+// records for rays deferred from the lane-per-ray phase to the wave-per-ray phase: grow-only,
+// one per work item up to RT_LONG_LIST_MAX (beyond that rays simply finish in the first phase)
+static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
+{
+    uint64_t want = work_items < RT_LONG_LIST_MAX ? work_items : RT_LONG_LIST_MAX;
+    if (want < 1024) want = 1024;
+    if (want <= ctx->long_cap) return RT_SUCCESS;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_long_list) { (void)hipFree(ctx->d_long_list); ctx->d_long_list = nullptr; ctx->long_cap = 0; }
+    RT_HIP(ctx, hipMalloc((void**)&ctx->d_long_list, want * trace_long_record_bytes()));
+    ctx->long_cap = (uint32_t)want;
+    return RT_SUCCESS;
+}
+
+// The trace kernel reports a failed frame (steal-queue overflow on a forced hand-off, slot time-out)
+// through one word of its control block; every synchronising call looks at it once per launch batch.
+static int check_trace_error(rt_ctx* ctx)
+{
+    if (!ctx->trace_launched) return RT_SUCCESS;
+    ctx->trace_launched = false;
+    uint32_t err = 0;
+    RT_HIP(ctx, hipMemcpy(&err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost));
+    if (err == 1) return RT_FAIL(ctx, "trace kernel: deferred-ray list full while a full traversal stack had to hand off work; frame invalid");
+    if (err) return RT_FAIL(ctx, "trace kernel: node pool of the wave-per-ray phase overflowed; frame invalid");
+    return RT_SUCCESS;
 }
 
 extern "C" {
@@ -38,18 +73,20 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     ctx->device = device_ordinal;
     if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc((void**)&ctx->d_ray_counter, 4096)) != hipSuccess) {
+        (e = hipMalloc(&ctx->d_trace_ctrl, trace_ctrl_bytes())) != hipSuccess) {
         RT_FAIL(nullptr, std::string("context creation failed: ") + hipGetErrorString(e));
-        if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+        free_ctx_buffers(ctx);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return RT_ERROR;
     }
     if (std::string(ctx->prop.gcnArchName).rfind("gfx950", 0) != 0) {
         RT_FAIL(nullptr, std::string("librtmi is built for gfx950 only, device is ") + ctx->prop.gcnArchName);
-        hipFree(ctx->d_ray_counter); hipStreamDestroy(ctx->own_stream); delete ctx;
+        free_ctx_buffers(ctx); (void)hipStreamDestroy(ctx->own_stream); delete ctx;
         return RT_ERROR;
     }
     ctx->stream = ctx->own_stream;
+    if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
     return RT_SUCCESS;
 }
@@ -59,8 +96,8 @@ void rt_ctx_destroy(rt_ctx* ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    if (ctx->d_ray_counter) hipFree(ctx->d_ray_counter);
-    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    free_ctx_buffers(ctx);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -78,7 +115,7 @@ int rt_ctx_synchronize(rt_ctx* ctx)
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RT_SUCCESS;
+    return check_trace_error(ctx);
 }
 
 int rt_ctx_device_info(const rt_ctx* ctx, int* compute_units, int* wave_size, uint64_t* lds_bytes, char* name,
@@ -131,7 +168,7 @@ int rt_buf_download(rt_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RT_SUCCESS;
+    return check_trace_error(ctx);
 }
 
 __global__ void k_fill_u32(uint32_t* dst, uint32_t pattern, uint64_t count)
@@ -288,9 +325,9 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_counters) hipFree(b->d_counters);
     if (b->d_trav) hipFree(b->d_trav);
     if (b->d_depth) hipFree(b->d_depth);
-    if (b->d_overflow) hipFree(b->d_overflow);
+    if (b->d_pos) hipFree(b->d_pos);
     b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
-    b->d_depth = nullptr; b->d_overflow = nullptr;
+    b->d_depth = nullptr; b->d_pos = nullptr;
 }
 
 void rt_bvh_destroy(rt_bvh* b)
@@ -319,6 +356,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         RT_HIP(ctx, hipMalloc((void**)&b->d_counters, (size_t)n * sizeof(uint32_t)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_depth, 256));
+        RT_HIP(ctx, hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t)));
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -342,21 +380,12 @@ int rt_bvh_construct(rt_bvh* b)
     launch_bitonic_sort(s, b->d_pairs, b->N);                     // 2. :195
     launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n);           // 3. :204
     launch_refit(s, b->d_nodes, b->d_counters, b->n);             // 4. :217
-    launch_relayout(s, b->d_nodes, b->d_trav, b->n, b->d_depth);  // traversal records + depth
+    launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n, b->d_depth);  // traversal records, DFS ranks, depth
     RT_HIP(ctx, hipGetLastError());
     uint32_t depth = 0;
     RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
     b->max_depth = depth;
-    uint64_t words = depth >= trace_lds_stack_entries() ? (uint64_t)(depth - trace_lds_stack_entries() + 2) : 0;
-    if (words != b->overflow_words_per_lane) {
-        if (b->d_overflow) { hipFree(b->d_overflow); b->d_overflow = nullptr; }
-        b->overflow_words_per_lane = words;
-        if (words) {
-            uint64_t lanes = trace_max_resident_lanes(ctx->prop.multiProcessorCount);
-            RT_HIP(ctx, hipMalloc((void**)&b->d_overflow, lanes * words * sizeof(uint32_t)));
-        }
-    }
     b->frame_initialised = false;
     b->built = true;
     return RT_SUCCESS;
@@ -365,10 +394,11 @@ int rt_bvh_construct(rt_bvh* b)
 static TraceLaunch make_launch(rt_bvh* b)
 {
     TraceLaunch t{};
-    t.trav = b->d_trav; t.scene = &b->scene->d; t.n_leaves = b->n;
-    t.work_counter = b->ctx->d_ray_counter;
-    t.overflow = b->d_overflow; t.overflow_words_per_lane = (uint32_t)b->overflow_words_per_lane;
+    t.trav = b->d_trav; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
+    t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
+    t.defer_budget = b->ctx->defer_budget;
     t.compute_units = b->ctx->prop.multiProcessorCount;
+    b->ctx->trace_launched = true;
     return t;
 }
 
@@ -388,6 +418,7 @@ int rt_bvh_generate_contacts_primary(rt_bvh* b, const rt_camera* cam, void* d_co
     if (!d_contacts) return RT_FAIL(ctx, "contacts buffer is null");
     if (check_camera(ctx, cam)) return RT_ERROR;
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, 0, 1))) return RT_ERROR;
     launch_trace_primary(ctx->stream, make_launch(b), *cam, 0, 1, false, (rt_contact*)d_contacts);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -403,6 +434,7 @@ int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint
     if (check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
     launch_trace_primary(ctx->stream, make_launch(b), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -416,6 +448,7 @@ int rt_bvh_generate_contacts_rays(rt_bvh* b, const void* d_rays, uint32_t ray_co
     if (ray_count == 0) return RT_SUCCESS;
     if (!d_rays || !d_contacts) return RT_FAIL(ctx, "null buffer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ensure_long_list(ctx, ray_count)) return RT_ERROR;
     launch_trace_rays(ctx->stream, make_launch(b), (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;

@@ -26,6 +26,7 @@ static_assert(sizeof(TravNode) == 64, "TravNode must be 64 bytes");
 
 #define RT_LEAF_FLAG 0x80000000u
 #define RT_SENTINEL 0xFFFFFFFFu   // stack sentinel, BVH.h:352
+#define RT_LONG_LIST_MAX (1u << 20)     // at most this many deferred-ray records (128 MiB)
 
 // One entry per mesh of the packed scene buffer (host walks the headers once at upload).
 struct MeshEntry {
@@ -63,7 +64,12 @@ struct rt_ctx {
     hipStream_t own_stream = nullptr;
     hipDeviceProp_t prop;
     mutable std::string last_error;
-    uint32_t* d_ray_counter = nullptr;   // persistent-wave work counters (one 128-B line each)
+    // shared state of the trace kernels (one launch at a time per context)
+    void* d_trace_ctrl = nullptr;
+    uint32_t* d_long_list = nullptr;      // deferred-ray records, grow-only
+    uint32_t long_cap = 0;
+    bool trace_launched = false;  // a trace launch has not been checked for its error word yet
+    uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
 };
 
 struct rt_scene {
@@ -86,8 +92,7 @@ struct rt_bvh {
     uint32_t* d_counters = nullptr;    // n visit counters (BVHManager.cpp:67)
     TravNode* d_trav = nullptr;        // n-1 traversal records
     uint32_t* d_depth = nullptr;       // max depth (1 word)
-    uint32_t* d_overflow = nullptr;    // deep-stack spill area
-    uint64_t overflow_words_per_lane = 0;
+    uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
     uint32_t max_depth = 0;
     bool frame_initialised = false;
     bool built = false;
@@ -113,7 +118,8 @@ void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
 void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs);
 void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n);
-void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, TravNode* trav, uint32_t n, uint32_t* depth_out);
+void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
+                     uint32_t n, uint32_t* depth_out);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
 int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch);
@@ -122,16 +128,20 @@ size_t scan_scratch_words(uint32_t n);
 struct TraceLaunch {
     const TravNode* trav;
     const DeviceScene* scene;
+    const uint32_t* pos;          // leaf -> position in the sorted pair array (DFS rank, tie rule)
     uint32_t n_leaves;
-    uint32_t* work_counter;       // zeroed by the launcher
-    uint32_t* overflow;           // may be null when max_depth fits the LDS stack
-    uint32_t overflow_words_per_lane;
+    void* ctrl;                   // TraceCtrl, zeroed by the launcher
+    uint32_t* long_list;          // records of rays deferred to the wave-per-ray phase
+    uint32_t long_cap;            // records available
+    uint32_t defer_budget;        // 0 = default
     int compute_units;
 };
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
-uint32_t trace_max_resident_lanes(int compute_units);
+size_t trace_ctrl_bytes();
+size_t trace_ctrl_error_offset();
+size_t trace_long_record_bytes();
 uint32_t trace_lds_stack_entries();
 // shade_kernels.hip
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,

@@ -1,40 +1,69 @@
 // trace_kernels.hip -- the hot path: BVH traversal + ray/AABB + ray/triangle for gfx950.
 //
 // Semantics are those of bvh_generate_contact (Include/CLData/AccelerationStructs/BVH.h:344-408):
-// iterative depth-first walk, child A first / child B pushed, NO closest-hit pruning, a child is
-// entered iff (AABBIntersect > 0 || origin inside the box) (BVH.h:366-369, AABB.h:126-142,178-184),
-// the closest hit is kept with a strict `<` (BVH.h:392), so among equal-t hits the first leaf in
-// DFS order wins.  The arithmetic is restated operation by operation (device_math.h).
+// a child is entered iff (AABBIntersect > 0 || origin inside the box) (BVH.h:366-369, AABB.h:126-142,
+// 178-184), there is NO closest-hit pruning, and the closest hit is kept with a strict `<` in an
+// A-first depth-first walk (BVH.h:371-392).  Hence
+//      result(ray) = lexicographic min of (t, DFS rank of the leaf) over every REACHED leaf with t > 0,
+// and because the radix tree is built over the sorted (morton, leaf) array, the DFS rank of a leaf is its
+// position in that array (child A covers [first,split], child B [split+1,last], BVH.h:299-305; checked
+// against an explicit DFS of the oracle's tree in tests).  The set of reached leaves does not depend on
+// the order in which sub-trees are walked, so ANY traversal order and ANY split of one ray's sub-trees
+// over lanes gives the reference's contact bit for bit, as long as ties are broken by that position.
+// The arithmetic itself is restated operation by operation (device_math.h, no FMA contraction).
 //
-// What is different is the machine mapping (MI355X, wave64):
-//  * persistent waves: a fixed grid sized to the chip pulls rays from a global work counter;
-//    a lane whose ray has finished is refilled with a fresh ray (ballot + prefix popcount
-//    packing) as soon as enough lanes of its wave are idle, instead of idling until the
-//    slowest ray of a 64-ray work-group is done (reference: one work-item per ray, WG = 64,
-//    BVHManager.cpp:264-270);
-//  * the traversal stack lives in LDS, one private column per lane ([level][lane] => no bank
-//    conflicts); only trees deeper than the LDS part spill to a per-lane global area;
-//  * one inner-node visit = one 64-byte record holding both child boxes and both child ids
-//    (TravNode) instead of a 48-byte node + two dependent 32-byte box fetches;
-//  * leaves read an SoA triangle table (v0, e1, e2 as float4) instead of chasing
-//    ModelHeader/MeshHeader.dataSize chains and ushort indices (SceneBufferParser.h:175-217);
-//    edges and the geometric normal are ray independent and are precomputed with the same
-//    operations (build_kernels.hip);
-//  * leaf tests are postponed: a lane parks one reached leaf and keeps walking inner nodes; the
-//    wave runs the triangle test when a lane needs its slot again or is about to finish, so the
-//    triangle code is not executed on every iteration.  Per lane the leaves are still tested in
-//    DFS order, which is all the tie rule needs;
-//  * pixels are walked in 8x8 blocks inside 64x64 tiles, so a wave's rays are neighbours.
+// Machine mapping (MI355X, wave64, 256 CUs), two kernels per frame:
+//  k_trace (phase 0), one ray per lane, persistent waves:
+//   * the grid is sized to what is resident; a wave's first 8x8-pixel block is static, further blocks
+//     come from one global counter (one atomic per 64 rays); lanes whose ray has finished are refilled
+//     (ballot + prefix-popcount packing) instead of idling until the slowest ray of the block is done;
+//   * the per-lane traversal stack lives in LDS ([level][lane]: one bank per lane, no conflicts);
+//   * one inner-node visit = one 64-byte record holding both child boxes and both child ids (TravNode)
+//     instead of a 48-byte node + two dependent 32-byte box fetches (BVH.h:359-364);
+//   * leaves read an SoA triangle table (v0, e1, e2 as float4) instead of chasing ModelHeader /
+//     MeshHeader.dataSize chains and ushort indices (SceneBufferParser.h:175-217); edges and the
+//     geometric normal are ray independent and precomputed with the same operations;
+//   * leaf tests are postponed: a lane parks one reached leaf and keeps walking inner nodes; the wave
+//     runs the triangle code only when a lane needs its slot again or is about to finish;
+//   * a ray that exceeds an iteration budget, or whose stack is full, is DEFERRED: its state (pending
+//     sub-trees, best hit so far) goes to a compact list.  Duplicate Morton codes make a few rays
+//     visit thousands of nodes while most visit a handful; walked by one lane each they
+//     would set the frame time.
+//  k_trace_long (phase 1), one ray per WAVE: the 64 lanes walk the deferred ray's sub-trees together
+//     out of an LDS node pool (64 nodes per step, children appended with ballot/prefix-popcount
+//     compaction, leaves collected in a second pool and tested 64 at a time), then reduce their
+//     (t, position) candidates with a wave-wide lexicographic min.
 #include "rtmi_internal.h"
 #include "device_math.h"
 
 #define TRACE_BLOCK 256u
 #define TRACE_WAVES (TRACE_BLOCK / 64u)
-#define LDS_STACK 24u            // entries per lane kept in LDS (observed need at 1080p: <= 18)
+#define LDS_STACK 24u            // entries per lane in phase 0 (observed need at 1080p: <= 18)
 #define NO_LEAF 0xFFFFFFFEu
-#define REFILL_MIN_IDLE 16       // refill a wave once this many lanes are idle
+#define REFILL_MIN_IDLE 16u      // refill a wave once this many lanes are idle
+#define DEFER_BUDGET_DEFAULT 768u   // phase-0 iterations after which a ray moves to the long-ray list
+#define LONG_REC_WORDS 32u       // 128-byte record per deferred ray
+#define POOL_INNER 2048u         // phase-1 LDS pool of pending inner nodes (per wave)
+#define POOL_LEAF 256u           // phase-1 LDS pool of pending leaves (per wave)
+
+typedef __attribute__((address_space(1))) unsigned int gu32;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 uint32_t trace_lds_stack_entries() { return LDS_STACK; }
+
+// control block, zeroed before every launch; every word on its own 128-byte line
+struct TraceCtrl {
+    uint32_t next_block;  uint32_t p0[31];   // dynamic part of the primary work: next 64-ray block
+    uint32_t long_count;  uint32_t p1[31];   // deferred rays
+    uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
+};
+static_assert(sizeof(TraceCtrl) == 3 * 128, "TraceCtrl layout");
+size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
+size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
+size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
+
+// record of a deferred ray (LONG_REC_WORDS words)
+enum { LR_WORK = 0, LR_CUR = 1, LR_SP = 2, LR_BEST_LEAF = 3, LR_BEST_T = 4, LR_EXTRA = 5, LR_PENDING = 6, LR_STACK = 8 };
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
@@ -42,13 +71,16 @@ struct TraceArgs {
     const float4* __restrict__ e1;
     const float4* __restrict__ e2;
     const float4* __restrict__ nrm;
-    uint32_t* work_counter;
-    uint32_t* overflow;
-    uint32_t overflow_words_per_lane;
-    uint32_t total_work;
+    const uint32_t* __restrict__ pos;      // leaf -> position in the sorted (morton, leaf) array
+    TraceCtrl* ctrl;
+    uint32_t* long_list;                   // long_cap records
+    uint32_t long_cap;
+    uint32_t defer_budget;
+    uint32_t total_work;                   // work items (multiple of 4096 for primary frames)
+    uint32_t n_waves;                      // waves in the grid
     // primary rays
     rt_camera cam;
-    uint32_t rank, nranks, tiles_x, total_tiles;
+    uint32_t rank, nranks, tiles_x;
     uint32_t compact;
     // ray buffer
     const rt_ray* __restrict__ rays;
@@ -59,32 +91,34 @@ struct RayState {
     f3 o, d, inv;
     float best_t;
     uint32_t best_leaf;
+    uint32_t work;           // work item (ray) index
     uint32_t out_index;      // where the contact is stored
     uint32_t pixel;          // Contact.pixelIndex
 };
 
 // one child of an inner node: AABBIntersect (AABB.h:126-142) folded with the validity rule of
 // BVH.h:368-369.  `tmin*flag > 0` <=> `flag && tmin > 0` (x*1.0f == x; x*0.0f is +-0 or NaN).
-__device__ __forceinline__ bool child_valid(const float lo[3], const float hi[3], const RayState& r,
-                                            bool sx, bool sy, bool sz)
+// Branch free on purpose (bit-wise & and |): both children are always evaluated.
+__device__ __forceinline__ bool child_valid(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                            const RayState& r, bool sx, bool sy, bool sz)
 {
-    float tmin  = ((sx ? hi[0] : lo[0]) - r.o.x) * r.inv.x;
-    float tmax  = ((sx ? lo[0] : hi[0]) - r.o.x) * r.inv.x;
-    float tymin = ((sy ? hi[1] : lo[1]) - r.o.y) * r.inv.y;
-    float tymax = ((sy ? lo[1] : hi[1]) - r.o.y) * r.inv.y;
-    bool flag = !((tmin > tymax) || (tymin > tmax));
+    float tmin  = ((sx ? hix : lox) - r.o.x) * r.inv.x;
+    float tmax  = ((sx ? lox : hix) - r.o.x) * r.inv.x;
+    float tymin = ((sy ? hiy : loy) - r.o.y) * r.inv.y;
+    float tymax = ((sy ? loy : hiy) - r.o.y) * r.inv.y;
+    bool flag = !((tmin > tymax) | (tymin > tmax));
     tmin = RMAX(tmin, tymin);
     tmax = RMIN(tmax, tymax);
-    float tzmin = ((sz ? hi[2] : lo[2]) - r.o.z) * r.inv.z;
-    float tzmax = ((sz ? lo[2] : hi[2]) - r.o.z) * r.inv.z;
-    flag = flag && !((tmin > tzmax) || (tzmin > tmax));
+    float tzmin = ((sz ? hiz : loz) - r.o.z) * r.inv.z;
+    float tzmax = ((sz ? loz : hiz) - r.o.z) * r.inv.z;
+    flag = flag & !((tmin > tzmax) | (tzmin > tmax));
     tmin = RMAX(tmin, tzmin);
-    bool inside = (lo[0] <= r.o.x) && (r.o.x <= hi[0]) && (lo[1] <= r.o.y) && (r.o.y <= hi[1]) &&
-                  (lo[2] <= r.o.z) && (r.o.z <= hi[2]);
-    return (flag && (tmin > 0.0f)) || inside;
+    bool inside = (lox <= r.o.x) & (r.o.x <= hix) & (loy <= r.o.y) & (r.o.y <= hiy) & (loz <= r.o.z) & (r.o.z <= hiz);
+    return (flag & (tmin > 0.0f)) | inside;
 }
 
-// triangleIntersect, Triangle.h:66-107, against precomputed edges; keeps (t, leaf) under BVH.h:392.
+// triangleIntersect, Triangle.h:66-107, against precomputed edges; keeps the lexicographic min of
+// (t, position) -- the strict `<` of BVH.h:392 in DFS order.
 __device__ __forceinline__ void leaf_test(const TraceArgs& a, uint32_t leaf, RayState& r)
 {
     float4 v0 = a.v0[leaf], E1 = a.e1[leaf], E2 = a.e2[leaf];
@@ -95,19 +129,22 @@ __device__ __forceinline__ void leaf_test(const TraceArgs& a, uint32_t leaf, Ray
     float inv_det = 1.0f / det;
     f3 tvec = f3_sub(r.o, vert0);
     float u = f3_dot(tvec, pvec) * inv_det;
-    flag = flag && (u < 1.0f);
-    flag = flag && (u >= 0.0f);
+    flag = flag & (u < 1.0f);
+    flag = flag & (u >= 0.0f);
     f3 qvec = f3_cross(tvec, edge1);
     float v = f3_dot(r.d, qvec) * inv_det;
-    flag = flag && ((u + v) <= 1.0f);
-    flag = flag && (v >= 0.0f);
-    float t = f3_dot(edge2, qvec) * inv_det;      // "* flag" folded into the test below
-    if (flag && t > 0.0f && t < r.best_t) { r.best_t = t; r.best_leaf = leaf; }
+    flag = flag & ((u + v) <= 1.0f);
+    flag = flag & (v >= 0.0f);
+    float t = f3_dot(edge2, qvec) * inv_det;      // "* flag" (Triangle.h:104) folded into the test below
+    if (flag & (t > 0.0f)) {
+        if (t < r.best_t) { r.best_t = t; r.best_leaf = leaf; }
+        else if (t == r.best_t && r.best_leaf != NO_LEAF && a.pos[leaf] < a.pos[r.best_leaf]) r.best_leaf = leaf;
+    }
 }
 
 // work item -> pixel.  Work items enumerate this rank's 64x64 tiles; inside a tile the 64 8x8
 // blocks, inside a block the 64 pixels (one wave refill batch ~ one 8x8 block).
-__device__ __forceinline__ bool work_to_pixel(const TraceArgs& a, uint32_t w, uint32_t& pixel, uint32_t& slot)
+__device__ __forceinline__ bool work_to_pixel(const TraceArgs& a, uint32_t w, uint32_t& x, uint32_t& y, uint32_t& slot)
 {
     uint32_t ordinal = w >> 12;                 // owned tile ordinal (4096 px per tile)
     uint32_t within = w & 4095u;
@@ -116,12 +153,60 @@ __device__ __forceinline__ bool work_to_pixel(const TraceArgs& a, uint32_t w, ui
     uint32_t blk = within >> 6, lp = within & 63u;
     uint32_t ly = ((blk >> 3) << 3) + (lp >> 3);
     uint32_t lx = ((blk & 7u) << 3) + (lp & 7u);
-    uint32_t x = tx * RT_TILE + lx, y = ty * RT_TILE + ly;
+    x = tx * RT_TILE + lx; y = ty * RT_TILE + ly;
     slot = (ordinal << 12) + ly * RT_TILE + lx;
-    pixel = y * a.cam.resX + x;
     return x < a.cam.resX && y < a.cam.resY;
 }
 
+// loads the ray of work item w; false when the item is a slot outside the frame
+template <int PRIMARY>
+__device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayState& r, bool& sx, bool& sy, bool& sz)
+{
+    if (PRIMARY) {
+        uint32_t x, y, slot;
+        if (!work_to_pixel(a, w, x, y, slot)) return false;
+        generate_ray_xy(a.cam, x, y, r.o, r.d);
+        r.pixel = y * a.cam.resX + x;
+        r.out_index = a.compact ? slot : r.pixel;
+    } else {
+        // kernel generateContacts2, BVHKernels.cl:103-117
+        const float4* p = reinterpret_cast<const float4*>(a.rays + w);
+        float4 o = p[1], d = p[2];
+        r.o = f3{ o.x, o.y, o.z };
+        r.d = f3{ d.x, d.y, d.z };
+        r.pixel = w; r.out_index = w;
+    }
+    r.work = w;
+    r.inv = f3{ 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };   // INV_DIR_*, AABB.h:115-117
+    sx = 0.0f > r.inv.x; sy = 0.0f > r.inv.y; sz = 0.0f > r.inv.z;
+    r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Contact assembly, BVH.h:402-407 + BVHKernels.cl:95-96
+__device__ __forceinline__ void store_contact(const TraceArgs& a, uint32_t out_index, uint32_t pixel, float t, uint32_t leaf)
+{
+    float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t material = 0;
+    if (leaf != NO_LEAF) {
+        float4 n = a.nrm[leaf];
+        nt = make_float4(n.x, n.y, n.z, t);
+        material = __float_as_uint(a.v0[leaf].w);
+    }
+    uint4 head = make_uint4(pixel, material, 0u, 0u);
+    float4* o = reinterpret_cast<float4*>(a.out + out_index);
+    o[0] = *reinterpret_cast<float4*>(&head);
+    o[1] = nt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase 0: one ray per lane
+// ------------------------------------------------------------------------------------------------
 template <int PRIMARY>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
 {
@@ -129,64 +214,57 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t (*stack)[64] = s_stack[wave];
-    uint32_t* spill = a.overflow
-        ? a.overflow + (uint64_t)(blockIdx.x * TRACE_BLOCK + threadIdx.x) * a.overflow_words_per_lane
-        : nullptr;
+    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
+    gu32* next_block = (gu32*)&a.ctrl->next_block;
+    gu32* long_count = (gu32*)&a.ctrl->long_count;
+    gu32* error_word = (gu32*)&a.ctrl->error;
 
     RayState r;
     r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 };
-    r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.out_index = 0; r.pixel = 0;
+    r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.work = 0; r.out_index = 0; r.pixel = 0;
     bool sx = false, sy = false, sz = false;
     uint32_t cur = RT_SENTINEL;       // node to visit: inner record index, RT_LEAF_FLAG|leaf, or sentinel
     uint32_t pending = NO_LEAF;       // parked leaf
     uint32_t sp = 0;                  // entries on this lane's stack
+    uint32_t iters = 0;
     bool active = false;
-    bool exhausted = false;           // wave-uniform: the work counter ran dry
+    bool may_defer = true;            // false once the long-ray list turned out to be full
+
+    const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;          // 8x8 blocks (or 64-ray chunks)
+    uint32_t res_next = wave_gid << 6, res_end = res_next + 64u;   // reserved work items [res_next, res_end)
+    bool exhausted = wave_gid >= n_blocks8;                        // wave-uniform: no primary work left
 
     for (;;) {
         // ---------------- refill idle lanes (wavefront ballot / compaction) ----------------
-        uint64_t idle = __ballot(!active);
-        if (idle != 0ull && !exhausted) {
+        if (!exhausted) {
+            uint64_t idle = __ballot(!active);
             uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (n_idle >= REFILL_MIN_IDLE || n_idle == 64u) {
-                uint32_t base = 0;
-                int leader = __ffsll((unsigned long long)idle) - 1;
-                if ((int)lane == leader) base = atomicAdd(a.work_counter, n_idle);
-                base = (uint32_t)__shfl((int)base, leader, 64);
-                if (base + n_idle >= a.total_work) exhausted = true;
-                if (!active) {
-                    uint32_t w = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (w < a.total_work) {
-                        bool ok = true;
-                        if (PRIMARY) {
-                            uint32_t pixel, slot;
-                            ok = work_to_pixel(a, w, pixel, slot);
-                            if (ok) {
-                                generate_ray(a.cam, pixel, r.o, r.d);
-                                r.pixel = pixel;
-                                r.out_index = a.compact ? slot : pixel;
-                            } else if (a.compact) {
-                                // slot of a border tile that lies outside the frame: defined as "no contact"
-                                float4* o = reinterpret_cast<float4*>(a.out + slot);
-                                o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                                o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            }
-                        } else {
-                            // kernel generateContacts2, BVHKernels.cl:103-117
-                            const rt_ray ry = a.rays[w];
-                            r.o = f3{ ry.origin[0], ry.origin[1], ry.origin[2] };
-                            r.d = f3{ ry.direction[0], ry.direction[1], ry.direction[2] };
-                            r.pixel = w; r.out_index = w;
-                        }
-                        if (ok) {
-                            r.inv = f3{ 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };   // INV_DIR_*, AABB.h:115-117
-                            sx = 0.0f > r.inv.x; sy = 0.0f > r.inv.y; sz = 0.0f > r.inv.z;
-                            r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
-                            cur = 0u;              // root = inner record 0 (reference node index n)
-                            sp = 0; pending = NO_LEAF;
+            if (n_idle >= REFILL_MIN_IDLE) {
+                if (res_next == res_end) {
+                    uint32_t blk = 0;
+                    if (lane == 0) blk = a.n_waves + __hip_atomic_fetch_add(next_block, 1u, RLX_AGENT);
+                    blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
+                    if (blk >= n_blocks8) exhausted = true;
+                    else { res_next = blk << 6; res_end = res_next + 64u; }
+                }
+                if (!exhausted) {
+                    uint32_t w = res_next + lane_rank(idle);
+                    if (!active && w < res_end && w < a.total_work) {
+                        if (load_ray<PRIMARY>(a, w, r, sx, sy, sz)) {
+                            cur = 0u;                                     // root = inner record 0 (reference node n)
+                            sp = 0; pending = NO_LEAF; iters = 0;
                             active = true;
+                        } else if (PRIMARY && a.compact) {
+                            // slot of a border tile that lies outside the frame: defined as "no contact"
+                            uint32_t x, y, slot;
+                            work_to_pixel(a, w, x, y, slot);
+                            float4* o = reinterpret_cast<float4*>(a.out + slot);
+                            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         }
                     }
+                    uint32_t left = res_end - res_next;
+                    res_next += n_idle < left ? n_idle : left;
                 }
             }
         }
@@ -197,52 +275,66 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
 
         // ---------------- traversal steps until enough lanes have drained ----------------
         for (;;) {
+            uint32_t extra = RT_SENTINEL;     // child that did not fit on the stack (forces a deferral)
             if (active) {
+                iters++;
                 if (cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) == 0u) {
                     // inner node: one 64-byte record
                     const float4* p = reinterpret_cast<const float4*>(a.trav + cur);
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                    float alo[3] = { q0.x, q0.y, q0.z }, ahi[3] = { q1.x, q1.y, q1.z };
-                    float blo[3] = { q2.x, q2.y, q2.z }, bhi[3] = { q3.x, q3.y, q3.z };
                     uint32_t ca = __float_as_uint(q0.w), cb = __float_as_uint(q1.w);
-                    bool aValid = child_valid(alo, ahi, r, sx, sy, sz);
-                    bool bValid = child_valid(blo, bhi, r, sx, sy, sz);
-                    if (aValid && bValid) {
+                    bool aValid = child_valid(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz);
+                    bool bValid = child_valid(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz);
+                    if (aValid & bValid) {
                         cur = ca;
-                        if (sp < LDS_STACK) stack[sp][lane] = cb; else spill[sp - LDS_STACK] = cb;
-                        sp++;
-                    } else if (aValid) cur = ca;
-                    else if (bValid) cur = cb;
+                        if (sp < LDS_STACK) { stack[sp][lane] = cb; sp++; } else extra = cb;
+                    } else if (aValid | bValid) cur = aValid ? ca : cb;
                     else if (sp == 0) cur = RT_SENTINEL;
-                    else { sp--; cur = (sp < LDS_STACK) ? stack[sp][lane] : spill[sp - LDS_STACK]; }
+                    else { sp--; cur = stack[sp][lane]; }
                 }
                 // park a reached leaf if the slot is free, and move on
-                if (cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) != 0u && pending == NO_LEAF) {
+                if (extra == RT_SENTINEL && cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) != 0u && pending == NO_LEAF) {
                     pending = cur & ~RT_LEAF_FLAG;
                     if (sp == 0) cur = RT_SENTINEL;
-                    else { sp--; cur = (sp < LDS_STACK) ? stack[sp][lane] : spill[sp - LDS_STACK]; }
+                    else { sp--; cur = stack[sp][lane]; }
                 }
             }
             // a lane that needs its slot again (second leaf) or is about to finish forces the
             // wave through the triangle test for every parked leaf
-            bool must = active && pending != NO_LEAF &&
-                        (cur == RT_SENTINEL || (cur & RT_LEAF_FLAG) != 0u);
+            bool must = active && pending != NO_LEAF && (cur == RT_SENTINEL || (cur & RT_LEAF_FLAG) != 0u);
             if (__ballot(must) != 0ull) {
                 if (active && pending != NO_LEAF) { leaf_test(a, pending, r); pending = NO_LEAF; }
             }
-            // retire finished rays: Contact assembly, BVH.h:402-407 + BVHKernels.cl:95-96
-            if (active && cur == RT_SENTINEL && pending == NO_LEAF) {
-                float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                uint32_t material = 0;
-                if (r.best_leaf != NO_LEAF) {
-                    float4 n = a.nrm[r.best_leaf];
-                    nt = make_float4(n.x, n.y, n.z, r.best_t);
-                    material = __float_as_uint(a.v0[r.best_leaf].w);
+
+            // ---- defer long rays to phase 1 (budget exceeded, or stack full) ----
+            bool want_defer = active && cur != RT_SENTINEL &&
+                              (extra != RT_SENTINEL || (may_defer && iters >= a.defer_budget));
+            uint64_t deferring = __ballot(want_defer);
+            if (deferring != 0ull) {
+                uint32_t base = 0;
+                int leader = __ffsll((unsigned long long)deferring) - 1;
+                if ((int)lane == leader) base = __hip_atomic_fetch_add(long_count, (uint32_t)__popcll(deferring), RLX_AGENT);
+                base = (uint32_t)__shfl((int)base, leader, 64);
+                if (want_defer) {
+                    uint32_t idx = base + lane_rank(deferring);
+                    if (idx < a.long_cap) {
+                        uint32_t* rec = a.long_list + (uint64_t)idx * LONG_REC_WORDS;
+                        rec[LR_WORK] = r.work; rec[LR_CUR] = cur; rec[LR_SP] = sp; rec[LR_BEST_LEAF] = r.best_leaf;
+                        rec[LR_BEST_T] = __float_as_uint(r.best_t); rec[LR_EXTRA] = extra; rec[LR_PENDING] = pending;
+                        for (uint32_t k = 0; k < sp; k++) rec[LR_STACK + k] = stack[k][lane];
+                        active = false;
+                    } else if (extra != RT_SENTINEL) {
+                        __hip_atomic_store(error_word, 1u, RLX_AGENT);     // nowhere to put the sub-tree: frame invalid
+                        active = false;
+                    } else {
+                        may_defer = false;                                 // list full: finish the ray here
+                    }
                 }
-                uint4 head = make_uint4(r.pixel, material, 0u, 0u);
-                float4* o = reinterpret_cast<float4*>(a.out + r.out_index);
-                o[0] = *reinterpret_cast<float4*>(&head);
-                o[1] = nt;
+            }
+
+            // ---- retire finished rays ----
+            if (active && cur == RT_SENTINEL && pending == NO_LEAF) {
+                store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
                 active = false;
             }
             uint32_t n_active = (uint32_t)__popcll(__ballot(active));
@@ -252,38 +344,148 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
     }
 }
 
-uint32_t trace_max_resident_lanes(int compute_units)
+// ------------------------------------------------------------------------------------------------
+// phase 1: one deferred ray per wave, 64 lanes walk its sub-trees together
+// ------------------------------------------------------------------------------------------------
+template <int PRIMARY>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
 {
-    int blocks_per_cu = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<1>, TRACE_BLOCK, 0);
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    int b0 = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<0>, TRACE_BLOCK, 0);
-    if (b0 > blocks_per_cu) blocks_per_cu = b0;
-    return (uint32_t)compute_units * (uint32_t)blocks_per_cu * TRACE_BLOCK;
+    __shared__ uint32_t s_inner[TRACE_WAVES][POOL_INNER];
+    __shared__ uint32_t s_leaf[TRACE_WAVES][POOL_LEAF];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* inner = s_inner[wave];
+    uint32_t* leafp = s_leaf[wave];
+    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
+    gu32* error_word = (gu32*)&a.ctrl->error;
+    uint32_t count = a.ctrl->long_count;                  // written by the previous kernel
+    if (count > a.long_cap) count = a.long_cap;
+
+    for (uint32_t i = wave_gid; i < count; i += a.n_waves) {
+        const uint32_t* rec = a.long_list + (uint64_t)i * LONG_REC_WORDS;
+        // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
+        uint32_t work = rec[LR_WORK], rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
+        RayState r;
+        bool sx, sy, sz;
+        load_ray<PRIMARY>(a, work, r, sx, sy, sz);        // same ray in every lane
+        if (lane == 0) {                                  // lane 0 carries the best hit found in phase 0
+            r.best_leaf = rec[LR_BEST_LEAF];
+            r.best_t = __uint_as_float(rec[LR_BEST_T]);
+        }
+        // seed the pools: lanes 0..sp-1 take the stack, lanes 62/63 the current node and the extra child
+        uint32_t seed = RT_SENTINEL;
+        if (lane < rsp) seed = rec[LR_STACK + lane];
+        if (lane == 62) seed = rcur;
+        if (lane == 63) seed = rextra;
+        uint32_t n_inner = 0, n_leaf = 0;
+        {
+            bool is_in = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) == 0u;
+            bool is_lf = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) != 0u;
+            uint64_t mi = __ballot(is_in), ml = __ballot(is_lf);
+            if (is_in) inner[lane_rank(mi)] = seed;
+            if (is_lf) leafp[lane_rank(ml)] = seed & ~RT_LEAF_FLAG;
+            n_inner = (uint32_t)__popcll(mi); n_leaf = (uint32_t)__popcll(ml);
+            if (rpending != NO_LEAF) { if (lane == 0) leafp[n_leaf] = rpending; n_leaf++; }
+        }
+
+        while (n_inner != 0u || n_leaf != 0u) {
+            // ---- leaves, 64 at a time, when the pool is filling up or nothing else is left ----
+            if (n_leaf >= POOL_LEAF - 128u || n_inner == 0u) {
+                uint32_t k = n_leaf < 64u ? n_leaf : 64u;
+                if (lane < k) leaf_test(a, leafp[n_leaf - 1u - lane], r);
+                n_leaf -= k;
+                continue;
+            }
+            // ---- inner nodes: pop up to 64 from the top of the pool ----
+            // close to the pool's capacity the step degrades to a single-node depth-first walk,
+            // whose growth is bounded by the tree depth
+            uint32_t k = n_inner < 64u ? n_inner : 64u;
+            if (n_inner > POOL_INNER - 192u) k = 1u;
+            bool mine = lane < k;
+            uint32_t node = mine ? inner[n_inner - 1u - lane] : 0u;
+            n_inner -= k;
+            bool aIn = false, aLf = false, bIn = false, bLf = false;
+            uint32_t ca = 0, cb = 0;
+            if (mine) {
+                const float4* p = reinterpret_cast<const float4*>(a.trav + node);
+                float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                ca = __float_as_uint(q0.w); cb = __float_as_uint(q1.w);
+                bool aValid = child_valid(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz);
+                bool bValid = child_valid(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz);
+                aIn = aValid & ((ca & RT_LEAF_FLAG) == 0u); aLf = aValid & ((ca & RT_LEAF_FLAG) != 0u);
+                bIn = bValid & ((cb & RT_LEAF_FLAG) == 0u); bLf = bValid & ((cb & RT_LEAF_FLAG) != 0u);
+            }
+            uint64_t mai = __ballot(aIn), mbi = __ballot(bIn), mal = __ballot(aLf), mbl = __ballot(bLf);
+            uint32_t nai = (uint32_t)__popcll(mai), nbi = (uint32_t)__popcll(mbi);
+            uint32_t nal = (uint32_t)__popcll(mal), nbl = (uint32_t)__popcll(mbl);
+            if (n_inner + nai + nbi > POOL_INNER || n_leaf + nal + nbl > POOL_LEAF) {
+                if (lane == 0) __hip_atomic_store(error_word, 2u, RLX_AGENT);   // frame invalid, reported by the host
+                n_inner = 0; n_leaf = 0;
+                break;
+            }
+            if (aIn) inner[n_inner + lane_rank(mai)] = ca;
+            if (bIn) inner[n_inner + nai + lane_rank(mbi)] = cb;
+            if (aLf) leafp[n_leaf + lane_rank(mal)] = ca & ~RT_LEAF_FLAG;
+            if (bLf) leafp[n_leaf + nal + lane_rank(mbl)] = cb & ~RT_LEAF_FLAG;
+            n_inner += nai + nbi;
+            n_leaf += nal + nbl;
+        }
+
+        // ---- wave-wide lexicographic min of (t, position) ----
+        unsigned long long key = 0xFFFFFFFFFFFFFFFFull;
+        if (r.best_leaf != NO_LEAF) key = ((unsigned long long)__float_as_uint(r.best_t) << 32) | a.pos[r.best_leaf];
+        uint32_t leaf = r.best_leaf;
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long ok = (unsigned long long)__shfl_xor((long long)key, off, 64);
+            uint32_t ol = (uint32_t)__shfl_xor((int)leaf, off, 64);
+            if (ok < key) { key = ok; leaf = ol; }
+        }
+        if (lane == 0) {
+            float t = leaf != NO_LEAF ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
+            store_contact(a, r.out_index, r.pixel, t, leaf);
+        }
+    }
+}
+
+template <int PRIMARY>
+static uint32_t resident_blocks(int compute_units)
+{
+    int b0 = 0, b1 = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<PRIMARY>, TRACE_BLOCK, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY>, TRACE_BLOCK, 0);
+    if (b0 < 1) b0 = 1;
+    (void)b1;
+    return (uint32_t)compute_units * (uint32_t)b0;
 }
 
 template <int PRIMARY>
 static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 {
-    int blocks_per_cu = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<PRIMARY>, TRACE_BLOCK, 0);
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    uint32_t grid = (uint32_t)t.compute_units * (uint32_t)blocks_per_cu;
-    uint32_t need = (a.total_work + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    if (a.total_work == 0) return;
+    uint32_t grid = resident_blocks<PRIMARY>(t.compute_units);
+    uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
     if (grid > need) grid = need;
-    if (grid == 0) return;
-    hipMemsetAsync(t.work_counter, 0, sizeof(uint32_t), s);
+    a.n_waves = grid * TRACE_WAVES;
+    // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
+    (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
     hipLaunchKernelGGL(k_trace<PRIMARY>, dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+    // phase 1: the number of deferred rays lives on the device; a fixed grid strides over the list
+    int b1 = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY>, TRACE_BLOCK, 0);
+    if (b1 < 1) b1 = 1;
+    uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
+    a.n_waves = grid1 * TRACE_WAVES;
+    hipLaunchKernelGGL(k_trace_long<PRIMARY>, dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
 }
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
     a.trav = t.trav;
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
-    a.work_counter = t.work_counter;
-    a.overflow = t.overflow;
-    a.overflow_words_per_lane = t.overflow_words_per_lane;
+    a.pos = t.pos;
+    a.ctrl = (TraceCtrl*)t.ctrl;
+    a.long_list = t.long_list; a.long_cap = t.long_cap;
+    a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
 
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
@@ -294,9 +496,9 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.cam = cam;
     a.rank = rank; a.nranks = nranks;
     a.tiles_x = rt_tiles_x(cam.resX);
-    a.total_tiles = a.tiles_x * rt_tiles_y(cam.resY);
+    uint32_t total_tiles = a.tiles_x * rt_tiles_y(cam.resY);
     a.compact = compact ? 1u : 0u;
-    a.total_work = rt_owned_tiles(a.total_tiles, rank, nranks) * RT_TILE * RT_TILE;
+    a.total_work = rt_owned_tiles(total_tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.rays = nullptr;
     a.out = out;
     launch<1>(s, t, a);

@@ -65,6 +65,7 @@ def lib():
         L.orc_check_hierarchy.argtypes = [vp, u32, vp]
         L.orc_trace_primary.argtypes = [vp, vp, u32, vp, vp, vp, i32]
         L.orc_trace_primary_range.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, i32]
+        L.orc_trace_primary_visits.argtypes = [vp, vp, u32, vp, vp, vp, vp, i32]
         L.orc_trace_rays.argtypes = [vp, u32, vp, u32, vp, vp, vp, i32]
         L.orc_brute_primary.argtypes = [vp, vp, vp, i32]
         L.orc_shade_frame.argtypes = [vp, vp, u32, vp, vp, i32]
@@ -135,6 +136,15 @@ class BVH:
         lib().orc_trace_primary_range(_p(cam), _p(self.nodes), self.n, _p(self.scene.arr), first, count,
                                       _p(out), C.byref(st), nthreads or ncpu())
         return out, st
+
+    def trace_primary_visits(self, cam: np.ndarray, nthreads: int = 0):
+        npx = int(cam['resX'][0]) * int(cam['resY'][0])
+        out = np.zeros(npx, dtype=CONTACT)
+        visits = np.zeros(npx, dtype=np.uint32)
+        st = Stats()
+        lib().orc_trace_primary_visits(_p(cam), _p(self.nodes), self.n, _p(self.scene.arr), _p(out), _p(visits),
+                                       C.byref(st), nthreads or ncpu())
+        return out, visits, st
 
     def trace_rays(self, rays: np.ndarray, nthreads: int = 0):
         out = np.zeros(len(rays), dtype=CONTACT)

@@ -661,6 +661,7 @@ typedef struct {
     uint32_t first, count;
     volatile uint32_t* next;
     orc_stats st;
+    uint32_t* per_ray_inner;        /* optional: inner visits of every ray (load-balance analysis) */
     /* brute-force triangle table */
     const orc_f4* tri; const uint32_t* mat; uint32_t ntri;
 } job_t;
@@ -679,9 +680,11 @@ static void* worker(void* arg)
                 /* kernel generateContacts, BVHKernels.cl:84-98 */
                 uint32_t gid = j->first + k;
                 orc_ray r; orc_generate_ray(j->cam, gid, &r);
+                uint64_t before = j->st.inner_visits;
                 orc_contact c; orc_traverse(&r, j->nodes, j->n, j->scene, &c, &j->st);
                 c.pixelIndex = gid;
                 j->contacts[k] = c;
+                if (j->per_ray_inner) j->per_ray_inner[k] = (uint32_t)(j->st.inner_visits - before);
             } else if (j->kind == 1) {
                 /* kernel generateContacts2, BVHKernels.cl:103-117 */
                 orc_contact c; orc_traverse(&j->rays[k], j->nodes, j->n, j->scene, &c, &j->st);
@@ -744,6 +747,15 @@ void orc_trace_primary_range(const orc_camera* cam, const orc_bvh_node* nodes, u
     job_t j; memset(&j, 0, sizeof j);
     j.kind = 0; j.cam = cam; j.nodes = nodes; j.n = n; j.scene = (const char*)scene;
     j.contacts = contacts; j.first = first; j.count = count;
+    run_jobs(&j, nthreads, st);
+}
+
+void orc_trace_primary_visits(const orc_camera* cam, const orc_bvh_node* nodes, uint32_t n, const void* scene,
+                              orc_contact* contacts, uint32_t* inner_visits, orc_stats* st, int nthreads)
+{
+    job_t j; memset(&j, 0, sizeof j);
+    j.kind = 0; j.cam = cam; j.nodes = nodes; j.n = n; j.scene = (const char*)scene;
+    j.contacts = contacts; j.first = 0; j.count = cam->resX * cam->resY; j.per_ray_inner = inner_visits;
     run_jobs(&j, nthreads, st);
 }
 

@@ -91,6 +91,9 @@ void     orc_trace_primary(const orc_camera* cam, const orc_bvh_node* nodes, uin
                            orc_contact* contacts, orc_stats* st, int nthreads);              /* BVHKernels.cl:84-98 */
 void     orc_trace_primary_range(const orc_camera* cam, const orc_bvh_node* nodes, uint32_t n, const void* scene,
                            uint32_t first, uint32_t count, orc_contact* contacts, orc_stats* st, int nthreads);
+/* same as orc_trace_primary, also returning the inner-node visits of every ray */
+void     orc_trace_primary_visits(const orc_camera* cam, const orc_bvh_node* nodes, uint32_t n, const void* scene,
+                           orc_contact* contacts, uint32_t* inner_visits, orc_stats* st, int nthreads);
 void     orc_trace_rays(const orc_ray* rays, uint32_t count, const orc_bvh_node* nodes, uint32_t n,
                         const void* scene, orc_contact* contacts, orc_stats* st, int nthreads); /* BVHKernels.cl:103-117 */
 /* brute force over every triangle with the same triangle test (self-consistency check only) */
