@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the BVH primary-ray path (trace + Blinn-Phong shade) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One STEP = one frame of EACH of the five bundled TestModels scenes (Cube, Gardenlight, Tenryuu, ManFigure,
+ClumsyDragon; BASELINE.json configs[1]) at 1920x1080, demo default camera: BVH traversal (two HIP kernels) + shading.
+Scene buffers, BVHs and output buffers are resident in HBM before the timed region; BVH build time is reported
+separately.  With N > 1 every frame is cut into 64x64-pixel tiles dealt round-robin to the ranks (one process per GPU);
+each rank traces and shades its tiles into a compact buffer, ONE gather (RCCL over xGMI) brings them to rank 0, which
+scatters them back to pixel order -- total work per step is fixed, so scaling is "strong".
+
+The line printed by rank 0 also carries
+  roofline      algorithmic bytes of the traversal (56*I + 40*L + 32 per ray, I/L = inner visits / leaf tests under the
+                reference's traversal semantics, from the committed counter fixture tests/golden/frames.json) divided by
+                the traversal kernels' device time, measured with HIP events on the stream they run on, vs 8 TB/s HBM;
+  cpu_baseline  the CPU oracle (a restatement of the reference's host path) timed on this box's host cores on the same
+                five frames (rank 0, N = 1 only).  A reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCENES = ['cube', 'gardenlight', 'tenryuu', 'man', 'clumsydragon']
+RES = (1920, 1080)
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def load_scene_bytes(name):
+    """Packed scene buffer via the product's loader when built (C++ Scene::load), else the Python packer."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import scene_pack
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        return scene_pack.load_scene(os.path.join(ROOT, 'assets', 'scenes', name + '.txt'))
+    finally:
+        os.chdir(cwd)
+
+
+def demo_camera(scene_bytes, resx, resy):
+    """The Demo's default camera (OpenCLRayTracerDemo.cpp:202-217) as host code of the benchmark."""
+    from openclraytracer_amd import capi
+    f = np.frombuffer(scene_bytes, dtype='<f4', count=8, offset=64)
+    lo, hi = f[0:3].astype(np.float32), f[4:7].astype(np.float32)
+    half = (hi - lo) * np.float32(0.5)
+    cam = np.zeros(1, dtype=capi.CAMERA)
+    PI = np.float32(3.14159265359)
+    deg2rad = PI / np.float32(180.0)
+    cam['FOVDistance'] = (np.float32(resy) * np.float32(0.5)) / np.tan(np.float32(90.0) * np.float32(0.5) * deg2rad,
+                                                                       dtype=np.float32)
+    cam['resX'], cam['resY'], cam['supersamplingFactor'] = resx, resy, 1
+    m = np.zeros(12, dtype=np.float32)
+    m[0] = m[5] = m[10] = 1.0
+    m[3], m[7], m[11] = lo[0] + half[0], lo[1] + half[1], lo[2] - half[2]
+    cam['viewTransform'][0] = m
+    return cam
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from openclraytracer_amd import capi
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    ctx = capi.Context(local_rank)                      # raises without a gfx950 device: no fallback
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)                  # library work is ordered with torch / RCCL on this stream
+
+    frames_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'frames.json')))
+    key = '%dx%d' % RES
+    npx = RES[0] * RES[1]
+    work = []
+    build_ms = {}
+    for name in SCENES:
+        buf = load_scene_bytes(name)
+        scene = capi.DeviceScene(ctx, buf)
+        bvh = capi.DeviceBVH(ctx, scene)
+        t0 = time.perf_counter()
+        bvh.build()
+        bvh.build()
+        build_ms[name] = (time.perf_counter() - t0) * 1e3 / 2
+        cam = demo_camera(buf, *RES)
+        slots = capi.tiles_owned_pixels(cam, rank, world) if world > 1 else npx
+        item = dict(name=name, scene=scene, bvh=bvh, cam=cam, slots=slots,
+                    contacts=torch.empty(slots * 32, dtype=torch.uint8, device=dev),
+                    rgba=torch.empty((slots, 4), dtype=torch.float32, device=dev))
+        if world > 1:
+            slots0 = capi.tiles_owned_pixels(cam, 0, world)      # rank 0 owns the most tiles: gather slot size
+            item['slots0'] = slots0
+            item['send'] = torch.zeros((slots0, 4), dtype=torch.float32, device=dev)
+            if rank == 0:
+                item['gathered'] = torch.empty((world, slots0, 4), dtype=torch.float32, device=dev)
+                item['frame'] = torch.empty((npx, 4), dtype=torch.float32, device=dev)
+        work.append(item)
+
+    def step():
+        for it in work:
+            if world == 1:
+                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
+                capi.shade_blinn_phong_d(ctx, it['scene'], it['cam'], it['contacts'].data_ptr(), npx, it['rgba'].data_ptr())
+            else:
+                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
+                # shade straight into the fixed-size send buffer (ranks own slots <= slots0)
+                capi.shade_blinn_phong_tiled_d(ctx, it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
+                                               it['send'].data_ptr())
+                if rank == 0:
+                    dist.gather(it['send'], list(it['gathered'].unbind(0)), dst=0)
+                    capi.untile_rgba_d(ctx, it['cam'], world, it['gathered'].data_ptr(), it['slots0'], it['frame'].data_ptr())
+                else:
+                    dist.gather(it['send'], None, dst=0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kt = ctx.trace_kernel_times()
+    ctx.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rays_per_step = npx * len(SCENES)
+    value = rays_per_step * args.steps / elapsed / 1e6
+
+    # ---- per-scene device times (untimed extra pass, HIP events) and the roofline of the traversal kernels
+    per_scene = {}
+    tm = capi.Timer(ctx)
+    for it in work:
+        ctx.set_profiling(True)
+        tm.start()
+        for _ in range(5):
+            if world == 1:
+                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
+            else:
+                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
+        tm.stop()
+        ms = tm.elapsed_ms() / 5
+        k = ctx.trace_kernel_times()
+        fx = frames_fixture[it['name']][key]
+        alg = 56 * fx['inner_visits'] + 40 * fx['leaf_tests'] + 32 * fx['rays']
+        per_scene[it['name']] = dict(trace_ms=round(ms, 4), lane_phase_ms=round(k['lane_phase_ms'] / 5, 4),
+                                     wave_phase_ms=round(k['wave_phase_ms'] / 5, 4),
+                                     mrays_per_s=round(it['slots'] / ms / 1e3, 1),
+                                     inner_visits_per_ray=round(fx['inner_visits'] / fx['rays'], 2),
+                                     leaf_tests_per_ray=round(fx['leaf_tests'] / fx['rays'], 2),
+                                     algorithmic_bytes=alg, build_ms=round(build_ms[it['name']], 3))
+    ctx.set_profiling(False)
+    tm.close()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    launches = max(kt['launches'], 1)
+    trace_ms_avg = (kt['lane_phase_ms'] + kt['wave_phase_ms']) / launches          # k_trace + k_trace_long per frame
+    alg_total = sum(per_scene[n]['algorithmic_bytes'] for n in SCENES)
+    alg_per_launch = alg_total / len(SCENES) / world                                # this rank's share of an average frame
+    achieved = alg_per_launch / (trace_ms_avg * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    if os.path.exists(tpath) and world == 1:
+        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+    roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    kernel='k_trace<1> + k_trace_long<1> (one traversal launch pair per frame)',
+                    avg_launch_ms=round(trace_ms_avg, 4),
+                    avg_lane_phase_ms=round(kt['lane_phase_ms'] / launches, 4),
+                    avg_wave_phase_ms=round(kt['wave_phase_ms'] / launches, 4),
+                    algorithmic_bytes_per_launch=int(alg_per_launch))
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import oracle as orc                     # cpu_baseline leg only: the oracle is the thing timed here
+        cores = orc.ncpu()
+        t_cpu, rays_cpu = 0.0, 0
+        for name in SCENES:
+            osc = orc.Scene(load_scene_bytes(name))
+            ob = orc.BVH(osc, 0)
+            cam = osc.demo_camera(*RES)
+            t1 = time.perf_counter()
+            c, _ = ob.trace_primary(cam, nthreads=cores)
+            orc.shade_frame(osc, cam, c, nthreads=cores)
+            t_cpu += time.perf_counter() - t1
+            rays_cpu += len(c)
+        cpu_baseline = dict(value=round(rays_cpu / t_cpu / 1e6, 3), unit='Mrays/s', cores=cores, kind='port',
+                            sample='all five scenes, one full 1920x1080 frame each (trace + shade), BVH build excluded')
+
+    out = dict(metric='Mrays/s (primary rays, BVH trace + shade, bundled TestModels, 1920x1080)', value=round(value, 1),
+               unit='Mrays/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling='strong',
+               vs_baseline=None, dtype='f32', data='bundled TestModels OBJ scenes (shipped with the reference), demo default camera',
+               config=dict(workload='5 bundled TestModels scenes x 1920x1080 primary rays, BVH traversal + Blinn-Phong shading',
+                           rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES,
+                           parallelism=('single GPU' if world == 1 else
+                                        '64x64 frame tiles round-robin over %d ranks, one gather of RGBA to rank 0' % world)),
+               ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
+               roofline=roofline, cpu_baseline=cpu_baseline, per_scene=per_scene)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

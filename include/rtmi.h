@@ -141,6 +141,10 @@ int  rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2);
 int  rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n);
 
 /* ---- measurement helpers (HIP events on the context's stream) --------------------------- */
+/* per-kernel device time of the two traversal kernels (lane-per-ray phase, wave-per-ray phase), measured with
+ * HIP events recorded around them on the stream they run on; sums over the launches since the last query.   */
+int  rt_ctx_set_profiling(rt_ctx* ctx, int enable);
+int  rt_ctx_trace_kernel_times(rt_ctx* ctx, uint64_t* launches, double* lane_phase_ms, double* wave_phase_ms);
 int  rt_timer_create(rt_ctx* ctx, void** timer);
 int  rt_timer_start(rt_ctx* ctx, void* timer);
 int  rt_timer_stop(rt_ctx* ctx, void* timer);

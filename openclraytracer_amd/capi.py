@@ -33,7 +33,8 @@ SYMBOLS = [
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba',
-    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
+    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times',
+    'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
 ]
 
@@ -90,6 +91,8 @@ def load_library() -> C.CDLL:
     L.rt_untile_rgba.argtypes = [vp, vp, u32, vp, u32, vp]
     L.rt_sort_pairs_bitonic.argtypes = [vp, vp, u32]
     L.rt_scan_inclusive_u32.argtypes = [vp, vp, vp, u32]
+    L.rt_ctx_set_profiling.argtypes = [vp, i32]
+    L.rt_ctx_trace_kernel_times.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rt_timer_create.argtypes = [vp, pvp]
     L.rt_timer_start.argtypes = [vp, vp]
     L.rt_timer_stop.argtypes = [vp, vp]
@@ -132,6 +135,17 @@ class Context:
         name = C.create_string_buffer(64)
         self.check(self.lib.rt_ctx_device_info(self.h, C.byref(cu), C.byref(ws), C.byref(lds), name, 64))
         return dict(compute_units=cu.value, wave_size=ws.value, lds_bytes=lds.value, name=name.value.decode())
+
+    def set_profiling(self, on: bool):
+        self.check(self.lib.rt_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def trace_kernel_times(self) -> dict:
+        n, a, b = C.c_uint64(), C.c_double(), C.c_double()
+        self.check(self.lib.rt_ctx_trace_kernel_times(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return dict(launches=n.value, lane_phase_ms=a.value, wave_phase_ms=b.value)
+
+    def set_stream(self, stream: int | None):
+        self.check(self.lib.rt_ctx_set_stream(self.h, C.c_void_p(stream or 0)))
 
     # ---- CLBuffer-like helpers
     def alloc(self, nbytes: int) -> int:

@@ -97,6 +97,7 @@ void rt_ctx_destroy(rt_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     free_ctx_buffers(ctx);
+    for (hipEvent_t e : ctx->trace_events) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -397,6 +398,15 @@ static TraceLaunch make_launch(rt_bvh* b)
     t.trav = b->d_trav; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
+    t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
+    if (b->ctx->profiling) {
+        for (int k = 0; k < 3; k++) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            t.ev[k] = e;
+            b->ctx->trace_events.push_back(e);
+        }
+    }
     t.compute_units = b->ctx->prop.multiProcessorCount;
     b->ctx->trace_launched = true;
     return t;
@@ -559,6 +569,45 @@ int rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // scratch is freed below
     hipFree(scratch);
     if (e != hipSuccess) return RT_FAIL(ctx, std::string("scan failed: ") + hipGetErrorString(e));
+    return RT_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-kernel timing of the trace launches (HIP events on the stream the kernels run on)
+// ---------------------------------------------------------------------------------------
+static void drop_trace_events(rt_ctx* ctx)
+{
+    for (hipEvent_t e : ctx->trace_events) if (e) (void)hipEventDestroy(e);
+    ctx->trace_events.clear();
+}
+
+int rt_ctx_set_profiling(rt_ctx* ctx, int enable)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drop_trace_events(ctx);
+    ctx->profiling = enable != 0;
+    return RT_SUCCESS;
+}
+
+int rt_ctx_trace_kernel_times(rt_ctx* ctx, uint64_t* launches, double* lane_phase_ms, double* wave_phase_ms)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t n = 0; double a = 0.0, b = 0.0;
+    for (size_t i = 0; i + 2 < ctx->trace_events.size(); i += 3) {
+        hipEvent_t* e = &ctx->trace_events[i];
+        float m0 = 0.f, m1 = 0.f;
+        if (!e[0] || !e[1] || !e[2]) continue;
+        if (hipEventElapsedTime(&m0, e[0], e[1]) != hipSuccess || hipEventElapsedTime(&m1, e[1], e[2]) != hipSuccess) continue;
+        a += m0; b += m1; n++;
+    }
+    drop_trace_events(ctx);
+    if (launches) *launches = n;
+    if (lane_phase_ms) *lane_phase_ms = a;
+    if (wave_phase_ms) *wave_phase_ms = b;
     return RT_SUCCESS;
 }
 

@@ -70,6 +70,8 @@ struct rt_ctx {
     uint32_t long_cap = 0;
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
+    bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
+    std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
 };
 
 struct rt_scene {
@@ -134,6 +136,7 @@ struct TraceLaunch {
     uint32_t* long_list;          // records of rays deferred to the wave-per-ray phase
     uint32_t long_cap;            // records available
     uint32_t defer_budget;        // 0 = default
+    hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
     int compute_units;
 };
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,

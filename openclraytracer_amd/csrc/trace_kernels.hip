@@ -468,7 +468,9 @@ static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     a.n_waves = grid * TRACE_WAVES;
     // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
     (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
+    if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
     hipLaunchKernelGGL(k_trace<PRIMARY>, dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+    if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
     // phase 1: the number of deferred rays lives on the device; a fixed grid strides over the list
     int b1 = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY>, TRACE_BLOCK, 0);
@@ -476,6 +478,7 @@ static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
     a.n_waves = grid1 * TRACE_WAVES;
     hipLaunchKernelGGL(k_trace_long<PRIMARY>, dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
+    if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
 }
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
