@@ -76,9 +76,9 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from openclraytracer_amd import capi
+    from openclraytracer_amd import capi, frame_tiles
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    world =int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
@@ -134,11 +134,9 @@ def main():
                 # shade straight into the fixed-size send buffer (ranks own slots <= slots0)
                 capi.shade_blinn_phong_tiled_d(ctx, it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
                                                it['send'].data_ptr())
+                frame_tiles.gather_to_root(it['send'], world, rank, out=it.get('gathered'))   # the one collective
                 if rank == 0:
-                    dist.gather(it['send'], list(it['gathered'].unbind(0)), dst=0)
                     capi.untile_rgba_d(ctx, it['cam'], world, it['gathered'].data_ptr(), it['slots0'], it['frame'].data_ptr())
-                else:
-                    dist.gather(it['send'], None, dst=0)
 
     def fence():
         if dist is not None:

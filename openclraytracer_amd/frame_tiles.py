@@ -1,0 +1,63 @@
+"""Host logic of the multi-GPU frame: who owns which 64x64 tile, the single gather, and the host statement of
+the tiling contract of include/rtmi.h (used by bench.py on GPUs and by the 2-rank gloo test on CPU).
+
+New functionality (the reference is single-device): rays are independent, the scene and BVH
+are replicated, rank r of N owns tiles r, r+N, ...; the only exchange step is ONE gather of shaded RGBA.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TILE = 64
+
+
+def tiles_xy(resx: int, resy: int):
+    return (resx + TILE - 1) // TILE, (resy + TILE - 1) // TILE
+
+
+def owned_slots(resx: int, resy: int, rank: int, nranks: int) -> int:
+    """== rt_tiles_owned_pixels"""
+    tx, ty = tiles_xy(resx, resy)
+    total = tx * ty
+    return ((total - rank + nranks - 1) // nranks) * TILE * TILE if total > rank else 0
+
+
+def slot_map(resx: int, resy: int, nranks: int):
+    """for every pixel (row-major): owning rank and slot in that rank's compact buffer"""
+    tx, _ = tiles_xy(resx, resy)
+    y, x = np.divmod(np.arange(resx * resy, dtype=np.int64), resx)
+    px, py = x // TILE, y // TILE
+    tile = py * tx + px
+    rank = tile % nranks
+    slot = (tile // nranks) * (TILE * TILE) + (y - py * TILE) * TILE + (x - px * TILE)
+    return rank, slot
+
+
+def compact_from_frame(frame: np.ndarray, resx: int, resy: int, rank: int, nranks: int, slots: int) -> np.ndarray:
+    """what a rank's tiled shade kernel leaves in its compact buffer, given the full frame (host statement)"""
+    r, s = slot_map(resx, resy, nranks)
+    out = np.zeros((slots,) + frame.shape[1:], dtype=frame.dtype)
+    mine = r == rank
+    out[s[mine]] = frame[mine]
+    return out
+
+
+def untile_host(gathered: np.ndarray, resx: int, resy: int) -> np.ndarray:
+    """== rt_untile_rgba: gathered[rank, slot] -> frame[pixel]"""
+    nranks = gathered.shape[0]
+    r, s = slot_map(resx, resy, nranks)
+    return gathered[r, s]
+
+
+def gather_to_root(send, world: int, rank: int, out=None):
+    """THE collective of the path: one gather of equally sized compact buffers to rank 0
+    (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    if rank == 0:
+        if out is None:
+            out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        dist.gather(send, list(out.unbind(0)), dst=0)
+        return out
+    dist.gather(send, None, dst=0)
+    return None

@@ -1,0 +1,269 @@
+"""CPU suite (no GPU): the oracle against the committed fixtures and the reference-derived known answers,
+the loaders, and the C-ABI library's exported surface."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, ROOT, oracle_bvh, packed_scene
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def gold(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+# ---------------------------------------------------------------- loaders
+@pytest.mark.parametrize('name', MODELS)
+def test_scene_pack_matches_fixture(name):
+    buf = packed_scene(name)
+    g = gold('scenes.json')[name]
+    assert len(buf) == g['bytes'] and sha(buf) == g['sha256']
+    probe = gold('reference_probe.json')
+    import scene_pack
+    assert scene_pack.scene_header(buf)['totalNumberOfTriangles'] == probe['triangles'][name]
+
+
+def test_obj_parser_matches_reference_tinyobj_when_available():
+    """Where oracle/_ref/tinyobj_dump (the reference's own parser, built from /root/reference) exists, the
+    Python restatement must equal it field by field; its dump hashes are the committed fixture."""
+    import scene_pack
+    import subprocess
+    dumper = os.path.join(ROOT, 'oracle', '_ref', 'tinyobj_dump')
+    if not os.path.exists(dumper):
+        pytest.skip('oracle/_ref not built (no /root/reference on this box)')
+    g = gold('tinyobj.json')
+    models = {'cube': 'assets/testmodels/Cube/cube.obj', 'gardenlight': 'assets/testmodels/Gardenlight/gardenlight01.obj',
+              'tenryuu': 'assets/testmodels/Tenryuu/light-cruiser-tenryuu.obj'}
+    for name, obj in models.items():
+        out = '/tmp/_t_%s.bin' % name
+        subprocess.check_call([dumper, os.path.join(ROOT, obj), out])
+        assert sha(open(out, 'rb').read()) == g[name]['sha256']
+        rs, rm = scene_pack.load_tinyobj_dump(out)
+        ms, mm = scene_pack.parse_obj(os.path.join(ROOT, obj))
+        assert len(rs) == len(ms) and len(rm) == len(mm)
+        for a, b in zip(ms, rs):
+            assert a.positions.tobytes() == b.positions.tobytes()
+            assert a.indices.tobytes() == b.indices.tobytes()
+            assert a.material_ids.tobytes() == b.material_ids.tobytes()
+        for a, b in zip(mm, rm):
+            assert a.as_floats().tobytes() == b.as_floats().tobytes()
+
+
+def test_tinyobj_float_parser_quirks():
+    import scene_pack
+    ok, v = scene_pack.try_parse_double('0.1`')
+    assert ok and np.float32(v) == np.float32(0.1)
+    assert scene_pack.try_parse_double('-.5')[0] is False          # needs a digit before the dot
+    assert scene_pack.try_parse_double('1e')[0] is False
+    ok, v = scene_pack.try_parse_double('11e2')
+    assert ok and v == 1100.0
+    ok, v = scene_pack.try_parse_double('-0')
+    assert ok and v == 0.0
+
+
+def test_scene_file_edge_cases(tmp_path):
+    """empty scene, unknown keys, light-only scene, bad light values (Scene.cpp:233-346)."""
+    import scene_pack
+    p = tmp_path / 's.txt'
+    p.write_text('FOO bar\nLIGHT 1.0 2.0 3.0 4.0\nLIGHT x 2 3 4\n\nnokey\n')
+    raw = scene_pack.parse_scene_file(str(p))
+    assert sorted(raw) == ['FOO', 'LIGHT']
+    buf = scene_pack.pack_scene(raw, [])
+    h = scene_pack.scene_header(buf)
+    assert h['numberOfLights'] == 2 and h['numberOfModels'] == 0 and h['totalNumberOfTriangles'] == 0
+    lights = np.frombuffer(buf, dtype='<f4', count=8, offset=96).reshape(2, 4)
+    assert lights[0].tolist() == [1.0, 2.0, 3.0, 4.0]
+    assert lights[1].tolist() == [0.0, 0.0, 0.0, 0.0]               # invalid light line stays zero
+    assert h['totalDataSize'] == 96 + 32
+
+
+# ---------------------------------------------------------------- oracle vs fixtures
+def test_struct_sizes_match_reference_probe():
+    import oracle as orc
+    for k, v in gold('reference_probe.json')['struct_sizes'].items():
+        got = orc.lib().orc_sizeof(k.encode())
+        if got:
+            assert got == v, k
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_bvh_fixture_and_invariants(name):
+    """hashes + the invariants of Include/Testing/BVHTest.h and sortingTest.h."""
+    _, b = oracle_bvh(name)
+    g = gold('bvh.json')[name]
+    assert b.n == g['leaves'] and b.N == g['morton_items']
+    assert sha(b.pairs.tobytes()) == g['pairs_sha256'] and sha(b.nodes.tobytes()) == g['nodes_sha256']
+    rc, depth = b.check_hierarchy()
+    assert rc == 0 and depth == g['depth']
+    assert depth + 1 == gold('reference_probe.json')['tree_depth_nodes'][name]
+    keys = b.pairs['key']
+    assert (np.diff(keys.astype(np.int64)) >= 0).all()                       # sorted
+    assert sorted(b.pairs['value'][:b.n].tolist()) == list(range(b.n))        # permutation of the leaves
+    assert (b.pairs['key'][b.n:] == 0xFFFFFFFF).all()                         # padding stays at the end
+    # parent box contains child boxes (testBoundingBoxCorrectness)
+    nodes = b.nodes
+    inner = np.arange(b.n, 2 * b.n - 1)
+    for side in (1, 2):
+        ch = nodes['data'][inner, side]
+        assert (nodes['lo'][inner, :3] <= nodes['lo'][ch, :3]).all()
+        assert (nodes['hi'][inner, :3] >= nodes['hi'][ch, :3]).all()
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_dfs_leaf_order_is_sorted_pair_order(name):
+    """the fact the HIP kernels' tie rule rests on: A-first DFS visits leaves in sorted-array order."""
+    _, b = oracle_bvh(name)
+    n, data = b.n, b.nodes['data']
+    order, stack = [], [n]
+    while stack:
+        c = stack.pop()
+        if c < n:
+            order.append(c)
+        else:
+            stack.append(int(data[c][2]))
+            stack.append(int(data[c][1]))
+    assert np.array_equal(np.array(order, dtype=np.uint32), b.pairs['value'][:n])
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_trace_matches_fixture_and_reference_probe(name):
+    osc, b = oracle_bvh(name)
+    fx = gold('frames.json')[name]
+    probe = gold('reference_probe.json')
+    for key in ('64x48', '640x480'):
+        w, h = map(int, key.split('x'))
+        cam = osc.demo_camera(w, h)
+        assert [int(x) for x in cam.view(np.uint32).ravel()] == fx[key]['camera_bits']
+        c, st = b.trace_primary(cam)
+        g = fx[key]
+        assert sha(c.tobytes()) == g['contacts_sha256']
+        assert (st.hits, st.inner_visits, st.leaf_tests, st.max_stack) == (g['hits'], g['inner_visits'],
+                                                                           g['leaf_tests'], g['max_stack'])
+        if key == '640x480':     # numbers produced by the reference's own headers during the survey
+            assert round(st.inner_visits / len(c), 1) == probe['inner_visits_per_ray_640x480'][name]
+            assert round(st.leaf_tests / len(c), 1) == probe['leaf_tests_per_ray_640x480'][name]
+            assert st.max_stack == probe['max_stack_640x480'][name]
+        elif name in probe['hits_64x48_fixed']:
+            assert st.hits == probe['hits_64x48_fixed'][name]
+
+
+@pytest.mark.parametrize('name,res', [('cube', (64, 48)), ('gardenlight', (64, 48)), ('tenryuu', (40, 30))])
+def test_bvh_equals_brute_force(name, res):
+    """FIXED-mode property recorded by the survey for the reference: BVH contacts == brute force, t bit-exact."""
+    import oracle as orc
+    osc, b = oracle_bvh(name)
+    cam = osc.demo_camera(*res)
+    c, _ = b.trace_primary(cam)
+    br = orc.brute_primary(osc, cam)
+    assert np.array_equal(c['normal_t'][:, 3].view(np.uint32), br['normal_t'][:, 3].view(np.uint32))
+
+
+def test_small_contact_and_rgba_fixtures():
+    import oracle as orc
+    z = np.load(os.path.join(GOLD, 'contacts_64x48.npz'))
+    for name in MODELS:
+        osc, b = oracle_bvh(name)
+        cam = osc.demo_camera(64, 48)
+        c, _ = b.trace_primary(cam)
+        assert np.array_equal(c.view(np.uint8).reshape(-1, 32), z[name + '_contacts'])
+        rgba = orc.shade_frame(osc, cam, c)
+        want = z[name + '_rgba']
+        assert np.allclose(rgba, want, rtol=1e-5, atol=0)
+        miss = c['normal_t'][:, 3] <= 0
+        assert (rgba[miss] == 0).all() and (rgba[~miss][:, 3] == 1).all()
+
+
+def test_trace_rays_equals_primary_and_handles_edge_cases():
+    import oracle as orc
+    osc, b = oracle_bvh('gardenlight')
+    cam = osc.demo_camera(32, 24)
+    rays = orc.generate_rays(cam)
+    c1, _ = b.trace_primary(cam)
+    c2, _ = b.trace_rays(rays)
+    assert c1.tobytes() == c2.tobytes()
+    empty, _ = b.trace_rays(rays[:0])
+    assert len(empty) == 0
+    # axis-parallel and degenerate directions (1/0 = inf, 0*inf = NaN paths of AABB.h:126-142)
+    odd = rays[:4].copy()
+    odd['direction'][0] = (0, 0, 1, 0)
+    odd['direction'][1] = (0, 1, 0, 0)
+    odd['direction'][2] = (0, 0, 0, 0)
+    odd['direction'][3] = (np.nan, 0, 1, 0)
+    c3, _ = b.trace_rays(odd)
+    assert np.isfinite(c3['normal_t'][:, 3]).all()
+
+
+def test_kat_scan_and_sort():
+    import oracle as orc
+    kat = gold('kat.json')
+    rng = np.random.default_rng(1234)
+    for n in [2, 64, 1024, 65536]:
+        a = rng.integers(0, 1 << 10, size=n, dtype=np.uint32)
+        s = orc.scan_inclusive(a)
+        assert np.array_equal(s, np.cumsum(a, dtype=np.uint64).astype(np.uint32))          # ps[i] == in[i] + ps[i-1]
+        assert sha(s.tobytes()) == kat['scan_%d' % n]
+        pairs = np.zeros(n, dtype=orc.PAIR)
+        pairs['key'] = rng.integers(0, 16, size=n, dtype=np.uint32)
+        pairs['value'] = np.arange(n, dtype=np.uint32)
+        out = orc.bitonic_sort(pairs)
+        assert (np.diff(out['key'].astype(np.int64)) >= 0).all()
+        assert sorted(out['value'].tolist()) == list(range(n))                              # key/value integrity
+        assert sha(out.tobytes()) == kat['sort_%d' % n]
+
+
+# ---------------------------------------------------------------- the C-ABI library (no compute without a GPU)
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'rtmi.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(rt_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    from openclraytracer_amd import capi
+    assert declared_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from openclraytracer_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        pytest.fail('librtmi.so is not built: run __graft_entry__.build()')
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+    assert lib.rt_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a gfx950 device context creation must fail loudly (no fallback path)."""
+    import torch
+    from openclraytracer_amd import capi
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    with pytest.raises(capi.RtError):
+        capi.Context(0)
+
+
+def test_tile_slot_map_is_a_bijection():
+    from openclraytracer_amd import capi
+    for (w, h, n) in [(1920, 1080, 8), (640, 480, 2), (65, 64, 3), (64, 64, 1)]:
+        rank, slot = capi.tile_slot_map(w, h, n)
+        cam = np.zeros(1, dtype=capi.CAMERA)
+        cam['resX'], cam['resY'] = w, h
+        seen = set()
+        for r in range(n):
+            owned = capi.tiles_owned_pixels(cam, r, n)
+            s = slot[rank == r]
+            assert s.size == 0 or s.max() < owned
+            assert len(set(s.tolist())) == s.size
+            seen.update((r, int(x)) for x in s)
+        assert len(seen) == w * h

@@ -1,0 +1,76 @@
+"""World-size-2 gloo test (CPU) of the N > 1 frame path: tile ownership, the single gather, untile."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, res, name, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch
+    import torch.distributed as dist
+    import oracle as orc
+    from conftest import oracle_bvh
+    from openclraytracer_amd import frame_tiles as ft
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        osc, b = oracle_bvh(name)
+        cam = osc.demo_camera(*res)
+        # every rank holds the replicated scene; the checker computes the frame, the rank keeps only its tiles
+        c, _ = b.trace_primary(cam, nthreads=2)
+        frame = orc.shade_frame(osc, cam, c, nthreads=2)
+        slots0 = ft.owned_slots(res[0], res[1], 0, world)
+        mine = ft.owned_slots(res[0], res[1], rank, world)
+        send = np.zeros((slots0, 4), dtype=np.float32)
+        send[:mine] = ft.compact_from_frame(frame, res[0], res[1], rank, world, mine)
+        out = ft.gather_to_root(torch.from_numpy(send), world, rank)
+        if rank == 0:
+            got = ft.untile_host(out.numpy(), res[0], res[1])
+            ret['equal'] = bool(np.array_equal(got, frame))
+            ret['hits'] = int((frame[:, 3] > 0).sum())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('res', [(200, 150), (128, 64)])
+def test_two_rank_gather_reassembles_the_frame(res):
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context('spawn').Process(target=_worker, args=(r, world, port, res, 'gardenlight', ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert ret['equal'] and ret['hits'] > 0
+
+
+def test_slot_contract_matches_c_abi():
+    from openclraytracer_amd import capi, frame_tiles as ft
+    for (w, h, n) in [(1920, 1080, 8), (1920, 1080, 4), (640, 480, 2), (63, 65, 3)]:
+        cam = np.zeros(1, dtype=capi.CAMERA)
+        cam['resX'], cam['resY'] = w, h
+        for r in range(n):
+            assert capi.tiles_owned_pixels(cam, r, n) == ft.owned_slots(w, h, r, n)
+        a = capi.tile_slot_map(w, h, n)
+        b = ft.slot_map(w, h, n)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
