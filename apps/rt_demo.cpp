@@ -1,0 +1,107 @@
+// rt_demo -- headless counterpart of the reference's GLUT demo (src/Demos/OpenCLRayTracerDemo/OpenCLRayTracerDemo.cpp):
+// the same five switches (-winH -winW -accStruct -headersPath -scene, :66-73,513-552), the same main() sequence
+// (:130-266: load scene, upload, default camera, manager initialize / initializeFrame / construct) and the same
+// RTFrame() sequence (:271-326) with the host shading loop replaced by the device shading call, then a PPM/raw
+// dump instead of the GL point-sprite display.  Written against the reference's class names only.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <Algorithms/BVHManager.h>
+#include <CLData/CLStructs.h>
+#include <Scene/Scene.h>
+
+using namespace CLRayTracer;
+using namespace CLRayTracer::Common;
+using namespace CLRayTracer::OpenCLUtils;
+using namespace CLRayTracer::AccelerationStructures;
+
+#define CHECKED_CALL(result) if ((result) != Success) { std::cout << err; return 1; }
+
+int main(int argc, char* argv[])
+{
+    int window_width = 0, window_height = 0, frames = 1;
+    std::string scenePath, accStruct, headersPath, outPath, rawContacts;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        std::string k = argv[i], v = argv[i + 1];
+        if (k == "-winH") window_height = std::atoi(v.c_str());
+        else if (k == "-winW") window_width = std::atoi(v.c_str());
+        else if (k == "-accStruct") accStruct = v;
+        else if (k == "-headersPath") headersPath = v;        // accepted and ignored: kernels are compiled offline
+        else if (k == "-scene") scenePath = v;
+        else if (k == "--frames") frames = std::atoi(v.c_str());
+        else if (k == "--out") outPath = v;
+        else if (k == "--contacts") rawContacts = v;
+    }
+    if (window_width <= 0 || window_height <= 0 || scenePath.empty() || accStruct.empty()) {
+        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH -headersPath dir -scene file.txt [--frames n] [--out img.ppm] [--contacts raw.bin]" << std::endl;
+        return 0;
+    }
+    if (accStruct != "BVH") { std::cout << "only -accStruct BVH is built so far (GRID = Two-Level Grid is the next row)" << std::endl; return 1; }
+    Errata err;
+    std::unique_ptr<CLExecutionContext> context;
+    try { context.reset(new CLExecutionContext(0)); }
+    catch (const CLInterfaceException& e) { std::cout << e; return 1; }
+
+    Scene scene;
+    CHECKED_CALL(scene.load(scenePath.c_str(), err));
+    const float* bb = reinterpret_cast<const float*>(scene.getHostSceneData() + 64);     // SceneHeader.modelsBoundingBox
+    std::cout << "Scene loaded: " << scene.getSceneDataSize() << " bytes" << std::endl;
+    CHECKED_CALL(scene.loadToGPU(*context, err));
+
+    // camera: OpenCLRayTracerDemo.cpp:202-217
+    Camera camera;
+    camera.resX = window_width; camera.resY = window_height;
+    camera.FOVDistance = FOVDistFromAngle(90, (float)window_width, (float)window_height);
+    camera.supersampilngFactor = 1;
+    CL_FLOAT3 half, cameraPosition;
+    half.x = (bb[4] - bb[0]) * 0.5f; half.y = (bb[5] - bb[1]) * 0.5f; half.z = (bb[6] - bb[2]) * 0.5f;
+    cameraPosition.x = bb[0] + half.x; cameraPosition.y = bb[1] + half.y; cameraPosition.z = bb[2] - half.z; cameraPosition.w = 0;
+    camera.viewTransform = identityTransform();
+    Quaternion cameraOrientation = zeroRotation();
+
+    std::unique_ptr<AccelerationStructureManager> accelerationStruct(new BVHManager(*context, scene));
+    CHECKED_CALL(accelerationStruct->initialize(err));
+    CHECKED_CALL(accelerationStruct->initializeFrame(err));
+    CHECKED_CALL(accelerationStruct->construct(err));
+
+    const size_t pixelCount = (size_t)window_width * window_height;
+    CLBuffer colorsBuffer(*context, pixelCount * sizeof(CL_FLOAT4), CLBufferFlags::ReadWrite);
+    std::vector<CL_FLOAT4> colors(pixelCount);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; f++) {
+        // RTFrame, OpenCLRayTracerDemo.cpp:271-326
+        normalizeQuaternion(&cameraOrientation);
+        setOrientationAndPos(&camera.viewTransform, cameraOrientation, cameraPosition);
+        CHECKED_CALL(accelerationStruct->generateContacts(camera, err));
+        unsigned contactsCount = (unsigned)pixelCount;
+        CHECKED_CALL(shadeBlinnPhong(*context, scene, camera, *accelerationStruct->getPrimaryContacts(), contactsCount, colorsBuffer, err));
+        CHECKED_CALL(colorsBuffer.copyToHost(colors.data(), err));
+    }
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
+    size_t hits = 0;
+    for (const CL_FLOAT4& c : colors) hits += c.w > 0;
+    std::cout << "frames " << frames << "  " << ms << " ms/frame (incl. read-back)  lit pixels " << hits << std::endl;
+    if (!rawContacts.empty()) {
+        std::vector<Contact> contacts(pixelCount);
+        std::vector<char> all(accelerationStruct->getPrimaryContacts()->getActualSize());
+        CHECKED_CALL(accelerationStruct->getPrimaryContacts()->copyToHost(all.data(), err));
+        FILE* fc = std::fopen(rawContacts.c_str(), "wb");
+        if (fc) { std::fwrite(all.data(), sizeof(Contact), pixelCount, fc); std::fclose(fc); }
+    }
+    if (!outPath.empty()) {
+        FILE* fo = std::fopen(outPath.c_str(), "wb");
+        if (!fo) { std::perror("fopen"); return 1; }
+        std::fprintf(fo, "P6\n%d %d\n255\n", window_width, window_height);
+        for (const CL_FLOAT4& c : colors) {
+            unsigned char px[3] = { (unsigned char)(c.x * 255.0f + 0.5f), (unsigned char)(c.y * 255.0f + 0.5f), (unsigned char)(c.z * 255.0f + 0.5f) };
+            std::fwrite(px, 1, 3, fo);
+        }
+        std::fclose(fo);
+    }
+    return 0;
+}

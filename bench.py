@@ -37,15 +37,16 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def load_scene_bytes(name):
-    """Packed scene buffer via the product's loader when built (C++ Scene::load), else the Python packer."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import scene_pack
-    cwd = os.getcwd()
-    os.chdir(ROOT)
-    try:
-        return scene_pack.load_scene(os.path.join(ROOT, 'assets', 'scenes', name + '.txt'))
-    finally:
-        os.chdir(cwd)
+    """Packed scene buffer through the PRODUCT's loader: the C++ Scene::load packing (apps/bin/scene_pack_tool,
+    openclraytracer_amd/csrc/host/src/SceneLoader.cpp)."""
+    import subprocess
+    import tempfile
+    tool = os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
+    if not os.path.exists(tool):
+        raise SystemExit('apps/bin/scene_pack_tool is not built: run __graft_entry__.build()')
+    with tempfile.NamedTemporaryFile(suffix='.bin') as tmp:
+        subprocess.check_call([tool, os.path.join('assets', 'scenes', name + '.txt'), tmp.name], cwd=ROOT)
+        return open(tmp.name, 'rb').read()
 
 
 def demo_camera(scene_bytes, resx, resy):

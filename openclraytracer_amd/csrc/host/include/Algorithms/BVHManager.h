@@ -1,0 +1,37 @@
+// Algorithms/BVHManager.h -- host interface of the BVH (OpenCLRayTracer/Include/Algorithms/BVHManager.h:59-126,
+// src/CLRayTracerEngine/BVHManager.cpp), implemented on rt_bvh_* of librtmi.so.
+#ifndef RTMI_HOST_BVHMANAGER_H
+#define RTMI_HOST_BVHMANAGER_H
+#include <Algorithms/AccelerationStructureManager.h>
+
+struct rt_bvh;
+
+namespace CLRayTracer { namespace AccelerationStructures {
+
+class BVHManager : public AccelerationStructureManager {
+public:
+    BVHManager(const OpenCLUtils::CLExecutionContext& context, const Scene& scene);
+    ~BVHManager() override;
+    Common::Result initialize(Common::Errata& err) override;
+    Common::Result initializeFrame(Common::Errata& err) override;
+    Common::Result construct(Common::Errata& err) override;
+    Common::Result generateContacts(Camera& cam, Common::Errata& err) override;
+    Common::Result generateContacts(OpenCLUtils::CLBuffer& rays, OpenCLUtils::CLBuffer& contacts,
+                                    const unsigned int rayCount, Common::Errata& err) override;
+    const SharedPtr<OpenCLUtils::CLBuffer> getPrimaryContacts() const override { return _primaryContactsArray; }
+    /** parity read-back of the hierarchy in the reference's 48-byte BVHNode layout (2n-1 nodes) */
+    Common::Result readNodes(void* hostNodes, Common::Errata& err) const;
+    unsigned int leavesCount() const { return _bvhLeavesCount; }
+protected:
+    unsigned int _bvhLeavesCount;
+    rt_bvh* _bvh;
+    SharedPtr<OpenCLUtils::CLBuffer> _primaryContactsArray;
+};
+
+/** the host shading loop of RTFrame (OpenCLRayTracerDemo.cpp:298-316) on the device: colors = float4 per pixel */
+Common::Result shadeBlinnPhong(const OpenCLUtils::CLExecutionContext& context, const Scene& scene, Camera& cam,
+                               const OpenCLUtils::CLBuffer& contacts, unsigned int contactCount,
+                               OpenCLUtils::CLBuffer& colors, Common::Errata& err);
+
+}}  // namespace
+#endif

@@ -651,14 +651,13 @@ def pack_scene(raw: Dict[str, List[str]], models: List[Tuple[List[ObjShape], Lis
                 verts = np.zeros((nv, 4), dtype='<f4')
                 verts[:, :3] = sh.positions.reshape(nv, 3)
                 buf[moff + MESH_HEADER_SIZE: moff + MESH_HEADER_SIZE + nv * VERTEX_SIZE] = verts.tobytes()
-                # min(a,b) = a<b?a:b accumulated in order == numpy min for non-NaN data
-                lo = np.minimum(lo, sh.positions.reshape(nv, 3).min(axis=0))
-                hi = np.maximum(hi, sh.positions.reshape(nv, 3).max(axis=0))
+                lo = _macro_min_fold(lo, sh.positions.reshape(nv, 3))
+                hi = _macro_max_fold(hi, sh.positions.reshape(nv, 3))
             ioff = moff + MESH_HEADER_SIZE + nv * VERTEX_SIZE
             buf[ioff: ioff + ni * INDEX_SIZE] = sh.indices.astype('<u2').tobytes()   # ushort truncation (Scene.cpp:430)
             # hdr->boundingBox = (minBounds,maxBounds); scene bbox = merge(model, scene)   (Scene.cpp:432-434)
-            scene_lo = np.minimum(lo, scene_lo)
-            scene_hi = np.maximum(hi, scene_hi)
+            scene_lo = np.where(lo < scene_lo, lo, scene_lo)       # MIN4(model, scene) = a < b ? a : b
+            scene_hi = np.where(hi > scene_hi, hi, scene_hi)
             moff += msize
         struct.pack_into('<4Q', buf, mbase, model_sizes[mi], len(shapes), model_tris, 0)
         struct.pack_into('<4f', buf, mbase + 32, float(lo[0]), float(lo[1]), float(lo[2]), 0.0)
@@ -669,6 +668,32 @@ def pack_scene(raw: Dict[str, List[str]], models: List[Tuple[List[ObjShape], Lis
     struct.pack_into('<4f', buf, 64, float(scene_lo[0]), float(scene_lo[1]), float(scene_lo[2]), 0.0)
     struct.pack_into('<4f', buf, 80, float(scene_hi[0]), float(scene_hi[1]), float(scene_hi[2]), 0.0)
     return bytes(buf)
+
+
+def _macro_min_fold(acc: np.ndarray, pts: np.ndarray) -> np.ndarray:
+    """acc = min(acc, v) for every vertex in order with min(a,b) = a < b ? a : b (CLPortability.h:147):
+    among equal values (+0 / -0) the LAST one met wins."""
+    out = acc.copy()
+    for k in range(3):
+        col = pts[:, k]
+        m = col.min()
+        if m < out[k] or not (out[k] < m):          # macro takes v whenever !(acc < v)
+            eq = np.nonzero(col == m)[0]
+            cand = col[eq[-1]]
+            # acc survives only if acc < every later value; it equals m only when acc == m came first
+            out[k] = cand if not (out[k] < m) else out[k]
+    return out.astype(np.float32)
+
+
+def _macro_max_fold(acc: np.ndarray, pts: np.ndarray) -> np.ndarray:
+    out = acc.copy()
+    for k in range(3):
+        col = pts[:, k]
+        m = col.max()
+        if not (out[k] > m):
+            eq = np.nonzero(col == m)[0]
+            out[k] = col[eq[-1]]
+    return out.astype(np.float32)
 
 
 def load_scene(scene_path: str, obj_loader=parse_obj) -> bytes:

@@ -87,6 +87,36 @@ def test_scene_file_edge_cases(tmp_path):
     assert h['totalDataSize'] == 96 + 32
 
 
+def _host_tools():
+    import subprocess
+    tool = os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
+    if not os.path.exists(tool):
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'openclraytracer_amd', 'csrc', 'host'),
+                               os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')])
+    return tool
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_cpp_scene_loader_equals_oracle_packer(name, tmp_path):
+    """the PRODUCT's C++ Scene::load packing (SceneLoader.cpp) == the oracle's packer == the committed hash"""
+    import subprocess
+    out = str(tmp_path / 's.bin')
+    subprocess.check_call([_host_tools(), os.path.join('assets', 'scenes', name + '.txt'), out], cwd=ROOT)
+    data = open(out, 'rb').read()
+    assert data == packed_scene(name)
+    assert sha(data) == gold('scenes.json')[name]['sha256']
+
+
+def test_cpp_scene_loader_error_behaviour(tmp_path):
+    import subprocess
+    r = subprocess.run([_host_tools(), str(tmp_path / 'missing.txt'), str(tmp_path / 'o.bin')], capture_output=True, text=True)
+    assert r.returncode == 1 and "couldn't be opened" in r.stderr
+    p = tmp_path / 's.txt'
+    p.write_text('LIGHT 0.0 10.0 -330.0 1000.0\nMESH nowhere/none.obj')
+    r = subprocess.run([_host_tools(), str(p), str(tmp_path / 'o.bin')], capture_output=True, text=True)
+    assert r.returncode == 1 and 'Cannot open file' in r.stderr
+
+
 # ---------------------------------------------------------------- oracle vs fixtures
 def test_struct_sizes_match_reference_probe():
     import oracle as orc

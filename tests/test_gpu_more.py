@@ -187,3 +187,23 @@ def test_rebuild_is_deterministic(gpu_ctx):
     for _ in range(3):
         gb.build()
         assert gb.read_nodes().tobytes() == a
+
+
+def test_cpp_host_mirror_end_to_end(gpu_ctx, tmp_path):
+    """the headless Demo written against the reference's class names (Scene, BVHManager, CLBuffer, Errata):
+    its contacts are the oracle's, bit for bit."""
+    import subprocess
+    osc, ob = oracle_bvh('gardenlight')
+    demo = os.path.join(ROOT, 'apps', 'bin', 'rt_demo')
+    assert os.path.exists(demo), 'apps/bin/rt_demo is not built: run __graft_entry__.build()'
+    raw, ppm = str(tmp_path / 'c.bin'), str(tmp_path / 'o.ppm')
+    r = subprocess.run([demo, '-winH', '120', '-winW', '160', '-accStruct', 'BVH', '-headersPath', 'unused', '-scene',
+                        os.path.join('assets', 'scenes', 'gardenlight.txt'), '--frames', '2', '--contacts', raw, '--out', ppm],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _ = ob.trace_primary(osc.demo_camera(160, 120))
+    assert open(raw, 'rb').read() == want.tobytes()
+    assert open(ppm, 'rb').read().startswith(b'P6\n160 120\n255\n')
+    r = subprocess.run([demo, '-winH', '8', '-winW', '8', '-accStruct', 'GRID', '-headersPath', 'x', '-scene', 'x'],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 1
