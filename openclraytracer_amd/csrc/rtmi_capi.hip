@@ -389,10 +389,11 @@ int rt_bvh_construct(rt_bvh* b)
     b->max_depth = depth;
     b->frame_initialised = false;
     b->built = true;
+    b->marked_valid = false;
     return RT_SUCCESS;
 }
 
-static TraceLaunch make_launch(rt_bvh* b)
+static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 {
     TraceLaunch t{};
     t.trav = b->d_trav; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
@@ -408,6 +409,15 @@ static TraceLaunch make_launch(rt_bvh* b)
         }
     }
     t.compute_units = b->ctx->prop.multiProcessorCount;
+    t.mark_inside = false;
+    if (cam) {
+        const float o[3] = { cam->viewTransform[3], cam->viewTransform[7], cam->viewTransform[11] };
+        if (!b->marked_valid || std::memcmp(o, b->marked_origin, sizeof o) != 0) {
+            t.mark_inside = true;
+            std::memcpy(b->marked_origin, o, sizeof o);
+            b->marked_valid = true;
+        }
+    }
     b->ctx->trace_launched = true;
     return t;
 }
@@ -429,7 +439,7 @@ int rt_bvh_generate_contacts_primary(rt_bvh* b, const rt_camera* cam, void* d_co
     if (check_camera(ctx, cam)) return RT_ERROR;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, 0, 1))) return RT_ERROR;
-    launch_trace_primary(ctx->stream, make_launch(b), *cam, 0, 1, false, (rt_contact*)d_contacts);
+    launch_trace_primary(ctx->stream, make_launch(b, cam), *cam, 0, 1, false, (rt_contact*)d_contacts);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }
@@ -445,7 +455,7 @@ int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
-    launch_trace_primary(ctx->stream, make_launch(b), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
+    launch_trace_primary(ctx->stream, make_launch(b, cam), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }

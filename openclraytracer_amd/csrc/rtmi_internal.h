@@ -96,6 +96,8 @@ struct rt_bvh {
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
     uint32_t max_depth = 0;
+    float marked_origin[3] = { 0, 0, 0 };   // camera position the records' inside bits were computed for
+    bool marked_valid = false;
     bool frame_initialised = false;
     bool built = false;
 };
@@ -137,6 +139,7 @@ struct TraceLaunch {
     uint32_t long_cap;            // records available
     uint32_t defer_budget;        // 0 = default
     hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
+    bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
     int compute_units;
 };
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,

@@ -41,7 +41,8 @@
 #define LDS_STACK 24u            // entries per lane in phase 0 (observed need at 1080p: <= 18)
 #define NO_LEAF 0xFFFFFFFEu
 #define REFILL_MIN_IDLE 16u      // refill a wave once this many lanes are idle
-#define DEFER_BUDGET_DEFAULT 768u   // phase-0 iterations after which a ray moves to the long-ray list
+#define DEFER_BUDGET_DEFAULT 1024u  // phase-0 iterations after which a ray moves to the long-ray list (untuned default)
+#define STRAGGLER_BUDGET 96u     // smallest deferral budget of a nearly empty wave once the primary work is gone
 #define LONG_REC_WORDS 32u       // 128-byte record per deferred ray
 #define POOL_INNER 2048u         // phase-1 LDS pool of pending inner nodes (per wave)
 #define POOL_LEAF 256u           // phase-1 LDS pool of pending leaves (per wave)
@@ -52,12 +53,13 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 uint32_t trace_lds_stack_entries() { return LDS_STACK; }
 
 // control block, zeroed before every launch; every word on its own 128-byte line
+#define WORK_SHARDS 16u
 struct TraceCtrl {
-    uint32_t next_block;  uint32_t p0[31];   // dynamic part of the primary work: next 64-ray block
+    struct { uint32_t next; uint32_t pad[31]; } shard[WORK_SHARDS];   // dynamic primary work: next 64-ray block per shard
     uint32_t long_count;  uint32_t p1[31];   // deferred rays
     uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
 };
-static_assert(sizeof(TraceCtrl) == 3 * 128, "TraceCtrl layout");
+static_assert(sizeof(TraceCtrl) == (WORK_SHARDS + 2) * 128, "TraceCtrl layout");
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
 size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
@@ -99,8 +101,11 @@ struct RayState {
 // one child of an inner node: AABBIntersect (AABB.h:126-142) folded with the validity rule of
 // BVH.h:368-369.  `tmin*flag > 0` <=> `flag && tmin > 0` (x*1.0f == x; x*0.0f is +-0 or NaN).
 // Branch free on purpose (bit-wise & and |): both children are always evaluated.
+// Primary rays share one origin (the camera position), so "origin inside the box" does not depend on the ray:
+// k_mark_inside evaluates it once per node and camera position and the primary kernels read the bit.
+template <int PRIMARY>
 __device__ __forceinline__ bool child_valid(float lox, float loy, float loz, float hix, float hiy, float hiz,
-                                            const RayState& r, bool sx, bool sy, bool sz)
+                                            const RayState& r, bool sx, bool sy, bool sz, bool inside_marked)
 {
     float tmin  = ((sx ? hix : lox) - r.o.x) * r.inv.x;
     float tmax  = ((sx ? lox : hix) - r.o.x) * r.inv.x;
@@ -113,8 +118,20 @@ __device__ __forceinline__ bool child_valid(float lox, float loy, float loz, flo
     float tzmax = ((sz ? loz : hiz) - r.o.z) * r.inv.z;
     flag = flag & !((tmin > tzmax) | (tzmin > tmax));
     tmin = RMAX(tmin, tzmin);
-    bool inside = (lox <= r.o.x) & (r.o.x <= hix) & (loy <= r.o.y) & (r.o.y <= hiy) & (loz <= r.o.z) & (r.o.z <= hiz);
+    bool inside = PRIMARY ? inside_marked
+                          : ((lox <= r.o.x) & (r.o.x <= hix) & (loy <= r.o.y) & (r.o.y <= hiy) & (loz <= r.o.z) & (r.o.z <= hiz));
     return (flag & (tmin > 0.0f)) | inside;
+}
+
+// isPointInside (AABB.h:178-184) of the camera position for both children of every inner record; bits 0 / 1 of pad0
+__global__ __launch_bounds__(256) void k_mark_inside(TravNode* trav, uint32_t n_inner, float ox, float oy, float oz)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    const TravNode t = trav[i];
+    bool ia = (t.a_lo[0] <= ox) & (ox <= t.a_hi[0]) & (t.a_lo[1] <= oy) & (oy <= t.a_hi[1]) & (t.a_lo[2] <= oz) & (oz <= t.a_hi[2]);
+    bool ib = (t.b_lo[0] <= ox) & (ox <= t.b_hi[0]) & (t.b_lo[1] <= oy) & (oy <= t.b_hi[1]) & (t.b_lo[2] <= oz) & (oz <= t.b_hi[2]);
+    trav[i].pad0 = (ia ? 1u : 0u) | (ib ? 2u : 0u);
 }
 
 // triangleIntersect, Triangle.h:66-107, against precomputed edges; keeps the lexicographic min of
@@ -215,7 +232,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t (*stack)[64] = s_stack[wave];
     const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
-    gu32* next_block = (gu32*)&a.ctrl->next_block;
     gu32* long_count = (gu32*)&a.ctrl->long_count;
     gu32* error_word = (gu32*)&a.ctrl->error;
 
@@ -233,6 +249,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
     const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;          // 8x8 blocks (or 64-ray chunks)
     uint32_t res_next = wave_gid << 6, res_end = res_next + 64u;   // reserved work items [res_next, res_end)
     bool exhausted = wave_gid >= n_blocks8;                        // wave-uniform: no primary work left
+    uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;     // wave-uniform: position in the shard walk
+    uint32_t drain_budget = a.defer_budget;                        // wave-uniform: current deferral budget
 
     for (;;) {
         // ---------------- refill idle lanes (wavefront ballot / compaction) ----------------
@@ -240,12 +258,24 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
             uint64_t idle = __ballot(!active);
             uint32_t n_idle = (uint32_t)__popcll(idle);
             if (n_idle >= REFILL_MIN_IDLE) {
-                if (res_next == res_end) {
-                    uint32_t blk = 0;
-                    if (lane == 0) blk = a.n_waves + __hip_atomic_fetch_add(next_block, 1u, RLX_AGENT);
-                    blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
-                    if (blk >= n_blocks8) exhausted = true;
-                    else { res_next = blk << 6; res_end = res_next + 64u; }
+                while (res_next == res_end && !exhausted) {
+                    // dynamic blocks [n_waves, n_blocks8) are cut into WORK_SHARDS contiguous shards, each with its
+                    // own counter line (one word saturates near 88 atomics/us: 26 k atomics were the whole frame time
+                    // of the easy scenes); a wave drains its home shard first and then walks the others
+                    uint32_t dyn = n_blocks8 > a.n_waves ? n_blocks8 - a.n_waves : 0u;
+                    uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
+                    uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
+                    uint32_t got = 0xFFFFFFFFu;
+                    if (lo < hi) {
+                        if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->shard[shard].next, 1u, RLX_AGENT);
+                        got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                    }
+                    if (lo < hi && got < hi - lo) {
+                        res_next = (a.n_waves + lo + got) << 6; res_end = res_next + 64u;
+                    } else {
+                        shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u;
+                        if (++shards_tried >= WORK_SHARDS) exhausted = true;
+                    }
                 }
                 if (!exhausted) {
                     uint32_t w = res_next + lane_rank(idle);
@@ -283,8 +313,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
                     const float4* p = reinterpret_cast<const float4*>(a.trav + cur);
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     uint32_t ca = __float_as_uint(q0.w), cb = __float_as_uint(q1.w);
-                    bool aValid = child_valid(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz);
-                    bool bValid = child_valid(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz);
+                    const uint32_t marks = __float_as_uint(q2.w);
+                    bool aValid = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                    bool bValid = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
                     if (aValid & bValid) {
                         cur = ca;
                         if (sp < LDS_STACK) { stack[sp][lane] = cb; sp++; } else extra = cb;
@@ -308,7 +339,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
 
             // ---- defer long rays to phase 1 (budget exceeded, or stack full) ----
             bool want_defer = active && cur != RT_SENTINEL &&
-                              (extra != RT_SENTINEL || (may_defer && iters >= a.defer_budget));
+                              (extra != RT_SENTINEL || (may_defer && iters >= drain_budget));
             uint64_t deferring = __ballot(want_defer);
             if (deferring != 0ull) {
                 uint32_t base = 0;
@@ -340,6 +371,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
             uint32_t n_active = (uint32_t)__popcll(__ballot(active));
             if (n_active == 0u) break;
             if (!exhausted && n_active <= 64u - REFILL_MIN_IDLE) break;
+            if (exhausted) {
+                // nothing left to refill with: the emptier the wave, the less a lane-per-ray step is worth, so the
+                // budget shrinks with the number of busy lanes and stragglers move to the wave-per-ray phase early
+                uint32_t b = (a.defer_budget * n_active) >> 6;
+                drain_budget = b < STRAGGLER_BUDGET ? STRAGGLER_BUDGET : b;
+            }
         }
     }
 }
@@ -410,8 +447,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
                 const float4* p = reinterpret_cast<const float4*>(a.trav + node);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 ca = __float_as_uint(q0.w); cb = __float_as_uint(q1.w);
-                bool aValid = child_valid(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz);
-                bool bValid = child_valid(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz);
+                const uint32_t marks = __float_as_uint(q2.w);
+                bool aValid = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                bool bValid = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
                 aIn = aValid & ((ca & RT_LEAF_FLAG) == 0u); aLf = aValid & ((ca & RT_LEAF_FLAG) != 0u);
                 bIn = bValid & ((cb & RT_LEAF_FLAG) == 0u); bLf = bValid & ((cb & RT_LEAF_FLAG) != 0u);
             }
@@ -504,6 +542,9 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.total_work = rt_owned_tiles(total_tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.rays = nullptr;
     a.out = out;
+    if (t.mark_inside && t.n_leaves > 1)
+        hipLaunchKernelGGL(k_mark_inside, dim3((t.n_leaves - 1 + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
+                           t.n_leaves - 1, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11]);
     launch<1>(s, t, a);
 }
 
