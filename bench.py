@@ -184,7 +184,8 @@ def main():
                                      mrays_per_s=round(it['slots'] / ms / 1e3, 1),
                                      inner_visits_per_ray=round(fx['inner_visits'] / fx['rays'], 2),
                                      leaf_tests_per_ray=round(fx['leaf_tests'] / fx['rays'], 2),
-                                     algorithmic_bytes=alg, build_ms=round(build_ms[it['name']], 3))
+                                     algorithmic_bytes=alg, build_ms=round(build_ms[it['name']], 3),
+                                     defer_budget=it['bvh'].trace_budget())
     ctx.set_profiling(False)
     tm.close()
 

@@ -390,6 +390,7 @@ int rt_bvh_construct(rt_bvh* b)
     b->frame_initialised = false;
     b->built = true;
     b->marked_valid = false;
+    b->tuned = false;
     return RT_SUCCESS;
 }
 
@@ -422,6 +423,42 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     return t;
 }
 
+// Primary frames: which deferral budget is best depends on the scene (a few very long rays: small budget; many
+// moderately long rays: no deferral), and every budget produces the same contacts.  The first frame of a
+// (BVH, resolution, tiling) combination therefore runs once per candidate, timed with HIP events on the stream,
+// and later frames use the fastest.  RTMI_DEFER_BUDGET fixes the budget and switches the calibration off.
+static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out)
+{
+    rt_ctx* ctx = b->ctx;
+    const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
+    if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key)) {
+        static const uint32_t candidates[] = { 256u, 512u, 1024u, 2048u, 1u << 20 };
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        RT_HIP(ctx, hipEventCreate(&e0));
+        RT_HIP(ctx, hipEventCreate(&e1));
+        float best_ms = 0.f; uint32_t best = 0;
+        for (uint32_t cand : candidates) {
+            TraceLaunch t = make_launch(b, cam);
+            t.defer_budget = cand;
+            (void)hipEventRecord(e0, ctx->stream);
+            launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
+            (void)hipEventRecord(e1, ctx->stream);
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best = 0; break; }
+            if (best == 0 || ms < best_ms) { best = cand; best_ms = ms; }
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        b->tuned = true; b->tuned_key = key; b->tuned_budget = best;
+        RT_HIP(ctx, hipGetLastError());
+        return RT_SUCCESS;                      // the last candidate's launch already produced the frame
+    }
+    TraceLaunch t = make_launch(b, cam);
+    if (ctx->defer_budget == 0 && b->tuned) t.defer_budget = b->tuned_budget;
+    launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
 static int check_camera(rt_ctx* ctx, const rt_camera* cam)
 {
     if (!cam) return RT_FAIL(ctx, "camera is null");
@@ -439,9 +476,7 @@ int rt_bvh_generate_contacts_primary(rt_bvh* b, const rt_camera* cam, void* d_co
     if (check_camera(ctx, cam)) return RT_ERROR;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, 0, 1))) return RT_ERROR;
-    launch_trace_primary(ctx->stream, make_launch(b, cam), *cam, 0, 1, false, (rt_contact*)d_contacts);
-    RT_HIP(ctx, hipGetLastError());
-    return RT_SUCCESS;
+    return trace_primary_tuned(b, cam, 0, 1, false, (rt_contact*)d_contacts);
 }
 
 int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks,
@@ -455,9 +490,7 @@ int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
-    launch_trace_primary(ctx->stream, make_launch(b, cam), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
-    RT_HIP(ctx, hipGetLastError());
-    return RT_SUCCESS;
+    return trace_primary_tuned(b, cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
 }
 
 int rt_bvh_generate_contacts_rays(rt_bvh* b, const void* d_rays, uint32_t ray_count, void* d_contacts)
@@ -488,6 +521,13 @@ int rt_bvh_read_morton_pairs(const rt_bvh* b, void* h_pairs, uint32_t* n_pow2)
     if (n_pow2) *n_pow2 = b->N;
     if (!h_pairs) return RT_SUCCESS;
     return rt_buf_download(b->ctx, h_pairs, b->d_pairs, (uint64_t)b->N * sizeof(uint2));
+}
+
+int rt_bvh_trace_budget(const rt_bvh* b, uint32_t* budget)
+{
+    if (!b || !budget) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
+    *budget = b->ctx->defer_budget ? b->ctx->defer_budget : (b->tuned ? b->tuned_budget : 0u);
+    return RT_SUCCESS;
 }
 
 int rt_bvh_info(const rt_bvh* b, uint32_t* leaves, uint32_t* morton_items, uint32_t* max_depth)

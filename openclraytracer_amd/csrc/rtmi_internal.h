@@ -98,6 +98,9 @@ struct rt_bvh {
     uint32_t max_depth = 0;
     float marked_origin[3] = { 0, 0, 0 };   // camera position the records' inside bits were computed for
     bool marked_valid = false;
+    bool tuned = false;                     // deferral budget calibrated for tuned_key
+    uint64_t tuned_key = 0;
+    uint32_t tuned_budget = 0;
     bool frame_initialised = false;
     bool built = false;
 };
