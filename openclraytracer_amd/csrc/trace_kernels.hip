@@ -56,10 +56,11 @@ uint32_t trace_lds_stack_entries() { return LDS_STACK; }
 #define WORK_SHARDS 16u
 struct TraceCtrl {
     struct { uint32_t next; uint32_t pad[31]; } shard[WORK_SHARDS];   // dynamic primary work: next 64-ray block per shard
+    struct { uint32_t next; uint32_t pad[31]; } lshard[WORK_SHARDS];  // phase 1: next deferred ray per shard
     uint32_t long_count;  uint32_t p1[31];   // deferred rays
     uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
 };
-static_assert(sizeof(TraceCtrl) == (WORK_SHARDS + 2) * 128, "TraceCtrl layout");
+static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 2) * 128, "TraceCtrl layout");
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
 size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
@@ -398,7 +399,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
     uint32_t count = a.ctrl->long_count;                  // written by the previous kernel
     if (count > a.long_cap) count = a.long_cap;
 
-    for (uint32_t i = wave_gid; i < count; i += a.n_waves) {
+    // deferred rays differ in length by an order of magnitude: the first task of a wave is static (its own index),
+    // further tasks are pulled from sharded counters, as in phase 0
+    uint32_t i = wave_gid;
+    uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
+    for (;;) {
+        if (i >= count) break;
         const uint32_t* rec = a.long_list + (uint64_t)i * LONG_REC_WORDS;
         // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
         uint32_t work = rec[LR_WORK], rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
@@ -482,6 +488,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             float t = leaf != NO_LEAF ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
             store_contact(a, r.out_index, r.pixel, t, leaf);
         }
+        // next task
+        i = 0xFFFFFFFFu;
+        uint32_t dyn = count > a.n_waves ? count - a.n_waves : 0u;
+        uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
+        while (i == 0xFFFFFFFFu && shards_tried < WORK_SHARDS) {
+            uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
+            uint32_t got = 0xFFFFFFFFu;
+            if (lo < hi) {
+                if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->lshard[shard].next, 1u, RLX_AGENT);
+                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            }
+            if (lo < hi && got < hi - lo) i = a.n_waves + lo + got;
+            else { shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u; shards_tried++; }
+        }
+        if (i == 0xFFFFFFFFu) break;
     }
 }
 
