@@ -297,3 +297,23 @@ def test_tile_slot_map_is_a_bijection():
             assert len(set(s.tolist())) == s.size
             seen.update((r, int(x)) for x in s)
         assert len(seen) == w * h
+
+
+def test_synthetic_scene_loaders_agree(tmp_path):
+    """Bunny-class stand-in (quads, 'o' groups, 35 k vertices in one shape): C++ loader == Python packer."""
+    import subprocess
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, 'assets', 'synth'))
+    import gen_scenes
+    import scene_pack
+    txt = gen_scenes.ensure()['synth_bunny']
+    out = str(tmp_path / 'b.bin')
+    subprocess.check_call([_host_tools(), os.path.relpath(txt, ROOT), out], cwd=ROOT)
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        want = scene_pack.load_scene(txt)
+    finally:
+        os.chdir(cwd)
+    assert open(out, 'rb').read() == want
+    assert scene_pack.scene_header(want)['totalNumberOfTriangles'] == 69564
