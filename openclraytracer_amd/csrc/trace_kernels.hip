@@ -46,6 +46,7 @@
 #define LONG_REC_WORDS 32u       // 128-byte record per deferred ray
 #define POOL_INNER 2048u         // phase-1 LDS pool of pending inner nodes (per wave)
 #define POOL_LEAF 256u           // phase-1 LDS pool of pending leaves (per wave)
+#define SPEC_THRESHOLD 16u       // phase 1: with fewer pending inner nodes than this the wave speculates along a chain
 
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -81,6 +82,7 @@ struct TraceArgs {
     uint32_t defer_budget;
     uint32_t total_work;                   // work items (multiple of 4096 for primary frames)
     uint32_t n_waves;                      // waves in the grid
+    uint32_t n_records;                    // inner records (leaves - 1)
     // primary rays
     rt_camera cam;
     uint32_t rank, nranks, tiles_x;
@@ -444,20 +446,42 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             // whose growth is bounded by the tree depth
             uint32_t k = n_inner < 64u ? n_inner : 64u;
             if (n_inner > POOL_INNER - 192u) k = 1u;
-            bool mine = lane < k;
-            uint32_t node = mine ? inner[n_inner - 1u - lane] : 0u;
+            // Spare lanes (pool thinner than the wave) run AHEAD along the chain below the top node.  Duplicate Morton codes make
+            // the radix tree a chain there (node i: child A = a leaf, child B = node i+1, BVH.h:138-160,190-215), and
+            // consecutive chain nodes are consecutive records.  Lane j speculatively tests record top+j; it counts
+            // only if every record before it is valid-B and links to its successor (prefix AND through a ballot),
+            // so exactly the reached nodes contribute -- up to 64 chain nodes per step instead of one.
+            // lanes 0..k-1 take the k popped nodes (lane 0 the top one); lanes k..63 run ahead along the chain below
+            // the top node: lane k+j-1 speculatively takes record top+j
+            const uint32_t top = inner[n_inner - 1u];
+            const bool spec_lane = lane >= k;
+            const uint32_t seq_j = spec_lane ? lane - k + 1u : 0u;          // position in the sequence top, top+1, ...
+            uint32_t node = spec_lane ? top + seq_j : inner[n_inner - 1u - (lane < k ? lane : 0u)];
+            bool mine = spec_lane ? node < a.n_records : true;
             n_inner -= k;
             bool aIn = false, aLf = false, bIn = false, bLf = false;
             uint32_t ca = 0, cb = 0;
+            bool bValid = false;
             if (mine) {
                 const float4* p = reinterpret_cast<const float4*>(a.trav + node);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 ca = __float_as_uint(q0.w); cb = __float_as_uint(q1.w);
                 const uint32_t marks = __float_as_uint(q2.w);
                 bool aValid = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
-                bool bValid = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
+                bValid = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
                 aIn = aValid & ((ca & RT_LEAF_FLAG) == 0u); aLf = aValid & ((ca & RT_LEAF_FLAG) != 0u);
                 bIn = bValid & ((cb & RT_LEAF_FLAG) == 0u); bLf = bValid & ((cb & RT_LEAF_FLAG) != 0u);
+            }
+            {
+                // link: this record hands over to the next record (valid child B that is the consecutive inner record)
+                uint64_t lk = __ballot(mine && bValid && cb == node + 1u);
+                uint64_t seq = (lk & 1ull) | (k < 64u ? ((lk >> k) << 1) : 0ull);          // links in sequence order
+                uint32_t reached = (uint32_t)__ffsll((unsigned long long)~seq);           // reached sequence elements
+                if (reached == 0u || reached > 65u - k) reached = 65u - k;
+                bool in_prefix = !spec_lane || seq_j < reached;
+                bool emits_b = spec_lane ? (seq_j + 1u == reached) : (lane == 0u ? reached == 1u : true);
+                aIn = aIn & in_prefix; aLf = aLf & in_prefix;
+                bIn = bIn & in_prefix & emits_b; bLf = bLf & in_prefix & emits_b;         // the chain's B child is emitted once, by its last reached node
             }
             uint64_t mai = __ballot(aIn), mbi = __ballot(bIn), mal = __ballot(aLf), mbl = __ballot(bLf);
             uint32_t nai = (uint32_t)__popcll(mai), nbi = (uint32_t)__popcll(mbi);
@@ -547,6 +571,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.pos = t.pos;
     a.ctrl = (TraceCtrl*)t.ctrl;
     a.long_list = t.long_list; a.long_cap = t.long_cap;
+    a.n_records = t.n_leaves - 1u;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
 

@@ -1,0 +1,31 @@
+"""Timing of BASELINE.json configs 3 and 5 (synthetic stand-ins) on one GPU: trace ms per frame, Mrays/s."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'assets', 'synth'))
+import numpy as np
+import gen_scenes
+from openclraytracer_amd import capi
+sys.path.insert(0, ROOT)
+import bench
+ctx = capi.Context(0)
+out = {}
+for name, res in [('synth_bunny', (1920, 1080)), ('synth_atrium', (1920, 1080)), ('synth_atrium', (3840, 2160))]:
+    txt = gen_scenes.ensure()[name]
+    tmp = '/tmp/_%s.bin' % name
+    subprocess.check_call([os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool'), os.path.relpath(txt, ROOT), tmp], cwd=ROOT)
+    buf = open(tmp, 'rb').read()
+    sc = capi.DeviceScene(ctx, buf); bvh = capi.DeviceBVH(ctx, sc).build()
+    cam = bench.demo_camera(buf, *res)
+    npx = res[0] * res[1]
+    dc, dr = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+    bvh.generate_contacts_primary_d(cam, dc); ctx.synchronize()      # calibrates
+    tm = capi.Timer(ctx); K = 5
+    tm.start()
+    for _ in range(K):
+        bvh.generate_contacts_primary_d(cam, dc)
+        capi.shade_blinn_phong_d(ctx, sc, cam, dc, npx, dr)
+    tm.stop(); ms = tm.elapsed_ms() / K
+    out['%s_%dx%d' % (name, res[0], res[1])] = dict(ms_per_frame=round(ms, 3), mrays_per_s=round(npx / ms / 1e3, 1),
+                                                     triangles=sc.n_tris, depth=bvh.info()['max_depth'], budget=bvh.trace_budget())
+    ctx.free(dc); ctx.free(dr); bvh.close(); sc.close()
+print(json.dumps(out, indent=1))
