@@ -320,8 +320,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
                     bool aValid = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
                     bool bValid = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
                     if (aValid & bValid) {
-                        cur = ca;
-                        if (sp < LDS_STACK) { stack[sp][lane] = cb; sp++; } else extra = cb;
+                        const bool a_leaf = (ca & RT_LEAF_FLAG) != 0u, b_leaf = (cb & RT_LEAF_FLAG) != 0u;
+                        if (pending == NO_LEAF && (a_leaf | b_leaf)) {
+                            // one child is a leaf and the parking slot is free: park it right away and walk on with the
+                            // other child -- no stack round trip (the common step along a duplicate-code chain)
+                            pending = (a_leaf ? ca : cb) & ~RT_LEAF_FLAG;
+                            cur = a_leaf ? cb : ca;
+                        } else {
+                            cur = ca;
+                            if (sp < LDS_STACK) { stack[sp][lane] = cb; sp++; } else extra = cb;
+                        }
                     } else if (aValid | bValid) cur = aValid ? ca : cb;
                     else if (sp == 0) cur = RT_SENTINEL;
                     else { sp--; cur = stack[sp][lane]; }
