@@ -228,7 +228,7 @@ __device__ __forceinline__ void store_contact(const TraceArgs& a, uint32_t out_i
 // phase 0: one ray per lane
 // ------------------------------------------------------------------------------------------------
 template <int PRIMARY>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
 {
     __shared__ uint32_t s_stack[TRACE_WAVES][LDS_STACK][64];
     const uint32_t lane = threadIdx.x & 63u;

@@ -15,6 +15,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 benc
 echo "write done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1 || exit 1
 echo "sq done"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc_tcc -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_tcc.log 2>&1 || echo "tcc pass failed"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_tcc.log 2>&1 || echo "tcc pass failed"
 echo "tcc done"
 find $OUT -name "*.csv" | head -30
