@@ -87,6 +87,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     }
     ctx->stream = ctx->own_stream;
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1'; ctx->no_packet = env[0] == '0'; }
     *out = ctx;
     return RT_SUCCESS;
 }
@@ -327,6 +328,8 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_trav) hipFree(b->d_trav);
     if (b->d_depth) hipFree(b->d_depth);
     if (b->d_pos) hipFree(b->d_pos);
+    if (b->d_packet_spill) hipFree(b->d_packet_spill);
+    b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
     b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
     b->d_depth = nullptr; b->d_pos = nullptr;
 }
@@ -387,6 +390,15 @@ int rt_bvh_construct(rt_bvh* b)
     RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
     b->max_depth = depth;
+    {   // packet kernel: (node, lane mask) stack entries beyond the LDS part live in a per-wave global area
+        uint32_t need = depth + 8u > trace_packet_stack_entries() ? depth + 8u - trace_packet_stack_entries() : 0u;
+        if (need != b->packet_spill_entries) {
+            if (b->d_packet_spill) { (void)hipFree(b->d_packet_spill); b->d_packet_spill = nullptr; }
+            b->packet_spill_entries = need;
+            b->packet_max_blocks = trace_packet_max_blocks(ctx->prop.multiProcessorCount);
+            if (need) RT_HIP(ctx, hipMalloc((void**)&b->d_packet_spill, (size_t)b->packet_max_blocks * 4u * need * 3u * sizeof(uint32_t)));
+        }
+    }
     b->frame_initialised = false;
     b->built = true;
     b->marked_valid = false;
@@ -400,6 +412,8 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.trav = b->d_trav; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
+    t.packet = false;
+    t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_max_blocks = b->packet_max_blocks;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
     if (b->ctx->profiling) {
         for (int k = 0; k < 3; k++) {
@@ -431,29 +445,33 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
 {
     rt_ctx* ctx = b->ctx;
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
-    if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key)) {
-        static const uint32_t candidates[] = { 256u, 512u, 1024u, 2048u, 1u << 20 };
+    if (ctx->defer_budget == 0 && !ctx->force_packet && (!b->tuned || b->tuned_key != key)) {
+        // candidate 0 = the packet kernel, the others = deferral budgets of the lane-per-ray / wave-per-ray pair
+        static const uint32_t candidates[] = { 0u, 256u, 512u, 1024u, 2048u, 1u << 20 };
         hipEvent_t e0 = nullptr, e1 = nullptr;
         RT_HIP(ctx, hipEventCreate(&e0));
         RT_HIP(ctx, hipEventCreate(&e1));
-        float best_ms = 0.f; uint32_t best = 0;
+        float best_ms = 0.f; uint32_t best = 1024u; bool have = false;
         for (uint32_t cand : candidates) {
+            if (cand == 0u && ctx->no_packet) continue;
             TraceLaunch t = make_launch(b, cam);
+            t.packet = cand == 0u;
             t.defer_budget = cand;
             (void)hipEventRecord(e0, ctx->stream);
             launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
             (void)hipEventRecord(e1, ctx->stream);
             float ms = 0.f;
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best = 0; break; }
-            if (best == 0 || ms < best_ms) { best = cand; best_ms = ms; }
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { have = false; break; }
+            if (!have || ms < best_ms) { best = cand; best_ms = ms; have = true; }
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        b->tuned = true; b->tuned_key = key; b->tuned_budget = best;
+        b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best == 0u;
         RT_HIP(ctx, hipGetLastError());
         return RT_SUCCESS;                      // the last candidate's launch already produced the frame
     }
     TraceLaunch t = make_launch(b, cam);
-    if (ctx->defer_budget == 0 && b->tuned) t.defer_budget = b->tuned_budget;
+    if (ctx->defer_budget == 0 && b->tuned) { t.defer_budget = b->tuned_budget; t.packet = b->tuned_packet; }
+    if (ctx->force_packet) t.packet = true;
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;

@@ -71,6 +71,7 @@ struct rt_ctx {
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
     bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
+    bool force_packet = false, no_packet = false;   // tuning knobs (env RTMI_PACKET=1 / 0)
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
 };
 
@@ -95,12 +96,16 @@ struct rt_bvh {
     TravNode* d_trav = nullptr;        // n-1 traversal records
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
+    uint32_t* d_packet_spill = nullptr;   // packet kernel: stack overflow area, sized from the tree depth
+    uint32_t packet_spill_entries = 0;
+    uint32_t packet_max_blocks = 0;
     uint32_t max_depth = 0;
     float marked_origin[3] = { 0, 0, 0 };   // camera position the records' inside bits were computed for
     bool marked_valid = false;
     bool tuned = false;                     // deferral budget calibrated for tuned_key
     uint64_t tuned_key = 0;
-    uint32_t tuned_budget = 0;
+    uint32_t tuned_budget = 0;              // 0 = packet kernel, else deferral budget of the two-phase kernels
+    bool tuned_packet = false;
     bool frame_initialised = false;
     bool built = false;
 };
@@ -143,6 +148,10 @@ struct TraceLaunch {
     uint32_t defer_budget;        // 0 = default
     hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
     bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
+    bool packet;                  // primary rays: packet kernel (one 8x8 block per wave) instead of the two-phase kernels
+    uint32_t* packet_spill;       // per-wave overflow area of the packet stack (null when the tree is shallow)
+    uint32_t packet_spill_entries;
+    uint32_t packet_max_blocks;   // grid the spill area was sized for
     int compute_units;
 };
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
@@ -151,6 +160,8 @@ void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, 
 size_t trace_ctrl_bytes();
 size_t trace_ctrl_error_offset();
 size_t trace_long_record_bytes();
+uint32_t trace_packet_stack_entries();
+uint32_t trace_packet_max_blocks(int compute_units);
 uint32_t trace_lds_stack_entries();
 // shade_kernels.hip
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,

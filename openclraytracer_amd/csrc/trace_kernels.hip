@@ -83,6 +83,8 @@ struct TraceArgs {
     uint32_t total_work;                   // work items (multiple of 4096 for primary frames)
     uint32_t n_waves;                      // waves in the grid
     uint32_t n_records;                    // inner records (leaves - 1)
+    uint32_t* packet_spill;                // packet kernel: per-wave overflow of the (node, mask) stack
+    uint32_t packet_spill_entries;
     // primary rays
     rt_camera cam;
     uint32_t rank, nranks, tiles_x;
@@ -392,6 +394,141 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// packet traversal: one 8x8-pixel block of primary rays per wave, ONE node at a time for all 64 rays
+// ------------------------------------------------------------------------------------------------
+// The lane-per-ray kernel is bound by the vector memory pipe: every lane gathers its own 64-byte record
+// (measured ~190 address-processing cycles per wave step and CU, insensitive to occupancy; HBM idle).
+// Neighbouring primary rays reach almost the same nodes, only at different times.  Here the wave walks the
+// tree ONCE for its 64 rays: the node is wave-uniform, so its record comes through the SCALAR cache into
+// SGPRs (no vector-memory traffic at all) and each lane only evaluates its own ray against it.  A lane takes
+// part in a node iff its own ray found every ancestor valid (per-lane `in` flag; the DFS stack holds
+// (node, lane mask) pairs), so every ray still sees exactly the leaves the reference's walk reaches and keeps
+// the lexicographic (t, position) minimum: the contacts are bit-identical.
+typedef const __attribute__((address_space(4))) float cf4;        // constant address space: uniform loads become s_load
+typedef const __attribute__((address_space(4))) uint32_t cu32;
+__device__ __forceinline__ cf4* as_const(const void* p) { return (cf4*)(unsigned long long)p; }
+__device__ __forceinline__ float4 ld_const4(const void* p) { cf4* f = as_const(p); return make_float4(f[0], f[1], f[2], f[3]); }
+#define PACKET_STACK 96u
+
+__device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t leaf, RayState& r)
+{
+    float4 v0 = ld_const4(a.v0 + leaf), E1 = ld_const4(a.e1 + leaf), E2 = ld_const4(a.e2 + leaf);
+    f3 vert0 = f3_from4(v0), edge1 = f3_from4(E1), edge2 = f3_from4(E2);
+    f3 pvec = f3_cross(r.d, edge2);
+    float det = f3_dot(edge1, pvec);
+    bool flag = fabsf(det) >= FLT_EPSILON;
+    float inv_det = 1.0f / det;
+    f3 tvec = f3_sub(r.o, vert0);
+    float u = f3_dot(tvec, pvec) * inv_det;
+    flag = flag & (u < 1.0f);
+    flag = flag & (u >= 0.0f);
+    f3 qvec = f3_cross(tvec, edge1);
+    float v = f3_dot(r.d, qvec) * inv_det;
+    flag = flag & ((u + v) <= 1.0f);
+    flag = flag & (v >= 0.0f);
+    float t = f3_dot(edge2, qvec) * inv_det;
+    if (flag & (t > 0.0f)) {
+        if (t < r.best_t) { r.best_t = t; r.best_leaf = leaf; }
+        else if (t == r.best_t && r.best_leaf != NO_LEAF && a.pos[leaf] < a.pos[r.best_leaf]) r.best_leaf = leaf;
+    }
+}
+
+template <int PRIMARY>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
+{
+    __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
+    __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
+    __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
+    uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
+    // deep stacks spill to a per-wave global area (3 words per entry)
+    uint32_t* spill = a.packet_spill ? a.packet_spill + (uint64_t)wave_gid * a.packet_spill_entries * 3u : nullptr;
+
+    const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;
+    uint32_t blk = wave_gid;
+    uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
+    for (;;) {
+        if (blk >= n_blocks8) break;
+        const uint32_t w = (blk << 6) + lane;
+        RayState r;
+        bool sx = false, sy = false, sz = false;
+        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+        r.work = w; r.out_index = 0; r.pixel = 0;
+        bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
+        if (PRIMARY && a.compact && !ok && w < a.total_work) {
+            uint32_t x, y, slot;
+            work_to_pixel(a, w, x, y, slot);
+            float4* o = reinterpret_cast<float4*>(a.out + slot);
+            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        bool in = ok;
+        uint32_t sp = 0;
+        uint32_t node = 0;                               // wave-uniform: root record
+        bool walking = __ballot(in) != 0ull;
+        while (walking) {
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+            const float4* p = reinterpret_cast<const float4*>(a.trav + un);
+            const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
+            const uint32_t ca = __float_as_uint(q0.w), cb = __float_as_uint(q1.w);
+            const uint32_t marks = __float_as_uint(q2.w);
+            bool aV = false, bV = false;
+            if (in) {
+                aV = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                bV = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
+            }
+            uint64_t mA = __ballot(aV), mB = __ballot(bV);
+            if ((ca & RT_LEAF_FLAG) != 0u) { if (mA != 0ull) { if (aV) leaf_test_uniform(a, ca & ~RT_LEAF_FLAG, r); } mA = 0ull; }
+            if ((cb & RT_LEAF_FLAG) != 0u) { if (mB != 0ull) { if (bV) leaf_test_uniform(a, cb & ~RT_LEAF_FLAG, r); } mB = 0ull; }
+            if (mA != 0ull && mB != 0ull) {
+                // both inner children wanted: B waits on the stack with the lanes that want it
+                if (sp < PACKET_STACK) {
+                    if (lane == 0) { st_node[sp] = cb; st_lo[sp] = (uint32_t)mB; st_hi[sp] = (uint32_t)(mB >> 32); }
+                } else if (spill && sp - PACKET_STACK < a.packet_spill_entries) {
+                    if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = cb; e[1] = (uint32_t)mB; e[2] = (uint32_t)(mB >> 32); }
+                } else {
+                    if (lane == 0) __hip_atomic_store((gu32*)&a.ctrl->error, 3u, RLX_AGENT);     // frame invalid
+                }
+                sp++;
+                node = ca; in = aV;
+            } else if (mA != 0ull) { node = ca; in = aV; }
+            else if (mB != 0ull) { node = cb; in = bV; }
+            else {
+                if (sp == 0u) { walking = false; }
+                else {
+                    sp--;
+                    uint32_t nn, lo, hi;
+                    if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
+                    else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                    node = nn;
+                    in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+                }
+            }
+        }
+        if (ok) store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
+
+        // next block: dynamic, sharded (as in k_trace)
+        blk = 0xFFFFFFFFu;
+        uint32_t dyn = n_blocks8 > a.n_waves ? n_blocks8 - a.n_waves : 0u;
+        uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
+        while (blk == 0xFFFFFFFFu && shards_tried < WORK_SHARDS) {
+            uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
+            uint32_t got = 0xFFFFFFFFu;
+            if (lo < hi) {
+                if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->shard[shard].next, 1u, RLX_AGENT);
+                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            }
+            if (lo < hi && got < hi - lo) blk = a.n_waves + lo + got;
+            else { shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u; shards_tried++; }
+        }
+        if (blk == 0xFFFFFFFFu) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // phase 1: one deferred ray per wave, 64 lanes walk its sub-trees together
 // ------------------------------------------------------------------------------------------------
@@ -553,12 +690,26 @@ template <int PRIMARY>
 static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 {
     if (a.total_work == 0) return;
-    uint32_t grid = resident_blocks<PRIMARY>(t.compute_units);
-    uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
-    if (grid > need) grid = need;
-    a.n_waves = grid * TRACE_WAVES;
     // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
     (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
+    uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
+    if (PRIMARY && t.packet) {
+        int bp = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY>, TRACE_BLOCK, 0);
+        if (bp < 1) bp = 1;
+        uint32_t grid = (uint32_t)t.compute_units * (uint32_t)bp;
+        if (grid > need) grid = need;
+        if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
+        a.n_waves = grid * TRACE_WAVES;
+        if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
+        hipLaunchKernelGGL(k_trace_packet<PRIMARY>, dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+        if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
+        if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
+        return;
+    }
+    uint32_t grid = resident_blocks<PRIMARY>(t.compute_units);
+    if (grid > need) grid = need;
+    a.n_waves = grid * TRACE_WAVES;
     if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
     hipLaunchKernelGGL(k_trace<PRIMARY>, dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
     if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
@@ -572,6 +723,15 @@ static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
 }
 
+uint32_t trace_packet_stack_entries() { return PACKET_STACK; }
+uint32_t trace_packet_max_blocks(int compute_units)
+{
+    int bp = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<1>, TRACE_BLOCK, 0);
+    if (bp < 1) bp = 1;
+    return (uint32_t)compute_units * (uint32_t)bp;
+}
+
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
     a.trav = t.trav;
@@ -580,6 +740,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.ctrl = (TraceCtrl*)t.ctrl;
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = t.n_leaves - 1u;
+    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
 
