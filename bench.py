@@ -179,13 +179,13 @@ def main():
         k = ctx.trace_kernel_times()
         fx = frames_fixture[it['name']][key]
         alg = 56 * fx['inner_visits'] + 40 * fx['leaf_tests'] + 32 * fx['rays']
-        per_scene[it['name']] = dict(trace_ms=round(ms, 4), lane_phase_ms=round(k['lane_phase_ms'] / 5, 4),
-                                     wave_phase_ms=round(k['wave_phase_ms'] / 5, 4),
+        per_scene[it['name']] = dict(trace_ms=round(ms, 4), first_kernel_ms=round(k['lane_phase_ms'] / 5, 4),
+                                     wave_per_ray_ms=round(k['wave_phase_ms'] / 5, 4),
                                      mrays_per_s=round(it['slots'] / ms / 1e3, 1),
                                      inner_visits_per_ray=round(fx['inner_visits'] / fx['rays'], 2),
                                      leaf_tests_per_ray=round(fx['leaf_tests'] / fx['rays'], 2),
                                      algorithmic_bytes=alg, build_ms=round(build_ms[it['name']], 3),
-                                     defer_budget=it['bvh'].trace_budget())
+                                     strategy=it['bvh'].trace_strategy())
     ctx.set_profiling(False)
     tm.close()
 
@@ -205,10 +205,10 @@ def main():
         traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
     roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
-                    kernel='k_trace<1> + k_trace_long<1> (one traversal launch pair per frame)',
+                    kernel='traversal launch of one frame: k_trace_packet<1> or k_trace<1>, then k_trace_long<1> (+ k_resolve_split<1>)',
                     avg_launch_ms=round(trace_ms_avg, 4),
-                    avg_lane_phase_ms=round(kt['lane_phase_ms'] / launches, 4),
-                    avg_wave_phase_ms=round(kt['wave_phase_ms'] / launches, 4),
+                    avg_first_kernel_ms=round(kt['lane_phase_ms'] / launches, 4),
+                    avg_wave_per_ray_ms=round(kt['wave_phase_ms'] / launches, 4),
                     algorithmic_bytes_per_launch=int(alg_per_launch))
 
     cpu_baseline = None

@@ -23,7 +23,10 @@ static void free_ctx_buffers(rt_ctx* ctx)
 {
     if (ctx->d_trace_ctrl) (void)hipFree(ctx->d_trace_ctrl);
     if (ctx->d_long_list) (void)hipFree(ctx->d_long_list);
+    if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+    if (ctx->d_split_list) (void)hipFree(ctx->d_split_list);
     ctx->d_trace_ctrl = nullptr; ctx->d_long_list = nullptr; ctx->long_cap = 0;
+    ctx->d_keys = nullptr; ctx->keys_cap = 0; ctx->d_split_list = nullptr;
 }
 
 // records for rays deferred from the lane-per-ray phase to the wave-per-ray phase: grow-only,
@@ -32,11 +35,20 @@ static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
 {
     uint64_t want = work_items < RT_LONG_LIST_MAX ? work_items : RT_LONG_LIST_MAX;
     if (want < 1024) want = 1024;
-    if (want <= ctx->long_cap) return RT_SUCCESS;
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_long_list) { (void)hipFree(ctx->d_long_list); ctx->d_long_list = nullptr; ctx->long_cap = 0; }
-    RT_HIP(ctx, hipMalloc((void**)&ctx->d_long_list, want * trace_long_record_bytes()));
-    ctx->long_cap = (uint32_t)want;
+    if (want > ctx->long_cap) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_long_list) { (void)hipFree(ctx->d_long_list); ctx->d_long_list = nullptr; ctx->long_cap = 0; }
+        if (ctx->d_split_list) { (void)hipFree(ctx->d_split_list); ctx->d_split_list = nullptr; }
+        RT_HIP(ctx, hipMalloc((void**)&ctx->d_long_list, want * trace_long_record_bytes()));
+        RT_HIP(ctx, hipMalloc((void**)&ctx->d_split_list, want * sizeof(uint32_t)));
+        ctx->long_cap = (uint32_t)want;
+    }
+    if (work_items > ctx->keys_cap) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_keys) { (void)hipFree(ctx->d_keys); ctx->d_keys = nullptr; ctx->keys_cap = 0; }
+        RT_HIP(ctx, hipMalloc((void**)&ctx->d_keys, work_items * sizeof(unsigned long long)));
+        ctx->keys_cap = work_items;
+    }
     return RT_SUCCESS;
 }
 
@@ -413,6 +425,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false;
+    t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_max_blocks = b->packet_max_blocks;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
     if (b->ctx->profiling) {
@@ -445,33 +458,37 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
 {
     rt_ctx* ctx = b->ctx;
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
-    if (ctx->defer_budget == 0 && !ctx->force_packet && (!b->tuned || b->tuned_key != key)) {
-        // candidate 0 = the packet kernel, the others = deferral budgets of the lane-per-ray / wave-per-ray pair
-        static const uint32_t candidates[] = { 0u, 256u, 512u, 1024u, 2048u, 1u << 20 };
+    if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key)) {
+        // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
+        // kernel) hands its remaining sub-trees to the wave-per-ray kernel
+        static const struct { bool packet; uint32_t budget; } candidates[] = {
+            { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
+            { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
         hipEvent_t e0 = nullptr, e1 = nullptr;
         RT_HIP(ctx, hipEventCreate(&e0));
         RT_HIP(ctx, hipEventCreate(&e1));
-        float best_ms = 0.f; uint32_t best = 1024u; bool have = false;
-        for (uint32_t cand : candidates) {
-            if (cand == 0u && ctx->no_packet) continue;
+        float best_ms = 0.f; uint32_t best = 1024u; bool best_packet = false; bool have = false;
+        for (const auto& cand : candidates) {
+            if (cand.packet && ctx->no_packet) continue;
+            if (!cand.packet && ctx->force_packet) continue;
             TraceLaunch t = make_launch(b, cam);
-            t.packet = cand == 0u;
-            t.defer_budget = cand;
+            t.packet = cand.packet;
+            t.defer_budget = cand.budget;
             (void)hipEventRecord(e0, ctx->stream);
             launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
             (void)hipEventRecord(e1, ctx->stream);
             float ms = 0.f;
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { have = false; break; }
-            if (!have || ms < best_ms) { best = cand; best_ms = ms; have = true; }
+            if (!have || ms < best_ms) { best = cand.budget; best_packet = cand.packet; best_ms = ms; have = true; }
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best == 0u;
+        b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best_packet;
         RT_HIP(ctx, hipGetLastError());
         return RT_SUCCESS;                      // the last candidate's launch already produced the frame
     }
     TraceLaunch t = make_launch(b, cam);
     if (ctx->defer_budget == 0 && b->tuned) { t.defer_budget = b->tuned_budget; t.packet = b->tuned_packet; }
-    if (ctx->force_packet) t.packet = true;
+    if (ctx->defer_budget != 0 && ctx->force_packet) t.packet = true;
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -541,10 +558,12 @@ int rt_bvh_read_morton_pairs(const rt_bvh* b, void* h_pairs, uint32_t* n_pow2)
     return rt_buf_download(b->ctx, h_pairs, b->d_pairs, (uint64_t)b->N * sizeof(uint2));
 }
 
-int rt_bvh_trace_budget(const rt_bvh* b, uint32_t* budget)
+int rt_bvh_trace_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget)
 {
-    if (!b || !budget) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
-    *budget = b->ctx->defer_budget ? b->ctx->defer_budget : (b->tuned ? b->tuned_budget : 0u);
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    const rt_ctx* ctx = b->ctx;
+    if (budget) *budget = ctx->defer_budget ? ctx->defer_budget : (b->tuned ? b->tuned_budget : 0u);
+    if (packet_kernel) *packet_kernel = ctx->defer_budget ? (ctx->force_packet ? 1 : 0) : (b->tuned && b->tuned_packet ? 1 : 0);
     return RT_SUCCESS;
 }
 

@@ -68,6 +68,9 @@ struct rt_ctx {
     void* d_trace_ctrl = nullptr;
     uint32_t* d_long_list = nullptr;      // deferred-ray records, grow-only
     uint32_t long_cap = 0;
+    unsigned long long* d_keys = nullptr;   // packet kernel: (t, position) keys of split rays, one per work item, grow-only
+    uint64_t keys_cap = 0;
+    uint32_t* d_split_list = nullptr;       // long_cap entries
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
     bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
@@ -150,6 +153,9 @@ struct TraceLaunch {
     bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
     bool packet;                  // primary rays: packet kernel (one 8x8 block per wave) instead of the two-phase kernels
     uint32_t* packet_spill;       // per-wave overflow area of the packet stack (null when the tree is shallow)
+    unsigned long long* keys;     // per work item, split rays only
+    uint32_t* split_list;         // long_cap entries
+    const uint2* pairs;           // sorted (morton, leaf): position -> leaf
     uint32_t packet_spill_entries;
     uint32_t packet_max_blocks;   // grid the spill area was sized for
     int compute_units;

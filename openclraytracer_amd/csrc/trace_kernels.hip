@@ -59,15 +59,18 @@ struct TraceCtrl {
     struct { uint32_t next; uint32_t pad[31]; } shard[WORK_SHARDS];   // dynamic primary work: next 64-ray block per shard
     struct { uint32_t next; uint32_t pad[31]; } lshard[WORK_SHARDS];  // phase 1: next deferred ray per shard
     uint32_t long_count;  uint32_t p1[31];   // deferred rays
+    uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
     uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
 };
-static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 2) * 128, "TraceCtrl layout");
+static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 3) * 128, "TraceCtrl layout");
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
 size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
 
 // record of a deferred ray (LONG_REC_WORDS words)
-enum { LR_WORK = 0, LR_CUR = 1, LR_SP = 2, LR_BEST_LEAF = 3, LR_BEST_T = 4, LR_EXTRA = 5, LR_PENDING = 6, LR_STACK = 8 };
+enum { LR_WORK = 0, LR_CUR = 1, LR_SP = 2, LR_BEST_LEAF = 3, LR_BEST_T = 4, LR_EXTRA = 5, LR_PENDING = 6, LR_PARTIAL = 7, LR_STACK = 8 };
+#define KEY_NONE 0xFFFFFFFFFFFFFFFFull
+typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
@@ -83,6 +86,9 @@ struct TraceArgs {
     uint32_t total_work;                   // work items (multiple of 4096 for primary frames)
     uint32_t n_waves;                      // waves in the grid
     uint32_t n_records;                    // inner records (leaves - 1)
+    unsigned long long* keys;              // (t bits << 32 | position) per work item, used by split rays only
+    uint32_t* split_list;                  // work items of split rays (long_cap entries)
+    const uint2* __restrict__ pairs;       // position -> leaf
     uint32_t* packet_spill;                // packet kernel: per-wave overflow of the (node, mask) stack
     uint32_t packet_spill_entries;
     // primary rays
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                     if (idx < a.long_cap) {
                         uint32_t* rec = a.long_list + (uint64_t)idx * LONG_REC_WORDS;
                         rec[LR_WORK] = r.work; rec[LR_CUR] = cur; rec[LR_SP] = sp; rec[LR_BEST_LEAF] = r.best_leaf;
-                        rec[LR_BEST_T] = __float_as_uint(r.best_t); rec[LR_EXTRA] = extra; rec[LR_PENDING] = pending;
+                        rec[LR_BEST_T] = __float_as_uint(r.best_t); rec[LR_EXTRA] = extra; rec[LR_PENDING] = pending; rec[LR_PARTIAL] = 0u;
                         for (uint32_t k = 0; k < sp; k++) rec[LR_STACK + k] = stack[k][lane];
                         active = false;
                     } else if (extra != RT_SENTINEL) {
@@ -411,6 +417,8 @@ typedef const __attribute__((address_space(4))) uint32_t cu32;
 __device__ __forceinline__ cf4* as_const(const void* p) { return (cf4*)(unsigned long long)p; }
 __device__ __forceinline__ float4 ld_const4(const void* p) { cf4* f = as_const(p); return make_float4(f[0], f[1], f[2], f[3]); }
 #define PACKET_STACK 96u
+#define PACKET_LOW_LANES 4u        // "a handful of lanes"
+#define PACKET_LOW_RUN 24u         // consecutive low-occupancy steps before the block sheds sub-trees
 
 __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t leaf, RayState& r)
 {
@@ -467,10 +475,55 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
             o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         bool in = ok;
+        bool split = false;                              // some sub-tree of this lane's ray went to phase 1
         uint32_t sp = 0;
         uint32_t node = 0;                               // wave-uniform: root record
+        uint32_t low_run = 0;                            // consecutive steps with very few lanes taking part
+        uint32_t steps = 0;                              // nodes this block has walked
         bool walking = __ballot(in) != 0ull;
         while (walking) {
+            // A block that keeps walking with a handful of lanes wastes the wave, and a block that walks thousands of
+            // nodes sets the frame time.  After PACKET_LOW_RUN low-occupancy steps the current node -- after `defer_budget`
+            // steps everything the block has left (current node and every stack entry) -- is handed, per taking-part lane,
+            // to the wave-per-ray kernel as a (ray, sub-tree) task: long duplicate-code chains are walked 64 records at a
+            // time there.  Parts of such a split ray meet in a 64-bit atomicMin on (t, position); k_resolve_split writes
+            // the contact.
+            {
+                uint64_t mi = __ballot(in);
+                uint32_t n_in = (uint32_t)__popcll(mi);
+                low_run = n_in <= PACKET_LOW_LANES ? low_run + 1u : 0u;
+                steps++;
+                if (((low_run >= PACKET_LOW_RUN && steps * 4u > a.defer_budget) || steps > a.defer_budget) && a.long_cap != 0u) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&a.ctrl->long_count, n_in, RLX_AGENT);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    bool room = base + n_in <= a.long_cap;            // wave-uniform: all or nothing
+                    if (room) {
+                        if (in) {
+                            if (!split) {
+                                split = true;
+                                uint32_t si = __hip_atomic_fetch_add((gu32*)&a.ctrl->split_count, 1u, RLX_AGENT);
+                                if (si < a.long_cap) a.split_list[si] = w;
+                                __hip_atomic_exchange((gu64*)a.keys + w, KEY_NONE, RLX_AGENT);
+                            }
+                            uint32_t* rec = a.long_list + (uint64_t)(base + lane_rank(mi)) * LONG_REC_WORDS;
+                            rec[LR_WORK] = w; rec[LR_CUR] = node; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
+                            rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF;
+                            rec[LR_PARTIAL] = 1u;
+                        }
+                        // continue with the next stack entry
+                        if (sp == 0u) { walking = false; continue; }
+                        sp--;
+                        uint32_t nn, lo, hi;
+                        if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
+                        else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                        node = nn;
+                        in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+                        continue;
+                    }
+                    low_run = 0; steps = 0;                          // list full: keep walking here
+                }
+            }
             const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
             const float4* p = reinterpret_cast<const float4*>(a.trav + un);
             const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
@@ -509,7 +562,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                 }
             }
         }
-        if (ok) store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
+        if (ok) {
+            store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
+            if (split && r.best_leaf != NO_LEAF)
+                __hip_atomic_fetch_min((gu64*)a.keys + w, ((unsigned long long)__float_as_uint(r.best_t) << 32) | a.pos[r.best_leaf], RLX_AGENT);
+        }
 
         // next block: dynamic, sharded (as in k_trace)
         blk = 0xFFFFFFFFu;
@@ -555,6 +612,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         const uint32_t* rec = a.long_list + (uint64_t)i * LONG_REC_WORDS;
         // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
         uint32_t work = rec[LR_WORK], rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
+        const bool partial = rec[LR_PARTIAL] != 0u;      // a sub-tree of a ray the packet kernel keeps walking elsewhere
         RayState r;
         bool sx, sy, sz;
         load_ray<PRIMARY>(a, work, r, sx, sy, sz);        // same ray in every lane
@@ -654,8 +712,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             if (ok < key) { key = ok; leaf = ol; }
         }
         if (lane == 0) {
-            float t = leaf != NO_LEAF ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
-            store_contact(a, r.out_index, r.pixel, t, leaf);
+            if (partial) {
+                if (leaf != NO_LEAF) __hip_atomic_fetch_min((gu64*)a.keys + work, key, RLX_AGENT);   // meets the other parts in k_resolve_split
+            } else {
+                float t = leaf != NO_LEAF ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
+                store_contact(a, r.out_index, r.pixel, t, leaf);
+            }
         }
         // next task
         i = 0xFFFFFFFFu;
@@ -672,6 +734,27 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             else { shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u; shards_tried++; }
         }
         if (i == 0xFFFFFFFFu) break;
+    }
+}
+
+// split rays (packet kernel): the minimum of all parts' (t, position) keys becomes the contact; leaf = pairs[position].y
+template <int PRIMARY>
+__global__ __launch_bounds__(256) void k_resolve_split(TraceArgs a)
+{
+    uint32_t count = a.ctrl->split_count;
+    if (count > a.long_cap) count = a.long_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        uint32_t w = a.split_list[i];
+        unsigned long long key = __hip_atomic_load((gu64*)a.keys + w, RLX_AGENT);
+        if (key == KEY_NONE) continue;                 // no hit in any part: the block's own "no contact" stands
+        uint32_t out_index = w, pixel = w;
+        if (PRIMARY) {
+            uint32_t x, y, slot;
+            work_to_pixel(a, w, x, y, slot);
+            pixel = y * a.cam.resX + x;
+            out_index = a.compact ? slot : pixel;
+        }
+        store_contact(a, out_index, pixel, __uint_as_float((uint32_t)(key >> 32)), a.pairs[(uint32_t)key].y);
     }
 }
 
@@ -704,6 +787,12 @@ static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         hipLaunchKernelGGL(k_trace_packet<PRIMARY>, dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
+        int b1 = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY>, TRACE_BLOCK, 0);
+        if (b1 < 1) b1 = 1;
+        a.n_waves = (uint32_t)t.compute_units * (uint32_t)b1 * TRACE_WAVES;
+        hipLaunchKernelGGL(k_trace_long<PRIMARY>, dim3(a.n_waves / TRACE_WAVES), dim3(TRACE_BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_resolve_split<PRIMARY>, dim3(64), dim3(256), 0, s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
@@ -741,6 +830,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = t.n_leaves - 1u;
     a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries;
+    a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
 

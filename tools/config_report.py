@@ -26,6 +26,6 @@ for name, res in [('synth_bunny', (1920, 1080)), ('synth_atrium', (1920, 1080)),
         capi.shade_blinn_phong_d(ctx, sc, cam, dc, npx, dr)
     tm.stop(); ms = tm.elapsed_ms() / K
     out['%s_%dx%d' % (name, res[0], res[1])] = dict(ms_per_frame=round(ms, 3), mrays_per_s=round(npx / ms / 1e3, 1),
-                                                     triangles=sc.n_tris, depth=bvh.info()['max_depth'], budget=bvh.trace_budget())
+                                                     triangles=sc.n_tris, depth=bvh.info()['max_depth'], strategy=bvh.trace_strategy())
     ctx.free(dc); ctx.free(dr); bvh.close(); sc.close()
 print(json.dumps(out, indent=1))
