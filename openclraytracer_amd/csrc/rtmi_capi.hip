@@ -424,7 +424,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.trav = b->d_trav; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
-    t.packet = false;
+    t.packet = false; t.calibrating = false;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_max_blocks = b->packet_max_blocks;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
@@ -474,6 +474,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             TraceLaunch t = make_launch(b, cam);
             t.packet = cand.packet;
             t.defer_budget = cand.budget;
+            t.calibrating = true;
             (void)hipEventRecord(e0, ctx->stream);
             launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
             (void)hipEventRecord(e1, ctx->stream);

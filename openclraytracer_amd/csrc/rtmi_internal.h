@@ -151,6 +151,7 @@ struct TraceLaunch {
     uint32_t defer_budget;        // 0 = default
     hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
     bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
+    bool calibrating;             // launch belongs to the first-frame calibration (separate kernel names in profiles)
     bool packet;                  // primary rays: packet kernel (one 8x8 block per wave) instead of the two-phase kernels
     uint32_t* packet_spill;       // per-wave overflow area of the packet stack (null when the tree is shallow)
     unsigned long long* keys;     // per work item, split rays only

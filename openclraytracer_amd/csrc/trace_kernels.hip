@@ -235,7 +235,7 @@ __device__ __forceinline__ void store_contact(const TraceArgs& a, uint32_t out_i
 // ------------------------------------------------------------------------------------------------
 // phase 0: one ray per lane
 // ------------------------------------------------------------------------------------------------
-template <int PRIMARY>
+template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
 {
     __shared__ uint32_t s_stack[TRACE_WAVES][LDS_STACK][64];
@@ -443,7 +443,7 @@ __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t l
     }
 }
 
-template <int PRIMARY>
+template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 {
     __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
@@ -521,7 +521,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                         in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
                         continue;
                     }
-                    low_run = 0; steps = 0;                          // list full: keep walking here
+                    // list full: keep walking here.  Slots this reservation still owns below the capacity must not
+                    // be left with stale bytes (phase 1 reads every record below min(count, capacity)): mark them void
+                    if (in) {
+                        uint32_t idx = base + lane_rank(mi);
+                        if (idx < a.long_cap) a.long_list[(uint64_t)idx * LONG_REC_WORDS + LR_WORK] = 0xFFFFFFFFu;
+                    }
+                    low_run = 0; steps = 0;
                 }
             }
             const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 // ------------------------------------------------------------------------------------------------
 // phase 1: one deferred ray per wave, 64 lanes walk its sub-trees together
 // ------------------------------------------------------------------------------------------------
-template <int PRIMARY>
+template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
 {
     __shared__ uint32_t s_inner[TRACE_WAVES][POOL_INNER];
@@ -613,20 +619,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
         uint32_t work = rec[LR_WORK], rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
         const bool partial = rec[LR_PARTIAL] != 0u;      // a sub-tree of a ray the packet kernel keeps walking elsewhere
+        const bool void_record = work == 0xFFFFFFFFu;     // reserved by a block that found the list full
         RayState r;
         bool sx, sy, sz;
-        load_ray<PRIMARY>(a, work, r, sx, sy, sz);        // same ray in every lane
+        load_ray<PRIMARY>(a, void_record ? 0u : work, r, sx, sy, sz);        // same ray in every lane
         if (lane == 0) {                                  // lane 0 carries the best hit found in phase 0
             r.best_leaf = rec[LR_BEST_LEAF];
             r.best_t = __uint_as_float(rec[LR_BEST_T]);
         }
         // seed the pools: lanes 0..sp-1 take the stack, lanes 62/63 the current node and the extra child
         uint32_t seed = RT_SENTINEL;
-        if (lane < rsp) seed = rec[LR_STACK + lane];
-        if (lane == 62) seed = rcur;
-        if (lane == 63) seed = rextra;
+        if (!void_record && lane < rsp) seed = rec[LR_STACK + lane];
+        if (!void_record && lane == 62) seed = rcur;
+        if (!void_record && lane == 63) seed = rextra;
         uint32_t n_inner = 0, n_leaf = 0;
-        {
+        if (!void_record) {
             bool is_in = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) == 0u;
             bool is_lf = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) != 0u;
             uint64_t mi = __ballot(is_in), ml = __ballot(is_lf);
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             uint32_t ol = (uint32_t)__shfl_xor((int)leaf, off, 64);
             if (ok < key) { key = ok; leaf = ol; }
         }
-        if (lane == 0) {
+        if (lane == 0 && !void_record) {
             if (partial) {
                 if (leaf != NO_LEAF) __hip_atomic_fetch_min((gu64*)a.keys + work, key, RLX_AGENT);   // meets the other parts in k_resolve_split
             } else {
@@ -738,7 +745,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
 }
 
 // split rays (packet kernel): the minimum of all parts' (t, position) keys becomes the contact; leaf = pairs[position].y
-template <int PRIMARY>
+template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(256) void k_resolve_split(TraceArgs a)
 {
     uint32_t count = a.ctrl->split_count;
@@ -758,65 +765,62 @@ __global__ __launch_bounds__(256) void k_resolve_split(TraceArgs a)
     }
 }
 
-template <int PRIMARY>
-static uint32_t resident_blocks(int compute_units)
-{
-    int b0 = 0, b1 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<PRIMARY>, TRACE_BLOCK, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY>, TRACE_BLOCK, 0);
-    if (b0 < 1) b0 = 1;
-    (void)b1;
-    return (uint32_t)compute_units * (uint32_t)b0;
-}
-
-template <int PRIMARY>
-static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
+// CAL = 1 marks the launches of the first-frame calibration: same code under different kernel names, so that
+// profiles (rocprofv3 --stats) keep them apart from the frames that count
+template <int PRIMARY, int CAL>
+static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 {
     if (a.total_work == 0) return;
     // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
     (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
     uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
+    int b1 = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0);
+    if (b1 < 1) b1 = 1;
+    const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
     if (PRIMARY && t.packet) {
         int bp = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY>, TRACE_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY, CAL>, TRACE_BLOCK, 0);
         if (bp < 1) bp = 1;
         uint32_t grid = (uint32_t)t.compute_units * (uint32_t)bp;
         if (grid > need) grid = need;
         if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
         a.n_waves = grid * TRACE_WAVES;
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
-        hipLaunchKernelGGL(k_trace_packet<PRIMARY>, dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+        hipLaunchKernelGGL((k_trace_packet<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
-        int b1 = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY>, TRACE_BLOCK, 0);
-        if (b1 < 1) b1 = 1;
-        a.n_waves = (uint32_t)t.compute_units * (uint32_t)b1 * TRACE_WAVES;
-        hipLaunchKernelGGL(k_trace_long<PRIMARY>, dim3(a.n_waves / TRACE_WAVES), dim3(TRACE_BLOCK), 0, s, a);
-        hipLaunchKernelGGL(k_resolve_split<PRIMARY>, dim3(64), dim3(256), 0, s, a);
+        a.n_waves = grid1 * TRACE_WAVES;
+        hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
+        hipLaunchKernelGGL((k_resolve_split<PRIMARY, CAL>), dim3(64), dim3(256), 0, s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
-    uint32_t grid = resident_blocks<PRIMARY>(t.compute_units);
+    int b0 = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<PRIMARY, CAL>, TRACE_BLOCK, 0);
+    if (b0 < 1) b0 = 1;
+    uint32_t grid = (uint32_t)t.compute_units * (uint32_t)b0;
     if (grid > need) grid = need;
     a.n_waves = grid * TRACE_WAVES;
     if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
-    hipLaunchKernelGGL(k_trace<PRIMARY>, dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_trace<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
     if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
-    // phase 1: the number of deferred rays lives on the device; a fixed grid strides over the list
-    int b1 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY>, TRACE_BLOCK, 0);
-    if (b1 < 1) b1 = 1;
-    uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
+    // wave-per-ray phase: the number of deferred rays lives on the device; a fixed grid pulls from the list
     a.n_waves = grid1 * TRACE_WAVES;
-    hipLaunchKernelGGL(k_trace_long<PRIMARY>, dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
     if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
+}
+
+template <int PRIMARY>
+static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
+{
+    if (t.calibrating) launch_tagged<PRIMARY, 1>(s, t, a); else launch_tagged<PRIMARY, 0>(s, t, a);
 }
 
 uint32_t trace_packet_stack_entries() { return PACKET_STACK; }
 uint32_t trace_packet_max_blocks(int compute_units)
 {
     int bp = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<1>, TRACE_BLOCK, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<1, 0>, TRACE_BLOCK, 0);
     if (bp < 1) bp = 1;
     return (uint32_t)compute_units * (uint32_t)bp;
 }
