@@ -33,8 +33,9 @@ static void free_ctx_buffers(rt_ctx* ctx)
 // one per work item up to RT_LONG_LIST_MAX (beyond that rays simply finish in the first phase)
 static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
 {
-    uint64_t want = work_items < RT_LONG_LIST_MAX ? work_items : RT_LONG_LIST_MAX;
-    if (want < 1024) want = 1024;
+    uint64_t limit = ctx->long_list_limit ? ctx->long_list_limit : RT_LONG_LIST_MAX;
+    uint64_t want = work_items < limit ? work_items : limit;
+    if (want < 1024 && !ctx->long_list_limit) want = 1024;
     if (want > ctx->long_cap) {
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_long_list) { (void)hipFree(ctx->d_long_list); ctx->d_long_list = nullptr; ctx->long_cap = 0; }
@@ -99,6 +100,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     }
     ctx->stream = ctx->own_stream;
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1'; ctx->no_packet = env[0] == '0'; }
     *out = ctx;
     return RT_SUCCESS;

@@ -207,3 +207,34 @@ def test_cpp_host_mirror_end_to_end(gpu_ctx, tmp_path):
     r = subprocess.run([demo, '-winH', '8', '-winW', '8', '-accStruct', 'GRID', '-headersPath', 'x', '-scene', 'x'],
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 1
+
+
+@pytest.mark.parametrize('packet,budget,list_max', [('1', '64', '3000'), ('1', '16', '70'), ('0', '32', '1000'),
+                                                     ('0', '1048576', '0'), ('1', '1048576', '0')])
+def test_forced_trace_strategies_and_full_deferred_list(packet, budget, list_max, monkeypatch):
+    """every (kernel, budget) strategy the first-frame calibration can pick gives the reference's contacts, also when the
+    deferred-ray list is far too small for what the kernels want to hand over (list-full path: rays keep walking in
+    place, reserved-but-unwritten slots are void records)."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    monkeypatch.setenv('RTMI_PACKET', packet)
+    monkeypatch.setenv('RTMI_DEFER_BUDGET', budget)
+    if list_max != '0':
+        monkeypatch.setenv('RTMI_LONG_LIST_MAX', list_max)
+    ctx = capi.Context(0)
+    try:
+        # the lane-per-ray kernel may only run out of list where no ray outgrows its 24-entry LDS stack (a forced
+        # hand-off with a full list is a reported error, not a silent wrong frame): man's tree is 187 levels deep
+        cases = (('tenryuu', (320, 240)),) if (packet == '0' and list_max != '0') else (('tenryuu', (320, 240)), ('man', (200, 150)))
+        for name, res in cases:
+            osc, ob = oracle_bvh(name)
+            sc = capi.DeviceScene(ctx, packed_scene(name))
+            gb = capi.DeviceBVH(ctx, sc).build()
+            cam = osc.demo_camera(*res)
+            want, _ = ob.trace_primary(cam)
+            for _ in range(2):                                   # second frame reuses stale list contents
+                got = gb.generate_contacts_primary(as_capi_camera(cam))
+                assert got.tobytes() == want.tobytes(), (name, packet, budget, list_max)
+            gb.close(); sc.close()
+    finally:
+        ctx.close()
