@@ -20,10 +20,16 @@ rows.sort()
 with open('profiles/%s_bench_pmc_summary.csv' % R, 'w') as f:
     f.write('kernel,counter,dispatches,mean_per_dispatch,min,max\n')
     for r in rows: f.write('%s,%s,%d,%.3f,%.3f,%.3f\n' % r)
-m = {(k, c): mean for k, c, n, mean, _, _ in rows}
-fetch = m.get(('k_trace<1>', 'FETCH_SIZE'), 0) + m.get(('k_trace_long<1>', 'FETCH_SIZE'), 0)
-write = m.get(('k_trace<1>', 'WRITE_SIZE'), 0) + m.get(('k_trace_long<1>', 'WRITE_SIZE'), 0)
-json.dump({'round': R, 'source': 'profiles/%s_bench_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 4; includes the calibration launches of the first frame)' % R,
+tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
+for k, c, n, mean, _, _ in rows:
+    tot[(k, c)] = mean * n; cnt[(k, c)] = n
+# steady-state traversal kernels carry the template tag <1, 0> (calibration candidates of the first frame are <1, 1>);
+# one frame launch = one first-phase kernel (k_trace or k_trace_packet) + its k_trace_long (+ k_resolve_split)
+steady = [k for k in {k for k, _ in tot} if k.startswith(('k_trace', 'k_resolve_split')) and k.endswith('<1, 0>')]
+frames = sum(cnt[(k, 'FETCH_SIZE')] for k in steady if k.startswith(('k_trace<', 'k_trace_packet<')))
+fetch = sum(tot[(k, 'FETCH_SIZE')] for k in steady) / max(frames, 1)
+write = sum(tot[(k, 'WRITE_SIZE')] for k in steady) / max(frames, 1)
+json.dump({'round': R, 'source': 'profiles/%s_bench_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 4; steady-state kernels only, summed over the kernels of a frame launch and averaged over %d frame launches)' % (R, frames),
            'fetch_size_kb_raw': fetch, 'write_size_kb': write,
            'correction': 'FETCH_SIZE doubled (gfx950 reports half of a streamed read, MI355X_MICROARCH.md HBM section); uncalibrated for this access pattern',
            'hbm_bytes_per_launch': int((2 * fetch + write) * 1024)}, open('profiles/traffic_latest.json', 'w'), indent=1)
@@ -31,3 +37,14 @@ print(open('profiles/traffic_latest.json').read())
 for l in open('profiles/%s_bench_kernel_stats.csv' % R).read().splitlines()[:6]: print(l)
 for k, c, n, mean, _, _ in rows:
     if 'k_trace' in k: print(k, c, n, '%.4g' % mean)
+# frame-launch duration from the kernel-trace stats: must agree with bench.py's live HIP-event figure (roofline.avg_launch_ms)
+ks = list(csv.DictReader(open('profiles/%s_bench_kernel_stats.csv' % R)))
+nm = lambda r: r['Name'].split('(')[0].replace('void ', '')
+st = [r for r in ks if nm(r).startswith(('k_trace', 'k_resolve_split')) and nm(r).endswith('<1, 0>')]
+nfr = sum(int(r['Calls']) for r in st if nm(r).startswith(('k_trace<', 'k_trace_packet<')))
+summ = {'round': R, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline',
+        'frame_launches': nfr,
+        'avg_frame_launch_ms': sum(float(r['TotalDurationNs']) for r in st) / max(nfr, 1) / 1e6,
+        'kernels': {nm(r): {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3, 'total_ms': float(r['TotalDurationNs']) / 1e6} for r in ks if nm(r).startswith('k_')}}
+json.dump(summ, open('profiles/%s_frame_launch_summary.json' % R, 'w'), indent=1)
+print('avg frame launch ms (rocprof):', summ['avg_frame_launch_ms'], 'over', nfr)
