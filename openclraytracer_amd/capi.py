@@ -22,6 +22,12 @@ CONTACT = np.dtype([('pixelIndex', '<u4'), ('materialIndex', '<u4'), ('pad', '<u
                     ('normalAndDistance', '<f4', 4)])
 BVH_NODE = np.dtype([('data', '<u4', 4), ('boundsMin', '<f4', 4), ('boundsMax', '<f4', 4)])
 PAIR = np.dtype([('key', '<u4'), ('value', '<u4')])
+GRID_DATA = np.dtype([('res', '<u4', 3), ('step', '<f4', 3), ('leafDensity', '<f4'), ('padTo64', '<f4'),
+                      ('box_lo', '<f4', 4), ('box_hi', '<f4', 4)])
+TOP_CELL = np.dtype([('res', '<u4', 3), ('firstLeafIdx', '<u4')])
+TLG_INFO_FIELDS = ('cells', 'pairs_count', 'pairs_pow2', 'leaf_cells_count', 'leaf_pairs_count', 'leaf_pairs_pow2',
+                   'written_leaf_pairs')
+assert GRID_DATA.itemsize == 64 and TOP_CELL.itemsize == 16
 assert CAMERA.itemsize == 64 and RAY.itemsize == 48 and CONTACT.itemsize == 32 and BVH_NODE.itemsize == 48
 
 # every symbol include/rtmi.h declares (tests check the library exports all of them)
@@ -36,6 +42,9 @@ SYMBOLS = [
     'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
+    'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
+    'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
+    'rt_tlg_info_get', 'rt_tlg_read', 'rt_tlg_pow_third',
 ]
 
 
@@ -99,6 +108,17 @@ def load_library() -> C.CDLL:
     L.rt_timer_stop.argtypes = [vp, vp]
     L.rt_timer_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.rt_timer_destroy.argtypes = [vp, vp]; L.rt_timer_destroy.restype = None
+    L.rt_tlg_create.argtypes = [vp, vp, pvp]
+    L.rt_tlg_destroy.argtypes = [vp]; L.rt_tlg_destroy.restype = None
+    L.rt_tlg_set_densities.argtypes = [vp, C.c_float, C.c_float]
+    L.rt_tlg_initialize_frame.argtypes = [vp]
+    L.rt_tlg_construct.argtypes = [vp]
+    L.rt_tlg_generate_contacts_primary.argtypes = [vp, vp, vp]
+    L.rt_tlg_generate_contacts_rays.argtypes = [vp, vp, u32, vp]
+    L.rt_tlg_generate_contacts_primary_tiled.argtypes = [vp, vp, u32, u32, vp]
+    L.rt_tlg_info_get.argtypes = [vp, vp]
+    L.rt_tlg_read.argtypes = [vp, i32, vp, u64]
+    L.rt_tlg_pow_third.argtypes = [C.c_float]; L.rt_tlg_pow_third.restype = C.c_float
     _lib = L
     return L
 
@@ -313,6 +333,65 @@ class DeviceBVH:
             return self.ctx.download(dc, len(rays), CONTACT)
         finally:
             self.ctx.free(dr); self.ctx.free(dc)
+
+
+class DeviceTLG:
+    """rt_tlg: the device side of TwoLevelGridManager (create = ctor+initialize)."""
+    GRID_DATA, TOP_CELLS, TOP_PAIRS, CELL_RANGES, LEAF_PAIRS, LEAF_RANGES = range(6)
+
+    def __init__(self, ctx: Context, scene: DeviceScene, top_density: float = 2.0, leaf_density: float = 2.0):
+        self.ctx, self.scene = ctx, scene
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rt_tlg_create(ctx.h, scene.h, C.byref(h)))
+        self.h = h
+        ctx.check(ctx.lib.rt_tlg_set_densities(self.h, top_density, leaf_density))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rt_tlg_destroy(self.h)
+            self.h = None
+
+    def initialize_frame(self):
+        self.ctx.check(self.ctx.lib.rt_tlg_initialize_frame(self.h))
+
+    def construct(self):
+        self.ctx.check(self.ctx.lib.rt_tlg_construct(self.h))
+
+    def build(self):
+        self.initialize_frame()
+        self.construct()
+        return self
+
+    def info(self) -> dict:
+        a = np.zeros(len(TLG_INFO_FIELDS), dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.rt_tlg_info_get(self.h, _p(a)))
+        return dict(zip(TLG_INFO_FIELDS, (int(x) for x in a)))
+
+    def read(self, what: int) -> np.ndarray:
+        i = self.info()
+        dtype, count = {0: (GRID_DATA, 1), 1: (TOP_CELL, i['cells']), 2: (PAIR, i['pairs_pow2']), 3: (PAIR, i['cells']),
+                        4: (PAIR, i['leaf_pairs_pow2']), 5: (PAIR, i['leaf_cells_count'])}[what]
+        out = np.zeros(count, dtype=dtype)
+        self.ctx.check(self.ctx.lib.rt_tlg_read(self.h, what, _p(out) if count else None, out.nbytes))
+        return out
+
+    def generate_contacts_primary_d(self, cam: np.ndarray, d_contacts: int):
+        self.ctx.check(self.ctx.lib.rt_tlg_generate_contacts_primary(self.h, _p(cam), C.c_void_p(d_contacts)))
+
+    def generate_contacts_primary_tiled_d(self, cam: np.ndarray, rank: int, nranks: int, d_contacts: int):
+        self.ctx.check(self.ctx.lib.rt_tlg_generate_contacts_primary_tiled(self.h, _p(cam), rank, nranks,
+                                                                           C.c_void_p(d_contacts)))
+
+    def generate_contacts_rays_d(self, d_rays: int, count: int, d_contacts: int):
+        self.ctx.check(self.ctx.lib.rt_tlg_generate_contacts_rays(self.h, C.c_void_p(d_rays), count,
+                                                                  C.c_void_p(d_contacts)))
+
+    generate_contacts_primary = DeviceBVH.generate_contacts_primary
+    generate_contacts_rays = DeviceBVH.generate_contacts_rays
+
+
+def tlg_pow_third(x: float) -> float:
+    return float(load_library().rt_tlg_pow_third(C.c_float(x)))
 
 
 def shade_blinn_phong_d(ctx: Context, scene: DeviceScene, cam: np.ndarray, d_contacts: int, count: int, d_rgba: int):

@@ -283,6 +283,7 @@ int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_
     d.n_lights = (uint32_t)nLights; d.n_spheres = (uint32_t)nSpheres; d.n_materials = (uint32_t)nMaterials;
     std::memcpy(d.bb_lo, s + 64, 12);
     std::memcpy(d.bb_hi, s + 80, 12);
+    std::memcpy(&sc->bb_w[0], s + 76, 4); std::memcpy(&sc->bb_w[1], s + 92, 4);
     launch_gather_triangles(ctx->stream, d);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -497,7 +498,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     return RT_SUCCESS;
 }
 
-static int check_camera(rt_ctx* ctx, const rt_camera* cam)
+int rt_check_camera(rt_ctx* ctx, const rt_camera* cam)
 {
     if (!cam) return RT_FAIL(ctx, "camera is null");
     if (cam->resX == 0 || cam->resY == 0) return RT_FAIL(ctx, "camera resolution is zero");
@@ -511,7 +512,7 @@ int rt_bvh_generate_contacts_primary(rt_bvh* b, const rt_camera* cam, void* d_co
     rt_ctx* ctx = b->ctx;
     if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (!d_contacts) return RT_FAIL(ctx, "contacts buffer is null");
-    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, 0, 1))) return RT_ERROR;
     return trace_primary_tuned(b, cam, 0, 1, false, (rt_contact*)d_contacts);
@@ -524,7 +525,7 @@ int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint
     rt_ctx* ctx = b->ctx;
     if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (!d_contacts_compact) return RT_FAIL(ctx, "contacts buffer is null");
-    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
@@ -586,7 +587,7 @@ int rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* ca
                          uint32_t contact_count, void* d_rgba)
 {
     if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
-    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (!d_rgba || (contact_count && !d_contacts)) return RT_FAIL(ctx, "null buffer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (contact_count == 0) {
@@ -609,7 +610,7 @@ int rt_shade_blinn_phong_tiled(rt_ctx* ctx, const rt_scene* scene, const rt_came
                                const void* d_contacts_compact, void* d_rgba_compact)
 {
     if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
-    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
     if (!d_contacts_compact || !d_rgba_compact) return RT_FAIL(ctx, "null buffer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -624,7 +625,7 @@ int rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const voi
                    void* d_rgba_frame)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
-    if (check_camera(ctx, cam)) return RT_ERROR;
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || !d_rgba_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
     if (slots_per_rank < rt_tiles_owned_pixels(cam, 0, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
     RT_HIP(ctx, hipSetDevice(ctx->device));

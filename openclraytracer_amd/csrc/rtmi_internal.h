@@ -86,6 +86,7 @@ struct rt_scene {
     void* d_bytes = nullptr;
     void* d_meshes = nullptr;
     void* d_tri = nullptr;     // one allocation backing the SoA arrays
+    float bb_w[2] = { 0, 0 };  // .w of SceneHeader.modelsBoundingBox bounds (carried into GridData.box verbatim)
 };
 
 struct rt_bvh {
@@ -114,10 +115,32 @@ struct rt_bvh {
     bool built = false;
 };
 
+struct rt_tlg {
+    rt_ctx* ctx = nullptr;
+    const rt_scene* scene = nullptr;
+    float top_density = 2.0f, leaf_density = 2.0f;    // TwoLevelGridManager.cpp:66-67
+    rt_grid_data grid{};
+    rt_tlg_info info{};
+    uint32_t n = 0;
+    uint32_t* d_counters = nullptr;     // max(n, cells, pairs) words
+    uint32_t* d_scan = nullptr;
+    uint32_t* d_scan_scratch = nullptr;
+    uint64_t counters_cap = 0;
+    uint2* d_cell_ranges = nullptr;     // cells
+    rt_top_cell* d_top = nullptr;       // cells
+    uint2* d_pairs = nullptr;           // pairs_pow2
+    uint2* d_leaf_pairs = nullptr;      // leaf_pairs_pow2
+    uint2* d_leaf_ranges = nullptr;     // leaf_cells_count
+    uint32_t* d_written = nullptr;      // 1 word
+    bool frame_initialised = false;
+    bool built = false;
+};
+
 // ---------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------
 int rt_fail(const rt_ctx* ctx, const char* file, int line, const char* func, const std::string& msg);
+extern "C" __attribute__((visibility("hidden"))) int rt_check_camera(rt_ctx* ctx, const rt_camera* cam);
 #define RT_FAIL(ctx, msg) rt_fail((ctx), __FILE__, __LINE__, __func__, (msg))
 #define RT_HIP(ctx, expr)                                                                       \
     do {                                                                                        \
@@ -171,6 +194,26 @@ size_t trace_long_record_bytes();
 uint32_t trace_packet_stack_entries();
 uint32_t trace_packet_max_blocks(int compute_units);
 uint32_t trace_lds_stack_entries();
+// tlg_kernels.hip
+struct TlgLaunch {
+    rt_grid_data grid;
+    const rt_top_cell* top;
+    const uint2* leaf_ranges;
+    const uint2* leaf_pairs;
+    const DeviceScene* scene;
+};
+void launch_tlg_count_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, uint32_t* counters);
+void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs);
+void launch_segment_bounds(hipStream_t s, const uint2* sorted, uint32_t count, uint2* ranges);
+void launch_tlg_cell_res(hipStream_t s, const rt_grid_data& g, const uint2* ranges, uint32_t cells, rt_top_cell* top, uint32_t* leaves);
+void launch_tlg_first_leaf(hipStream_t s, rt_top_cell* top, const uint32_t* scan, uint32_t cells);
+void launch_tlg_count_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
+                           const DeviceScene& sc, uint32_t* counters);
+void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
+                          const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* leaf_pairs, uint32_t* written_total);
+void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks, bool compact,
+                              rt_contact* out);
+void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 // shade_kernels.hip
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,
                   uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks);

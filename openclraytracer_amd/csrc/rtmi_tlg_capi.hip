@@ -1,0 +1,285 @@
+// rtmi_tlg_capi.hip -- C ABI of the Two-Level Grid manager (include/rtmi.h, rt_tlg_*): the host logic of
+// AccelerationStructures::TwoLevelGridManager (src/CLRayTracerEngine/TwoLevelGridManager.cpp:60-600) on the HIP kernels
+// of tlg_kernels.hip and the scan / bitonic-network primitives of sort_scan_kernels.hip.
+#include "rtmi_internal.h"
+#include "tlg_math.h"
+
+#include <cstring>
+#include <new>
+
+// largestPowerOfTwo(x) << 1 (RTKernelUtils.h:160-164, TwoLevelGridManager.cpp:165,167,239,398): always > x
+static uint32_t pow2_above(uint32_t x)
+{
+    if (x == 0) return 1;
+    uint64_t p = 1;
+    while (p * 2 <= x) p *= 2;
+    return (uint32_t)(p * 2);
+}
+
+int rt_tlg_create(rt_ctx* ctx, const rt_scene* scene, rt_tlg** out)
+{
+    if (!ctx || !scene || !out) return RT_FAIL(ctx, "null argument");
+    *out = nullptr;
+    if (scene->ctx != ctx) return RT_FAIL(ctx, "scene belongs to another context");
+    rt_tlg* g = new (std::nothrow) rt_tlg();
+    if (!g) return RT_FAIL(ctx, "out of host memory");
+    g->ctx = ctx; g->scene = scene;
+    *out = g;
+    return RT_SUCCESS;
+}
+
+static void free_tlg_buffers(rt_tlg* g)
+{
+    void** ptrs[] = { (void**)&g->d_counters, (void**)&g->d_scan, (void**)&g->d_scan_scratch, (void**)&g->d_cell_ranges, (void**)&g->d_top,
+                      (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written };
+    for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    g->counters_cap = 0;
+}
+
+void rt_tlg_destroy(rt_tlg* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    free_tlg_buffers(g);
+    delete g;
+}
+
+int rt_tlg_set_densities(rt_tlg* g, float top_level, float leaf)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    if (!(top_level > 0.0f) || !(leaf > 0.0f)) return RT_FAIL(g->ctx, "densities must be positive");
+    g->top_density = top_level; g->leaf_density = leaf;
+    return RT_SUCCESS;
+}
+
+// calculateGridData + getResolution, TwoLevelGridManager.cpp:566-600
+static int calculate_grid_data(rt_tlg* g)
+{
+    const DeviceScene& sc = g->scene->d;
+    rt_grid_data& G = g->grid;
+    std::memset(&G, 0, sizeof G);
+    for (int k = 0; k < 3; k++) { G.box_lo[k] = sc.bb_lo[k]; G.box_hi[k] = sc.bb_hi[k]; }
+    G.box_lo[3] = g->scene->bb_w[0]; G.box_hi[3] = g->scene->bb_w[1];
+    const float deltaX = G.box_hi[0] - G.box_lo[0], deltaY = G.box_hi[1] - G.box_lo[1], deltaZ = G.box_hi[2] - G.box_lo[2];
+    const float volume = deltaX * deltaY * deltaZ;                        // boxVolume, AABB.h:243-249
+    const float prims = (float)sc.n_tris;
+    const float a = tlg_pow_third(g->top_density * prims / volume);
+    G.resX = tlg_f2u(deltaX * a); G.resY = tlg_f2u(deltaY * a); G.resZ = tlg_f2u(deltaZ * a);
+    if (G.resX == 0 || G.resY == 0 || G.resZ == 0)
+        return RT_FAIL(g->ctx, "scene bounding box is degenerate: the grid resolution has a zero axis");
+    if ((uint64_t)G.resX * G.resY * G.resZ > 0x40000000ull) return RT_FAIL(g->ctx, "grid resolution too large");
+    G.stepX = (G.box_hi[0] - G.box_lo[0]) / (float)G.resX;
+    G.stepY = (G.box_hi[1] - G.box_lo[1]) / (float)G.resY;
+    G.stepZ = (G.box_hi[2] - G.box_lo[2]) / (float)G.resZ;
+    G.leafDensity = g->leaf_density;
+    return RT_SUCCESS;
+}
+
+static int ensure_counters(rt_tlg* g, uint64_t words)
+{
+    rt_ctx* ctx = g->ctx;
+    if (words <= g->counters_cap) return RT_SUCCESS;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (g->d_counters) { (void)hipFree(g->d_counters); g->d_counters = nullptr; }
+    if (g->d_scan) { (void)hipFree(g->d_scan); g->d_scan = nullptr; }
+    if (g->d_scan_scratch) { (void)hipFree(g->d_scan_scratch); g->d_scan_scratch = nullptr; }
+    g->counters_cap = 0;
+    RT_HIP(ctx, hipMalloc((void**)&g->d_counters, words * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&g->d_scan, words * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&g->d_scan_scratch, scan_scratch_words((uint32_t)words) * sizeof(uint32_t)));
+    g->counters_cap = words;
+    return RT_SUCCESS;
+}
+
+int rt_tlg_initialize_frame(rt_tlg* g)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    g->n = g->scene->d.n_tris;
+    if (g->n == 0) return RT_FAIL(ctx, "the scene has no triangles");
+    if (calculate_grid_data(g)) return RT_ERROR;
+    const uint32_t cells = g->grid.resX * g->grid.resY * g->grid.resZ;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cells != g->info.cells || !g->d_top) {
+        if (g->d_cell_ranges) { (void)hipFree(g->d_cell_ranges); g->d_cell_ranges = nullptr; }
+        if (g->d_top) { (void)hipFree(g->d_top); g->d_top = nullptr; }
+        RT_HIP(ctx, hipMalloc((void**)&g->d_cell_ranges, (size_t)cells * sizeof(uint2)));
+        RT_HIP(ctx, hipMalloc((void**)&g->d_top, (size_t)cells * sizeof(rt_top_cell)));
+    }
+    if (!g->d_written) RT_HIP(ctx, hipMalloc((void**)&g->d_written, 256));
+    g->info = rt_tlg_info{};
+    g->info.cells = cells;
+    if (ensure_counters(g, g->n > cells ? g->n : cells)) return RT_ERROR;
+    // TwoLevelGridManager.cpp:181-199: counters, scan output, cell ranges and top-level cells start zeroed
+    RT_HIP(ctx, hipMemsetAsync(g->d_counters, 0, g->counters_cap * sizeof(uint32_t), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_scan, 0, g->counters_cap * sizeof(uint32_t), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_cell_ranges, 0, (size_t)cells * sizeof(uint2), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_top, 0, (size_t)cells * sizeof(rt_top_cell), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_written, 0, 4, ctx->stream));
+    g->frame_initialised = true;
+    g->built = false;
+    return RT_SUCCESS;
+}
+
+// one 4-byte read-back of the last element of a scan (TwoLevelGridManager.cpp:237,345,393)
+static int read_word(rt_ctx* ctx, const uint32_t* d_src, uint32_t* out)
+{
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(out, d_src, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_SUCCESS;
+}
+
+int rt_tlg_construct(rt_tlg* g)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    if (!g->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const DeviceScene& sc = g->scene->d;
+    const rt_grid_data& G = g->grid;
+    const uint32_t n = g->n, cells = g->info.cells;
+
+    // 1. cells overlapped by every triangle's box, scan, pair count                               (:213-238)
+    launch_tlg_count_top(s, G, sc, g->d_counters);
+    launch_scan_inclusive(s, g->d_counters, g->d_scan, n, g->d_scan_scratch);
+    uint32_t pairs = 0;
+    if (read_word(ctx, g->d_scan + (n - 1), &pairs)) return RT_ERROR;
+    if (pairs == 0) return RT_FAIL(ctx, "no (cell, triangle) pairs: nothing to build");
+    if (pairs > 0x3FFFFFFFu) return RT_FAIL(ctx, "too many (cell, triangle) pairs");
+    const uint32_t pairs_pow2 = pow2_above(pairs);
+    if (pairs_pow2 != g->info.pairs_pow2 || !g->d_pairs) {
+        if (g->d_pairs) { (void)hipFree(g->d_pairs); g->d_pairs = nullptr; }
+        RT_HIP(ctx, hipMalloc((void**)&g->d_pairs, (size_t)pairs_pow2 * sizeof(uint2)));
+    }
+    g->info.pairs_count = pairs; g->info.pairs_pow2 = pairs_pow2;
+    RT_HIP(ctx, hipMemsetAsync(g->d_pairs, 0xFF, (size_t)pairs_pow2 * sizeof(uint2), s));         // :248-250
+    // 2. emit (cell, triangle), sort by cell                                                        (:252-267)
+    launch_tlg_emit_top(s, G, sc, g->d_scan, g->d_counters, g->d_pairs);
+    launch_bitonic_sort(s, g->d_pairs, pairs_pow2);
+    // 3. [first, end) of every top-level cell, leaf resolution, leaf-cell count                    (:269-346)
+    launch_segment_bounds(s, g->d_pairs, pairs, g->d_cell_ranges);
+    RT_HIP(ctx, hipMemsetAsync(g->d_counters, 0, g->counters_cap * sizeof(uint32_t), s));
+    RT_HIP(ctx, hipMemsetAsync(g->d_scan, 0, g->counters_cap * sizeof(uint32_t), s));
+    launch_tlg_cell_res(s, G, g->d_cell_ranges, cells, g->d_top, g->d_counters);
+    launch_scan_inclusive(s, g->d_counters, g->d_scan, cells, g->d_scan_scratch);
+    uint32_t leaf_cells = 0;
+    if (read_word(ctx, g->d_scan + (cells - 1), &leaf_cells)) return RT_ERROR;
+    launch_tlg_first_leaf(s, g->d_top, g->d_scan, cells);                                           // :347-360
+    g->info.leaf_cells_count = leaf_cells;
+    // 4. leaf cells overlapped per top-level pair, scan, leaf pair count                            (:362-395)
+    if (ensure_counters(g, pairs)) return RT_ERROR;
+    launch_tlg_count_leaf(s, G, g->d_pairs, pairs, g->d_top, sc, g->d_counters);
+    launch_scan_inclusive(s, g->d_counters, g->d_scan, pairs, g->d_scan_scratch);
+    uint32_t leaf_pairs = 0;
+    if (read_word(ctx, g->d_scan + (pairs - 1), &leaf_pairs)) return RT_ERROR;
+    if (leaf_pairs > 0x3FFFFFFFu) return RT_FAIL(ctx, "too many (leaf cell, triangle) pairs");
+    const uint32_t leaf_pow2 = pow2_above(leaf_pairs);
+    if (g->d_leaf_pairs) { (void)hipFree(g->d_leaf_pairs); g->d_leaf_pairs = nullptr; }
+    if (g->d_leaf_ranges) { (void)hipFree(g->d_leaf_ranges); g->d_leaf_ranges = nullptr; }
+    RT_HIP(ctx, hipMalloc((void**)&g->d_leaf_pairs, (size_t)leaf_pow2 * sizeof(uint2)));
+    RT_HIP(ctx, hipMalloc((void**)&g->d_leaf_ranges, (size_t)(leaf_cells ? leaf_cells : 1) * sizeof(uint2)));
+    g->info.leaf_pairs_count = leaf_pairs; g->info.leaf_pairs_pow2 = leaf_pow2;
+    RT_HIP(ctx, hipMemsetAsync(g->d_leaf_pairs, 0xFF, (size_t)leaf_pow2 * sizeof(uint2), s));     // :404-408
+    RT_HIP(ctx, hipMemsetAsync(g->d_leaf_ranges, 0, (size_t)(leaf_cells ? leaf_cells : 1) * sizeof(uint2), s));
+    // 5. emit (leaf cell, triangle) with the exact triangle / box test, sort, leaf ranges          (:410-466)
+    launch_tlg_emit_leaf(s, G, g->d_pairs, pairs, g->d_top, sc, g->d_scan, g->d_counters, g->d_leaf_pairs, g->d_written);
+    launch_bitonic_sort(s, g->d_leaf_pairs, leaf_pow2);
+    launch_segment_bounds(s, g->d_leaf_pairs, leaf_pairs, g->d_leaf_ranges);
+    uint32_t written = 0;
+    if (read_word(ctx, g->d_written, &written)) return RT_ERROR;        // construct() returns with the build finished
+    g->info.written_leaf_pairs = written;
+    g->frame_initialised = false;
+    g->built = true;
+    return RT_SUCCESS;
+}
+
+static TlgLaunch make_tlg_launch(const rt_tlg* g)
+{
+    TlgLaunch t{};
+    t.grid = g->grid; t.top = g->d_top; t.leaf_ranges = g->d_leaf_ranges; t.leaf_pairs = g->d_leaf_pairs; t.scene = &g->scene->d;
+    return t;
+}
+
+int rt_tlg_generate_contacts_primary(rt_tlg* g, const rt_camera* cam, void* d_contacts)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    if (!g->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (!d_contacts) return RT_FAIL(ctx, "contacts buffer is null");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_tlg_trace_primary(ctx->stream, make_tlg_launch(g), *cam, 0, 1, false, (rt_contact*)d_contacts);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_tlg_generate_contacts_primary_tiled(rt_tlg* g, const rt_camera* cam, uint32_t rank, uint32_t nranks, void* d_contacts_compact)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    if (!g->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (!d_contacts_compact) return RT_FAIL(ctx, "contacts buffer is null");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_tlg_trace_primary(ctx->stream, make_tlg_launch(g), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_tlg_generate_contacts_rays(rt_tlg* g, const void* d_rays, uint32_t ray_count, void* d_contacts)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    if (!g->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (ray_count == 0) return RT_SUCCESS;
+    if (!d_rays || !d_contacts) return RT_FAIL(ctx, "null buffer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    launch_tlg_trace_rays(ctx->stream, make_tlg_launch(g), (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_tlg_info_get(const rt_tlg* g, rt_tlg_info* out)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    if (!out) return RT_FAIL(g->ctx, "null argument");
+    *out = g->info;
+    return RT_SUCCESS;
+}
+
+int rt_tlg_read(const rt_tlg* g, int what, void* h_dst, uint64_t bytes)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    if (!h_dst) return RT_FAIL(ctx, "null argument");
+    if (what == RT_TLG_GRID_DATA) {
+        if (!g->frame_initialised && !g->built) return RT_FAIL(ctx, "initializeFrame has not run");
+        if (bytes != sizeof(rt_grid_data)) return RT_FAIL(ctx, "size mismatch");
+        std::memcpy(h_dst, &g->grid, sizeof(rt_grid_data));
+        return RT_SUCCESS;
+    }
+    if (!g->built) return RT_FAIL(ctx, "the grid is not built");
+    const void* src = nullptr;
+    uint64_t want = 0;
+    switch (what) {
+    case RT_TLG_TOP_CELLS:   src = g->d_top;         want = (uint64_t)g->info.cells * sizeof(rt_top_cell); break;
+    case RT_TLG_TOP_PAIRS:   src = g->d_pairs;       want = (uint64_t)g->info.pairs_pow2 * sizeof(uint2); break;
+    case RT_TLG_CELL_RANGES: src = g->d_cell_ranges; want = (uint64_t)g->info.cells * sizeof(uint2); break;
+    case RT_TLG_LEAF_PAIRS:  src = g->d_leaf_pairs;  want = (uint64_t)g->info.leaf_pairs_pow2 * sizeof(uint2); break;
+    case RT_TLG_LEAF_RANGES: src = g->d_leaf_ranges; want = (uint64_t)g->info.leaf_cells_count * sizeof(uint2); break;
+    default: return RT_FAIL(ctx, "unknown build product");
+    }
+    if (bytes != want) return RT_FAIL(ctx, "size mismatch");
+    if (want == 0) return RT_SUCCESS;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(h_dst, src, want, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_SUCCESS;
+}
+
+float rt_tlg_pow_third(float x) { return tlg_pow_third(x); }

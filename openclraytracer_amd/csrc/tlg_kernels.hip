@@ -1,0 +1,511 @@
+// tlg_kernels.hip -- Two-Level Grid (Kalojanov et al.) build and traversal for gfx950.
+//
+// Restates, with the FIXED readings of SURVEY.md 8(c) (see include/rtmi.h, rt_tlg_*):
+//   build      OpenCLRayTracer/src/CLRayTracerEngine/TwoLevelGridKernels.cl:43-221 and
+//              Include/CLData/AccelerationStructs/TwoLevelGrid.h:55-403, AABB.h:219-226,389-540
+//   traversal  TwoLevelGrid.h:419-678 (tlg_generate_contact / processTopLevelCell), kernels TwoLevelGridKernels.cl:228-270
+// Data the reference re-reads from the packed scene buffer per pair / per ray comes from the SoA triangle table.
+#include "rtmi_internal.h"
+#include "device_math.h"
+#include "tlg_math.h"
+
+#define TLG_BLOCK 256
+
+// ------------------------------------------------------------------------------------------------
+// build
+// ------------------------------------------------------------------------------------------------
+
+// float cell span of a triangle's bounding box: countOverlappingCells (TwoLevelGrid.h:86-99) and
+// writeOverlappingPairs (:146-150) evaluate the same expressions
+__device__ __forceinline__ void top_span(const rt_grid_data& g, float4 a, float4 b, float4 c, float s[3], float e[3])
+{
+    const float lo[3] = { RMIN(a.x, RMIN(b.x, c.x)), RMIN(a.y, RMIN(b.y, c.y)), RMIN(a.z, RMIN(b.z, c.z)) };
+    const float hi[3] = { RMAX(a.x, RMAX(b.x, c.x)), RMAX(a.y, RMAX(b.y, c.y)), RMAX(a.z, RMAX(b.z, c.z)) };
+    const float org[3] = { g.box_lo[0], g.box_lo[1], g.box_lo[2] };
+    const float step[3] = { g.stepX, g.stepY, g.stepZ };
+    const float last[3] = { (float)(g.resX - 1), (float)(g.resY - 1), (float)(g.resZ - 1) };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float fs = floorf((lo[k] - org[k]) / step[k]);
+        float fe = floorf((hi[k] - org[k]) / step[k]);
+        s[k] = RMIN(fs, last[k]);
+        e[k] = RMIN(fe, last[k]);
+    }
+}
+
+// prepareDataKernel -> prepareGridData (TwoLevelGridKernels.cl:43-51; all n triangles)
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_count_top(rt_grid_data g, const float4* __restrict__ v0, const float4* __restrict__ v1,
+                                                             const float4* __restrict__ v2, uint32_t n, uint32_t* __restrict__ counters)
+{
+    uint32_t i = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float s[3], e[3];
+    top_span(g, v0[i], v1[i], v2[i], s, e);
+    float cx = (e[0] - s[0]) + 1.0f, cy = (e[1] - s[1]) + 1.0f, cz = (e[2] - s[2]) + 1.0f;
+    counters[i] = tlg_f2u(cx * cy * cz);
+}
+
+// writePairsKernel -> writePairs -> writeOverlappingPairs (TwoLevelGrid.h:138-188)
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_emit_top(rt_grid_data g, const float4* __restrict__ v0, const float4* __restrict__ v1,
+                                                            const float4* __restrict__ v2, uint32_t n, const uint32_t* __restrict__ scan,
+                                                            const uint32_t* __restrict__ counters, uint2* __restrict__ pairs)
+{
+    uint32_t i = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float s[3], e[3];
+    top_span(g, v0[i], v1[i], v2[i], s, e);
+    const uint32_t mx[3] = { g.resX - 1, g.resY - 1, g.resZ - 1 };
+    uint32_t c0[3], c1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        c0[k] = tlg_f2u(s[k]); c0[k] = c0[k] > mx[k] ? mx[k] : c0[k];
+        c1[k] = tlg_f2u(e[k]); c1[k] = c1[k] > mx[k] ? mx[k] : c1[k];
+    }
+    const uint32_t cnt = counters[i];
+    const uint32_t first = scan[i] - cnt;
+    uint32_t w = 0;
+    for (uint32_t z = c0[2]; z <= c1[2]; z++)
+        for (uint32_t y = c0[1]; y <= c1[1]; y++)
+            for (uint32_t x = c0[0]; x <= c1[0]; x++) {
+                if (w < cnt) pairs[first + w] = make_uint2(z * g.resX * g.resY + y * g.resX + x, i);   // getCellIndex :55-59
+                w++;
+            }
+}
+
+// extractCellRangesKernel / extractLeafCellsKernel (TwoLevelGridKernels.cl:71-116,176-221): [first, end) of every key
+// in the sorted array.  One thread per element over the whole array (the reference's LDS indexing only works in
+// work-group 0), the last range closes at `count`, UINT_MAX holes never become a cell.
+__global__ __launch_bounds__(TLG_BLOCK) void k_segment_bounds(const uint2* __restrict__ sorted, uint32_t count, uint2* __restrict__ ranges)
+{
+    uint32_t i = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t me = sorted[i].x;
+    if (i + 1 < count) {
+        const uint32_t right = sorted[i + 1].x;
+        if (right > me) {
+            ranges[me].y = i + 1;
+            if (right != 0xFFFFFFFFu) ranges[right].x = i + 1;
+        }
+    } else if (me != 0xFFFFFFFFu) ranges[me].y = count;
+}
+
+// countLeavesAndFillCellKernel -> fillTopLevelCell -> calcLeafCellResolution (TwoLevelGrid.h:193-225)
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_cell_res(rt_grid_data g, const uint2* __restrict__ ranges, uint32_t cells,
+                                                            rt_top_cell* __restrict__ top, uint32_t* __restrict__ leaves)
+{
+    uint32_t c = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (c >= cells) return;
+    const uint2 r = ranges[c];
+    const uint32_t prims = r.y - r.x;
+    const float volume = g.stepX * g.stepY * g.stepZ;
+    const float a = tlg_pow_third(g.leafDensity * (float)prims / volume);
+    rt_top_cell t;
+    t.resX = tlg_f2u(floorf(g.stepX * a)); t.resY = tlg_f2u(floorf(g.stepY * a)); t.resZ = tlg_f2u(floorf(g.stepZ * a));
+    t.firstLeafIdx = 0;
+    top[c] = t;
+    leaves[c] = t.resX * t.resY * t.resZ;
+}
+
+// updateTopLevelCellsWithLeafRange (TwoLevelGridKernels.cl:129-136)
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_first_leaf(rt_top_cell* __restrict__ top, const uint32_t* __restrict__ scan, uint32_t cells)
+{
+    uint32_t c = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (c == 0 || c >= cells) return;
+    top[c].firstLeafIdx = scan[c - 1];
+}
+
+struct LeafGeom { float stepX, stepY, stepZ, baseX, baseY, baseZ; };
+// leaf-cell geometry of one top-level cell (TwoLevelGrid.h:268-275 and :347-353: same expressions)
+__device__ __forceinline__ LeafGeom leaf_geometry(const rt_grid_data& g, const rt_top_cell& tc, uint32_t topIdx)
+{
+    LeafGeom L;
+    L.stepX = g.stepX / (float)tc.resX;
+    L.stepY = g.stepY / (float)tc.resY;
+    L.stepZ = g.stepZ / (float)tc.resZ;
+    const uint32_t a = g.resX * g.resY;                           // getCellRefFromIndex :69-75
+    const uint32_t z = topIdx / a, b = topIdx - a * z;
+    const uint32_t cx = b % g.resX, cy = b / g.resX;
+    L.baseX = g.box_lo[0] + (float)cx * g.stepX;
+    L.baseY = g.box_lo[1] + (float)cy * g.stepY;
+    L.baseZ = g.box_lo[2] + (float)z * g.stepZ;
+    return L;
+}
+
+// calculateTriangleAABB, AABB.h:61-79 (one axis)
+__device__ __forceinline__ void tri_axis_bounds(float a, float b, float c, float& lo, float& hi)
+{
+    lo = RMIN(a, b); hi = RMAX(a, b);
+    lo = RMIN(lo, c); hi = RMAX(hi, c);
+    const float flat = (float)(uint32_t)((hi - lo) < FLT_EPSILON);
+    hi += flat * FLT_EPSILON;
+    lo -= flat * FLT_EPSILON;
+}
+
+// one axis of AABBOverlaps (AABB.h:219-226) between leaf cell i and the triangle's box.  The 3-D predicate is the AND
+// of three per-axis predicates that depend on that axis' index only, so the number of overlapping leaf cells of
+// countOverlappingLeafCells' triple loop (TwoLevelGrid.h:277-291) is the product of three per-axis counts.
+__device__ __forceinline__ bool axis_overlaps(float base, float step, uint32_t i, float tlo, float thi)
+{
+    const float lo = base + (float)i * step, hi = lo + step;
+    return !(RMIN(hi, thi) < RMAX(lo, tlo));
+}
+
+__device__ __forceinline__ void axis_range(float base, float step, uint32_t res, float tlo, float thi,
+                                           uint32_t& count, uint32_t& first, uint32_t& last)
+{
+    count = 0; first = 0; last = 0;
+    for (uint32_t i = 0; i < res; i++)
+        if (axis_overlaps(base, step, i, tlo, thi)) { if (!count) first = i; last = i; count++; }
+}
+
+// prepareGridDataForLeaves -> countLeafPairs -> countOverlappingLeafCells (TwoLevelGrid.h:262-323)
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_count_leaf(rt_grid_data g, const uint2* __restrict__ pairs, uint32_t pairs_count,
+                                                              const rt_top_cell* __restrict__ top, const float4* __restrict__ v0,
+                                                              const float4* __restrict__ v1, const float4* __restrict__ v2,
+                                                              uint32_t* __restrict__ counters)
+{
+    uint32_t p = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (p >= pairs_count) return;
+    const uint2 pr = pairs[p];
+    const rt_top_cell tc = top[pr.x];
+    const float4 a = v0[pr.y], b = v1[pr.y], c = v2[pr.y];
+    const LeafGeom L = leaf_geometry(g, tc, pr.x);
+    float lo, hi;
+    uint32_t nx, ny, nz, f, l;
+    tri_axis_bounds(a.x, b.x, c.x, lo, hi); axis_range(L.baseX, L.stepX, tc.resX, lo, hi, nx, f, l);
+    tri_axis_bounds(a.y, b.y, c.y, lo, hi); axis_range(L.baseY, L.stepY, tc.resY, lo, hi, ny, f, l);
+    tri_axis_bounds(a.z, b.z, c.z, lo, hi); axis_range(L.baseZ, L.stepZ, tc.resZ, lo, hi, nz, f, l);
+    counters[p] = (tc.resX && tc.resY && tc.resZ) ? nx * ny * nz : 0u;
+}
+
+// sign() of OpenCL C 6.12.4
+__device__ __forceinline__ float cl_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : (x == 0.0f ? x : 0.0f)); }
+
+// AABBTriangleIntersect (AABB.h:477-540) with planeBoxOverlap (:455-475) and the AXISTEST macros (:389-453)
+__device__ __forceinline__ bool aabb_triangle_intersect(f3 c, f3 h, f3 v0, f3 v1, f3 v2)
+{
+    bool yes = true;
+    v0 = f3_sub(c, v0); v1 = f3_sub(c, v1); v2 = f3_sub(c, v2);
+#define AXISTEST(pa_, pb_, rad_)                                            \
+    do { const float pa = (pa_), pb = (pb_); const float mn = RMIN(pa, pb), mx = RMAX(pa, pb); const float rad = (rad_); \
+         yes = yes && (mn <= rad && mx >= -rad); } while (0)
+    {
+        f3 e = f3_sub(v1, v0);
+        float fex = fabsf(e.x), fey = fabsf(e.y), fez = fabsf(e.z);
+        AXISTEST(e.z * v0.y - e.y * v0.z, e.z * v2.y - e.y * v2.z, fez * h.y + fey * h.z);
+        AXISTEST(-e.z * v0.x + e.x * v0.z, -e.z * v2.x + e.x * v2.z, fez * h.x + fex * h.z);
+        AXISTEST(e.y * v1.x - e.x * v1.y, e.y * v2.x - e.x * v2.y, fey * h.x + fex * h.y);
+        e = f3_sub(v2, v1);
+        fex = fabsf(e.x); fey = fabsf(e.y); fez = fabsf(e.z);
+        AXISTEST(e.z * v0.y - e.y * v0.z, e.z * v2.y - e.y * v2.z, fez * h.y + fey * h.z);
+        AXISTEST(-e.z * v0.x + e.x * v0.z, -e.z * v2.x + e.x * v2.z, fez * h.x + fex * h.z);
+        AXISTEST(e.y * v0.x - e.x * v0.y, e.y * v1.x - e.x * v1.y, fey * h.x + fex * h.y);
+        e = f3_sub(v0, v2);
+        fex = fabsf(e.x); fey = fabsf(e.y); fez = fabsf(e.z);
+        AXISTEST(e.z * v0.y - e.y * v0.z, e.z * v1.y - e.y * v1.z, fez * h.y + fey * h.z);
+        AXISTEST(-e.z * v0.x + e.x * v0.z, -e.z * v1.x + e.x * v1.z, fez * h.x + fex * h.z);
+        AXISTEST(e.y * v1.x - e.x * v1.y, e.y * v2.x - e.x * v2.y, fey * h.x + fex * h.y);
+    }
+#undef AXISTEST
+    float mn, mx;
+    mn = RMIN(v0.x, RMIN(v1.x, v2.x)); mx = RMAX(v0.x, RMAX(v1.x, v2.x));
+    yes = yes && (mn <= h.x && mx >= -h.x);
+    mn = RMIN(v0.y, RMIN(v1.y, v2.y)); mx = RMAX(v0.y, RMAX(v1.y, v2.y));
+    yes = yes && (mn <= h.y && mx >= -h.y);
+    mn = RMIN(v0.z, RMIN(v1.z, v2.z)); mx = RMAX(v0.z, RMAX(v1.z, v2.z));
+    yes = yes && (mn <= h.z && mx >= -h.z);
+    const f3 normal = f3_cross(f3_sub(v1, v0), f3_sub(v2, v1));
+    f3 vmin, vmax;
+    vmin.x = -cl_sign(normal.x) * h.x - v0.x; vmax.x = cl_sign(normal.x) * h.x - v0.x;
+    vmin.y = -cl_sign(normal.y) * h.y - v0.y; vmax.y = cl_sign(normal.y) * h.y - v0.y;
+    vmin.z = -cl_sign(normal.z) * h.z - v0.z; vmax.z = cl_sign(normal.z) * h.z - v0.z;
+    yes = yes && (f3_dot(normal, vmin) <= 0.0f);
+    yes = yes && (f3_dot(normal, vmax) >= 0.0f);
+    return yes;
+}
+
+// writeLeafPairsKernel -> writeLeafPairs -> writeOverlappingLeafPairs (TwoLevelGrid.h:338-403).
+// The reference runs the exact test on every leaf cell of the top-level cell; a cell can only pass when its box
+// overlaps the triangle's box on every axis up to rounding, so the loops here cover the per-axis overlap ranges widened
+// by one cell: the same cells pass, in the same z-y-x order.  At most `counted` pairs are written (FIXED reading: the
+// reference would run into its neighbour's slots).
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_emit_leaf(rt_grid_data g, const uint2* __restrict__ pairs, uint32_t pairs_count,
+                                                             const rt_top_cell* __restrict__ top, const float4* __restrict__ v0,
+                                                             const float4* __restrict__ v1, const float4* __restrict__ v2,
+                                                             const uint32_t* __restrict__ scan, const uint32_t* __restrict__ counters,
+                                                             uint2* __restrict__ leaf_pairs, uint32_t* __restrict__ written_total)
+{
+    uint32_t p = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (p >= pairs_count) return;
+    const uint32_t cnt = counters[p];
+    if (cnt == 0) return;
+    const uint2 pr = pairs[p];
+    const rt_top_cell tc = top[pr.x];
+    const float4 a4 = v0[pr.y], b4 = v1[pr.y], c4 = v2[pr.y];
+    const LeafGeom L = leaf_geometry(g, tc, pr.x);
+    float lo, hi;
+    uint32_t n, fx, lx, fy, ly, fz, lz;
+    tri_axis_bounds(a4.x, b4.x, c4.x, lo, hi); axis_range(L.baseX, L.stepX, tc.resX, lo, hi, n, fx, lx);
+    tri_axis_bounds(a4.y, b4.y, c4.y, lo, hi); axis_range(L.baseY, L.stepY, tc.resY, lo, hi, n, fy, ly);
+    tri_axis_bounds(a4.z, b4.z, c4.z, lo, hi); axis_range(L.baseZ, L.stepZ, tc.resZ, lo, hi, n, fz, lz);
+    fx = fx ? fx - 1 : 0; fy = fy ? fy - 1 : 0; fz = fz ? fz - 1 : 0;
+    lx = lx + 1 < tc.resX ? lx + 1 : tc.resX - 1; ly = ly + 1 < tc.resY ? ly + 1 : tc.resY - 1; lz = lz + 1 < tc.resZ ? lz + 1 : tc.resZ - 1;
+    const f3 half = f3{ L.stepX * 0.5f, L.stepY * 0.5f, L.stepZ * 0.5f };
+    const f3 A = f3_from4(a4), B = f3_from4(b4), C = f3_from4(c4);
+    const uint32_t first = scan[p] - cnt;
+    uint32_t w = 0;
+    for (uint32_t z = fz; z <= lz; z++)
+        for (uint32_t y = fy; y <= ly; y++)
+            for (uint32_t x = fx; x <= lx; x++) {
+                const f3 c = f3{ L.baseX + (float)x * L.stepX + half.x, L.baseY + (float)y * L.stepY + half.y,
+                                 L.baseZ + (float)z * L.stepZ + half.z };
+                if (aabb_triangle_intersect(c, half, A, B, C)) {
+                    if (w < cnt)
+                        leaf_pairs[first + w] = make_uint2(z * tc.resX * tc.resY + y * tc.resX + x + tc.firstLeafIdx, pr.y);
+                    w++;
+                }
+            }
+    if (w > cnt) w = cnt;
+    if (w) atomicAdd(written_total, w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// traversal
+// ------------------------------------------------------------------------------------------------
+struct TlgTraceArgs {
+    rt_grid_data grid;
+    const rt_top_cell* __restrict__ top;
+    const uint2* __restrict__ leaf_ranges;
+    const uint2* __restrict__ leaf_pairs;
+    const float4* __restrict__ v0;
+    const float4* __restrict__ e1;
+    const float4* __restrict__ e2;
+    const float4* __restrict__ nrm;
+    uint32_t total_work;
+    rt_camera cam;
+    uint32_t rank, nranks, tiles_x, compact;
+    const rt_ray* __restrict__ rays;
+    rt_contact* __restrict__ out;
+};
+
+// the DDA set-up both levels share: TwoLevelGrid.h:436-500 (leaf level) and :575-640 (top level)
+struct Dda {
+    float nx, ny, nz;        // next[]
+    float dtx, dty, dtz;     // dt[]
+    int ix, iy, iz;          // idx[]
+    int sx, sy, sz;          // step[]
+    int ex, ey, ez;          // stop[]
+    float t0, tmaxmax;
+};
+
+__device__ __forceinline__ void dda_axis_setup(float o, float d, float lo, float hi, uint32_t res, float& tmin, float& tmax)
+{
+    const float a = 1.0f / d;            // the z axis divides the double literal 1.0 (:445,584): same value after rounding
+    tmin = ((a >= 0.0f ? lo : hi) - o) * a;
+    tmax = ((a >= 0.0f ? hi : lo) - o) * a;
+}
+
+__device__ __forceinline__ void dda_axis_finish(float p, float d, float lo, float hi, uint32_t res, float tmin, float tmax,
+                                                float& next, float& dt, int& idx, int& step, int& stop)
+{
+    float f = (p - lo) * (float)res / (hi - lo);
+    const float top = (float)res - 1;
+    f = RMAX(f, 0.0f); f = RMIN(f, top);              // clamp(v,l,h) = min(max(v,l),h), CLPortability.h:401
+    idx = (int)f;
+    dt = (tmax - tmin) / (float)res;
+    if (d > 0.0f) {
+        next = tmin + (float)(idx + 1) * dt;
+        step = 1; stop = (int)res;
+    } else {
+        next = d == 0.0f ? FLT_MAX : tmin + (float)(res - (uint32_t)idx) * dt;
+        step = -1; stop = -1;
+    }
+}
+
+__device__ __forceinline__ void dda_setup(f3 o, f3 d, f3 lo, f3 hi, uint32_t rx, uint32_t ry, uint32_t rz, Dda& s)
+{
+    float txmin, txmax, tymin, tymax, tzmin, tzmax;
+    dda_axis_setup(o.x, d.x, lo.x, hi.x, rx, txmin, txmax);
+    dda_axis_setup(o.y, d.y, lo.y, hi.y, ry, tymin, tymax);
+    dda_axis_setup(o.z, d.z, lo.z, hi.z, rz, tzmin, tzmax);
+    s.t0 = RMIN(txmin, RMIN(tymin, tzmin));
+    s.tmaxmax = RMAX(txmax, RMAX(tymax, tzmax));
+    const bool inside = (lo.x <= o.x) && (o.x <= hi.x) && (lo.y <= o.y) && (o.y <= hi.y) && (lo.z <= o.z) && (o.z <= hi.z);
+    f3 p = o;
+    if (!inside) p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
+    dda_axis_finish(p.x, d.x, lo.x, hi.x, rx, txmin, txmax, s.nx, s.dtx, s.ix, s.sx, s.ex);
+    dda_axis_finish(p.y, d.y, lo.y, hi.y, ry, tymin, tymax, s.ny, s.dty, s.iy, s.sy, s.ey);
+    dda_axis_finish(p.z, d.z, lo.z, hi.z, rz, tzmin, tzmax, s.nz, s.dtz, s.iz, s.sz, s.ez);
+}
+
+// `minimal = min(next[x], min(next[y], next[z])); while (minimal != next[axis]) axis++`; -1: no axis (all NaN), the
+// ray ends with NO_CONTACT (FIXED reading; the reference runs off the array)
+__device__ __forceinline__ int dda_axis(const Dda& s)
+{
+    const float minimal = RMIN(s.nx, RMIN(s.ny, s.nz));
+    return minimal == s.nx ? 0 : (minimal == s.ny ? 1 : (minimal == s.nz ? 2 : -1));
+}
+
+// next[axis] += dt[axis]; idx[axis] += step[axis]; returns idx[axis] == stop[axis]
+__device__ __forceinline__ bool dda_advance(Dda& s, int axis)
+{
+    if (axis == 0) { s.nx += s.dtx; s.ix += s.sx; return s.ix == s.ex; }
+    if (axis == 1) { s.ny += s.dty; s.iy += s.sy; return s.iy == s.ey; }
+    s.nz += s.dtz; s.iz += s.sz; return s.iz == s.ez;
+}
+
+template <int PRIMARY>
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace(TlgTraceArgs a)
+{
+    const uint32_t w = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (w >= a.total_work) return;
+    f3 o, d;
+    uint32_t pixel, out_index;
+    if (PRIMARY) {
+        // work item -> pixel: this rank's 64x64 tiles, inside a tile 8x8 blocks (one wave = one block), as in trace_kernels.hip
+        const uint32_t ordinal = w >> 12, within = w & 4095u;
+        const uint32_t tile = ordinal * a.nranks + a.rank;
+        const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const uint32_t blk = within >> 6, lp = within & 63u;
+        const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3), lx = ((blk & 7u) << 3) + (lp & 7u);
+        const uint32_t x = tx * RT_TILE + lx, y = ty * RT_TILE + ly;
+        if (x >= a.cam.resX || y >= a.cam.resY) return;
+        generate_ray_xy(a.cam, x, y, o, d);
+        pixel = y * a.cam.resX + x;
+        out_index = a.compact ? (ordinal << 12) + ly * RT_TILE + lx : pixel;
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(a.rays + w);
+        const float4 ro = p[1], rd = p[2];
+        o = f3{ ro.x, ro.y, ro.z }; d = f3{ rd.x, rd.y, rd.z };
+        pixel = w; out_index = w;
+    }
+    const rt_grid_data& g = a.grid;
+    const f3 glo = f3{ g.box_lo[0], g.box_lo[1], g.box_lo[2] }, ghi = f3{ g.box_hi[0], g.box_hi[1], g.box_hi[2] };
+
+    float best_t = 0.0f;                    // NO_CONTACT (CLStructs.h:124)
+    uint32_t best_tri = 0xFFFFFFFFu;
+
+    Dda T;
+    dda_setup(o, d, glo, ghi, g.resX, g.resY, g.resZ, T);
+    bool done = T.t0 > T.tmaxmax;            // TwoLevelGrid.h:590-591
+    while (!done) {
+        const rt_top_cell tc = a.top[(uint32_t)T.iz * g.resX * g.resY + (uint32_t)T.iy * g.resX + (uint32_t)T.ix];
+        const int taxis = dda_axis(T);
+        if (!(tc.resX == 0 || tc.resY == 0 || tc.resZ == 0)) {
+            // processTopLevelCell, TwoLevelGrid.h:419-545
+            f3 clo, chi;
+            clo.x = glo.x + (float)T.ix * g.stepX; clo.y = glo.y + (float)T.iy * g.stepY; clo.z = glo.z + (float)T.iz * g.stepZ;
+            chi.x = clo.x + g.stepX; chi.y = clo.y + g.stepY; chi.z = clo.z + g.stepZ;
+            Dda Lf;
+            dda_setup(o, d, clo, chi, tc.resX, tc.resY, tc.resZ, Lf);
+            float cell_t = FLT_MAX;
+            uint32_t cell_tri = 0xFFFFFFFFu;
+            for (;;) {
+                const int laxis = dda_axis(Lf);
+                const uint32_t leaf = (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
+                const uint2 range = a.leaf_ranges[leaf];
+                for (uint32_t i = range.x; i < range.y; i++) {
+                    const uint32_t tri = a.leaf_pairs[i].y;
+                    // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions)
+                    const f3 vert0 = f3_from4(a.v0[tri]), edge1 = f3_from4(a.e1[tri]), edge2 = f3_from4(a.e2[tri]);
+                    const f3 pvec = f3_cross(d, edge2);
+                    const float det = f3_dot(edge1, pvec);
+                    bool flag = fabsf(det) >= FLT_EPSILON;
+                    const float inv_det = 1.0f / det;
+                    const f3 tvec = f3_sub(o, vert0);
+                    const float u = f3_dot(tvec, pvec) * inv_det;
+                    flag = flag & (u < 1.0f) & (u >= 0.0f);
+                    const f3 qvec = f3_cross(tvec, edge1);
+                    const float v = f3_dot(d, qvec) * inv_det;
+                    flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
+                    const float t = f3_dot(edge2, qvec) * inv_det;        // "* flag" folded into the test
+                    if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
+                }
+                if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
+                if (laxis < 0) break;
+                if (dda_advance(Lf, laxis)) break;                        // :542-545
+            }
+            if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
+        }
+        if (taxis < 0) break;
+        if (dda_advance(T, taxis)) break;                                 // :672-676
+    }
+
+    float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t material = 0;
+    if (best_tri != 0xFFFFFFFFu) {
+        const float4 n = a.nrm[best_tri];
+        nt = make_float4(n.x, n.y, n.z, best_t);
+        material = __float_as_uint(a.v0[best_tri].w);
+    }
+    const uint4 head = make_uint4(pixel, material, 0u, 0u);
+    float4* dst = reinterpret_cast<float4*>(a.out + out_index);
+    dst[0] = *reinterpret_cast<const float4*>(&head);
+    dst[1] = nt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline dim3 blocks_for(uint32_t n) { return dim3((n + TLG_BLOCK - 1) / TLG_BLOCK); }
+
+void launch_tlg_count_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, uint32_t* counters)
+{
+    hipLaunchKernelGGL(k_tlg_count_top, blocks_for(sc.n_tris), dim3(TLG_BLOCK), 0, s, g, sc.v0, sc.v1, sc.v2, sc.n_tris, counters);
+}
+void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs)
+{
+    hipLaunchKernelGGL(k_tlg_emit_top, blocks_for(sc.n_tris), dim3(TLG_BLOCK), 0, s, g, sc.v0, sc.v1, sc.v2, sc.n_tris, scan, counters, pairs);
+}
+void launch_segment_bounds(hipStream_t s, const uint2* sorted, uint32_t count, uint2* ranges)
+{
+    if (count) hipLaunchKernelGGL(k_segment_bounds, blocks_for(count), dim3(TLG_BLOCK), 0, s, sorted, count, ranges);
+}
+void launch_tlg_cell_res(hipStream_t s, const rt_grid_data& g, const uint2* ranges, uint32_t cells, rt_top_cell* top, uint32_t* leaves)
+{
+    hipLaunchKernelGGL(k_tlg_cell_res, blocks_for(cells), dim3(TLG_BLOCK), 0, s, g, ranges, cells, top, leaves);
+}
+void launch_tlg_first_leaf(hipStream_t s, rt_top_cell* top, const uint32_t* scan, uint32_t cells)
+{
+    hipLaunchKernelGGL(k_tlg_first_leaf, blocks_for(cells), dim3(TLG_BLOCK), 0, s, top, scan, cells);
+}
+void launch_tlg_count_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
+                           const DeviceScene& sc, uint32_t* counters)
+{
+    if (pairs_count)
+        hipLaunchKernelGGL(k_tlg_count_leaf, blocks_for(pairs_count), dim3(TLG_BLOCK), 0, s, g, pairs, pairs_count, top, sc.v0, sc.v1, sc.v2, counters);
+}
+void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
+                          const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* leaf_pairs, uint32_t* written_total)
+{
+    if (pairs_count)
+        hipLaunchKernelGGL(k_tlg_emit_leaf, blocks_for(pairs_count), dim3(TLG_BLOCK), 0, s, g, pairs, pairs_count, top, sc.v0, sc.v1, sc.v2,
+                           scan, counters, leaf_pairs, written_total);
+}
+
+static TlgTraceArgs tlg_args(const TlgLaunch& t)
+{
+    TlgTraceArgs a{};
+    a.grid = t.grid; a.top = t.top; a.leaf_ranges = t.leaf_ranges; a.leaf_pairs = t.leaf_pairs;
+    a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
+    return a;
+}
+
+void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks, bool compact,
+                              rt_contact* out)
+{
+    TlgTraceArgs a = tlg_args(t);
+    a.cam = cam; a.rank = rank; a.nranks = nranks; a.compact = compact ? 1u : 0u;
+    a.tiles_x = rt_tiles_x(cam.resX);
+    const uint32_t tiles = rt_tiles_x(cam.resX) * rt_tiles_y(cam.resY);
+    a.total_work = rt_owned_tiles(tiles, rank, nranks) * RT_TILE * RT_TILE;
+    a.out = out;
+    if (a.total_work) hipLaunchKernelGGL(k_tlg_trace<1>, blocks_for(a.total_work), dim3(TLG_BLOCK), 0, s, a);
+}
+
+void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)
+{
+    TlgTraceArgs a = tlg_args(t);
+    a.rays = rays; a.total_work = count; a.out = out;
+    if (count) hipLaunchKernelGGL(k_tlg_trace<0>, blocks_for(count), dim3(TLG_BLOCK), 0, s, a);
+}

@@ -23,6 +23,25 @@ CAMERA = np.dtype([('FOVDistance', '<f4'), ('resX', '<u4'), ('resY', '<u4'), ('s
                    ('m', '<f4', 12)])                                             # 64 B  CLStructs.h:44-51
 
 
+GRID_DATA = np.dtype([('res', '<u4', 3), ('step', '<f4', 3), ('leafDensity', '<f4'), ('padTo64', '<f4'),
+                      ('lo', '<f4', 4), ('hi', '<f4', 4)])                        # 64 B  TwoLevelGridData.h:52-64
+TOP_CELL = np.dtype([('res', '<u4', 3), ('firstLeafIdx', '<u4')])                 # 16 B  TwoLevelGridData.h:41-47
+TLG_INFO_FIELDS = ('cells', 'pairs_count', 'pairs_pow2', 'leaf_cells_count', 'leaf_pairs_count', 'leaf_pairs_pow2',
+                   'written_leaf_pairs', 'dropped_leaf_pairs', 'nonempty_cells', 'flat_cells')
+
+
+class F4(C.Structure):
+    _fields_ = [('x', C.c_float), ('y', C.c_float), ('z', C.c_float), ('w', C.c_float)]
+
+
+class TLGStats(C.Structure):
+    _fields_ = [('top_visits', C.c_uint64), ('leaf_visits', C.c_uint64), ('tri_tests', C.c_uint64),
+                ('hits', C.c_uint64), ('dropped_rays', C.c_uint64), ('sum_t', C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class Stats(C.Structure):
     _fields_ = [('inner_visits', C.c_uint64), ('leaf_tests', C.c_uint64), ('hits', C.c_uint64),
                 ('max_stack', C.c_uint32), ('pad_', C.c_uint32), ('sum_t', C.c_double)]
@@ -33,7 +52,7 @@ class Stats(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(HERE, f) for f in ('rt_oracle.c', 'tlg_oracle.c', 'rt_oracle.h') if
+    src = [os.path.join(HERE, f) for f in ('rt_oracle.c', 'tlg_oracle.c', 'rt_oracle.h', 'tlg_oracle.h') if
            os.path.exists(os.path.join(HERE, f))]
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
@@ -70,6 +89,20 @@ def lib():
         L.orc_brute_primary.argtypes = [vp, vp, vp, i32]
         L.orc_shade_frame.argtypes = [vp, vp, u32, vp, vp, i32]
         L.orc_scan_inclusive_u32.argtypes = [vp, vp, u32]
+        f32 = C.c_float
+        L.orc_pow_third.restype = f32
+        L.orc_pow_third.argtypes = [f32]
+        L.orc_aabb_triangle_intersect.argtypes = [F4, F4, F4, F4, F4]
+        L.orc_tlg_grid_data.argtypes = [vp, f32, f32, vp]
+        L.orc_tlg_build.restype = vp
+        L.orc_tlg_build.argtypes = [vp, f32, f32]
+        L.orc_tlg_free.argtypes = [vp]
+        L.orc_tlg_info_get.argtypes = [vp, vp]
+        for fn in ('grid', 'top_cells', 'top_pairs', 'cell_ranges', 'leaf_pairs', 'leaf_ranges'):
+            getattr(L, 'orc_tlg_' + fn).restype = vp
+            getattr(L, 'orc_tlg_' + fn).argtypes = [vp]
+        L.orc_tlg_trace_primary.argtypes = [vp, vp, vp, vp, i32]
+        L.orc_tlg_trace_rays.argtypes = [vp, vp, u32, vp, vp, i32]
         _lib = L
     return _lib
 
@@ -190,3 +223,57 @@ def scan_inclusive(a: np.ndarray) -> np.ndarray:
     out = np.zeros_like(a)
     lib().orc_scan_inclusive_u32(_p(a), _p(out), len(a))
     return out
+
+
+def _view(ptr, dtype, count):
+    """copy of `count` records behind a C pointer"""
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (dtype.itemsize * count)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+class TLG:
+    """Two-Level Grid built by the C oracle (tlg_oracle.c): TwoLevelGridManager::initializeFrame + construct."""
+
+    def __init__(self, scene: Scene, top_density: float = 2.0, leaf_density: float = 2.0):
+        self.scene = scene
+        self.h = lib().orc_tlg_build(_p(scene.arr), top_density, leaf_density)
+        if not self.h:
+            raise RuntimeError('orc_tlg_build failed (degenerate scene box)')
+        info = np.zeros(len(TLG_INFO_FIELDS), dtype=np.uint32)
+        lib().orc_tlg_info_get(self.h, _p(info))
+        self.info = dict(zip(TLG_INFO_FIELDS, (int(x) for x in info)))
+        L, i = lib(), self.info
+        self.grid = _view(L.orc_tlg_grid(self.h), GRID_DATA, 1)
+        self.top_cells = _view(L.orc_tlg_top_cells(self.h), TOP_CELL, i['cells'])
+        self.top_pairs = _view(L.orc_tlg_top_pairs(self.h), PAIR, i['pairs_pow2'])
+        self.cell_ranges = _view(L.orc_tlg_cell_ranges(self.h), PAIR, i['cells'])
+        self.leaf_pairs = _view(L.orc_tlg_leaf_pairs(self.h), PAIR, i['leaf_pairs_pow2'])
+        self.leaf_ranges = _view(L.orc_tlg_leaf_ranges(self.h), PAIR, i['leaf_cells_count'])
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_tlg_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def trace_primary(self, cam: np.ndarray, nthreads: int = 0):
+        n = int(cam['resX'][0]) * int(cam['resY'][0])
+        out = np.zeros(n, dtype=CONTACT)
+        st = TLGStats()
+        lib().orc_tlg_trace_primary(self.h, _p(cam), _p(out), C.byref(st), nthreads or ncpu())
+        return out, st.as_dict()
+
+    def trace_rays(self, rays: np.ndarray, nthreads: int = 0):
+        out = np.zeros(len(rays), dtype=CONTACT)
+        st = TLGStats()
+        if len(rays):
+            lib().orc_tlg_trace_rays(self.h, _p(rays), len(rays), _p(out), C.byref(st), nthreads or ncpu())
+        return out, st.as_dict()
+
+
+def pow_third(x: float) -> float:
+    return float(lib().orc_pow_third(C.c_float(x)))

@@ -1,0 +1,162 @@
+"""GPU parity of the Two-Level Grid (rt_tlg_*, through the C ABI) against the oracle: every build product and every
+contact bit for bit (BASELINE.json configs[3] path: TLG build + trace)."""
+import numpy as np
+import pytest
+
+from conftest import MODELS, as_capi_camera, packed_scene
+
+pytestmark = pytest.mark.gpu
+
+_otlg, _gtlg = {}, {}
+
+
+def oracle_tlg(name, dens=(2.0, 2.0)):
+    import oracle as orc
+    key = (name, dens)
+    if key not in _otlg:
+        sc = orc.Scene(packed_scene(name))
+        _otlg[key] = (sc, orc.TLG(sc, *dens))
+    return _otlg[key]
+
+
+def gpu_tlg(ctx, name, dens=(2.0, 2.0)):
+    from openclraytracer_amd import capi
+    key = (name, dens)
+    if key not in _gtlg:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        _gtlg[key] = (sc, capi.DeviceTLG(ctx, sc, *dens).build())
+    return _gtlg[key]
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_build_products_bit_exact(gpu_ctx, name):
+    _, og = oracle_tlg(name)
+    _, gg = gpu_tlg(gpu_ctx, name)
+    info = gg.info()
+    for k in info:
+        assert info[k] == og.info[k], k
+    T = type(gg)
+    assert gg.read(T.GRID_DATA).tobytes() == og.grid.tobytes()
+    assert gg.read(T.TOP_PAIRS).tobytes() == og.top_pairs.tobytes()
+    assert gg.read(T.CELL_RANGES).tobytes() == og.cell_ranges.tobytes()
+    assert gg.read(T.TOP_CELLS).tobytes() == og.top_cells.tobytes()
+    assert gg.read(T.LEAF_PAIRS).tobytes() == og.leaf_pairs.tobytes()
+    assert gg.read(T.LEAF_RANGES).tobytes() == og.leaf_ranges.tobytes()
+
+
+@pytest.mark.parametrize('name,res', [('cube', (64, 48)), ('gardenlight', (64, 48)), ('gardenlight', (333, 251)),
+                                      ('tenryuu', (640, 480)), ('man', (640, 480)), ('clumsydragon', (640, 480))])
+def test_trace_primary_bit_exact(gpu_ctx, name, res):
+    osc, og = oracle_tlg(name)
+    _, gg = gpu_tlg(gpu_ctx, name)
+    cam = osc.demo_camera(*res)
+    want, _ = og.trace_primary(cam)
+    got = gg.generate_contacts_primary(as_capi_camera(cam))
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_trace_primary_full_hd_bit_exact(gpu_ctx, name):
+    osc, og = oracle_tlg(name)
+    _, gg = gpu_tlg(gpu_ctx, name)
+    cam = osc.demo_camera(1920, 1080)
+    want, _ = og.trace_primary(cam)
+    got = gg.generate_contacts_primary(as_capi_camera(cam))
+    assert got.tobytes() == want.tobytes()
+
+
+def test_other_densities_and_rebuild(gpu_ctx):
+    """setTopLevelDensity / setLeafDensity take effect at initializeFrame (TwoLevelGridManager.h:112-118)"""
+    from openclraytracer_amd import capi
+    name = 'gardenlight'
+    osc, _ = oracle_tlg(name)
+    sc = capi.DeviceScene(gpu_ctx, packed_scene(name))
+    g = capi.DeviceTLG(gpu_ctx, sc)
+    try:
+        for dens in ((2.0, 2.0), (5.0, 1.2), (0.7, 3.5), (2.0, 2.0)):
+            _, og = oracle_tlg(name, dens)
+            gpu_ctx.check(gpu_ctx.lib.rt_tlg_set_densities(g.h, dens[0], dens[1]))
+            g.build()
+            assert g.info()['leaf_pairs_count'] == og.info['leaf_pairs_count']
+            assert g.read(g.LEAF_PAIRS).tobytes() == og.leaf_pairs.tobytes()
+            cam = osc.demo_camera(200, 150)
+            want, _ = og.trace_primary(cam)
+            assert g.generate_contacts_primary(as_capi_camera(cam)).tobytes() == want.tobytes()
+    finally:
+        g.close(); sc.close()
+
+
+def test_ray_buffer_random_and_degenerate(gpu_ctx):
+    """generateContacts(CLBuffer& rays, ...) (TwoLevelGridKernels.cl:251-270): incoherent rays, origins inside and outside
+    the grid, axis-parallel / zero / NaN directions, a count that is not a multiple of 64"""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, og = oracle_tlg('tenryuu')
+    _, gg = gpu_tlg(gpu_ctx, 'tenryuu')
+    rng = np.random.default_rng(9)
+    n = 10007
+    rays = np.zeros(n, dtype=orc.RAY)
+    rays['idx'] = np.arange(n)
+    rays['origin'][:, :3] = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays['direction'][:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays['direction'][0, :3] = (0, 0, 1)
+    rays['direction'][1, :3] = (0, 1, 0)
+    rays['direction'][2, :3] = (1, 0, 0)
+    rays['direction'][3, :3] = (0, 0, 0)
+    rays['direction'][4, :3] = (np.nan, 0, 1)
+    rays['direction'][5, :3] = (1e-42, 0.6, 0.8)         # denormal component: 1/d overflows
+    rays['direction'][6, :3] = (-0.0, -0.6, 0.8)
+    rays['origin'][7, :3] = (0, 0.5, 0)
+    want, st = og.trace_rays(rays)
+    got = gg.generate_contacts_rays(rays.view(capi.RAY))
+    assert got.tobytes() == want.tobytes()
+    assert st['hits'] > 100
+    assert len(gg.generate_contacts_rays(rays[:0].view(capi.RAY))) == 0
+    assert gg.generate_contacts_rays(rays[:1].view(capi.RAY)).tobytes() == want[:1].tobytes()
+
+
+@pytest.mark.parametrize('nranks', [2, 3])
+def test_tiled_frame_equals_untiled(gpu_ctx, nranks):
+    from openclraytracer_amd import capi, frame_tiles
+    osc, og = oracle_tlg('clumsydragon')
+    _, gg = gpu_tlg(gpu_ctx, 'clumsydragon')
+    cam = osc.demo_camera(500, 300)
+    ccam = as_capi_camera(cam)
+    want, _ = og.trace_primary(cam)
+    npx = 500 * 300
+    frame = np.zeros(npx, dtype=capi.CONTACT)
+    owner, slot = frame_tiles.slot_map(500, 300, nranks)
+    for rank in range(nranks):
+        slots = capi.tiles_owned_pixels(ccam, rank, nranks)
+        d = gpu_ctx.alloc(max(slots, 1) * 32)
+        try:
+            gpu_ctx.fill_u32(d, 0xDEADBEEF, max(slots, 1) * 8)
+            gg.generate_contacts_primary_tiled_d(ccam, rank, nranks, d)
+            compact = gpu_ctx.download(d, slots, capi.CONTACT)
+        finally:
+            gpu_ctx.free(d)
+        mine = owner == rank
+        frame[mine] = compact[slot[mine]]
+    assert frame.tobytes() == want.tobytes()
+
+
+def test_error_behaviour(gpu_ctx):
+    from openclraytracer_amd import capi
+    sc = capi.DeviceScene(gpu_ctx, packed_scene('cube'))
+    g = capi.DeviceTLG(gpu_ctx, sc)
+    try:
+        with pytest.raises(capi.RtError, match='initializeFrame must precede construct'):
+            g.construct()
+        g.initialize_frame()
+        cam = as_capi_camera(oracle_tlg('cube')[0].demo_camera(8, 8))
+        with pytest.raises(capi.RtError, match='construct must precede generateContacts'):
+            g.generate_contacts_primary(cam)
+        with pytest.raises(capi.RtError, match='densities must be positive'):
+            gpu_ctx.check(gpu_ctx.lib.rt_tlg_set_densities(g.h, 0.0, 2.0))
+        g.construct()
+        with pytest.raises(capi.RtError, match='size mismatch'):
+            out = np.zeros(3, dtype=np.uint8)
+            gpu_ctx.check(gpu_ctx.lib.rt_tlg_read(g.h, g.TOP_CELLS, out.ctypes.data, 3))
+    finally:
+        g.close(); sc.close()
