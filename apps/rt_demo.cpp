@@ -12,6 +12,7 @@
 #include <vector>
 
 #include <Algorithms/BVHManager.h>
+#include <Algorithms/TwoLevelGridManager.h>
 #include <CLData/CLStructs.h>
 #include <Scene/Scene.h>
 
@@ -38,10 +39,11 @@ int main(int argc, char* argv[])
         else if (k == "--contacts") rawContacts = v;
     }
     if (window_width <= 0 || window_height <= 0 || scenePath.empty() || accStruct.empty()) {
-        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH -headersPath dir -scene file.txt [--frames n] [--out img.ppm] [--contacts raw.bin]" << std::endl;
+        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm] [--contacts raw.bin]" << std::endl;
         return 0;
     }
-    if (accStruct != "BVH") { std::cout << "only -accStruct BVH is built so far (GRID = Two-Level Grid is the next row)" << std::endl; return 1; }
+    if (accStruct != "BVH" && accStruct != "GRID") {              // OpenCLRayTracerDemo.cpp:221-224
+        std::cout << "Unsupported acceleration structure: " << accStruct << " (BVH or GRID)" << std::endl; return 1; }
     Errata err;
     std::unique_ptr<CLExecutionContext> context;
     try { context.reset(new CLExecutionContext(0)); }
@@ -64,7 +66,9 @@ int main(int argc, char* argv[])
     camera.viewTransform = identityTransform();
     Quaternion cameraOrientation = zeroRotation();
 
-    std::unique_ptr<AccelerationStructureManager> accelerationStruct(new BVHManager(*context, scene));
+    std::unique_ptr<AccelerationStructureManager> accelerationStruct;
+    if (accStruct == "BVH") accelerationStruct.reset(new BVHManager(*context, scene));
+    else accelerationStruct.reset(new TwoLevelGridManager(*context, scene));
     CHECKED_CALL(accelerationStruct->initialize(err));
     CHECKED_CALL(accelerationStruct->initializeFrame(err));
     CHECKED_CALL(accelerationStruct->construct(err));

@@ -9,6 +9,9 @@
 struct alignas(16) CL_FLOAT4_ { float x, y, z, w; };
 typedef CL_FLOAT4_ CL_FLOAT4;
 typedef CL_FLOAT4_ CL_FLOAT3;      // cl_float3 is a 16-byte type on the host
+typedef float CL_FLOAT;
+typedef uint32_t CL_UINT;
+struct alignas(16) CL_UINT3 { uint32_t x, y, z, w; };   // cl_uint3 is a 16-byte type on the host
 
 struct alignas(16) Matrix4 { float data[12]; };                       // Transform.h:150-154
 struct alignas(16) Quaternion { float r, i, j, k; };                  // Transform.h:44-70

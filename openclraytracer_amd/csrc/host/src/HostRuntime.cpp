@@ -4,6 +4,7 @@
 #include <new>
 
 #include <Algorithms/BVHManager.h>
+#include <Algorithms/TwoLevelGridManager.h>
 #include <CLData/CLStructs.h>
 #include <OpenCLUtils/CLBuffer.h>
 #include <OpenCLUtils/CLExecutionContext.h>
@@ -156,6 +157,69 @@ Result BVHManager::readNodes(void* hostNodes, Errata& err) const
     if (!_bvh) { FILL_ERRATA(err, "BVH not built"); return Error; }
     RTMI_CHECK(_context, rt_bvh_read_nodes(_bvh, hostNodes), err);
     return Success;
+}
+
+// ------------------------------------------------------------------ TwoLevelGridManager (TwoLevelGridManager.cpp:60-600)
+TwoLevelGridManager::TwoLevelGridManager(const CLExecutionContext& context, const Scene& scene)
+    : AccelerationStructureManager(context, scene), _topLevelDensity(2.0f), _leafDensity(2.0f),   // :66-67
+      _pairsCount(0), _leafPairsCount(0), _leafCellsCount(0), _tlg(nullptr)
+{
+}
+TwoLevelGridManager::~TwoLevelGridManager() { if (_tlg) rt_tlg_destroy(_tlg); }
+
+Result TwoLevelGridManager::initialize(Errata& err)
+{
+    if (_tlg) return Success;
+    if (!_scene.deviceHandle()) { FILL_ERRATA(err, "Scene::loadToGPU must precede initialize"); return Error; }
+    RTMI_CHECK(_context, rt_tlg_create(_context.handle(), _scene.deviceHandle(), &_tlg), err);
+    return Success;
+}
+Result TwoLevelGridManager::initializeFrame(Errata& err)
+{
+    if (!_tlg) { FILL_ERRATA(err, "initialize must precede initializeFrame"); return Error; }
+    RTMI_CHECK(_context, rt_tlg_set_densities(_tlg, _topLevelDensity, _leafDensity), err);
+    RTMI_CHECK(_context, rt_tlg_initialize_frame(_tlg), err);          // calculateGridData + buffers, :160-201
+    return Success;
+}
+Result TwoLevelGridManager::construct(Errata& err)
+{
+    if (!_tlg) { FILL_ERRATA(err, "initialize must precede construct"); return Error; }
+    RTMI_CHECK(_context, rt_tlg_construct(_tlg), err);
+    rt_tlg_info info;
+    RTMI_CHECK(_context, rt_tlg_info_get(_tlg, &info), err);
+    _pairsCount = info.pairs_count; _leafPairsCount = info.leaf_pairs_count; _leafCellsCount = info.leaf_cells_count;
+    return Success;
+}
+Result TwoLevelGridManager::generateContacts(Camera& cam, Errata& err)
+{
+    if (!_tlg) { FILL_ERRATA(err, "initialize must precede generateContacts"); return Error; }
+    size_t contactBufSize = (size_t)cam.resX * cam.resY * sizeof(Contact);
+    try {                                                                       // TwoLevelGridManager.cpp:478-482
+        if (_primaryContactsArray) _primaryContactsArray->resize(contactBufSize);
+        else _primaryContactsArray.reset(new CLBuffer(_context, contactBufSize, CLBufferFlags::ReadWrite));
+    } catch (const CLInterfaceException& e) { err = e; return Error; }
+    RTMI_CHECK(_context, rt_tlg_generate_contacts_primary(_tlg, reinterpret_cast<const rt_camera*>(&cam),
+                                                           _primaryContactsArray->getCLMem()), err);
+    RTMI_CHECK(_context, rt_ctx_synchronize(_context.handle()), err);           // flush + wait, :504-510
+    return Success;
+}
+Result TwoLevelGridManager::generateContacts(CLBuffer& rays, CLBuffer& contacts, const unsigned int rayCount, Errata& err)
+{
+    if (!_tlg) { FILL_ERRATA(err, "initialize must precede generateContacts"); return Error; }
+    if ((size_t)rayCount * sizeof(Ray) > rays.getActualSize() || (size_t)rayCount * sizeof(Contact) > contacts.getActualSize()) {
+        FILL_ERRATA(err, "rayCount exceeds the ray or contact buffer");
+        return Error;
+    }
+    RTMI_CHECK(_context, rt_tlg_generate_contacts_rays(_tlg, rays.getCLMem(), rayCount, contacts.getCLMem()), err);
+    RTMI_CHECK(_context, rt_ctx_synchronize(_context.handle()), err);
+    return Success;
+}
+CL_UINT3 TwoLevelGridManager::getResolution() const
+{
+    CL_UINT3 r = { 0, 0, 0, 0 };
+    rt_grid_data g;
+    if (_tlg && rt_tlg_read(_tlg, RT_TLG_GRID_DATA, &g, sizeof g) == RT_SUCCESS) { r.x = g.resX; r.y = g.resY; r.z = g.resZ; }
+    return r;
 }
 
 Result CLRayTracer::AccelerationStructures::shadeBlinnPhong(const CLExecutionContext& context, const Scene& scene, Camera& cam,

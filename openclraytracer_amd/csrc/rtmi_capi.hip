@@ -43,12 +43,16 @@ static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
         RT_HIP(ctx, hipMalloc((void**)&ctx->d_long_list, want * trace_long_record_bytes()));
         RT_HIP(ctx, hipMalloc((void**)&ctx->d_split_list, want * sizeof(uint32_t)));
         ctx->long_cap = (uint32_t)want;
+        // test knob: what recycled device memory looks like
+        if (ctx->poison & 1) RT_HIP(ctx, hipMemsetAsync(ctx->d_long_list, 0xCD, want * trace_long_record_bytes(), ctx->stream));
+        if (ctx->poison & 2) RT_HIP(ctx, hipMemsetAsync(ctx->d_split_list, 0xCD, want * sizeof(uint32_t), ctx->stream));
     }
     if (work_items > ctx->keys_cap) {
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_keys) { (void)hipFree(ctx->d_keys); ctx->d_keys = nullptr; ctx->keys_cap = 0; }
         RT_HIP(ctx, hipMalloc((void**)&ctx->d_keys, work_items * sizeof(unsigned long long)));
         ctx->keys_cap = work_items;
+        if (ctx->poison & 4) RT_HIP(ctx, hipMemsetAsync(ctx->d_keys, 0xCD, work_items * sizeof(unsigned long long), ctx->stream));
     }
     return RT_SUCCESS;
 }
@@ -62,6 +66,8 @@ static int check_trace_error(rt_ctx* ctx)
     uint32_t err = 0;
     RT_HIP(ctx, hipMemcpy(&err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost));
     if (err == 1) return RT_FAIL(ctx, "trace kernel: deferred-ray list full while a full traversal stack had to hand off work; frame invalid");
+    if (err == 3) return RT_FAIL(ctx, "trace kernel: packet stack overflowed its spill area; frame invalid");
+    if (err == 4) return RT_FAIL(ctx, "trace kernel: a deferred-ray record does not describe a task of this launch; frame invalid");
     if (err) return RT_FAIL(ctx, "trace kernel: node pool of the wave-per-ray phase overflowed; frame invalid");
     return RT_SUCCESS;
 }
@@ -101,6 +107,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     ctx->stream = ctx->own_stream;
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1'; ctx->no_packet = env[0] == '0'; }
     *out = ctx;
     return RT_SUCCESS;

@@ -75,6 +75,7 @@ struct rt_ctx {
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
     bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
     bool force_packet = false, no_packet = false;   // tuning knobs (env RTMI_PACKET=1 / 0)
+    int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
 };

@@ -619,11 +619,22 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
         uint32_t work = rec[LR_WORK], rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
         const bool partial = rec[LR_PARTIAL] != 0u;      // a sub-tree of a ray the packet kernel keeps walking elsewhere
-        const bool void_record = work == 0xFFFFFFFFu;     // reserved by a block that found the list full
+        bool void_record = work == 0xFFFFFFFFu;           // reserved by a block that found the list full
+        {   // a record that does not describe a task of this launch must never be walked (it would read anywhere):
+            // report it through the error word and skip it
+            const uint32_t n_leaves = a.n_records + 1u;
+            auto bad_id = [&](uint32_t id) {
+                return id != RT_SENTINEL && ((id & RT_LEAF_FLAG) ? (id & ~RT_LEAF_FLAG) >= n_leaves : id >= a.n_records);
+            };
+            const bool bad = !void_record && (work >= a.total_work || rsp > LDS_STACK || bad_id(rcur) || bad_id(rextra) ||
+                                              (rpending != NO_LEAF && rpending >= n_leaves) ||
+                                              (rec[LR_BEST_LEAF] != NO_LEAF && rec[LR_BEST_LEAF] >= n_leaves));
+            if (bad) { if (lane == 0) __hip_atomic_store(error_word, 4u, RLX_AGENT); void_record = true; }
+        }
         RayState r;
         bool sx, sy, sz;
         load_ray<PRIMARY>(a, void_record ? 0u : work, r, sx, sy, sz);        // same ray in every lane
-        if (lane == 0) {                                  // lane 0 carries the best hit found in phase 0
+        if (lane == 0 && !void_record) {                  // lane 0 carries the best hit found in phase 0
             r.best_leaf = rec[LR_BEST_LEAF];
             r.best_t = __uint_as_float(rec[LR_BEST_T]);
         }

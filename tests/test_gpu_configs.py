@@ -1,4 +1,4 @@
-"""BASELINE.json configs 3 and 5 on the seeded procedural stand-ins (the real Bunny / Sponza are not shipped with
+"""BASELINE.json configs 3, 4 and 5 on the seeded procedural stand-ins (the real Bunny / Sponza are not shipped with
 the reference): full-size parity against the oracle through the C ABI."""
 import os
 import subprocess
@@ -39,6 +39,29 @@ def test_config3_bunny_class_full_hd(gpu_ctx):
     assert got.tobytes() == want.tobytes()
     assert st.hits > 300000
     gb.close(); sc.close()
+
+
+def test_config4_atrium_class_two_level_grid_full_hd(gpu_ctx):
+    """~262 k triangles, Two-Level Grid build (densities 2.0 / 2.0) + trace at 1920x1080: build products and every contact
+    bit-exact against the oracle."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    buf = _synth_scene_bytes('synth_atrium')
+    osc = orc.Scene(buf)
+    og = orc.TLG(osc)
+    sc = capi.DeviceScene(gpu_ctx, buf)
+    gg = capi.DeviceTLG(gpu_ctx, sc).build()
+    info = gg.info()
+    assert all(info[k] == og.info[k] for k in info)
+    assert gg.read(gg.TOP_CELLS).tobytes() == og.top_cells.tobytes()
+    assert gg.read(gg.LEAF_PAIRS).tobytes() == og.leaf_pairs.tobytes()
+    assert gg.read(gg.LEAF_RANGES).tobytes() == og.leaf_ranges.tobytes()
+    cam = osc.demo_camera(1920, 1080)
+    want, st = og.trace_primary(cam)
+    got = gg.generate_contacts_primary(as_capi_camera(cam))
+    assert got.tobytes() == want.tobytes()
+    assert st['hits'] > 500000
+    gg.close(); sc.close()
 
 
 def test_config5_atrium_class_4k_tiled_over_8_ranks(gpu_ctx):

@@ -204,9 +204,17 @@ def test_cpp_host_mirror_end_to_end(gpu_ctx, tmp_path):
     want, _ = ob.trace_primary(osc.demo_camera(160, 120))
     assert open(raw, 'rb').read() == want.tobytes()
     assert open(ppm, 'rb').read().startswith(b'P6\n160 120\n255\n')
-    r = subprocess.run([demo, '-winH', '8', '-winW', '8', '-accStruct', 'GRID', '-headersPath', 'x', '-scene', 'x'],
+    r = subprocess.run([demo, '-winH', '8', '-winW', '8', '-accStruct', 'OCTREE', '-headersPath', 'x', '-scene', 'x'],
                        cwd=ROOT, capture_output=True, text=True)
-    assert r.returncode == 1
+    assert r.returncode == 1 and 'Unsupported acceleration structure' in r.stdout
+    # -accStruct GRID: TwoLevelGridManager behind the same abstract interface (OpenCLRayTracerDemo.cpp:221-224)
+    import oracle as orc
+    r = subprocess.run([demo, '-winH', '120', '-winW', '160', '-accStruct', 'GRID', '-headersPath', 'unused', '-scene',
+                        os.path.join('assets', 'scenes', 'gardenlight.txt'), '--frames', '2', '--contacts', raw],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _ = orc.TLG(osc).trace_primary(osc.demo_camera(160, 120))
+    assert open(raw, 'rb').read() == want.tobytes()
 
 
 @pytest.mark.parametrize('packet,budget,list_max', [('1', '64', '3000'), ('1', '16', '70'), ('0', '32', '1000'),
@@ -217,6 +225,7 @@ def test_forced_trace_strategies_and_full_deferred_list(packet, budget, list_max
     place, reserved-but-unwritten slots are void records)."""
     from openclraytracer_amd import capi
     from conftest import packed_scene
+    monkeypatch.setenv('RTMI_POISON', '7')        # new list / key buffers look like recycled memory, not zeros
     monkeypatch.setenv('RTMI_PACKET', packet)
     monkeypatch.setenv('RTMI_DEFER_BUDGET', budget)
     if list_max != '0':

@@ -28,4 +28,34 @@ for name, res in [('synth_bunny', (1920, 1080)), ('synth_atrium', (1920, 1080)),
     out['%s_%dx%d' % (name, res[0], res[1])] = dict(ms_per_frame=round(ms, 3), mrays_per_s=round(npx / ms / 1e3, 1),
                                                      triangles=sc.n_tris, depth=bvh.info()['max_depth'], strategy=bvh.trace_strategy())
     ctx.free(dc); ctx.free(dr); bvh.close(); sc.close()
+# config 4: Two-Level Grid build + trace (+ shade) on the atrium, and on the bundled models for comparison with the BVH
+for name, res in [('synth_atrium', (1920, 1080)), ('synth_bunny', (1920, 1080))] + [(s, (1920, 1080)) for s in bench.SCENES]:
+    if name.startswith('synth'):
+        buf = open('/tmp/_%s.bin' % name, 'rb').read()
+    else:
+        buf = bench.load_scene_bytes(name)
+    sc = capi.DeviceScene(ctx, buf); g = capi.DeviceTLG(ctx, sc)
+    tm = capi.Timer(ctx)
+    g.build(); ctx.synchronize()
+    tm.start()
+    for _ in range(3):
+        g.build()
+    tm.stop(); build_ms = tm.elapsed_ms() / 3
+    cam = bench.demo_camera(buf, *res)
+    npx = res[0] * res[1]
+    dc, dr = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+    g.generate_contacts_primary_d(cam, dc); ctx.synchronize()
+    K = 5
+    tm.start()
+    for _ in range(K):
+        g.generate_contacts_primary_d(cam, dc)
+    tm.stop(); trace_ms = tm.elapsed_ms() / K
+    tm.start()
+    for _ in range(K):
+        g.generate_contacts_primary_d(cam, dc)
+        capi.shade_blinn_phong_d(ctx, sc, cam, dc, npx, dr)
+    tm.stop(); ms = tm.elapsed_ms() / K
+    out['tlg_%s_%dx%d' % (name, res[0], res[1])] = dict(build_ms=round(build_ms, 3), trace_ms=round(trace_ms, 3), ms_per_frame=round(ms, 3),
+                                                         mrays_per_s=round(npx / ms / 1e3, 1), triangles=sc.n_tris, info=g.info())
+    ctx.free(dc); ctx.free(dr); g.close(); sc.close()
 print(json.dumps(out, indent=1))
