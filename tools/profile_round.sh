@@ -18,3 +18,6 @@ echo "sq done"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_tcc.log 2>&1 || echo "tcc pass failed"
 echo "tcc done"
 find $OUT -name "*.csv" | head -30
+# config 4 (Two-Level Grid build + trace on the atrium-class scene): kernel stats of its own command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tlg_stats -- python3 tools/tlg_config4.py > $OUT/tlg_config4.log 2>&1 || echo "tlg stats pass failed"
+echo "tlg done"

@@ -48,3 +48,11 @@ summ = {'round': R, 'command': 'rocprofv3 --kernel-trace --stats -- python3 benc
         'kernels': {nm(r): {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3, 'total_ms': float(r['TotalDurationNs']) / 1e6} for r in ks if nm(r).startswith('k_')}}
 json.dump(summ, open('profiles/%s_frame_launch_summary.json' % R, 'w'), indent=1)
 print('avg frame launch ms (rocprof):', summ['avg_frame_launch_ms'], 'over', nfr)
+try:
+    tl = newest("gpurun_out/%s/tlg_stats/*/*_kernel_stats.csv" % R)
+    shutil.copy(tl, 'profiles/%s_tlg_config4_kernel_stats.csv' % R)
+    line = [l for l in open('gpurun_out/%s/tlg_config4.log' % R) if l.startswith('{')][-1]
+    open('profiles/%s_tlg_config4_line.json' % R, 'w').write(line)
+    print(line)
+except Exception as e:
+    print('no tlg profile:', e)
