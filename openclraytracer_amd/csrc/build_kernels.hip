@@ -325,3 +325,31 @@ void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs
     (void)hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(k_tree_depth, dim3((n + 255) / 256), dim3(256), 0, s, nodes, n, depth_out);
 }
+
+// ----------------------------------------------------------------------------------------
+// 6. search tree: a second hierarchy over the SAME leaves (same 48-byte leaf nodes, same boxes), ordered by Morton codes
+//    of the box centres properly normalised to the model's box (the reference's normalizeScale divides by the extent
+//    without subtracting the minimum, RTKernelUtils.h:63-69, which is what makes its tree 94-10 835 levels deep).
+//    Only the key generation is new: the tree itself is built, refitted and re-laid-out by the kernels above.
+//    DESIGN.md section 2 shows why primary rays may walk this tree instead of the reference's and still produce the
+//    reference's contacts bit for bit.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_search_tree_keys(const rt_bvh_node* nodes, uint32_t n, uint2* pairs)
+{
+    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    const rt_bvh_node* root = &nodes[n];                 // reference root: union of all leaf boxes
+    float u[3];
+    for (int k = 0; k < 3; k++) {
+        float c = (nodes[leaf].boundsMin[k] + nodes[leaf].boundsMax[k]) * 0.5f;
+        float ext = root->boundsMax[k] - root->boundsMin[k];
+        float v = (c - root->boundsMin[k]) / ext;
+        u[k] = (v == v) ? v : 0.0f;                      // flat axis: 0/0
+    }
+    pairs[leaf] = make_uint2(morton3d(u[0], u[1], u[2]), leaf);
+}
+
+void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs)
+{
+    hipLaunchKernelGGL(k_search_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, ref_nodes, n, pairs);
+}

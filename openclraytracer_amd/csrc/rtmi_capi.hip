@@ -108,6 +108,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);
+    if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1'; ctx->no_packet = env[0] == '0'; }
     *out = ctx;
     return RT_SUCCESS;
@@ -352,6 +353,9 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_pos) hipFree(b->d_pos);
     if (b->d_packet_spill) hipFree(b->d_packet_spill);
     b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
+    if (b->d_search_trav) hipFree(b->d_search_trav);
+    if (b->d_tree_select) hipFree(b->d_tree_select);
+    b->d_search_trav = nullptr; b->d_tree_select = nullptr;
     b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
     b->d_depth = nullptr; b->d_pos = nullptr;
 }
@@ -383,6 +387,8 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         RT_HIP(ctx, hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_depth, 256));
         RT_HIP(ctx, hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t)));
+        RT_HIP(ctx, hipMalloc((void**)&b->d_tree_select, 256));
+        if (!ctx->no_search_tree) RT_HIP(ctx, hipMalloc((void**)&b->d_search_trav, (size_t)(n - 1) * sizeof(TravNode)));
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -410,8 +416,48 @@ int rt_bvh_construct(rt_bvh* b)
     RT_HIP(ctx, hipGetLastError());
     uint32_t depth = 0;
     RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
+    // search tree for primary rays: same leaves, better order.  Working buffers are temporary.
+    rt_bvh_node* s_nodes = nullptr; uint2* s_pairs = nullptr; uint32_t* s_counters = nullptr; uint32_t* s_pos = nullptr;
+    uint32_t search_depth = 0;
+    if (b->d_search_trav) {
+        const uint32_t n = b->n, N = b->N;
+        hipError_t e = hipMalloc((void**)&s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
+        if (e == hipSuccess) e = hipMalloc((void**)&s_pairs, (size_t)N * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc((void**)&s_counters, (size_t)n * sizeof(uint32_t) + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&s_pos, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) {
+            (void)hipMemsetAsync(s_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s);
+            (void)hipMemcpyAsync(s_nodes, b->d_nodes, (size_t)n * sizeof(rt_bvh_node), hipMemcpyDeviceToDevice, s);   // the leaves
+            (void)hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s);
+            (void)hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s);
+            launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
+            launch_bitonic_sort(s, s_pairs, N);
+            launch_radix_tree(s, s_nodes, s_pairs, n);
+            launch_refit(s, s_nodes, s_counters, n);
+            uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
+            launch_relayout(s, s_nodes, s_pairs, b->d_search_trav, s_pos, n, s_depth);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s);
+        }
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(s);
+            if (s_nodes) (void)hipFree(s_nodes); if (s_pairs) (void)hipFree(s_pairs);
+            if (s_counters) (void)hipFree(s_counters); if (s_pos) (void)hipFree(s_pos);
+            return RT_FAIL(ctx, std::string("search tree build failed: ") + hipGetErrorString(e));
+        }
+    }
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
+    if (s_nodes) (void)hipFree(s_nodes);
+    if (s_pairs) (void)hipFree(s_pairs);
+    if (s_counters) (void)hipFree(s_counters);
+    if (s_pos) (void)hipFree(s_pos);
     b->max_depth = depth;
+    b->search_depth = search_depth;
+    if (b->d_search_trav && search_depth + 8u > trace_packet_stack_entries()) {
+        // a degenerate model (thousands of coincident box centres) can make this tree deep as well: not worth a spill area
+        RT_HIP(ctx, hipFree(b->d_search_trav));
+        b->d_search_trav = nullptr;
+    }
     {   // packet kernel: (node, lane mask) stack entries beyond the LDS part live in a per-wave global area
         uint32_t need = depth + 8u > trace_packet_stack_entries() ? depth + 8u - trace_packet_stack_entries() : 0u;
         if (need != b->packet_spill_entries) {
@@ -431,7 +477,7 @@ int rt_bvh_construct(rt_bvh* b)
 static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 {
     TraceLaunch t{};
-    t.trav = b->d_trav; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
+    t.trav = b->d_trav; t.trav_search = cam ? b->d_search_trav : nullptr; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.calibrating = false;

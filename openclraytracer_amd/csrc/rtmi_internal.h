@@ -76,6 +76,7 @@ struct rt_ctx {
     bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
     bool force_packet = false, no_packet = false;   // tuning knobs (env RTMI_PACKET=1 / 0)
     int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
+    bool no_search_tree = false;  // knob (env RTMI_SEARCH_TREE=0): primary rays walk the reference tree
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
 };
@@ -102,6 +103,9 @@ struct rt_bvh {
     TravNode* d_trav = nullptr;        // n-1 traversal records
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
+    TravNode* d_search_trav = nullptr; // n-1 records of the search tree (primary rays), null when disabled
+    uint32_t* d_tree_select = nullptr; // 1 word: 1 = this camera must walk the reference tree (written by k_prepare_camera)
+    uint32_t search_depth = 0;
     uint32_t* d_packet_spill = nullptr;   // packet kernel: stack overflow area, sized from the tree depth
     uint32_t packet_spill_entries = 0;
     uint32_t packet_max_blocks = 0;
@@ -160,6 +164,7 @@ void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, ui
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n);
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t* depth_out);
+void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
 int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch);
@@ -167,6 +172,8 @@ size_t scan_scratch_words(uint32_t n);
 // trace_kernels.hip
 struct TraceLaunch {
     const TravNode* trav;
+    const TravNode* trav_search;  // primary rays: walked instead of `trav` unless *tree_select != 0 (null: disabled)
+    const uint32_t* tree_select;
     const DeviceScene* scene;
     const uint32_t* pos;          // leaf -> position in the sorted pair array (DFS rank, tie rule)
     uint32_t n_leaves;

@@ -74,6 +74,8 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
+    const TravNode* __restrict__ trav_search;   // primary rays: the search tree (same leaves), null = none
+    const uint32_t* __restrict__ tree_select;   // primary rays: *tree_select != 0 -> this camera must walk `trav`
     const float4* __restrict__ v0;
     const float4* __restrict__ e1;
     const float4* __restrict__ e2;
@@ -113,7 +115,7 @@ struct RayState {
 // BVH.h:368-369.  `tmin*flag > 0` <=> `flag && tmin > 0` (x*1.0f == x; x*0.0f is +-0 or NaN).
 // Branch free on purpose (bit-wise & and |): both children are always evaluated.
 // Primary rays share one origin (the camera position), so "origin inside the box" does not depend on the ray:
-// k_mark_inside evaluates it once per node and camera position and the primary kernels read the bit.
+// k_prepare_camera evaluates it once per node and camera position and the primary kernels read the bit.
 template <int PRIMARY>
 __device__ __forceinline__ bool child_valid(float lox, float loy, float loz, float hix, float hiy, float hiz,
                                             const RayState& r, bool sx, bool sy, bool sz, bool inside_marked)
@@ -134,15 +136,34 @@ __device__ __forceinline__ bool child_valid(float lox, float loy, float loz, flo
     return (flag & (tmin > 0.0f)) | inside;
 }
 
-// isPointInside (AABB.h:178-184) of the camera position for both children of every inner record; bits 0 / 1 of pad0
-__global__ __launch_bounds__(256) void k_mark_inside(TravNode* trav, uint32_t n_inner, float ox, float oy, float oz)
+// Per camera position: (1) isPointInside (AABB.h:178-184) of the camera position for both children of every inner
+// record of both trees, bits 0 / 1 of pad0; (2) whether the camera lies exactly on a box plane.  Only then can a slab
+// product be 0 * inf = NaN (a ray with a zero direction component), which is the one case the equivalence argument
+// of the search tree excludes: *select = 1 sends the whole frame to the reference tree.
+// Every box of either tree appears as a child box of the reference records, or is a union of such boxes whose planes
+// are planes of leaf boxes or the FLT_MIN the reference starts its maxima from (BVH.h:310).
+__device__ __forceinline__ uint32_t inside_bits(const TravNode& t, float ox, float oy, float oz)
+{
+    bool ia = (t.a_lo[0] <= ox) & (ox <= t.a_hi[0]) & (t.a_lo[1] <= oy) & (oy <= t.a_hi[1]) & (t.a_lo[2] <= oz) & (oz <= t.a_hi[2]);
+    bool ib = (t.b_lo[0] <= ox) & (ox <= t.b_hi[0]) & (t.b_lo[1] <= oy) & (oy <= t.b_hi[1]) & (t.b_lo[2] <= oz) & (oz <= t.b_hi[2]);
+    return (ia ? 1u : 0u) | (ib ? 2u : 0u);
+}
+__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, TravNode* trav_search, uint32_t n_inner, float ox, float oy, float oz,
+                                                        uint32_t* select)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inner) return;
     const TravNode t = trav[i];
-    bool ia = (t.a_lo[0] <= ox) & (ox <= t.a_hi[0]) & (t.a_lo[1] <= oy) & (oy <= t.a_hi[1]) & (t.a_lo[2] <= oz) & (oz <= t.a_hi[2]);
-    bool ib = (t.b_lo[0] <= ox) & (ox <= t.b_hi[0]) & (t.b_lo[1] <= oy) & (oy <= t.b_hi[1]) & (t.b_lo[2] <= oz) & (oz <= t.b_hi[2]);
-    trav[i].pad0 = (ia ? 1u : 0u) | (ib ? 2u : 0u);
+    trav[i].pad0 = inside_bits(t, ox, oy, oz);
+    if (trav_search) {
+        const TravNode u = trav_search[i];
+        trav_search[i].pad0 = inside_bits(u, ox, oy, oz);
+        const float o[3] = { ox, oy, oz };
+        bool on_plane = false;
+        for (int k = 0; k < 3; k++)
+            on_plane |= (o[k] == t.a_lo[k]) | (o[k] == t.a_hi[k]) | (o[k] == t.b_lo[k]) | (o[k] == t.b_hi[k]) | (o[k] == FLT_MIN);
+        if (on_plane) __hip_atomic_store(select, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // triangleIntersect, Triangle.h:66-107, against precomputed edges; keeps the lexicographic min of
@@ -238,6 +259,7 @@ __device__ __forceinline__ void store_contact(const TraceArgs& a, uint32_t out_i
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
 {
+    if (PRIMARY && a.trav_search != nullptr && *a.tree_select == 0u) a.trav = a.trav_search;   // primary rays: search tree unless the camera forbids it
     __shared__ uint32_t s_stack[TRACE_WAVES][LDS_STACK][64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -446,6 +468,7 @@ __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t l
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 {
+    if (PRIMARY && a.trav_search != nullptr && *a.tree_select == 0u) a.trav = a.trav_search;   // primary rays: search tree unless the camera forbids it
     __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
     __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
     __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
@@ -598,6 +621,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
 {
+    if (PRIMARY && a.trav_search != nullptr && *a.tree_select == 0u) a.trav = a.trav_search;   // primary rays: search tree unless the camera forbids it
     __shared__ uint32_t s_inner[TRACE_WAVES][POOL_INNER];
     __shared__ uint32_t s_leaf[TRACE_WAVES][POOL_LEAF];
     const uint32_t lane = threadIdx.x & 63u;
@@ -838,7 +862,7 @@ uint32_t trace_packet_max_blocks(int compute_units)
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
-    a.trav = t.trav;
+    a.trav = t.trav; a.trav_search = t.trav_search; a.tree_select = t.tree_select;
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
     a.pos = t.pos;
     a.ctrl = (TraceCtrl*)t.ctrl;
@@ -862,9 +886,12 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.total_work = rt_owned_tiles(total_tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.rays = nullptr;
     a.out = out;
-    if (t.mark_inside && t.n_leaves > 1)
-        hipLaunchKernelGGL(k_mark_inside, dim3((t.n_leaves - 1 + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
-                           t.n_leaves - 1, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11]);
+    if (t.mark_inside && t.n_leaves > 1) {
+        (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
+        hipLaunchKernelGGL(k_prepare_camera, dim3((t.n_leaves - 1 + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
+                           const_cast<TravNode*>(t.trav_search), t.n_leaves - 1, cam.viewTransform[3], cam.viewTransform[7],
+                           cam.viewTransform[11], const_cast<uint32_t*>(t.tree_select));
+    }
     launch<1>(s, t, a);
 }
 
@@ -876,5 +903,6 @@ void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, 
     a.rays = rays;
     a.out = out;
     a.nranks = 1;
+    a.trav_search = nullptr;                 // arbitrary rays walk the reference tree
     launch<0>(s, t, a);
 }
