@@ -119,6 +119,15 @@ int  rt_bvh_info(const rt_bvh* bvh, uint32_t* leaves, uint32_t* morton_items, ui
  * calibrated yet); env RTMI_DEFER_BUDGET=<n> (+ RTMI_PACKET=0/1) fixes it.  Speed knobs only: every setting gives the
  * same contacts.                                                                                                      */
 int  rt_bvh_trace_strategy(const rt_bvh* bvh, int* packet_kernel, uint32_t* budget);
+/* Primary rays (all with the camera position as origin) walk a second hierarchy over the same leaf boxes, ordered by
+ * properly normalised Morton codes (depth ~25-50 instead of the reference tree's 94-10 835).  A leaf whose box passes the
+ * reference's child test has only ancestors that pass it, in ANY hierarchy of nested boxes over these leaves, so the set of
+ * triangles tested -- and with the reference's (t, depth-first rank) tie rule the contact -- is the reference's, bit for
+ * bit.  The one excluded case, a camera coordinate equal to a box plane (0 * inf = NaN for rays
+ * with a zero direction component), is detected on the device per camera and sends that frame to the reference tree.
+ * depth = 0: no search tree (env RTMI_SEARCH_TREE=0, or a degenerate model); used = 1 when the last camera prepared for
+ * this BVH walks the search tree (synchronises).  The ray-buffer entry point always walks the reference tree.           */
+int  rt_bvh_search_tree(const rt_bvh* bvh, uint32_t* depth, int* used_by_last_camera);
 
 /* ---- Two-Level Grid: AccelerationStructures::TwoLevelGridManager (Include/Algorithms/TwoLevelGridManager.h:61-178,
  *      src/CLRayTracerEngine/TwoLevelGridManager.cpp), the manager behind `-accStruct GRID` ----------------------------

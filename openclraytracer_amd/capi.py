@@ -37,7 +37,7 @@ SYMBOLS = [
     'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
-    'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
+    'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba',
     'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     L.rt_bvh_read_morton_pairs.argtypes = [vp, vp, C.POINTER(u32)]
     L.rt_bvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.rt_bvh_trace_strategy.argtypes = [vp, C.POINTER(i32), C.POINTER(u32)]
+    L.rt_bvh_search_tree.argtypes = [vp, C.POINTER(u32), C.POINTER(i32)]
     L.rt_shade_blinn_phong.argtypes = [vp, vp, vp, vp, u32, vp]
     L.rt_tiles_owned_pixels.argtypes = [vp, u32, u32]; L.rt_tiles_owned_pixels.restype = u32
     L.rt_bvh_generate_contacts_primary_tiled.argtypes = [vp, vp, u32, u32, vp]
@@ -285,6 +286,11 @@ class DeviceBVH:
         k, v = C.c_int(), C.c_uint32()
         self.ctx.check(self.ctx.lib.rt_bvh_trace_strategy(self.h, C.byref(k), C.byref(v)))
         return dict(kernel='packet' if k.value else 'lane-per-ray', budget=v.value)
+
+    def search_tree(self) -> dict:
+        d, u = C.c_uint32(), C.c_int()
+        self.ctx.check(self.ctx.lib.rt_bvh_search_tree(self.h, C.byref(d), C.byref(u)))
+        return dict(depth=d.value, used_by_last_camera=u.value)   # 0 no, 1 every ray, 2 all but the rays with a zero direction component on a plane axis
 
     def trace_budget(self) -> int:
         return self.trace_strategy()['budget']

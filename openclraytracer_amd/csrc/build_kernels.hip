@@ -276,7 +276,7 @@ void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_
 // ----------------------------------------------------------------------------------------
 // 5. re-layout into 64-byte traversal records + tree depth (sizes the deep-stack spill area)
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_relayout(const rt_bvh_node* nodes, TravNode* trav, uint32_t n)
+__global__ __launch_bounds__(256) void k_relayout(const rt_bvh_node* nodes, TravNode* trav, uint32_t n, uint32_t id_offset)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void k_relayout(const rt_bvh_node* nodes, Trav
         t.a_lo[k] = nodes[ca].boundsMin[k]; t.a_hi[k] = nodes[ca].boundsMax[k];
         t.b_lo[k] = nodes[cb].boundsMin[k]; t.b_hi[k] = nodes[cb].boundsMax[k];
     }
-    t.child_a = ca < n ? (RT_LEAF_FLAG | ca) : ca - n;
-    t.child_b = cb < n ? (RT_LEAF_FLAG | cb) : cb - n;
+    t.child_a = ca < n ? (RT_LEAF_FLAG | ca) : ca - n + id_offset;    // id_offset: where this tree's records start in the array
+    t.child_b = cb < n ? (RT_LEAF_FLAG | cb) : cb - n + id_offset;
     t.pad0 = 0; t.pad1 = 0;
     trav[i] = t;
 }
@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void k_leaf_positions(const uint2* pairs, uint
 }
 
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t* depth_out)
+                     uint32_t n, uint32_t* depth_out, uint32_t id_offset)
 {
-    hipLaunchKernelGGL(k_relayout, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, trav, n);
+    hipLaunchKernelGGL(k_relayout, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, trav, n, id_offset);
     hipLaunchKernelGGL(k_leaf_positions, dim3((n + 255) / 256), dim3(256), 0, s, pairs, pos, n);
     (void)hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(k_tree_depth, dim3((n + 255) / 256), dim3(256), 0, s, nodes, n, depth_out);

@@ -353,9 +353,8 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_pos) hipFree(b->d_pos);
     if (b->d_packet_spill) hipFree(b->d_packet_spill);
     b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
-    if (b->d_search_trav) hipFree(b->d_search_trav);
     if (b->d_tree_select) hipFree(b->d_tree_select);
-    b->d_search_trav = nullptr; b->d_tree_select = nullptr;
+    b->d_tree_select = nullptr; b->have_search_tree = false;
     b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
     b->d_depth = nullptr; b->d_pos = nullptr;
 }
@@ -384,11 +383,10 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         RT_HIP(ctx, hipMalloc((void**)&b->d_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_pairs, (size_t)N * sizeof(uint2)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_counters, (size_t)n * sizeof(uint32_t)));
-        RT_HIP(ctx, hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode)));
+        RT_HIP(ctx, hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode) * (ctx->no_search_tree ? 1u : 2u)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_depth, 256));
         RT_HIP(ctx, hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_tree_select, 256));
-        if (!ctx->no_search_tree) RT_HIP(ctx, hipMalloc((void**)&b->d_search_trav, (size_t)(n - 1) * sizeof(TravNode)));
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -419,7 +417,8 @@ int rt_bvh_construct(rt_bvh* b)
     // search tree for primary rays: same leaves, better order.  Working buffers are temporary.
     rt_bvh_node* s_nodes = nullptr; uint2* s_pairs = nullptr; uint32_t* s_counters = nullptr; uint32_t* s_pos = nullptr;
     uint32_t search_depth = 0;
-    if (b->d_search_trav) {
+    b->have_search_tree = false;
+    if (!ctx->no_search_tree) {
         const uint32_t n = b->n, N = b->N;
         hipError_t e = hipMalloc((void**)&s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
         if (e == hipSuccess) e = hipMalloc((void**)&s_pairs, (size_t)N * sizeof(uint2));
@@ -435,7 +434,7 @@ int rt_bvh_construct(rt_bvh* b)
             launch_radix_tree(s, s_nodes, s_pairs, n);
             launch_refit(s, s_nodes, s_counters, n);
             uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
-            launch_relayout(s, s_nodes, s_pairs, b->d_search_trav, s_pos, n, s_depth);
+            launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, s_depth, n - 1);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s);
         }
@@ -453,11 +452,8 @@ int rt_bvh_construct(rt_bvh* b)
     if (s_pos) (void)hipFree(s_pos);
     b->max_depth = depth;
     b->search_depth = search_depth;
-    if (b->d_search_trav && search_depth + 8u > trace_packet_stack_entries()) {
-        // a degenerate model (thousands of coincident box centres) can make this tree deep as well: not worth a spill area
-        RT_HIP(ctx, hipFree(b->d_search_trav));
-        b->d_search_trav = nullptr;
-    }
+    // a degenerate model (thousands of coincident box centres) makes this tree as deep as the reference's: no gain then
+    b->have_search_tree = !ctx->no_search_tree && search_depth != 0 && search_depth < depth;
     {   // packet kernel: (node, lane mask) stack entries beyond the LDS part live in a per-wave global area
         uint32_t need = depth + 8u > trace_packet_stack_entries() ? depth + 8u - trace_packet_stack_entries() : 0u;
         if (need != b->packet_spill_entries) {
@@ -477,7 +473,7 @@ int rt_bvh_construct(rt_bvh* b)
 static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 {
     TraceLaunch t{};
-    t.trav = b->d_trav; t.trav_search = cam ? b->d_search_trav : nullptr; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
+    t.trav = b->d_trav; t.search_root = (cam && b->have_search_tree) ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.calibrating = false;
@@ -621,6 +617,24 @@ int rt_bvh_trace_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget)
     const rt_ctx* ctx = b->ctx;
     if (budget) *budget = ctx->defer_budget ? ctx->defer_budget : (b->tuned ? b->tuned_budget : 0u);
     if (packet_kernel) *packet_kernel = ctx->defer_budget ? (ctx->force_packet ? 1 : 0) : (b->tuned && b->tuned_packet ? 1 : 0);
+    return RT_SUCCESS;
+}
+
+int rt_bvh_search_tree(const rt_bvh* b, uint32_t* depth, int* used_by_last_camera)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (depth) *depth = b->have_search_tree ? b->search_depth : 0u;
+    if (used_by_last_camera) {
+        *used_by_last_camera = 0;
+        if (b->have_search_tree && b->built && b->marked_valid) {
+            uint32_t sel = 7;
+            RT_HIP(ctx, hipSetDevice(ctx->device));
+            RT_HIP(ctx, hipMemcpyAsync(&sel, b->d_tree_select, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            *used_by_last_camera = sel == 0u ? 1 : 2;      // 2: only rays without a zero direction component on the camera's plane axes
+        }
+    }
     return RT_SUCCESS;
 }
 

@@ -103,8 +103,8 @@ struct rt_bvh {
     TravNode* d_trav = nullptr;        // n-1 traversal records
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
-    TravNode* d_search_trav = nullptr; // n-1 records of the search tree (primary rays), null when disabled
-    uint32_t* d_tree_select = nullptr; // 1 word: 1 = this camera must walk the reference tree (written by k_prepare_camera)
+    bool have_search_tree = false;     // d_trav holds 2(n-1) records: reference tree, then the search tree (primary rays)
+    uint32_t* d_tree_select = nullptr; // 1 word, bit k: the camera's coordinate k equals a box plane (k_prepare_camera)
     uint32_t search_depth = 0;
     uint32_t* d_packet_spill = nullptr;   // packet kernel: stack overflow area, sized from the tree depth
     uint32_t packet_spill_entries = 0;
@@ -163,7 +163,7 @@ void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nod
 void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n);
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t* depth_out);
+                     uint32_t n, uint32_t* depth_out, uint32_t id_offset = 0);
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
@@ -171,9 +171,9 @@ int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uin
 size_t scan_scratch_words(uint32_t n);
 // trace_kernels.hip
 struct TraceLaunch {
-    const TravNode* trav;
-    const TravNode* trav_search;  // primary rays: walked instead of `trav` unless *tree_select != 0 (null: disabled)
-    const uint32_t* tree_select;
+    const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)
+    uint32_t search_root;         // primary rays: root record of the search tree, 0 = none (walk the reference tree)
+    const uint32_t* tree_select;  // per camera: bit k set = the camera's coordinate k equals a box plane
     const DeviceScene* scene;
     const uint32_t* pos;          // leaf -> position in the sorted pair array (DFS rank, tie rule)
     uint32_t n_leaves;

@@ -74,8 +74,8 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
-    const TravNode* __restrict__ trav_search;   // primary rays: the search tree (same leaves), null = none
-    const uint32_t* __restrict__ tree_select;   // primary rays: *tree_select != 0 -> this camera must walk `trav`
+    uint32_t search_root;                       // primary rays: root record of the search tree (same leaves), 0 = none
+    const uint32_t* __restrict__ tree_select;   // primary rays: bit k = the camera's coordinate k equals a box plane
     const float4* __restrict__ v0;
     const float4* __restrict__ e1;
     const float4* __restrict__ e2;
@@ -87,7 +87,8 @@ struct TraceArgs {
     uint32_t defer_budget;
     uint32_t total_work;                   // work items (multiple of 4096 for primary frames)
     uint32_t n_waves;                      // waves in the grid
-    uint32_t n_records;                    // inner records (leaves - 1)
+    uint32_t n_records;                    // inner records in `trav`: leaves - 1 per tree
+    uint32_t n_leaves;
     unsigned long long* keys;              // (t bits << 32 | position) per work item, used by split rays only
     uint32_t* split_list;                  // work items of split rays (long_cap entries)
     const uint2* __restrict__ pairs;       // position -> leaf
@@ -139,7 +140,8 @@ __device__ __forceinline__ bool child_valid(float lox, float loy, float loz, flo
 // Per camera position: (1) isPointInside (AABB.h:178-184) of the camera position for both children of every inner
 // record of both trees, bits 0 / 1 of pad0; (2) whether the camera lies exactly on a box plane.  Only then can a slab
 // product be 0 * inf = NaN (a ray with a zero direction component), which is the one case the equivalence argument
-// of the search tree excludes: *select = 1 sends the whole frame to the reference tree.
+// of the search tree excludes: bit k of *select says "the camera's coordinate k is a box plane", and
+// rays whose 1/direction is not finite on such an axis start at the reference tree's root instead (ray_root).
 // Every box of either tree appears as a child box of the reference records, or is a union of such boxes whose planes
 // are planes of leaf boxes or the FLT_MIN the reference starts its maxima from (BVH.h:310).
 __device__ __forceinline__ uint32_t inside_bits(const TravNode& t, float ox, float oy, float oz)
@@ -148,21 +150,19 @@ __device__ __forceinline__ uint32_t inside_bits(const TravNode& t, float ox, flo
     bool ib = (t.b_lo[0] <= ox) & (ox <= t.b_hi[0]) & (t.b_lo[1] <= oy) & (oy <= t.b_hi[1]) & (t.b_lo[2] <= oz) & (oz <= t.b_hi[2]);
     return (ia ? 1u : 0u) | (ib ? 2u : 0u);
 }
-__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, TravNode* trav_search, uint32_t n_inner, float ox, float oy, float oz,
+__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, uint32_t n_records, uint32_t n_reference, float ox, float oy, float oz,
                                                         uint32_t* select)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_inner) return;
+    if (i >= n_records) return;
     const TravNode t = trav[i];
     trav[i].pad0 = inside_bits(t, ox, oy, oz);
-    if (trav_search) {
-        const TravNode u = trav_search[i];
-        trav_search[i].pad0 = inside_bits(u, ox, oy, oz);
+    if (i < n_reference && n_records > n_reference) {       // plane test over the reference records, when there is a search tree
         const float o[3] = { ox, oy, oz };
-        bool on_plane = false;
+        uint32_t bits = 0;
         for (int k = 0; k < 3; k++)
-            on_plane |= (o[k] == t.a_lo[k]) | (o[k] == t.a_hi[k]) | (o[k] == t.b_lo[k]) | (o[k] == t.b_hi[k]) | (o[k] == FLT_MIN);
-        if (on_plane) __hip_atomic_store(select, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((o[k] == t.a_lo[k]) | (o[k] == t.a_hi[k]) | (o[k] == t.b_lo[k]) | (o[k] == t.b_hi[k]) | (o[k] == FLT_MIN)) bits |= 1u << k;
+        if (bits) __hip_atomic_fetch_or(select, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -232,6 +232,17 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayStat
     return true;
 }
 
+// root record a ray starts from: the search tree's, unless there is none or the ray could produce 0 * inf in a slab test
+// (camera coordinate on a box plane AND 1/direction not finite on that axis: zero, denormal or NaN direction component)
+template <int PRIMARY>
+__device__ __forceinline__ uint32_t ray_root(const TraceArgs& a, const RayState& r, uint32_t plane_bits)
+{
+    if (!PRIMARY || a.search_root == 0u) return 0u;
+    const bool risky = ((plane_bits & 1u) && !(fabsf(r.inv.x) <= FLT_MAX)) | ((plane_bits & 2u) && !(fabsf(r.inv.y) <= FLT_MAX)) |
+                       ((plane_bits & 4u) && !(fabsf(r.inv.z) <= FLT_MAX));
+    return risky ? 0u : a.search_root;
+}
+
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -259,7 +270,6 @@ __device__ __forceinline__ void store_contact(const TraceArgs& a, uint32_t out_i
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
 {
-    if (PRIMARY && a.trav_search != nullptr && *a.tree_select == 0u) a.trav = a.trav_search;   // primary rays: search tree unless the camera forbids it
     __shared__ uint32_t s_stack[TRACE_WAVES][LDS_STACK][64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
     const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
     gu32* long_count = (gu32*)&a.ctrl->long_count;
     gu32* error_word = (gu32*)&a.ctrl->error;
+    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
 
     RayState r;
     r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 };
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                     uint32_t w = res_next + lane_rank(idle);
                     if (!active && w < res_end && w < a.total_work) {
                         if (load_ray<PRIMARY>(a, w, r, sx, sy, sz)) {
-                            cur = 0u;                                     // root = inner record 0 (reference node n)
+                            cur = ray_root<PRIMARY>(a, r, plane_bits);    // record 0 = the reference root (node n), or the search tree's root
                             sp = 0; pending = NO_LEAF; iters = 0;
                             active = true;
                         } else if (PRIMARY && a.compact) {
@@ -468,7 +479,6 @@ __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t l
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 {
-    if (PRIMARY && a.trav_search != nullptr && *a.tree_select == 0u) a.trav = a.trav_search;   // primary rays: search tree unless the camera forbids it
     __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
     __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
     __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
@@ -479,6 +489,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
     // deep stacks spill to a per-wave global area (3 words per entry)
     uint32_t* spill = a.packet_spill ? a.packet_spill + (uint64_t)wave_gid * a.packet_spill_entries * 3u : nullptr;
 
+    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
     const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;
     uint32_t blk = wave_gid;
     uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
@@ -501,6 +512,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
         bool split = false;                              // some sub-tree of this lane's ray went to phase 1
         uint32_t sp = 0;
         uint32_t node = 0;                               // wave-uniform: root record
+        if (PRIMARY && a.search_root != 0u) {
+            // the block walks the search tree; lanes whose ray must use the reference tree (ray_root) wait on the stack
+            // as an ordinary (node, lane mask) entry with the reference root
+            const bool on_ref = ok && ray_root<PRIMARY>(a, r, plane_bits) == 0u;
+            const uint64_t m_ref = __ballot(on_ref), m_search = __ballot(ok && !on_ref);
+            if (m_search != 0ull) {
+                node = a.search_root; in = ok && !on_ref;
+                if (m_ref != 0ull) {
+                    if (lane == 0) { st_node[0] = 0u; st_lo[0] = (uint32_t)m_ref; st_hi[0] = (uint32_t)(m_ref >> 32); }
+                    sp = 1;
+                }
+            }
+        }
         uint32_t low_run = 0;                            // consecutive steps with very few lanes taking part
         uint32_t steps = 0;                              // nodes this block has walked
         bool walking = __ballot(in) != 0ull;
@@ -621,7 +645,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
 {
-    if (PRIMARY && a.trav_search != nullptr && *a.tree_select == 0u) a.trav = a.trav_search;   // primary rays: search tree unless the camera forbids it
     __shared__ uint32_t s_inner[TRACE_WAVES][POOL_INNER];
     __shared__ uint32_t s_leaf[TRACE_WAVES][POOL_LEAF];
     const uint32_t lane = threadIdx.x & 63u;
@@ -646,7 +669,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         bool void_record = work == 0xFFFFFFFFu;           // reserved by a block that found the list full
         {   // a record that does not describe a task of this launch must never be walked (it would read anywhere):
             // report it through the error word and skip it
-            const uint32_t n_leaves = a.n_records + 1u;
+            const uint32_t n_leaves = a.n_leaves;
             auto bad_id = [&](uint32_t id) {
                 return id != RT_SENTINEL && ((id & RT_LEAF_FLAG) ? (id & ~RT_LEAF_FLAG) >= n_leaves : id >= a.n_records);
             };
@@ -862,12 +885,13 @@ uint32_t trace_packet_max_blocks(int compute_units)
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
-    a.trav = t.trav; a.trav_search = t.trav_search; a.tree_select = t.tree_select;
+    a.trav = t.trav; a.search_root = t.search_root; a.tree_select = t.tree_select;
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
     a.pos = t.pos;
     a.ctrl = (TraceCtrl*)t.ctrl;
     a.long_list = t.long_list; a.long_cap = t.long_cap;
-    a.n_records = t.n_leaves - 1u;
+    a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
+    a.n_leaves = t.n_leaves;
     a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries;
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
@@ -888,9 +912,9 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.out = out;
     if (t.mark_inside && t.n_leaves > 1) {
         (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
-        hipLaunchKernelGGL(k_prepare_camera, dim3((t.n_leaves - 1 + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
-                           const_cast<TravNode*>(t.trav_search), t.n_leaves - 1, cam.viewTransform[3], cam.viewTransform[7],
-                           cam.viewTransform[11], const_cast<uint32_t*>(t.tree_select));
+        const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
+        hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav), n_all, n_ref,
+                           cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11], const_cast<uint32_t*>(t.tree_select));
     }
     launch<1>(s, t, a);
 }
@@ -903,6 +927,7 @@ void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, 
     a.rays = rays;
     a.out = out;
     a.nranks = 1;
-    a.trav_search = nullptr;                 // arbitrary rays walk the reference tree
+    a.search_root = 0u;                      // arbitrary rays walk the reference tree
+    a.n_records = t.n_leaves - 1u;
     launch<0>(s, t, a);
 }

@@ -247,3 +247,60 @@ def test_forced_trace_strategies_and_full_deferred_list(packet, budget, list_max
             gb.close(); sc.close()
     finally:
         ctx.close()
+
+
+def test_search_tree_is_an_implementation_detail(monkeypatch):
+    """primary rays walk the search tree by default and the reference tree with RTMI_SEARCH_TREE=0: same bytes, and both
+    are the oracle's (which walks the reference tree in the reference's order)"""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    frames = {}
+    for knob in ('1', '0'):
+        monkeypatch.setenv('RTMI_SEARCH_TREE', knob)
+        ctx = capi.Context(0)
+        try:
+            for name, res in (('tenryuu', (400, 300)), ('man', (320, 240)), ('cube', (64, 48))):
+                osc, ob = oracle_bvh(name)
+                sc = capi.DeviceScene(ctx, packed_scene(name))
+                gb = capi.DeviceBVH(ctx, sc).build()
+                cam = osc.demo_camera(*res)
+                frames[(name, knob)] = gb.generate_contacts_primary(as_capi_camera(cam))
+                st = gb.search_tree()
+                if knob == '0':
+                    assert st['depth'] == 0 and st['used_by_last_camera'] == 0
+                elif name != 'cube':                          # 12 triangles: the reference tree is as shallow as it gets
+                    assert 0 < st['depth'] < gb.info()['max_depth'] and st['used_by_last_camera'] == 1
+                if knob == '1':
+                    want, _ = ob.trace_primary(cam)
+                    assert frames[(name, knob)].tobytes() == want.tobytes()
+                gb.close(); sc.close()
+        finally:
+            ctx.close()
+    for name in ('tenryuu', 'man', 'cube'):
+        assert frames[(name, '1')].tobytes() == frames[(name, '0')].tobytes()
+
+
+@pytest.mark.parametrize('name', ['man', 'clumsydragon'])
+def test_camera_on_a_box_plane_falls_back_to_the_reference_tree(gpu_ctx, name):
+    """camera x == 0 == a plane of leaf boxes of these models, and the middle pixel column has direction.x == 0: the slab
+    test multiplies 0 by inf there (NaN), the one case the search-tree argument excludes.  The device notices the plane
+    and starts exactly those rays at the reference tree's root; contacts are the oracle's either way."""
+    osc, ob = oracle_bvh(name)
+    _, gb = gpu_bvh(gpu_ctx, name)
+    cam = osc.demo_camera(160, 120).copy()
+    planes = np.concatenate([ob.nodes['lo'][:ob.n, 0], ob.nodes['hi'][:ob.n, 0]])
+    assert (planes == 0.0).any()
+    cam['m'][0][3] = 0.0                                      # camera position x (Transform.h:282-295: translation column)
+    import oracle as orc
+    rays = orc.generate_rays(cam)
+    assert (rays['direction'][:, 0] == 0.0).sum() == 120      # one pixel column
+    want, _ = ob.trace_primary(cam)
+    got = gb.generate_contacts_primary(as_capi_camera(cam))
+    assert got.tobytes() == want.tobytes()
+    assert gb.search_tree()['used_by_last_camera'] == 2       # plane noticed: that pixel column starts at the reference root
+    cam2 = osc.demo_camera(160, 120)
+    cam2['m'][0][3] = 0.123                                   # no plane there
+    assert not (planes == np.float32(0.123)).any()
+    want2, _ = ob.trace_primary(cam2)
+    assert gb.generate_contacts_primary(as_capi_camera(cam2)).tobytes() == want2.tobytes()
+    assert gb.search_tree()['used_by_last_camera'] == 1
