@@ -12,9 +12,11 @@ each rank traces and shades its tiles into a compact buffer, ONE gather (RCCL ov
 scatters them back to pixel order -- total work per step is fixed, so scaling is "strong".
 
 The line printed by rank 0 also carries
-  roofline      algorithmic bytes of the traversal (56*I + 40*L + 32 per ray, I/L = inner visits / leaf tests under the
-                reference's traversal semantics, from the committed counter fixture tests/golden/frames.json) divided by
-                the traversal kernels' device time, measured with HIP events on the stream they run on, vs 8 TB/s HBM;
+  roofline      algorithmic bytes of the traversal (56*I + 40*L + 32 per ray; I / L = inner records walked / triangles
+                tested, from the committed counter fixtures tests/golden/search_tree_frames.json for the hierarchy the
+                kernels walk and tests/golden/frames.json for the reference's own traversal order, both computed by the
+                oracle, never taken from the GPU run) divided by the traversal kernels' device time, measured with HIP
+                events on the stream they run on, vs 8 TB/s HBM;
   cpu_baseline  the CPU oracle (a restatement of the reference's host path) timed on this box's host cores on the same
                 five frames (rank 0, N = 1 only).  A reported baseline, not the target.
 """
@@ -99,6 +101,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)                  # library work is ordered with torch / RCCL on this stream
 
     frames_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'frames.json')))
+    search_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'search_tree_frames.json')))
     key = '%dx%d' % RES
     npx = RES[0] * RES[1]
     work = []
@@ -126,6 +129,7 @@ def main():
         work.append(item)
 
     def step():
+        pending = []
         for it in work:
             if world == 1:
                 it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
@@ -135,9 +139,13 @@ def main():
                 # shade straight into the fixed-size send buffer (ranks own slots <= slots0)
                 capi.shade_blinn_phong_tiled_d(ctx, it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
                                                it['send'].data_ptr())
-                frame_tiles.gather_to_root(it['send'], world, rank, out=it.get('gathered'))   # the one collective
-                if rank == 0:
-                    capi.untile_rgba_d(ctx, it['cam'], world, it['gathered'].data_ptr(), it['slots0'], it['frame'].data_ptr())
+                # the one collective of a frame, on the communicator's stream: the next frame's kernels overlap it
+                _, w = frame_tiles.gather_to_root(it['send'], world, rank, out=it.get('gathered'), async_op=True)
+                pending.append((it, w))
+        for it, w in pending:
+            w.wait()                                   # orders this stream behind the gather
+            if rank == 0:
+                capi.untile_rgba_d(ctx, it['cam'], world, it['gathered'].data_ptr(), it['slots0'], it['frame'].data_ptr())
 
     def fence():
         if dist is not None:
@@ -179,12 +187,20 @@ def main():
         k = ctx.trace_kernel_times()
         fx = frames_fixture[it['name']][key]
         alg = 56 * fx['inner_visits'] + 40 * fx['leaf_tests'] + 32 * fx['rays']
+        # bytes of the records actually walked: primary rays use the search tree (same leaves, fewer inner nodes) when the
+        # BVH has one; counts from tests/golden/search_tree_frames.json (make_golden_search.py)
+        st = it['bvh'].search_tree()
+        walked = alg
+        if st['depth'] and st['used_by_last_camera']:
+            sx = search_fixture[it['name']][key]
+            walked = 56 * sx['inner_visits'] + 40 * sx['leaf_tests'] + 32 * sx['rays']
         per_scene[it['name']] = dict(trace_ms=round(ms, 4), first_kernel_ms=round(k['lane_phase_ms'] / 5, 4),
                                      wave_per_ray_ms=round(k['wave_phase_ms'] / 5, 4),
                                      mrays_per_s=round(it['slots'] / ms / 1e3, 1),
                                      inner_visits_per_ray=round(fx['inner_visits'] / fx['rays'], 2),
                                      leaf_tests_per_ray=round(fx['leaf_tests'] / fx['rays'], 2),
-                                     algorithmic_bytes=alg, build_ms=round(build_ms[it['name']], 3),
+                                     algorithmic_bytes=alg, walked_bytes=walked, search_tree_depth=st['depth'],
+                                     reference_tree_depth=it['bvh'].info()['max_depth'], build_ms=round(build_ms[it['name']], 3),
                                      strategy=it['bvh'].trace_strategy())
     ctx.set_profiling(False)
     tm.close()
@@ -198,7 +214,9 @@ def main():
     trace_ms_avg = (kt['lane_phase_ms'] + kt['wave_phase_ms']) / launches          # k_trace + k_trace_long per frame
     alg_total = sum(per_scene[n]['algorithmic_bytes'] for n in SCENES)
     alg_per_launch = alg_total / len(SCENES) / world                                # this rank's share of an average frame
-    achieved = alg_per_launch / (trace_ms_avg * 1e-3) / 1e9
+    walked_per_launch = sum(per_scene[n]['walked_bytes'] for n in SCENES) / len(SCENES) / world
+    achieved = walked_per_launch / (trace_ms_avg * 1e-3) / 1e9                      # bytes of the records the kernels walk
+    achieved_ref = alg_per_launch / (trace_ms_avg * 1e-3) / 1e9                     # the reference algorithm's bytes
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
     if os.path.exists(tpath) and world == 1:
@@ -209,7 +227,12 @@ def main():
                     avg_launch_ms=round(trace_ms_avg, 4),
                     avg_first_kernel_ms=round(kt['lane_phase_ms'] / launches, 4),
                     avg_wave_per_ray_ms=round(kt['wave_phase_ms'] / launches, 4),
-                    algorithmic_bytes_per_launch=int(alg_per_launch))
+                    algorithmic_bytes_per_launch=int(walked_per_launch),
+                    reference_algorithm_bytes_per_launch=int(alg_per_launch),
+                    achieved_reference_algorithm=round(achieved_ref, 1),
+                    note='achieved/frac count 56 B per inner record + 40 B per triangle + 32 B contact of the hierarchy actually '
+                         'walked (search tree over the reference leaves); *_reference_algorithm is the same time against the bytes '
+                         'the reference traversal order would touch (SURVEY.md 8(d)); traffic = measured HBM bytes per launch')
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:

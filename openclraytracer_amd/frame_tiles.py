@@ -49,15 +49,19 @@ def untile_host(gathered: np.ndarray, resx: int, resy: int) -> np.ndarray:
     return gathered[r, s]
 
 
-def gather_to_root(send, world: int, rank: int, out=None):
+def gather_to_root(send, world: int, rank: int, out=None, async_op: bool = False):
     """THE collective of the path: one gather of equally sized compact buffers to rank 0
-    (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU)."""
+    (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU).
+
+    async_op=True returns (out, work): the gather runs on the communicator's own stream behind the work already queued
+    on the caller's stream, so the next frame's kernels overlap it; `work.wait()` orders the caller's stream behind it."""
     import torch
     import torch.distributed as dist
     if rank == 0:
         if out is None:
             out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-        dist.gather(send, list(out.unbind(0)), dst=0)
-        return out
-    dist.gather(send, None, dst=0)
-    return None
+        work = dist.gather(send, list(out.unbind(0)), dst=0, async_op=async_op)
+    else:
+        work = dist.gather(send, None, dst=0, async_op=async_op)
+        out = None
+    return (out, work) if async_op else out

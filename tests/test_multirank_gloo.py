@@ -38,7 +38,13 @@ def _worker(rank, world, port, res, name, ret):
         mine = ft.owned_slots(res[0], res[1], rank, world)
         send = np.zeros((slots0, 4), dtype=np.float32)
         send[:mine] = ft.compact_from_frame(frame, res[0], res[1], rank, world, mine)
-        out = ft.gather_to_root(torch.from_numpy(send), world, rank)
+        # bench.py's pattern: the gather is issued asynchronously (the next frame's kernels overlap it on the GPU) and
+        # waited for before the frame is untiled; the synchronous form must give the same buffer
+        out, work_handle = ft.gather_to_root(torch.from_numpy(send), world, rank, async_op=True)
+        work_handle.wait()
+        out_sync = ft.gather_to_root(torch.from_numpy(send), world, rank)
+        if rank == 0:
+            assert torch.equal(out, out_sync)
         if rank == 0:
             got = ft.untile_host(out.numpy(), res[0], res[1])
             ret['equal'] = bool(np.array_equal(got, frame))
