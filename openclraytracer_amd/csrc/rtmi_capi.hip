@@ -117,8 +117,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
 void rt_ctx_destroy(rt_ctx* ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     free_ctx_buffers(ctx);
     for (hipEvent_t e : ctx->trace_events) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -307,10 +307,10 @@ int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_
 void rt_scene_destroy(rt_scene* sc)
 {
     if (!sc) return;
-    if (sc->ctx) { hipSetDevice(sc->ctx->device); hipStreamSynchronize(sc->ctx->stream); }
-    if (sc->d_bytes) hipFree(sc->d_bytes);
-    if (sc->d_meshes) hipFree(sc->d_meshes);
-    if (sc->d_tri) hipFree(sc->d_tri);
+    if (sc->ctx) { (void)hipSetDevice(sc->ctx->device); (void)hipStreamSynchronize(sc->ctx->stream); }
+    if (sc->d_bytes) (void)hipFree(sc->d_bytes);
+    if (sc->d_meshes) (void)hipFree(sc->d_meshes);
+    if (sc->d_tri) (void)hipFree(sc->d_tri);
     delete sc;
 }
 
@@ -345,15 +345,15 @@ int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** 
 
 static void free_build_buffers(rt_bvh* b)
 {
-    if (b->d_nodes) hipFree(b->d_nodes);
-    if (b->d_pairs) hipFree(b->d_pairs);
-    if (b->d_counters) hipFree(b->d_counters);
-    if (b->d_trav) hipFree(b->d_trav);
-    if (b->d_depth) hipFree(b->d_depth);
-    if (b->d_pos) hipFree(b->d_pos);
-    if (b->d_packet_spill) hipFree(b->d_packet_spill);
+    if (b->d_nodes) (void)hipFree(b->d_nodes);
+    if (b->d_pairs) (void)hipFree(b->d_pairs);
+    if (b->d_counters) (void)hipFree(b->d_counters);
+    if (b->d_trav) (void)hipFree(b->d_trav);
+    if (b->d_depth) (void)hipFree(b->d_depth);
+    if (b->d_pos) (void)hipFree(b->d_pos);
+    if (b->d_packet_spill) (void)hipFree(b->d_packet_spill);
     b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
-    if (b->d_tree_select) hipFree(b->d_tree_select);
+    if (b->d_tree_select) (void)hipFree(b->d_tree_select);
     b->d_tree_select = nullptr; b->have_search_tree = false;
     b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
     b->d_depth = nullptr; b->d_pos = nullptr;
@@ -362,8 +362,8 @@ static void free_build_buffers(rt_bvh* b)
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    hipSetDevice(b->ctx->device);
-    hipStreamSynchronize(b->ctx->stream);
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
     free_build_buffers(b);
     delete b;
 }
@@ -725,7 +725,7 @@ int rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n
     launch_scan_inclusive(ctx->stream, (const uint32_t*)d_in, (uint32_t*)d_out, n, scratch);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // scratch is freed below
-    hipFree(scratch);
+    (void)hipFree(scratch);
     if (e != hipSuccess) return RT_FAIL(ctx, std::string("scan failed: ") + hipGetErrorString(e));
     return RT_SUCCESS;
 }
@@ -811,7 +811,7 @@ void rt_timer_destroy(rt_ctx* ctx, void* timer)
 {
     if (!timer) return;
     rt_timer* t = (rt_timer*)timer;
-    hipEventDestroy(t->start); hipEventDestroy(t->stop);
+    (void)hipEventDestroy(t->start); (void)hipEventDestroy(t->stop);
     delete t;
 }
 

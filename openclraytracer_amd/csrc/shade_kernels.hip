@@ -102,7 +102,7 @@ void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, co
     a.cam = cam;
     a.contacts = contacts; a.count = count; a.rgba = rgba;
     a.tiled = tiled ? 1u : 0u; a.rank = rank; a.nranks = nranks; a.tiles_x = rt_tiles_x(cam.resX);
-    if (!tiled) hipMemsetAsync(rgba, 0, (size_t)cam.resX * cam.resY * sizeof(float4), s);   // memset(colors,0), :298
+    if (!tiled) (void)hipMemsetAsync(rgba, 0, (size_t)cam.resX * cam.resY * sizeof(float4), s);   // memset(colors,0), :298
     hipLaunchKernelGGL(k_shade, dim3((count + 255) / 256), dim3(256), 0, s, a);
 }
 

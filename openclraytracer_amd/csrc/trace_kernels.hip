@@ -238,7 +238,7 @@ template <int PRIMARY>
 __device__ __forceinline__ uint32_t ray_root(const TraceArgs& a, const RayState& r, uint32_t plane_bits)
 {
     if (!PRIMARY || a.search_root == 0u) return 0u;
-    const bool risky = ((plane_bits & 1u) && !(fabsf(r.inv.x) <= FLT_MAX)) | ((plane_bits & 2u) && !(fabsf(r.inv.y) <= FLT_MAX)) |
+    const bool risky = ((plane_bits & 1u) && !(fabsf(r.inv.x) <= FLT_MAX)) || ((plane_bits & 2u) && !(fabsf(r.inv.y) <= FLT_MAX)) ||
                        ((plane_bits & 4u) && !(fabsf(r.inv.z) <= FLT_MAX));
     return risky ? 0u : a.search_root;
 }
