@@ -514,8 +514,8 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
         static const struct { bool packet; uint32_t budget; } candidates[] = {
-            { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
-            { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
+            { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
+            { false, 32u }, { false, 64u }, { false, 128u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
         hipEvent_t e0 = nullptr, e1 = nullptr;
         RT_HIP(ctx, hipEventCreate(&e0));
         RT_HIP(ctx, hipEventCreate(&e1));

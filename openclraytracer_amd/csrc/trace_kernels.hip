@@ -449,6 +449,16 @@ typedef const __attribute__((address_space(4))) float cf4;        // constant ad
 typedef const __attribute__((address_space(4))) uint32_t cu32;
 __device__ __forceinline__ cf4* as_const(const void* p) { return (cf4*)(unsigned long long)p; }
 __device__ __forceinline__ float4 ld_const4(const void* p) { cf4* f = as_const(p); return make_float4(f[0], f[1], f[2], f[3]); }
+struct NodeRec { float4 q0, q1, q2, q3; };
+// one 64-byte record through the scalar path (the index is wave-uniform)
+__device__ __forceinline__ NodeRec ld_record(const TravNode* trav, uint32_t node)
+{
+    node = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);       // uniform by construction: keeps the record in SGPRs
+    const float4* p = reinterpret_cast<const float4*>(trav + node);
+    NodeRec r;
+    r.q0 = ld_const4(p); r.q1 = ld_const4(p + 1); r.q2 = ld_const4(p + 2); r.q3 = ld_const4(p + 3);
+    return r;
+}
 #define PACKET_STACK 96u
 #define PACKET_LOW_LANES 4u        // "a handful of lanes"
 #define PACKET_LOW_RUN 24u         // consecutive low-occupancy steps before the block sheds sub-trees
@@ -528,6 +538,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
         uint32_t low_run = 0;                            // consecutive steps with very few lanes taking part
         uint32_t steps = 0;                              // nodes this block has walked
         bool walking = __ballot(in) != 0ull;
+        NodeRec cur = ld_record(a.trav, node);           // record of `node`, kept in registers across steps
         while (walking) {
             // A block that keeps walking with a handful of lanes wastes the wave, and a block that walks thousands of
             // nodes sets the frame time.  After PACKET_LOW_RUN low-occupancy steps the current node -- after `defer_budget`
@@ -564,8 +575,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                         uint32_t nn, lo, hi;
                         if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
                         else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
-                        node = nn;
+                        node = (uint32_t)__builtin_amdgcn_readfirstlane((int)nn);
                         in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+                        cur = ld_record(a.trav, node);
                         continue;
                     }
                     // list full: keep walking here.  Slots this reservation still owns below the capacity must not
@@ -577,10 +589,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                     low_run = 0; steps = 0;
                 }
             }
-            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
-            const float4* p = reinterpret_cast<const float4*>(a.trav + un);
-            const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
+            // the record of `node` is in registers (cur); both children's records are requested NOW, before the box
+            // tests, so that the scalar-cache / L2 latency of the next step runs under this step's arithmetic
+            // (a leaf child requests record 0 instead: harmless, never used)
+            const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, q3 = cur.q3;
             const uint32_t ca = __float_as_uint(q0.w), cb = __float_as_uint(q1.w);
+            const NodeRec recA = ld_record(a.trav, (ca & RT_LEAF_FLAG) ? 0u : ca);
+            const NodeRec recB = ld_record(a.trav, (cb & RT_LEAF_FLAG) ? 0u : cb);
             const uint32_t marks = __float_as_uint(q2.w);
             bool aV = false, bV = false;
             if (in) {
@@ -600,9 +615,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                     if (lane == 0) __hip_atomic_store((gu32*)&a.ctrl->error, 3u, RLX_AGENT);     // frame invalid
                 }
                 sp++;
-                node = ca; in = aV;
-            } else if (mA != 0ull) { node = ca; in = aV; }
-            else if (mB != 0ull) { node = cb; in = bV; }
+                node = ca; in = aV; cur = recA;
+            } else if (mA != 0ull) { node = ca; in = aV; cur = recA; }
+            else if (mB != 0ull) { node = cb; in = bV; cur = recB; }
             else {
                 if (sp == 0u) { walking = false; }
                 else {
@@ -610,8 +625,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                     uint32_t nn, lo, hi;
                     if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
                     else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
-                    node = nn;
+                    node = (uint32_t)__builtin_amdgcn_readfirstlane((int)nn);
                     in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+                    cur = ld_record(a.trav, node);
                 }
             }
         }
