@@ -519,7 +519,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         hipEvent_t e0 = nullptr, e1 = nullptr;
         RT_HIP(ctx, hipEventCreate(&e0));
         RT_HIP(ctx, hipEventCreate(&e1));
-        float best_ms = 0.f; uint32_t best = 1024u; bool best_packet = false; bool have = false;
+        float best_ms = 0.f; uint32_t best = 1024u; bool best_packet = false; bool have = false; bool last_failed = false;
         for (const auto& cand : candidates) {
             if (cand.packet && ctx->no_packet) continue;
             if (!cand.packet && ctx->force_packet) continue;
@@ -532,12 +532,19 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             (void)hipEventRecord(e1, ctx->stream);
             float ms = 0.f;
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { have = false; break; }
+            uint32_t cand_err = 0;
+            if (hipMemcpyAsync(&cand_err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { have = false; break; }
+            if (cand_err) { last_failed = true; continue; }              // e.g. a list too small for this strategy: not a candidate
+            last_failed = false;
             if (!have || ms < best_ms) { best = cand.budget; best_packet = cand.packet; best_ms = ms; have = true; }
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (!have) return RT_FAIL(ctx, "trace calibration: no strategy produced a valid frame");
         b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best_packet;
         RT_HIP(ctx, hipGetLastError());
-        return RT_SUCCESS;                      // the last candidate's launch already produced the frame
+        if (!last_failed) return RT_SUCCESS;    // the last candidate's launch already produced the frame
+        // otherwise fall through: trace once more with the strategy just chosen
     }
     TraceLaunch t = make_launch(b, cam);
     if (ctx->defer_budget == 0 && b->tuned) { t.defer_budget = b->tuned_budget; t.packet = b->tuned_packet; }
