@@ -1,0 +1,121 @@
+"""Seeded random scenes against the oracle on the GPU: triangle soups with flat, duplicate and tiny triangles, geometry on
+axis-aligned planes, cameras outside, inside and exactly on box planes.  Targets the search-tree equivalence (DESIGN.md
+section 2) and the tie rule: every contact must be the oracle's, bit for bit, for the BVH; the Two-Level Grid likewise."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, as_capi_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_scene(tmp_path, name, tris, mtl=True):
+    """tris[n,3,3] -> OBJ + scene file; returns the packed scene bytes (oracle packer)"""
+    import scene_pack
+    obj = tmp_path / (name + '.obj')
+    lines = []
+    if mtl:
+        (tmp_path / (name + '.mtl')).write_text('newmtl m0\nKd 0.8 0.2 0.2\nKa 0.1 0.1 0.1\nKs 0.3 0.3 0.3\nNs 20\n')
+        lines.append('mtllib %s.mtl' % name)
+    lines.append('o soup')
+    for t in tris:
+        for v in t:
+            lines.append('v %r %r %r' % (float(v[0]), float(v[1]), float(v[2])))
+    if mtl:
+        lines.append('usemtl m0')
+    for k in range(len(tris)):
+        lines.append('f %d %d %d' % (3 * k + 1, 3 * k + 2, 3 * k + 3))
+    obj.write_text('\n'.join(lines) + '\n')
+    txt = tmp_path / (name + '.txt')
+    txt.write_text('LIGHT 0.0 10.0 -30.0 1000.0\nMESH %s' % str(obj))
+    return scene_pack.load_scene(str(txt))
+
+
+def _soup(rng, n, kind):
+    if kind == 'uniform':
+        c = rng.uniform(-1, 1, size=(n, 1, 3))
+        return (c + rng.normal(scale=0.08, size=(n, 3, 3))).astype(np.float32)
+    if kind == 'clustered':                                  # many coincident centres: duplicate Morton codes in both trees
+        centres = rng.uniform(-1, 1, size=(8, 3))
+        c = centres[rng.integers(0, 8, size=n)][:, None, :]
+        return (c + rng.normal(scale=0.01, size=(n, 3, 3))).astype(np.float32)
+    if kind == 'lattice':                                    # axis-aligned quads on integer planes: flat boxes, shared planes, ties
+        out = []
+        for _ in range(n // 2):
+            ax = rng.integers(0, 3)
+            p = float(rng.integers(-2, 3))
+            u0, v0 = rng.integers(-2, 2, size=2).astype(float)
+            q = np.zeros((4, 3))
+            a, b = [k for k in range(3) if k != ax]
+            q[:, ax] = p
+            q[:, a] = [u0, u0 + 1, u0 + 1, u0]
+            q[:, b] = [v0, v0, v0 + 1, v0 + 1]
+            out += [q[[0, 1, 2]], q[[0, 2, 3]]]
+        return np.array(out, dtype=np.float32)
+    if kind == 'degenerate':                                 # zero-area, needle and repeated triangles among ordinary ones
+        t = _soup(rng, n, 'uniform')
+        t[::7, 2] = t[::7, 1]                                # two equal vertices
+        t[3::11] = t[2::11][:len(t[3::11])]                  # exact duplicates
+        t[5::13, 1] = t[5::13, 0] + np.float32(1e-7)
+        return t
+    raise ValueError(kind)
+
+
+def _cameras(orc, osc, res, rng, tris):
+    cams = [osc.demo_camera(*res)]
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    inside = osc.demo_camera(*res).copy()                    # camera in the middle of the geometry
+    inside['m'][0][3], inside['m'][0][7], inside['m'][0][11] = [float(x) for x in (lo + hi) * 0.5]
+    cams.append(inside)
+    onplane = osc.demo_camera(*res).copy()                   # camera coordinates equal to vertex coordinates (box planes)
+    v = tris.reshape(-1, 3)[rng.integers(0, len(tris) * 3)]
+    onplane['m'][0][3], onplane['m'][0][7] = float(v[0]), float(v[1])
+    cams.append(onplane)
+    rot = osc.demo_camera(*res).copy()                       # a rotated view: non-identity matrix, translation kept
+    a = 0.3
+    m = rot['m'][0]
+    m[0], m[2], m[8], m[10] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+    cams.append(rot)
+    return cams
+
+
+@pytest.mark.parametrize('seed,kind,n', [(1, 'uniform', 300), (2, 'clustered', 500), (3, 'lattice', 160), (4, 'degenerate', 400),
+                                         (5, 'uniform', 2), (6, 'lattice', 40), (7, 'clustered', 3000), (8, 'uniform', 1500),
+                                         (9, 'lattice', 600), (10, 'lattice', 12), (11, 'degenerate', 2500), (12, 'lattice', 300)])
+def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
+    import oracle as orc
+    from openclraytracer_amd import capi
+    rng = np.random.default_rng(seed)
+    tris = _soup(rng, n, kind)
+    buf = _write_scene(tmp_path, 'fuzz%d' % seed, tris)
+    osc = orc.Scene(buf)
+    assert osc.n_tris == len(tris)
+    ob = orc.BVH(osc, 0)
+    sc = capi.DeviceScene(gpu_ctx, buf)
+    gb = capi.DeviceBVH(gpu_ctx, sc).build()
+    assert gb.read_nodes().tobytes() == ob.nodes.tobytes()
+    res = (96, 64)
+    try:
+        for k, cam in enumerate(_cameras(orc, osc, res, rng, tris)):
+            want, _ = ob.trace_primary(cam)
+            got = gb.generate_contacts_primary(as_capi_camera(cam))
+            assert got.tobytes() == want.tobytes(), ('bvh', kind, seed, k, gb.search_tree())
+        try:
+            og = orc.TLG(osc)
+        except RuntimeError:
+            og = None                                           # degenerate box: the product must refuse as well
+        if og is None:
+            with pytest.raises(capi.RtError):
+                capi.DeviceTLG(gpu_ctx, sc).build()
+        else:
+            gg = capi.DeviceTLG(gpu_ctx, sc).build()
+            assert gg.read(gg.LEAF_PAIRS).tobytes() == og.leaf_pairs.tobytes()
+            for k, cam in enumerate(_cameras(orc, osc, res, rng, tris)):
+                want, _ = og.trace_primary(cam)
+                got = gg.generate_contacts_primary(as_capi_camera(cam))
+                assert got.tobytes() == want.tobytes(), ('grid', kind, seed, k)
+            gg.close()
+    finally:
+        gb.close(); sc.close()
