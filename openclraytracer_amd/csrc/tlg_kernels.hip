@@ -357,8 +357,16 @@ __device__ __forceinline__ bool dda_advance(Dda& s, int axis)
 template <int PRIMARY>
 __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace(TlgTraceArgs a)
 {
+    // Mailbox: a triangle lies in every leaf cell it overlaps, so a ray marching through the grid meets it again and again
+    // (61 % of all tests on the atrium).  The reference returns from the first leaf cell in which ANY triangle is hit
+    // (TwoLevelGrid.h:528-540), so whatever this ray tested before the current cell was a miss, and testing it again gives
+    // the same miss: the test is skipped when the triangle sits in a 16-entry direct-mapped table of tested triangles
+    // (per lane, LDS [entry][lane]: conflict free).  Results are unchanged by construction.
+    __shared__ uint32_t s_mailbox[16][TLG_BLOCK];
     const uint32_t w = blockIdx.x * TLG_BLOCK + threadIdx.x;
     if (w >= a.total_work) return;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s_mailbox[k][threadIdx.x] = 0xFFFFFFFFu;
     f3 o, d;
     uint32_t pixel, out_index;
     if (PRIMARY) {
@@ -406,6 +414,9 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace(TlgTraceArgs a)
                 const uint2 range = a.leaf_ranges[leaf];
                 for (uint32_t i = range.x; i < range.y; i++) {
                     const uint32_t tri = a.leaf_pairs[i].y;
+                    uint32_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
+                    if (*slot == tri) continue;                               // tested in an earlier cell: a miss, again
+                    *slot = tri;
                     // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions)
                     const f3 vert0 = f3_from4(a.v0[tri]), edge1 = f3_from4(a.e1[tri]), edge2 = f3_from4(a.e2[tri]);
                     const f3 pvec = f3_cross(d, edge2);

@@ -36,7 +36,7 @@ class F4(C.Structure):
 
 class TLGStats(C.Structure):
     _fields_ = [('top_visits', C.c_uint64), ('leaf_visits', C.c_uint64), ('tri_tests', C.c_uint64),
-                ('hits', C.c_uint64), ('dropped_rays', C.c_uint64), ('sum_t', C.c_double)]
+                ('hits', C.c_uint64), ('dropped_rays', C.c_uint64), ('sum_t', C.c_double), ('repeat_tests', C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

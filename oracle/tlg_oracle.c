@@ -455,7 +455,7 @@ static int dda_axis(const dda_t* d)
 
 /* processTopLevelCell, TwoLevelGrid.h:419-545.  returns 1 and fills out when a leaf cell produced a hit */
 static int process_top_cell(const orc_tlg* G, const orc_ray* ray, const orc_top_cell* tc, const orc_aabb* cellBox,
-                            orc_contact* out, orc_tlg_stats* st)
+                            orc_contact* out, orc_tlg_stats* st, uint32_t* mbox)
 {
     uint32_t res[3] = { tc->resX, tc->resY, tc->resZ };
     dda_t d;
@@ -472,7 +472,7 @@ static int process_top_cell(const orc_tlg* G, const orc_ray* ray, const orc_top_
             uint32_t tri = G->leaf_pairs[i].value;
             const orc_f4* v = G->tv + 3 * (size_t)tri;
             orc_f4 c = orc_triangle_intersect(v[0], v[1], v[2], ray->origin, ray->direction);
-            if (st) st->tri_tests++;
+            if (st) { st->tri_tests++; if (mbox[tri & 15u] == tri) st->repeat_tests++; mbox[tri & 15u] = tri; }
             if (c.w > 0 && c.w < best.w) { found = 1; best = c; material = G->tmat[tri]; }
         }
         if (found) {
@@ -494,6 +494,8 @@ void orc_tlg_traverse(const orc_tlg* G, const orc_ray* ray, orc_contact* out, or
     memset(out, 0, sizeof *out);                                               /* NO_CONTACT, CLStructs.h:124 */
     uint32_t res[3] = { g->resX, g->resY, g->resZ };
     dda_t d;
+    uint32_t mbox[16];
+    memset(mbox, 0xff, sizeof mbox);
     dda_setup(ray, &g->box, res, &d);
     if (d.t0 > d.tmaxmax) return;                                             /* :590-591 */
     for (;;) {
@@ -510,7 +512,7 @@ void orc_tlg_traverse(const orc_tlg* G, const orc_ray* ray, orc_contact* out, or
             cellBox.bounds[1].z = cellBox.bounds[0].z + g->stepZ;
             cellBox.bounds[0].w = cellBox.bounds[1].w = 0.0f;
             orc_contact c;
-            if (process_top_cell(G, ray, tc, &cellBox, &c, st)) {
+            if (process_top_cell(G, ray, tc, &cellBox, &c, st, mbox)) {
                 *out = c;
                 if (st) { st->hits++; st->sum_t += (double)c.normal_t.w; }
                 return;
@@ -570,6 +572,7 @@ static void run(const orc_tlg* G, const orc_camera* cam, const orc_ray* rays, ui
             st->top_visits += jobs[c].st.top_visits; st->leaf_visits += jobs[c].st.leaf_visits;
             st->tri_tests += jobs[c].st.tri_tests; st->hits += jobs[c].st.hits;
             st->dropped_rays += jobs[c].st.dropped_rays; st->sum_t += jobs[c].st.sum_t;
+            st->repeat_tests += jobs[c].st.repeat_tests;
         }
     }
     free(jobs); free(th);

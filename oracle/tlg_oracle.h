@@ -54,6 +54,7 @@ typedef struct {
     uint64_t hits;
     uint64_t dropped_rays;   /* rays ended by the NaN rule of the header comment */
     double   sum_t;
+    uint64_t repeat_tests;   /* tests of a triangle found in a 16-entry direct-mapped per-ray cache of tested triangles */
 } orc_tlg_stats;
 
 typedef struct orc_tlg orc_tlg;
