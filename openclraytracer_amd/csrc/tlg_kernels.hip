@@ -347,15 +347,19 @@ __device__ __forceinline__ int dda_axis(const Dda& s)
 }
 
 // next[axis] += dt[axis]; idx[axis] += step[axis]; returns idx[axis] == stop[axis]
+// (value selects on purpose: with branches the compiler turns next[] / dt[] / idx[] back into a scratch array indexed by axis)
 __device__ __forceinline__ bool dda_advance(Dda& s, int axis)
 {
-    if (axis == 0) { s.nx += s.dtx; s.ix += s.sx; return s.ix == s.ex; }
-    if (axis == 1) { s.ny += s.dty; s.iy += s.sy; return s.iy == s.ey; }
-    s.nz += s.dtz; s.iz += s.sz; return s.iz == s.ez;
+    const bool a0 = axis == 0, a1 = axis == 1, a2 = !(a0 | a1);
+    const float nx = s.nx + s.dtx, ny = s.ny + s.dty, nz = s.nz + s.dtz;
+    s.nx = a0 ? nx : s.nx; s.ny = a1 ? ny : s.ny; s.nz = a2 ? nz : s.nz;
+    s.ix += a0 ? s.sx : 0; s.iy += a1 ? s.sy : 0; s.iz += a2 ? s.sz : 0;
+    const bool hx = s.ix == s.ex, hy = s.iy == s.ey, hz = s.iz == s.ez;
+    return (a0 & hx) | (a1 & hy) | (a2 & hz);
 }
 
 template <int PRIMARY>
-__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace(TlgTraceArgs a)
+__global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_tlg_trace(TlgTraceArgs a)
 {
     // Mailbox: a triangle lies in every leaf cell it overlaps, so a ray marching through the grid meets it again and again
     // (61 % of all tests on the atrium).  The reference returns from the first leaf cell in which ANY triangle is hit
