@@ -44,7 +44,7 @@
 #define DEFER_BUDGET_DEFAULT 1024u  // phase-0 iterations after which a ray moves to the long-ray list (untuned default)
 #define STRAGGLER_BUDGET 96u     // smallest deferral budget of a nearly empty wave once the primary work is gone
 #define LONG_REC_WORDS 32u       // 128-byte record per deferred ray
-#define POOL_INNER 2048u         // phase-1 LDS pool of pending inner nodes (per wave)
+#define POOL_INNER 1024u         // phase-1 LDS pool of pending inner nodes (per wave)
 #define POOL_LEAF 256u           // phase-1 LDS pool of pending leaves (per wave)
 #define SPEC_THRESHOLD 16u       // phase 1: with fewer pending inner nodes than this the wave speculates along a chain
 
