@@ -175,6 +175,18 @@ float rt_tlg_pow_third(float x);
 int  rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
                           const void* d_contacts, uint32_t contact_count, void* d_rgba);
 
+/* ---- secondary rays (EXTENSION; the reference plans it, KNOWN_ISSUES_AND_TODO.txt 2.2: "generating rays from viewing
+ *      rays-scene contacts, and execute ray tracing kernel in loop") ---------------------------------------------------
+ * From the contacts of one bounce, the rays of the next, on the device: for every contact with a hit (t > 0), in contact
+ * order,  P = o + d*t,  Nf = N flipped against d,  origin = P + Nf*eps,  direction = normalize(target - origin) (shadow
+ * rays towards a light) or the mirrored d (reflection);  Ray.idx = Contact.pixelIndex.  The incoming rays are the camera's
+ * (cam != NULL, contacts of generateContacts(Camera&)) or d_rays_in[k] for contact k.  d_rays_out holds up to `count`
+ * rays; *out_count receives how many were written (synchronises).  Feed them to rt_bvh_generate_contacts_rays /
+ * rt_tlg_generate_contacts_rays.                                                                                        */
+enum { RT_RAYS_SHADOW = 0, RT_RAYS_REFLECT = 1 };
+int  rt_generate_secondary_rays(rt_ctx* ctx, const rt_camera* cam, const void* d_rays_in, const void* d_contacts, uint32_t count,
+                                int kind, const float target[3], float eps, void* d_rays_out, uint32_t* out_count);
+
 /* ---- framebuffer tiling for multi-GPU frames (new functionality) ---------
  * The frame is cut into tile x tile pixel squares (tile = 64), numbered row-major; rank r of
  * `nranks` owns tiles r, r+nranks, ...  The compact per-rank buffers are ordered by

@@ -44,7 +44,7 @@ SYMBOLS = [
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
     'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
-    'rt_tlg_info_get', 'rt_tlg_read', 'rt_tlg_pow_third',
+    'rt_tlg_info_get', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays',
 ]
 
 
@@ -120,6 +120,7 @@ def load_library() -> C.CDLL:
     L.rt_tlg_info_get.argtypes = [vp, vp]
     L.rt_tlg_read.argtypes = [vp, i32, vp, u64]
     L.rt_tlg_pow_third.argtypes = [C.c_float]; L.rt_tlg_pow_third.restype = C.c_float
+    L.rt_generate_secondary_rays.argtypes = [vp, vp, vp, vp, u32, i32, C.POINTER(C.c_float), C.c_float, vp, C.POINTER(u32)]
     _lib = L
     return L
 
@@ -414,6 +415,28 @@ def shade_blinn_phong(ctx: Context, scene: DeviceScene, cam: np.ndarray, contact
         return ctx.download(dr, npx * 4, np.float32).reshape(npx, 4)
     finally:
         ctx.free(dc); ctx.free(dr)
+
+
+def generate_secondary_rays(ctx: Context, contacts: np.ndarray, kind: int, target=(0.0, 0.0, 0.0), eps: float = 1e-3,
+                            cam: np.ndarray | None = None, rays_in: np.ndarray | None = None) -> np.ndarray:
+    """host round trip around rt_generate_secondary_rays (tests)"""
+    n = len(contacts)
+    dc, dr = ctx.alloc(max(contacts.nbytes, 32)), ctx.alloc(max(n, 1) * 48)
+    di = ctx.alloc(max(rays_in.nbytes, 48)) if rays_in is not None else None
+    try:
+        ctx.upload(dc, contacts)
+        if rays_in is not None:
+            ctx.upload(di, rays_in)
+        ctx.fill_u32(dr, 0xDEADBEEF, max(n, 1) * 12)
+        tgt = (C.c_float * 3)(*[float(x) for x in target])
+        cnt = C.c_uint32(0)
+        ctx.check(ctx.lib.rt_generate_secondary_rays(ctx.h, _p(cam) if cam is not None else None, C.c_void_p(di) if di else None,
+                                                     C.c_void_p(dc), n, kind, tgt, eps, C.c_void_p(dr), C.byref(cnt)))
+        return ctx.download(dr, cnt.value, RAY)
+    finally:
+        ctx.free(dc); ctx.free(dr)
+        if di:
+            ctx.free(di)
 
 
 def tiles_owned_pixels(cam: np.ndarray, rank: int, nranks: int) -> int:

@@ -33,5 +33,13 @@ Common::Result shadeBlinnPhong(const OpenCLUtils::CLExecutionContext& context, c
                                const OpenCLUtils::CLBuffer& contacts, unsigned int contactCount,
                                OpenCLUtils::CLBuffer& colors, Common::Errata& err);
 
+/** rays of the next bounce from the contacts of this one (extension; the reference plans it, KNOWN_ISSUES_AND_TODO.txt 2.2):
+ *  shadow rays towards `target` (kind 0) or reflections (kind 1), for every contact with a hit, in contact order.  Incoming
+ *  rays: the camera's (cam != NULL) or rays[k] for contact k.  outRays must hold contactCount rays; outCount = rays written. */
+Common::Result generateSecondaryRays(const OpenCLUtils::CLExecutionContext& context, Camera* cam, const OpenCLUtils::CLBuffer* rays,
+                                     const OpenCLUtils::CLBuffer& contacts, unsigned int contactCount, int kind,
+                                     const CL_FLOAT3& target, float eps, OpenCLUtils::CLBuffer& outRays, unsigned int& outCount,
+                                     Common::Errata& err);
+
 }}  // namespace
 #endif

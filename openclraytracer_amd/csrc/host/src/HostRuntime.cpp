@@ -234,3 +234,22 @@ Result CLRayTracer::AccelerationStructures::shadeBlinnPhong(const CLExecutionCon
                                              contacts.getCLMem(), contactCount, colors.getCLMem()), err);
     return Success;
 }
+
+Result CLRayTracer::AccelerationStructures::generateSecondaryRays(const CLExecutionContext& context, Camera* cam, const CLBuffer* rays,
+                                                                  const CLBuffer& contacts, unsigned int contactCount, int kind,
+                                                                  const CL_FLOAT3& target, float eps, CLBuffer& outRays,
+                                                                  unsigned int& outCount, Errata& err)
+{
+    outCount = 0;
+    if ((size_t)contactCount * sizeof(Contact) > contacts.getActualSize() || (size_t)contactCount * sizeof(Ray) > outRays.getActualSize() ||
+        (rays && (size_t)contactCount * sizeof(Ray) > rays->getActualSize())) {
+        FILL_ERRATA(err, "contactCount exceeds a buffer");
+        return Error;
+    }
+    const float tgt[3] = { target.x, target.y, target.z };
+    uint32_t n = 0;
+    RTMI_CHECK(context, rt_generate_secondary_rays(context.handle(), reinterpret_cast<const rt_camera*>(cam), rays ? rays->getCLMem() : nullptr,
+                                                   contacts.getCLMem(), contactCount, kind, tgt, eps, outRays.getCLMem(), &n), err);
+    outCount = n;
+    return Success;
+}

@@ -737,6 +737,37 @@ int rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n
     return RT_SUCCESS;
 }
 
+int rt_generate_secondary_rays(rt_ctx* ctx, const rt_camera* cam, const void* d_rays_in, const void* d_contacts, uint32_t count,
+                               int kind, const float target[3], float eps, void* d_rays_out, uint32_t* out_count)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (out_count) *out_count = 0;
+    if (count == 0) return RT_SUCCESS;
+    if (!d_contacts || !d_rays_out || !out_count) return RT_FAIL(ctx, "null argument");
+    if (!cam && !d_rays_in) return RT_FAIL(ctx, "either the camera or the incoming rays are needed");
+    if (kind != RT_RAYS_SHADOW && kind != RT_RAYS_REFLECT) return RT_FAIL(ctx, "unknown ray kind");
+    if (kind == RT_RAYS_SHADOW && !target) return RT_FAIL(ctx, "shadow rays need a target");
+    if (cam && rt_check_camera(ctx, cam)) return RT_ERROR;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t* tmp = nullptr;
+    const size_t words = 2 * (size_t)count + scan_scratch_words(count);
+    RT_HIP(ctx, hipMalloc((void**)&tmp, words * sizeof(uint32_t)));
+    uint32_t* flags = tmp; uint32_t* scan = tmp + count; uint32_t* scratch = tmp + 2 * (size_t)count;
+    const float zero[3] = { 0.0f, 0.0f, 0.0f };
+    launch_secondary_flags(ctx->stream, (const rt_contact*)d_contacts, count, flags);
+    launch_scan_inclusive(ctx->stream, flags, scan, count, scratch);
+    launch_secondary_emit(ctx->stream, cam, (const rt_ray*)d_rays_in, (const rt_contact*)d_contacts, count, scan, kind,
+                          target ? target : zero, eps, (rt_ray*)d_rays_out);
+    hipError_t e = hipGetLastError();
+    uint32_t n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, scan + (count - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return RT_FAIL(ctx, std::string("secondary ray generation failed: ") + hipGetErrorString(e));
+    *out_count = n;
+    return RT_SUCCESS;
+}
+
 // ---------------------------------------------------------------------------------------
 // per-kernel timing of the trace launches (HIP events on the stream the kernels run on)
 // ---------------------------------------------------------------------------------------

@@ -90,6 +90,8 @@ def lib():
         L.orc_shade_frame.argtypes = [vp, vp, u32, vp, vp, i32]
         L.orc_scan_inclusive_u32.argtypes = [vp, vp, u32]
         f32 = C.c_float
+        L.orc_generate_secondary_rays.restype = u32
+        L.orc_generate_secondary_rays.argtypes = [vp, vp, vp, u32, i32, F4, f32, vp]
         L.orc_pow_third.restype = f32
         L.orc_pow_third.argtypes = [f32]
         L.orc_aabb_triangle_intersect.argtypes = [F4, F4, F4, F4, F4]
@@ -277,3 +279,12 @@ class TLG:
 
 def pow_third(x: float) -> float:
     return float(lib().orc_pow_third(C.c_float(x)))
+
+
+def generate_secondary_rays(contacts: np.ndarray, kind: int, target=(0.0, 0.0, 0.0), eps: float = 1e-3,
+                            cam: np.ndarray | None = None, rays_in: np.ndarray | None = None) -> np.ndarray:
+    """rays for the next bounce (extension, reference TODO 2.2): kind 0 shadow rays towards `target`, 1 reflections"""
+    out = np.zeros(len(contacts), dtype=RAY)
+    n = lib().orc_generate_secondary_rays(_p(cam) if cam is not None else None, _p(rays_in) if rays_in is not None else None,
+                                          _p(contacts), len(contacts), kind, F4(target[0], target[1], target[2], 0.0), eps, _p(out))
+    return out[:n].copy()

@@ -878,3 +878,41 @@ void orc_scan_inclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n)
     uint32_t acc = 0;
     for (uint32_t i = 0; i < n; i++) { acc += in[i]; out[i] = acc; }
 }
+
+/* ------------------------------------------------------------------ */
+/* Secondary-ray generation (EXTENSION: the reference only plans it, KNOWN_ISSUES_AND_TODO.txt 2.2: "generating rays from   */
+/* viewing rays-scene contacts, and execute ray tracing kernel in loop").  This is the specification the product's          */
+/* rt_generate_secondary_rays follows, operation for operation; there is no reference code to restate.                      */
+/*   hit point      P = o + d * t                      (as Shading.h:93 computes it)                                         */
+/*   facing normal  Nf = dot(N, d) > 0 ? -N : N                                                                             */
+/*   origin         P + Nf * eps                                                                                            */
+/*   SHADOW:  direction = normalize(target - origin')   with origin' = the offset origin                                    */
+/*   REFLECT: direction = normalize(d - N * (2 * dot(d, N)))                                                                */
+/*   idx = contact.pixelIndex; contacts without a hit (t <= 0) emit nothing; output order = contact order                   */
+/* ------------------------------------------------------------------ */
+uint32_t orc_generate_secondary_rays(const orc_camera* cam, const orc_ray* rays_in, const orc_contact* contacts, uint32_t count,
+                                     int kind, orc_f4 target, float eps, orc_ray* out)
+{
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        const orc_contact* c = &contacts[k];
+        float t = c->normal_t.w;
+        if (!(t > 0.0f)) continue;
+        orc_ray in;
+        if (cam) orc_generate_ray(cam, c->pixelIndex, &in); else in = rays_in[k];
+        orc_f4 N = { c->normal_t.x, c->normal_t.y, c->normal_t.z, 0.0f };
+        orc_f4 P = v_add(in.origin, v_scale(in.direction, t));
+        float dn = v_dot(N, in.direction);
+        orc_f4 Nf = dn > 0.0f ? v_scale(N, -1.0f) : N;
+        orc_f4 O = v_add(P, v_scale(Nf, eps));
+        orc_f4 D;
+        if (kind == 0) D = v_normalize(v_sub(target, O));
+        else D = v_normalize(v_sub(in.direction, v_scale(N, 2.0f * v_dot(in.direction, N))));
+        memset(&out[n], 0, sizeof out[n]);
+        out[n].idx = c->pixelIndex;
+        out[n].origin = O; out[n].direction = D;
+        out[n].origin.w = 0.0f; out[n].direction.w = 0.0f;
+        n++;
+    }
+    return n;
+}

@@ -104,6 +104,11 @@ void     orc_shade_blinn_phong(const orc_camera* cam, const orc_contact* c, cons
 void     orc_shade_frame(const orc_camera* cam, const orc_contact* contacts, uint32_t count,
                          const void* scene, orc_f4* rgba /* [resX*resY], zeroed here */, int nthreads);
 
+/* ---- secondary rays (EXTENSION, reference TODO 2.2; see rt_oracle.c): kind 0 = shadow rays towards `target`, 1 = reflection */
+uint32_t orc_generate_secondary_rays(const orc_camera* cam /* or NULL */, const orc_ray* rays_in /* used when cam == NULL */,
+                                     const orc_contact* contacts, uint32_t count, int kind, orc_f4 target, float eps,
+                                     orc_ray* out /* [count] */);
+
 /* ---- primitives used by the builders */
 void     orc_scan_inclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n);  /* PrefixSumKernels.cl:28-106 semantics */
 

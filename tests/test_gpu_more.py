@@ -304,3 +304,37 @@ def test_camera_on_a_box_plane_falls_back_to_the_reference_tree(gpu_ctx, name):
     want2, _ = ob.trace_primary(cam2)
     assert gb.generate_contacts_primary(as_capi_camera(cam2)).tobytes() == want2.tobytes()
     assert gb.search_tree()['used_by_last_camera'] == 1
+
+
+@pytest.mark.parametrize('name,res', [('gardenlight', (160, 120)), ('tenryuu', (320, 240))])
+def test_secondary_rays_two_bounces(gpu_ctx, name, res):
+    """rt_generate_secondary_rays (extension, reference TODO 2.2): shadow rays from the primary contacts and reflections of
+    those, each traced through the ray-buffer entry point: rays and contacts equal the oracle's at every bounce."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, ob = oracle_bvh(name)
+    _, gb = gpu_bvh(gpu_ctx, name)
+    cam = osc.demo_camera(*res)
+    ccam = as_capi_camera(cam)
+    c0 = gb.generate_contacts_primary(ccam)
+    want0, _ = ob.trace_primary(cam)
+    assert c0.tobytes() == want0.tobytes()
+    light = (0.0, 10.0, -330.0)
+    # bounce 1: shadow rays towards the scene's light, from the camera's rays
+    want_r1 = orc.generate_secondary_rays(want0, 0, light, 1e-3, cam=cam)
+    got_r1 = capi.generate_secondary_rays(gpu_ctx, c0, 0, light, 1e-3, cam=ccam)
+    assert len(got_r1) == len(want_r1) == int((want0['normal_t'][:, 3] > 0).sum()) > 0
+    assert got_r1.tobytes() == want_r1.tobytes()
+    want_c1, _ = ob.trace_rays(want_r1)
+    got_c1 = gb.generate_contacts_rays(got_r1)
+    assert got_c1.tobytes() == want_c1.tobytes()
+    # bounce 2: reflections of the primary rays at the primary contacts, generated from an explicit ray buffer
+    rays0 = orc.generate_rays(cam)
+    want_r2 = orc.generate_secondary_rays(want0, 1, eps=1e-3, rays_in=rays0)
+    got_r2 = capi.generate_secondary_rays(gpu_ctx, c0, 1, eps=1e-3, rays_in=rays0.view(capi.RAY))
+    assert got_r2.tobytes() == want_r2.tobytes()
+    want_c2, _ = ob.trace_rays(want_r2)
+    assert gb.generate_contacts_rays(got_r2).tobytes() == want_c2.tobytes()
+    # nothing hit -> nothing emitted
+    none = np.zeros(7, dtype=capi.CONTACT)
+    assert len(capi.generate_secondary_rays(gpu_ctx, none, 0, light, 1e-3, cam=ccam)) == 0
