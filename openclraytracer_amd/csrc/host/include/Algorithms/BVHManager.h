@@ -3,6 +3,7 @@
 #ifndef RTMI_HOST_BVHMANAGER_H
 #define RTMI_HOST_BVHMANAGER_H
 #include <Algorithms/AccelerationStructureManager.h>
+#include <CLData/CLStructs.h>
 
 struct rt_bvh;
 
