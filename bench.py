@@ -76,6 +76,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--check-frames', action='store_true',
+                    help='N > 1: after the warm-up, rank 0 also traces every frame untiled and compares it with the gathered one')
     args = ap.parse_args()
 
     import torch
@@ -90,8 +92,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # RTMI_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo -- a functional rehearsal of the N > 1 path on a
+        # one-GPU box (RCCL refuses two ranks on one device); its timings mean nothing
+        rehearsal = os.environ.get('RTMI_BENCH_REHEARSAL') == '1'
+        if rehearsal:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -155,6 +165,20 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.check_frames and world > 1:
+        if args.warmup == 0:
+            step(); fence()
+        if rank == 0:
+            for it in work:
+                full_c = torch.empty(npx * 32, dtype=torch.uint8, device=dev)
+                full_rgba = torch.empty((npx, 4), dtype=torch.float32, device=dev)
+                it['bvh'].generate_contacts_primary_d(it['cam'], full_c.data_ptr())
+                capi.shade_blinn_phong_d(ctx, it['scene'], it['cam'], full_c.data_ptr(), npx, full_rgba.data_ptr())
+                torch.cuda.synchronize(dev)
+                if not torch.equal(full_rgba, it['frame']):
+                    raise SystemExit('frame check failed for %s: the gathered frame differs from the untiled one' % it['name'])
+            print('frame check ok: %d gathered frames equal the untiled ones' % len(work), file=sys.stderr)
+        fence()
     ctx.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -57,6 +57,18 @@ def gather_to_root(send, world: int, rank: int, out=None, async_op: bool = False
     on the caller's stream, so the next frame's kernels overlap it; `work.wait()` orders the caller's stream behind it."""
     import torch
     import torch.distributed as dist
+    if dist.get_backend() == 'gloo' and send.is_cuda:
+        # gloo has no device gather: stage through the host (rehearsals of the N > 1 path on a one-GPU box only)
+        host = gather_to_root(send.cpu(), world, rank)
+        if rank == 0:
+            if out is None:
+                out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+            out.copy_(host)
+
+        class _Done:
+            def wait(self):
+                return True
+        return (out if rank == 0 else None, _Done()) if async_op else (out if rank == 0 else None)
     if rank == 0:
         if out is None:
             out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)

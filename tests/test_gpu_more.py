@@ -338,3 +338,22 @@ def test_secondary_rays_two_bounces(gpu_ctx, name, res):
     # nothing hit -> nothing emitted
     none = np.zeros(7, dtype=capi.CONTACT)
     assert len(capi.generate_secondary_rays(gpu_ctx, none, 0, light, 1e-3, cam=ccam)) == 0
+
+
+def test_bench_two_rank_rehearsal_assembles_identical_frames():
+    """bench.py's N > 1 path end to end on this one GPU: two ranks (gloo instead of RCCL, which refuses two ranks on one
+    device) trace and shade their tiles of all five 1080p frames, gather, untile; rank 0 checks every assembled frame
+    against the untiled one (torch.equal on the RGBA buffers) and prints the contract's JSON line."""
+    import subprocess
+    import sys as _sys
+    env = dict(os.environ, RTMI_BENCH_REHEARSAL='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([_sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--check-frames'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'frame check ok: 5 gathered frames equal the untiled ones' in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['unit'] == 'Mrays/s' and out['value'] > 0
+    assert out['cpu_baseline'] is None and out['roofline']['traffic'] is None      # rank-0-at-N=1-only fields
