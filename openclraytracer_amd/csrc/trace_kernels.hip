@@ -551,7 +551,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                 uint32_t n_in = (uint32_t)__popcll(mi);
                 low_run = n_in <= PACKET_LOW_LANES ? low_run + 1u : 0u;
                 steps++;
-                if (((low_run >= PACKET_LOW_RUN && steps * 4u > a.defer_budget) || steps > a.defer_budget) && a.long_cap != 0u) {
+                if (((low_run >= PACKET_LOW_RUN && steps * 4u > a.defer_budget) || steps > a.defer_budget) && a.long_cap != 0u &&
+                    a.defer_budget < (1u << 20)) {                   // "no budget": nothing is ever handed over (the launcher skips phase 1)
                     uint32_t base = 0;
                     if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&a.ctrl->long_count, n_in, RLX_AGENT);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -863,9 +864,12 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         hipLaunchKernelGGL((k_trace_packet<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
-        a.n_waves = grid1 * TRACE_WAVES;
-        hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
-        hipLaunchKernelGGL((k_resolve_split<PRIMARY, CAL>), dim3(64), dim3(256), 0, s, a);
+        // without a budget the packet kernel hands nothing over: the wave-per-ray and resolve kernels would find empty lists
+        if (a.defer_budget < (1u << 20)) {
+            a.n_waves = grid1 * TRACE_WAVES;
+            hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
+            hipLaunchKernelGGL((k_resolve_split<PRIMARY, CAL>), dim3(64), dim3(256), 0, s, a);
+        }
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
