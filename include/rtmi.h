@@ -126,7 +126,9 @@ int  rt_bvh_trace_strategy(const rt_bvh* bvh, int* packet_kernel, uint32_t* budg
  * bit.  The one excluded case, a camera coordinate equal to a box plane (0 * inf = NaN for rays
  * with a zero direction component), is detected on the device per camera and sends that frame to the reference tree.
  * depth = 0: no search tree (env RTMI_SEARCH_TREE=0, or a degenerate model); used = 1 when the last camera prepared for
- * this BVH walks the search tree (synchronises).  The ray-buffer entry point always walks the reference tree.           */
+ * this BVH walks the search tree (1 every ray, 2 all but the zero-component rays; synchronises).  Rays of the ray-buffer
+ * entry point have arbitrary origins, so each decides for itself: the search tree if every 1/direction component is
+ * finite and at least ~1 in magnitude (normalised directions without a zero component), the reference tree otherwise.  */
 int  rt_bvh_search_tree(const rt_bvh* bvh, uint32_t* depth, int* used_by_last_camera);
 
 /* ---- Two-Level Grid: AccelerationStructures::TwoLevelGridManager (Include/Algorithms/TwoLevelGridManager.h:61-178,

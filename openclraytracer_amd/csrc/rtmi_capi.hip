@@ -473,7 +473,7 @@ int rt_bvh_construct(rt_bvh* b)
 static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 {
     TraceLaunch t{};
-    t.trav = b->d_trav; t.search_root = (cam && b->have_search_tree) ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
+    t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.calibrating = false;

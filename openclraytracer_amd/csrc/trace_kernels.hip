@@ -237,7 +237,15 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayStat
 template <int PRIMARY>
 __device__ __forceinline__ uint32_t ray_root(const TraceArgs& a, const RayState& r, uint32_t plane_bits)
 {
-    if (!PRIMARY || a.search_root == 0u) return 0u;
+    if (a.search_root == 0u) return 0u;
+    if (!PRIMARY) {
+        // arbitrary rays have arbitrary origins: no plane test is possible, so a ray may use the search tree only if none of
+        // its slab products can be 0 * inf or underflow -- every 1/d finite and not smaller than ~1 in magnitude, which
+        // normalised directions without a zero component satisfy
+        const float ax = fabsf(r.inv.x), ay = fabsf(r.inv.y), az = fabsf(r.inv.z);
+        const bool safe = (ax <= FLT_MAX) && (ay <= FLT_MAX) && (az <= FLT_MAX) && (ax >= 0.99f) && (ay >= 0.99f) && (az >= 0.99f);
+        return safe ? a.search_root : 0u;
+    }
     const bool risky = ((plane_bits & 1u) && !(fabsf(r.inv.x) <= FLT_MAX)) || ((plane_bits & 2u) && !(fabsf(r.inv.y) <= FLT_MAX)) ||
                        ((plane_bits & 4u) && !(fabsf(r.inv.z) <= FLT_MAX));
     return risky ? 0u : a.search_root;
@@ -947,7 +955,6 @@ void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, 
     a.rays = rays;
     a.out = out;
     a.nranks = 1;
-    a.search_root = 0u;                      // arbitrary rays walk the reference tree
-    a.n_records = t.n_leaves - 1u;
+    // arbitrary rays may use the search tree too, each under its own guard (ray_root)
     launch<0>(s, t, a);
 }

@@ -102,6 +102,23 @@ def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
             want, _ = ob.trace_primary(cam)
             got = gb.generate_contacts_primary(as_capi_camera(cam))
             assert got.tobytes() == want.tobytes(), ('bvh', kind, seed, k, gb.search_tree())
+        # ray-buffer entry point: each ray decides between the search tree and the reference tree (per-ray guard)
+        m = 2003
+        rays = np.zeros(m, dtype=orc.RAY)
+        rays['idx'] = np.arange(m)
+        lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+        rays['origin'][:, :3] = rng.uniform(lo - 1.0, hi + 1.0, size=(m, 3)).astype(np.float32)
+        rays['origin'][::5, :3] = tris.reshape(-1, 3)[rng.integers(0, len(tris) * 3, size=len(rays[::5]))]   # origins ON vertices (box planes)
+        dd = rng.normal(size=(m, 3)).astype(np.float32)
+        dd /= np.linalg.norm(dd, axis=1, keepdims=True).astype(np.float32)
+        dd[::7] *= np.float32(1000.0)                        # unnormalised: tiny 1/d -> reference tree
+        dd[3::7] *= np.float32(1e-3)                         # short directions: large 1/d -> search tree allowed
+        dd[1::11, 0] = 0.0                                   # zero components: 1/d infinite -> reference tree
+        dd[2::13, 1] = 0.0
+        rays['direction'][:, :3] = dd
+        want, _ = ob.trace_rays(rays)
+        got = gb.generate_contacts_rays(rays.view(capi.RAY))
+        assert got.tobytes() == want.tobytes(), ('bvh rays', kind, seed)
         try:
             og = orc.TLG(osc)
         except RuntimeError:
