@@ -857,14 +857,13 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
     (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
     uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
-    int b1 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0);
-    if (b1 < 1) b1 = 1;
+    // resident blocks per CU: a property of the code object, asked once per kernel (the query costs microseconds of host time)
+    static int b1 = 0;
+    if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
     if (PRIMARY && t.packet) {
-        int bp = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY, CAL>, TRACE_BLOCK, 0);
-        if (bp < 1) bp = 1;
+        static int bp = 0;
+        if (bp == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY, CAL>, TRACE_BLOCK, 0); if (bp < 1) bp = 1; }
         uint32_t grid = (uint32_t)t.compute_units * (uint32_t)bp;
         if (grid > need) grid = need;
         if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
@@ -881,9 +880,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
-    int b0 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<PRIMARY, CAL>, TRACE_BLOCK, 0);
-    if (b0 < 1) b0 = 1;
+    static int b0 = 0;
+    if (b0 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b0 < 1) b0 = 1; }
     uint32_t grid = (uint32_t)t.compute_units * (uint32_t)b0;
     if (grid > need) grid = need;
     a.n_waves = grid * TRACE_WAVES;
