@@ -29,6 +29,8 @@ public:
     inline CL_FLOAT getLeafDensity() const { return _leafDensity; }
     /** grid resolution of the last initializeFrame (TwoLevelGridManager.h:127) */
     CL_UINT3 getResolution() const;
+    /** bounding box of the associated scene = box of the grid (TwoLevelGridManager.h:129-134, .cpp:605-608) */
+    struct AABB getBounds() const;
     /** sizes of the last build: (cell, triangle) pairs and (leaf cell, triangle) pairs incl. holes, leaf cells */
     unsigned int pairsCount() const { return _pairsCount; }
     unsigned int leafPairsCount() const { return _leafPairsCount; }

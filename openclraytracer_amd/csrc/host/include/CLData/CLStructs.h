@@ -13,6 +13,7 @@ typedef float CL_FLOAT;
 typedef uint32_t CL_UINT;
 struct alignas(16) CL_UINT3 { uint32_t x, y, z, w; };   // cl_uint3 is a 16-byte type on the host
 
+struct alignas(16) AABB { CL_FLOAT4 bounds[2]; };                       // Primitives/AABB.h:47-52
 struct alignas(16) Matrix4 { float data[12]; };                       // Transform.h:150-154
 struct alignas(16) Quaternion { float r, i, j, k; };                  // Transform.h:44-70
 

@@ -214,6 +214,12 @@ Result TwoLevelGridManager::generateContacts(CLBuffer& rays, CLBuffer& contacts,
     RTMI_CHECK(_context, rt_ctx_synchronize(_context.handle()), err);
     return Success;
 }
+struct AABB TwoLevelGridManager::getBounds() const
+{
+    struct AABB b;
+    std::memcpy(&b, _scene.getHostSceneData() + 64, sizeof b);          // SceneHeader.modelsBoundingBox
+    return b;
+}
 CL_UINT3 TwoLevelGridManager::getResolution() const
 {
     CL_UINT3 r = { 0, 0, 0, 0 };
