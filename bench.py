@@ -273,8 +273,29 @@ def main():
             orc.shade_frame(osc, cam, c, nthreads=cores)
             t_cpu += time.perf_counter() - t1
             rays_cpu += len(c)
+        # the same path on ONE thread (SURVEY.md 8(d) asks for both), on a bounded sample: 320x180 frames of the five scenes
+        t_one, rays_one = 0.0, 0
+        for name in SCENES:
+            osc = orc.Scene(load_scene_bytes(name))
+            ob = orc.BVH(osc, 0)
+            cam = osc.demo_camera(320, 180)
+            t1 = time.perf_counter()
+            c, _ = ob.trace_primary(cam, nthreads=1)
+            orc.shade_frame(osc, cam, c, nthreads=1)
+            t_one += time.perf_counter() - t1
+            rays_one += len(c)
+        model = 'unknown'
+        try:
+            for ln in open('/proc/cpuinfo'):
+                if ln.startswith('model name'):
+                    model = ln.split(':', 1)[1].strip()
+                    break
+        except OSError:
+            pass
         cpu_baseline = dict(value=round(rays_cpu / t_cpu / 1e6, 3), unit='Mrays/s', cores=cores, kind='port',
-                            sample='all five scenes, one full 1920x1080 frame each (trace + shade), BVH build excluded')
+                            sample='all five scenes, one full 1920x1080 frame each (trace + shade), BVH build excluded',
+                            single_thread_value=round(rays_one / t_one / 1e6, 4),
+                            single_thread_sample='the five scenes at 320x180 (trace + shade), one thread', cpu_model=model)
 
     out = dict(metric='Mrays/s (primary rays, BVH trace + shade, bundled TestModels, 1920x1080)', value=round(value, 1),
                unit='Mrays/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
