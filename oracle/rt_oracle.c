@@ -664,6 +664,7 @@ typedef struct {
     uint32_t* per_ray_inner;        /* optional: inner visits of every ray (load-balance analysis) */
     /* brute-force triangle table */
     const orc_f4* tri; const uint32_t* mat; uint32_t ntri;
+    char pad_[256];                 /* one job per thread: keeps the per-visit counters of two threads on different cache lines */
 } job_t;
 
 enum { CHUNK = 256 };
