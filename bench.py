@@ -264,13 +264,15 @@ def main():
         import oracle as orc                     # cpu_baseline leg only: the oracle is the thing timed here
         cores = orc.ncpu()
         t_cpu, rays_cpu = 0.0, 0
+        c_buf = np.zeros(npx, dtype=orc.CONTACT)              # output buffers live outside the timed region, pages touched
+        rgba_buf = np.zeros((npx, 4), dtype=np.float32)
         for name in SCENES:
             osc = orc.Scene(load_scene_bytes(name))
             ob = orc.BVH(osc, 0)
             cam = osc.demo_camera(*RES)
             t1 = time.perf_counter()
-            c, _ = ob.trace_primary(cam, nthreads=cores)
-            orc.shade_frame(osc, cam, c, nthreads=cores)
+            c, _ = ob.trace_primary(cam, nthreads=cores, out=c_buf)
+            orc.shade_frame(osc, cam, c, nthreads=cores, out=rgba_buf)
             t_cpu += time.perf_counter() - t1
             rays_cpu += len(c)
         # the same path on ONE thread (SURVEY.md 8(d) asks for both), on a bounded sample: 320x180 frames of the five scenes

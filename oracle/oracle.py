@@ -114,10 +114,25 @@ def _p(a):
 
 
 def ncpu() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a
+    16-CPU share of its 256 hardware threads to a one-GPU job)"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 class Scene:
@@ -162,11 +177,12 @@ class BVH:
         rc = lib().orc_check_hierarchy(_p(self.nodes), self.n, C.byref(d))
         return rc, d.value
 
-    def trace_primary(self, cam: np.ndarray, nthreads: int = 0, first: int = 0, count: int | None = None):
+    def trace_primary(self, cam: np.ndarray, nthreads: int = 0, first: int = 0, count: int | None = None, out: np.ndarray | None = None):
         npx = int(cam['resX'][0]) * int(cam['resY'][0])
         if count is None:
             count = npx - first
-        out = np.zeros(count, dtype=CONTACT)
+        if out is None:
+            out = np.zeros(count, dtype=CONTACT)
         st = Stats()
         lib().orc_trace_primary_range(_p(cam), _p(self.nodes), self.n, _p(self.scene.arr), first, count,
                                       _p(out), C.byref(st), nthreads or ncpu())
@@ -207,9 +223,9 @@ def generate_rays(cam: np.ndarray, first: int = 0, count: int | None = None) -> 
     return rays
 
 
-def shade_frame(scene: Scene, cam: np.ndarray, contacts: np.ndarray, nthreads: int = 0) -> np.ndarray:
+def shade_frame(scene: Scene, cam: np.ndarray, contacts: np.ndarray, nthreads: int = 0, out: np.ndarray | None = None) -> np.ndarray:
     npx = int(cam['resX'][0]) * int(cam['resY'][0])
-    rgba = np.zeros((npx, 4), dtype=np.float32)
+    rgba = np.zeros((npx, 4), dtype=np.float32) if out is None else out      # the C side clears it (memset(colors, 0))
     lib().orc_shade_frame(_p(cam), _p(contacts), len(contacts), _p(scene.arr), _p(rgba), nthreads or ncpu())
     return rgba
 
