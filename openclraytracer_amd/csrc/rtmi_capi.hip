@@ -57,7 +57,7 @@ static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
     return RT_SUCCESS;
 }
 
-// The trace kernel reports a failed frame (steal-queue overflow on a forced hand-off, slot time-out)
+// The trace kernels report a failed frame (deferred list full on a forced hand-off, pool / stack overflow, bad record)
 // through one word of its control block; every synchronising call looks at it once per launch batch.
 static int check_trace_error(rt_ctx* ctx)
 {

@@ -12,11 +12,18 @@
 // over lanes gives the reference's contact bit for bit, as long as ties are broken by that position.
 // The arithmetic itself is restated operation by operation (device_math.h, no FMA contraction).
 //
-// Machine mapping (MI355X, wave64, 256 CUs), two kernels per frame:
-//  k_trace (phase 0), one ray per lane, persistent waves:
-//   * the grid is sized to what is resident; a wave's first 8x8-pixel block is static, further blocks
-//     come from one global counter (one atomic per 64 rays); lanes whose ray has finished are refilled
-//     (ballot + prefix-popcount packing) instead of idling until the slowest ray of the block is done;
+// For the same reason the hierarchy itself is free: a leaf whose box passes the child test has only ancestors that pass
+// it in ANY hierarchy of nested boxes over these leaves (monotone rounding), so rays may walk the
+// "search tree" -- a second hierarchy over the same leaves in properly normalised Morton order, appended to the reference
+// tree's records -- unless a slab product could be 0 * inf (ray_root).
+//
+// Machine mapping (MI355X, wave64, 256 CUs).  A frame is one first-phase kernel plus, when work was handed over,
+// k_trace_long (+ k_resolve_split); which first-phase kernel and which budget is calibrated per BVH on the first frame
+// (rtmi_capi.hip, trace_primary_tuned):
+//  k_trace, one ray per lane, persistent waves:
+//   * the grid is sized to what is resident; a wave's first 8x8-pixel block is static, further blocks come from 16
+//     sharded counters (one atomic per 64 rays); lanes whose ray has finished are refilled (ballot + prefix-popcount
+//     packing) instead of idling until the slowest ray of the block is done;
 //   * the per-lane traversal stack lives in LDS ([level][lane]: one bank per lane, no conflicts);
 //   * one inner-node visit = one 64-byte record holding both child boxes and both child ids (TravNode)
 //     instead of a 48-byte node + two dependent 32-byte box fetches (BVH.h:359-364);
@@ -25,28 +32,31 @@
 //     geometric normal are ray independent and precomputed with the same operations;
 //   * leaf tests are postponed: a lane parks one reached leaf and keeps walking inner nodes; the wave
 //     runs the triangle code only when a lane needs its slot again or is about to finish;
-//   * a ray that exceeds an iteration budget, or whose stack is full, is DEFERRED: its state (pending
-//     sub-trees, best hit so far) goes to a compact list.  Duplicate Morton codes make a few rays
-//     visit thousands of nodes while most visit a handful; walked by one lane each they
-//     would set the frame time.
-//  k_trace_long (phase 1), one ray per WAVE: the 64 lanes walk the deferred ray's sub-trees together
-//     out of an LDS node pool (64 nodes per step, children appended with ballot/prefix-popcount
-//     compaction, leaves collected in a second pool and tested 64 at a time), then reduce their
+//   * a ray that exceeds the iteration budget, or whose stack is full, is DEFERRED: its state (pending
+//     sub-trees, best hit so far) goes to a compact list.  A few rays visit thousands of nodes while most
+//     visit a handful; walked by one lane each they would set the frame time.
+//  k_trace_packet, one 8x8-pixel block per wave: the node is wave-uniform, its record comes through the scalar path
+//     and stays in registers, both children's records are requested before the box tests; (node, lane mask) pairs wait
+//     on an LDS stack; sub-trees only a handful of lanes still want, or everything left once a budget is spent, go to
+//     the deferred list as per-ray partial records whose results meet in a 64-bit atomicMin on (t, position).
+//  k_trace_long, one deferred record per WAVE: the 64 lanes walk the ray's sub-trees together out of an LDS node pool
+//     (64 nodes per step, children appended with ballot/prefix-popcount compaction, spare lanes running ahead along
+//     duplicate-code chains, leaves collected in a second pool and tested 64 at a time), then reduce their
 //     (t, position) candidates with a wave-wide lexicographic min.
+//  k_prepare_camera, per camera position: "camera inside child box" bits of every record and the camera-on-a-plane bits.
 #include "rtmi_internal.h"
 #include "device_math.h"
 
 #define TRACE_BLOCK 256u
 #define TRACE_WAVES (TRACE_BLOCK / 64u)
-#define LDS_STACK 24u            // entries per lane in phase 0 (observed need at 1080p: <= 18)
+#define LDS_STACK 24u            // stack entries per lane in k_trace (observed need at 1080p: <= 18)
 #define NO_LEAF 0xFFFFFFFEu
 #define REFILL_MIN_IDLE 16u      // refill a wave once this many lanes are idle
-#define DEFER_BUDGET_DEFAULT 1024u  // phase-0 iterations after which a ray moves to the long-ray list (untuned default)
+#define DEFER_BUDGET_DEFAULT 1024u  // k_trace iterations after which a ray moves to the deferred list (default when nothing was calibrated)
 #define STRAGGLER_BUDGET 96u     // smallest deferral budget of a nearly empty wave once the primary work is gone
 #define LONG_REC_WORDS 32u       // 128-byte record per deferred ray
 #define POOL_INNER 1024u         // phase-1 LDS pool of pending inner nodes (per wave)
 #define POOL_LEAF 256u           // phase-1 LDS pool of pending leaves (per wave)
-#define SPEC_THRESHOLD 16u       // phase 1: with fewer pending inner nodes than this the wave speculates along a chain
 
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
