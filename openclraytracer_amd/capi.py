@@ -286,7 +286,7 @@ class DeviceBVH:
     def trace_strategy(self) -> dict:
         k, v = C.c_int(), C.c_uint32()
         self.ctx.check(self.ctx.lib.rt_bvh_trace_strategy(self.h, C.byref(k), C.byref(v)))
-        return dict(kernel='packet' if k.value else 'lane-per-ray', budget=v.value)
+        return dict(kernel={0: 'lane-per-ray', 1: 'packet', 2: 'packet4'}[k.value], budget=v.value)
 
     def search_tree(self) -> dict:
         d, u = C.c_uint32(), C.c_int()

@@ -353,3 +353,49 @@ void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32
 {
     hipLaunchKernelGGL(k_search_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, ref_nodes, n, pairs);
 }
+
+// ----------------------------------------------------------------------------------------
+// 7. four-wide records for the packet kernel: node i with its inner children replaced by their children.  Skipping the
+//    inner children's own boxes is allowed for the same reason the search tree is (any nested hierarchy over the leaves
+//    reaches the same leaves); one wave step then descends two levels.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t n_records)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_records) return;
+    const TravNode t = trav[i];
+    float lo[4][3], hi[4][3];
+    uint32_t id[4];
+    int n = 0;
+    for (int c = 0; c < 2; c++) {
+        const uint32_t cid = c ? t.child_b : t.child_a;
+        const float* clo = c ? t.b_lo : t.a_lo;
+        const float* chi = c ? t.b_hi : t.a_hi;
+        if (cid & RT_LEAF_FLAG) {
+            for (int k = 0; k < 3; k++) { lo[n][k] = clo[k]; hi[n][k] = chi[k]; }
+            id[n++] = cid;
+        } else {
+            const TravNode u = trav[cid];
+            for (int k = 0; k < 3; k++) { lo[n][k] = u.a_lo[k]; hi[n][k] = u.a_hi[k]; }
+            id[n++] = u.child_a;
+            for (int k = 0; k < 3; k++) { lo[n][k] = u.b_lo[k]; hi[n][k] = u.b_hi[k]; }
+            id[n++] = u.child_b;
+        }
+    }
+    for (; n < 4; n++) { for (int k = 0; k < 3; k++) { lo[n][k] = FLT_MAX; hi[n][k] = -FLT_MAX; } id[n] = RT_SENTINEL; }
+    QuadNode q;
+    q.q[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], __uint_as_float(id[0]));
+    q.q[1] = make_float4(hi[0][0], hi[0][1], hi[0][2], __uint_as_float(id[1]));
+    q.q[2] = make_float4(lo[1][0], lo[1][1], lo[1][2], __uint_as_float(id[2]));
+    q.q[3] = make_float4(hi[1][0], hi[1][1], hi[1][2], __uint_as_float(id[3]));
+    q.q[4] = make_float4(lo[2][0], lo[2][1], lo[2][2], 0.0f);
+    q.q[5] = make_float4(hi[2][0], hi[2][1], hi[2][2], 0.0f);
+    q.q[6] = make_float4(lo[3][0], lo[3][1], lo[3][2], 0.0f);
+    q.q[7] = make_float4(hi[3][0], hi[3][1], hi[3][2], 0.0f);
+    quad[i] = q;
+}
+
+void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records)
+{
+    hipLaunchKernelGGL(k_relayout_quad, dim3((n_records + 255) / 256), dim3(256), 0, s, trav, quad, n_records);
+}

@@ -109,7 +109,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
-    if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1'; ctx->no_packet = env[0] == '0'; }
+    if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
+    if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
     *out = ctx;
     return RT_SUCCESS;
 }
@@ -349,6 +350,8 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_pairs) (void)hipFree(b->d_pairs);
     if (b->d_counters) (void)hipFree(b->d_counters);
     if (b->d_trav) (void)hipFree(b->d_trav);
+    if (b->d_quad) (void)hipFree(b->d_quad);
+    b->d_quad = nullptr;
     if (b->d_depth) (void)hipFree(b->d_depth);
     if (b->d_pos) (void)hipFree(b->d_pos);
     if (b->d_packet_spill) (void)hipFree(b->d_packet_spill);
@@ -387,6 +390,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         RT_HIP(ctx, hipMalloc((void**)&b->d_depth, 256));
         RT_HIP(ctx, hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_tree_select, 256));
+        if (!ctx->no_packet4) RT_HIP(ctx, hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * (ctx->no_search_tree ? 1u : 2u)));
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -445,6 +449,7 @@ int rt_bvh_construct(rt_bvh* b)
             return RT_FAIL(ctx, std::string("search tree build failed: ") + hipGetErrorString(e));
         }
     }
+    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (ctx->no_search_tree ? 1u : 2u));
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
     if (s_nodes) (void)hipFree(s_nodes);
     if (s_pairs) (void)hipFree(s_pairs);
@@ -455,7 +460,9 @@ int rt_bvh_construct(rt_bvh* b)
     // a degenerate model (thousands of coincident box centres) makes this tree as deep as the reference's: no gain then
     b->have_search_tree = !ctx->no_search_tree && search_depth != 0 && search_depth < depth;
     {   // packet kernel: (node, lane mask) stack entries beyond the LDS part live in a per-wave global area
-        uint32_t need = depth + 8u > trace_packet_stack_entries() ? depth + 8u - trace_packet_stack_entries() : 0u;
+        // the four-wide packet kernel pushes up to three entries per two levels
+        const uint32_t deepest = b->d_quad ? 2u * depth + 16u : depth + 8u;
+        uint32_t need = deepest > trace_packet_stack_entries() ? deepest - trace_packet_stack_entries() : 0u;
         if (need != b->packet_spill_entries) {
             if (b->d_packet_spill) { (void)hipFree(b->d_packet_spill); b->d_packet_spill = nullptr; }
             b->packet_spill_entries = need;
@@ -476,7 +483,8 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
-    t.packet = false; t.calibrating = false;
+    t.packet = false; t.packet4 = false; t.calibrating = false;
+    t.quad = b->d_quad;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_max_blocks = b->packet_max_blocks;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
@@ -513,18 +521,20 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key)) {
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
-        static const struct { bool packet; uint32_t budget; } candidates[] = {
+        static const struct { bool packet; uint32_t budget; bool quad; } candidates[] = {
+            { true, 1u << 20, true },
             { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
             { false, 32u }, { false, 64u }, { false, 128u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
         hipEvent_t e0 = nullptr, e1 = nullptr;
         RT_HIP(ctx, hipEventCreate(&e0));
         RT_HIP(ctx, hipEventCreate(&e1));
-        float best_ms = 0.f; uint32_t best = 1024u; bool best_packet = false; bool have = false; bool last_failed = false;
+        float best_ms = 0.f; uint32_t best = 1024u; bool best_packet = false; bool best_quad = false; bool have = false; bool last_failed = false;
         for (const auto& cand : candidates) {
             if (cand.packet && ctx->no_packet) continue;
             if (!cand.packet && ctx->force_packet) continue;
             TraceLaunch t = make_launch(b, cam);
-            t.packet = cand.packet;
+            if (cand.quad && !b->d_quad) continue;
+            t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
             t.calibrating = true;
             (void)hipEventRecord(e0, ctx->stream);
@@ -537,18 +547,18 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
                 hipStreamSynchronize(ctx->stream) != hipSuccess) { have = false; break; }
             if (cand_err) { last_failed = true; continue; }              // e.g. a list too small for this strategy: not a candidate
             last_failed = false;
-            if (!have || ms < best_ms) { best = cand.budget; best_packet = cand.packet; best_ms = ms; have = true; }
+            if (!have || ms < best_ms) { best = cand.budget; best_packet = cand.packet; best_quad = cand.quad; best_ms = ms; have = true; }
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (!have) return RT_FAIL(ctx, "trace calibration: no strategy produced a valid frame");
-        b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best_packet;
+        b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best_packet; b->tuned_quad = best_quad;
         RT_HIP(ctx, hipGetLastError());
         if (!last_failed) return RT_SUCCESS;    // the last candidate's launch already produced the frame
         // otherwise fall through: trace once more with the strategy just chosen
     }
     TraceLaunch t = make_launch(b, cam);
-    if (ctx->defer_budget == 0 && b->tuned) { t.defer_budget = b->tuned_budget; t.packet = b->tuned_packet; }
-    if (ctx->defer_budget != 0 && ctx->force_packet) t.packet = true;
+    if (ctx->defer_budget == 0 && b->tuned) { t.defer_budget = b->tuned_budget; t.packet = b->tuned_packet; t.packet4 = b->tuned_quad; }
+    if (ctx->defer_budget != 0 && ctx->force_packet) { t.packet = true; t.packet4 = ctx->force_packet4 && b->d_quad; }
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -623,7 +633,8 @@ int rt_bvh_trace_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget)
     if (!b) return RT_FAIL(nullptr, "bvh is null");
     const rt_ctx* ctx = b->ctx;
     if (budget) *budget = ctx->defer_budget ? ctx->defer_budget : (b->tuned ? b->tuned_budget : 0u);
-    if (packet_kernel) *packet_kernel = ctx->defer_budget ? (ctx->force_packet ? 1 : 0) : (b->tuned && b->tuned_packet ? 1 : 0);
+    if (packet_kernel) *packet_kernel = ctx->defer_budget ? (ctx->force_packet ? (ctx->force_packet4 && b->d_quad ? 2 : 1) : 0)
+                                                          : (b->tuned && b->tuned_packet ? (b->tuned_quad ? 2 : 1) : 0);
     return RT_SUCCESS;
 }
 

@@ -24,6 +24,12 @@ struct __attribute__((aligned(16))) TravNode {
 };
 static_assert(sizeof(TravNode) == 64, "TravNode must be 64 bytes");
 
+// Four-wide view of the same hierarchies for the packet kernel: record i = inner node i with its inner children replaced
+// by THEIR children (2-4 slots).  q[0..7] as scalar-loadable float4: (lo0,id0) (hi0,id1) (lo1,id2) (hi1,id3) (lo2,marks)
+// (hi2,-) (lo3,-) (hi3,-); ids are the binary record indices / RT_LEAF_FLAG|leaf, empty slot = RT_SENTINEL.
+struct __attribute__((aligned(16))) QuadNode { float4 q[8]; };
+static_assert(sizeof(QuadNode) == 128, "QuadNode must be 128 bytes");
+
 #define RT_LEAF_FLAG 0x80000000u
 #define RT_SENTINEL 0xFFFFFFFFu   // stack sentinel, BVH.h:352
 #define RT_LONG_LIST_MAX (1u << 20)     // at most this many deferred-ray records (128 MiB)
@@ -74,7 +80,8 @@ struct rt_ctx {
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
     bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
-    bool force_packet = false, no_packet = false;   // tuning knobs (env RTMI_PACKET=1 / 0)
+    bool force_packet = false, no_packet = false;   // tuning knobs (env RTMI_PACKET=1 / 0; 4 = the four-wide packet kernel)
+    bool force_packet4 = false, no_packet4 = false; // env RTMI_PACKET=4 / RTMI_PACKET4=0 (no four-wide records at all)
     int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
     bool no_search_tree = false;  // knob (env RTMI_SEARCH_TREE=0): primary rays walk the reference tree
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
@@ -100,7 +107,8 @@ struct rt_bvh {
     rt_bvh_node* d_nodes = nullptr;    // reference layout, 2n-1 entries
     uint2* d_pairs = nullptr;          // N (morton, leaf)
     uint32_t* d_counters = nullptr;    // n visit counters (BVHManager.cpp:67)
-    TravNode* d_trav = nullptr;        // n-1 traversal records
+    TravNode* d_trav = nullptr;        // traversal records: reference tree, then the search tree
+    QuadNode* d_quad = nullptr;        // four-wide records of the same nodes (packet kernel), null when disabled
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
     bool have_search_tree = false;     // d_trav holds 2(n-1) records: reference tree, then the search tree (primary rays)
@@ -116,6 +124,7 @@ struct rt_bvh {
     uint64_t tuned_key = 0;
     uint32_t tuned_budget = 0;              // 0 = packet kernel, else deferral budget of the two-phase kernels
     bool tuned_packet = false;
+    bool tuned_quad = false;                // with tuned_packet: the four-wide packet kernel
     bool frame_initialised = false;
     bool built = false;
 };
@@ -164,6 +173,7 @@ void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, ui
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n);
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t* depth_out, uint32_t id_offset = 0);
+void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records);
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
@@ -172,6 +182,7 @@ size_t scan_scratch_words(uint32_t n);
 // trace_kernels.hip
 struct TraceLaunch {
     const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)
+    const QuadNode* quad;         // four-wide records (null: the packet kernel walks the binary records)
     uint32_t search_root;         // primary rays: root record of the search tree, 0 = none (walk the reference tree)
     const uint32_t* tree_select;  // per camera: bit k set = the camera's coordinate k equals a box plane
     const DeviceScene* scene;
@@ -184,6 +195,7 @@ struct TraceLaunch {
     hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
     bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
     bool calibrating;             // launch belongs to the first-frame calibration (separate kernel names in profiles)
+    bool packet4;                 // with packet: walk the four-wide records
     bool packet;                  // primary rays: packet kernel (one 8x8 block per wave) instead of the two-phase kernels
     uint32_t* packet_spill;       // per-wave overflow area of the packet stack (null when the tree is shallow)
     unsigned long long* keys;     // per work item, split rays only

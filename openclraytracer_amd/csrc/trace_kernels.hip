@@ -84,6 +84,7 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
+    const QuadNode* __restrict__ quad;          // four-wide records of the same nodes (k_trace_packet4), may be null
     uint32_t search_root;                       // primary rays: root record of the search tree (same leaves), 0 = none
     const uint32_t* __restrict__ tree_select;   // primary rays: bit k = the camera's coordinate k equals a box plane
     const float4* __restrict__ v0;
@@ -160,13 +161,22 @@ __device__ __forceinline__ uint32_t inside_bits(const TravNode& t, float ox, flo
     bool ib = (t.b_lo[0] <= ox) & (ox <= t.b_hi[0]) & (t.b_lo[1] <= oy) & (oy <= t.b_hi[1]) & (t.b_lo[2] <= oz) & (oz <= t.b_hi[2]);
     return (ia ? 1u : 0u) | (ib ? 2u : 0u);
 }
-__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, uint32_t n_records, uint32_t n_reference, float ox, float oy, float oz,
-                                                        uint32_t* select)
+__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, QuadNode* quad, uint32_t n_records, uint32_t n_reference,
+                                                        float ox, float oy, float oz, uint32_t* select)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_records) return;
     const TravNode t = trav[i];
     trav[i].pad0 = inside_bits(t, ox, oy, oz);
+    if (quad) {                                            // the same bit per slot of the four-wide record
+        const QuadNode q = quad[i];
+        uint32_t bits = 0;
+        for (int k = 0; k < 4; k++) {
+            const float4 lo = q.q[2 * k], hi = q.q[2 * k + 1];
+            if ((lo.x <= ox) & (ox <= hi.x) & (lo.y <= oy) & (oy <= hi.y) & (lo.z <= oz) & (oz <= hi.z)) bits |= 1u << k;
+        }
+        reinterpret_cast<uint32_t*>(&quad[i].q[4])[3] = bits;
+    }
     if (i < n_reference && n_records > n_reference) {       // plane test over the reference records, when there is a search tree
         const float o[3] = { ox, oy, oz };
         uint32_t bits = 0;
@@ -675,6 +685,126 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// packet kernel on the four-wide records: one wave step tests up to four (grand)children and descends two levels of the
+// binary hierarchy, which halves the dependent chain  record -> box tests -> ballots -> next record  that bounds the
+// binary packet kernel.  Nothing is handed over to the wave-per-ray kernel here (the calibration chooses this kernel
+// only where whole blocks are cheap); everything else is as in k_trace_packet.
+// ------------------------------------------------------------------------------------------------
+template <int PRIMARY, int CAL>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
+{
+    __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
+    __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
+    __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
+    uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
+    uint32_t* spill = a.packet_spill ? a.packet_spill + (uint64_t)wave_gid * a.packet_spill_entries * 3u : nullptr;
+
+    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
+    const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;
+    uint32_t blk = wave_gid;
+    uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
+    for (;;) {
+        if (blk >= n_blocks8) break;
+        const uint32_t w = (blk << 6) + lane;
+        RayState r;
+        bool sx = false, sy = false, sz = false;
+        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+        r.work = w; r.out_index = 0; r.pixel = 0;
+        bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
+        if (PRIMARY && a.compact && !ok && w < a.total_work) {
+            uint32_t x, y, slot;
+            work_to_pixel(a, w, x, y, slot);
+            float4* o = reinterpret_cast<float4*>(a.out + slot);
+            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        bool in = ok;
+        uint32_t sp = 0;
+        uint32_t node = 0;
+        if (PRIMARY && a.search_root != 0u) {
+            const bool on_ref = ok && ray_root<PRIMARY>(a, r, plane_bits) == 0u;
+            const uint64_t m_ref = __ballot(on_ref), m_search = __ballot(ok && !on_ref);
+            if (m_search != 0ull) {
+                node = a.search_root; in = ok && !on_ref;
+                if (m_ref != 0ull) {
+                    if (lane == 0) { st_node[0] = 0u; st_lo[0] = (uint32_t)m_ref; st_hi[0] = (uint32_t)(m_ref >> 32); }
+                    sp = 1;
+                }
+            }
+        }
+        bool walking = __ballot(in) != 0ull;
+        while (walking) {
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+            const float4* p = reinterpret_cast<const float4*>(a.quad + un);
+            const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
+            const float4 q4 = ld_const4(p + 4), q5 = ld_const4(p + 5), q6 = ld_const4(p + 6), q7 = ld_const4(p + 7);
+            const uint32_t id0 = __float_as_uint(q0.w), id1 = __float_as_uint(q1.w), id2 = __float_as_uint(q2.w), id3 = __float_as_uint(q3.w);
+            const uint32_t marks = __float_as_uint(q4.w);
+            bool v0 = false, v1 = false, v2 = false, v3 = false;
+            if (in) {
+                v0 = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                v1 = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
+                v2 = (id2 != RT_SENTINEL) && child_valid<PRIMARY>(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, sx, sy, sz, (marks & 4u) != 0u);
+                v3 = (id3 != RT_SENTINEL) && child_valid<PRIMARY>(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, sx, sy, sz, (marks & 8u) != 0u);
+            }
+            uint64_t m[4] = { __ballot(v0), __ballot(v1), __ballot(v2), __ballot(v3) };
+            const uint32_t ids[4] = { id0, id1, id2, id3 };
+            // leaves are tested on the spot by the lanes that reached them
+            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) { if (v0) leaf_test_uniform(a, id0 & ~RT_LEAF_FLAG, r); } m[0] = 0ull; }
+            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) { if (v1) leaf_test_uniform(a, id1 & ~RT_LEAF_FLAG, r); } m[1] = 0ull; }
+            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) { if (v2) leaf_test_uniform(a, id2 & ~RT_LEAF_FLAG, r); } m[2] = 0ull; }
+            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) { if (v3) leaf_test_uniform(a, id3 & ~RT_LEAF_FLAG, r); } m[3] = 0ull; }
+            // the first wanted inner child is walked next, the others wait on the stack with their lanes
+            int first = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (m[k] == 0ull) continue;
+                if (first < 0) { first = k; continue; }
+                if (sp < PACKET_STACK) {
+                    if (lane == 0) { st_node[sp] = ids[k]; st_lo[sp] = (uint32_t)m[k]; st_hi[sp] = (uint32_t)(m[k] >> 32); }
+                } else if (spill && sp - PACKET_STACK < a.packet_spill_entries) {
+                    if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
+                } else {
+                    if (lane == 0) __hip_atomic_store((gu32*)&a.ctrl->error, 3u, RLX_AGENT);     // frame invalid
+                }
+                sp++;
+            }
+            if (first >= 0) {
+                node = ids[first];
+                in = ((m[first] >> lane) & 1ull) != 0ull;
+            } else if (sp == 0u) walking = false;
+            else {
+                sp--;
+                uint32_t nn, lo, hi;
+                if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
+                else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                node = nn;
+                in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+            }
+        }
+        if (ok) store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
+
+        blk = 0xFFFFFFFFu;
+        uint32_t dyn = n_blocks8 > a.n_waves ? n_blocks8 - a.n_waves : 0u;
+        uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
+        while (blk == 0xFFFFFFFFu && shards_tried < WORK_SHARDS) {
+            uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
+            uint32_t got = 0xFFFFFFFFu;
+            if (lo < hi) {
+                if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->shard[shard].next, 1u, RLX_AGENT);
+                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            }
+            if (lo < hi && got < hi - lo) blk = a.n_waves + lo + got;
+            else { shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u; shards_tried++; }
+        }
+        if (blk == 0xFFFFFFFFu) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // phase 1: one deferred ray per wave, 64 lanes walk its sub-trees together
 // ------------------------------------------------------------------------------------------------
 template <int PRIMARY, int CAL>
@@ -871,6 +1001,19 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     static int b1 = 0;
     if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
+    if (PRIMARY && t.packet && t.packet4 && t.quad) {
+        static int b4 = 0;
+        if (b4 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_trace_packet4<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b4 < 1) b4 = 1; }
+        uint32_t grid = (uint32_t)t.compute_units * (uint32_t)b4;
+        if (grid > need) grid = need;
+        if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
+        a.n_waves = grid * TRACE_WAVES;
+        if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
+        hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+        if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
+        if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
+        return;
+    }
     if (PRIMARY && t.packet) {
         static int bp = 0;
         if (bp == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY, CAL>, TRACE_BLOCK, 0); if (bp < 1) bp = 1; }
@@ -921,7 +1064,7 @@ uint32_t trace_packet_max_blocks(int compute_units)
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
-    a.trav = t.trav; a.search_root = t.search_root; a.tree_select = t.tree_select;
+    a.trav = t.trav; a.quad = t.quad; a.search_root = t.search_root; a.tree_select = t.tree_select;
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
     a.pos = t.pos;
     a.ctrl = (TraceCtrl*)t.ctrl;
@@ -949,8 +1092,9 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     if (t.mark_inside && t.n_leaves > 1) {
         (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
         const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
-        hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav), n_all, n_ref,
-                           cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11], const_cast<uint32_t*>(t.tree_select));
+        hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
+                           const_cast<QuadNode*>(t.quad), n_all, n_ref, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11],
+                           const_cast<uint32_t*>(t.tree_select));
     }
     launch<1>(s, t, a);
 }

@@ -218,7 +218,7 @@ def test_cpp_host_mirror_end_to_end(gpu_ctx, tmp_path):
 
 
 @pytest.mark.parametrize('packet,budget,list_max', [('1', '64', '3000'), ('1', '16', '70'), ('0', '32', '1000'),
-                                                     ('0', '1048576', '0'), ('1', '1048576', '0')])
+                                                     ('0', '1048576', '0'), ('1', '1048576', '0'), ('4', '1048576', '0')])
 def test_forced_trace_strategies_and_full_deferred_list(packet, budget, list_max, monkeypatch):
     """every (kernel, budget) strategy the first-frame calibration can pick gives the reference's contacts, also when the
     deferred-ray list is far too small for what the kernels want to hand over (list-full path: rays keep walking in
