@@ -247,7 +247,7 @@ def main():
         traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
     roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
-                    kernel='traversal launch of one frame: k_trace_packet<1, 0> or k_trace<1, 0>, then k_trace_long<1, 0> (+ k_resolve_split<1, 0>); <1, 1> = first-frame calibration launches, not counted',
+                    kernel='traversal launch of one frame: k_trace_packet4<1, 0>, k_trace_packet<1, 0> or k_trace<1, 0>, then k_trace_long<1, 0> (+ k_resolve_split<1, 0>) where work was handed over; <1, 1> = first-frame calibration launches, not counted',
                     avg_launch_ms=round(trace_ms_avg, 4),
                     avg_first_kernel_ms=round(kt['lane_phase_ms'] / launches, 4),
                     avg_wave_per_ray_ms=round(kt['wave_phase_ms'] / launches, 4),

@@ -113,11 +113,12 @@ int  rt_bvh_generate_contacts_rays(rt_bvh* bvh, const void* d_rays, uint32_t ray
 int  rt_bvh_read_nodes(const rt_bvh* bvh, void* h_nodes /* (2n-1) * 48 B */);
 int  rt_bvh_read_morton_pairs(const rt_bvh* bvh, void* h_pairs /* N * 8 B */, uint32_t* n_pow2);
 int  rt_bvh_info(const rt_bvh* bvh, uint32_t* leaves, uint32_t* morton_items, uint32_t* max_depth);
-/* How primary frames of this BVH are traced: with the packet kernel (one 8x8 pixel block per wave, node records through
- * the scalar cache) or with the lane-per-ray kernel, and after how many steps a block / a ray hands its remaining sub-trees
- * to the wave-per-ray kernel.  Calibrated on the first primary frame of a (resolution, tiling) combination (budget 0 = not
- * calibrated yet); env RTMI_DEFER_BUDGET=<n> (+ RTMI_PACKET=0/1) fixes it.  Speed knobs only: every setting gives the
- * same contacts.                                                                                                      */
+/* How primary frames of this BVH are traced: *packet_kernel = 0 lane-per-ray kernel, 1 packet kernel (one 8x8 pixel block
+ * per wave, node records through the scalar path), 2 four-wide packet kernel (records that hold a node's grandchildren: one
+ * wave step descends two levels); *budget = steps after which a block / a ray hands its remaining sub-trees to the
+ * wave-per-ray kernel (2^20 = never).  Calibrated on the first primary frame of a (resolution, tiling) combination
+ * (budget 0 = not calibrated yet); env RTMI_DEFER_BUDGET=<n> (+ RTMI_PACKET=0/1/4) fixes it.  Speed knobs only: every
+ * setting gives the same contacts.                                                                                     */
 int  rt_bvh_trace_strategy(const rt_bvh* bvh, int* packet_kernel, uint32_t* budget);
 /* Primary rays (all with the camera position as origin) walk a second hierarchy over the same leaf boxes, ordered by
  * properly normalised Morton codes (depth ~25-50 instead of the reference tree's 94-10 835).  A leaf whose box passes the

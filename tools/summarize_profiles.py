@@ -26,7 +26,7 @@ for k, c, n, mean, _, _ in rows:
 # steady-state traversal kernels carry the template tag <1, 0> (calibration candidates of the first frame are <1, 1>);
 # one frame launch = one first-phase kernel (k_trace or k_trace_packet) + its k_trace_long (+ k_resolve_split)
 steady = [k for k in {k for k, _ in tot} if k.startswith(('k_trace', 'k_resolve_split')) and k.endswith('<1, 0>')]
-frames = sum(cnt[(k, 'FETCH_SIZE')] for k in steady if k.startswith(('k_trace<', 'k_trace_packet<')))
+frames = sum(cnt[(k, 'FETCH_SIZE')] for k in steady if k.startswith(('k_trace<', 'k_trace_packet<', 'k_trace_packet4<')))
 fetch = sum(tot[(k, 'FETCH_SIZE')] for k in steady) / max(frames, 1)
 write = sum(tot[(k, 'WRITE_SIZE')] for k in steady) / max(frames, 1)
 json.dump({'round': R, 'source': 'profiles/%s_bench_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 4; steady-state kernels only, summed over the kernels of a frame launch and averaged over %d frame launches)' % (R, frames),
@@ -41,7 +41,7 @@ for k, c, n, mean, _, _ in rows:
 ks = list(csv.DictReader(open('profiles/%s_bench_kernel_stats.csv' % R)))
 nm = lambda r: r['Name'].split('(')[0].replace('void ', '')
 st = [r for r in ks if nm(r).startswith(('k_trace', 'k_resolve_split')) and nm(r).endswith('<1, 0>')]
-nfr = sum(int(r['Calls']) for r in st if nm(r).startswith(('k_trace<', 'k_trace_packet<')))
+nfr = sum(int(r['Calls']) for r in st if nm(r).startswith(('k_trace<', 'k_trace_packet<', 'k_trace_packet4<')))
 summ = {'round': R, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline',
         'frame_launches': nfr,
         'avg_frame_launch_ms': sum(float(r['TotalDurationNs']) for r in st) / max(nfr, 1) / 1e6,
