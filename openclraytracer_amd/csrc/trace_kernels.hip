@@ -380,7 +380,32 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
             uint32_t extra = RT_SENTINEL;     // child that did not fit on the stack (forces a deferral)
             if (active) {
                 iters++;
-                if (cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) == 0u) {
+                if (cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) == 0u && a.quad != nullptr && sp + 3u <= LDS_STACK) {
+                    // inner node, four-wide: the 128-byte record holds the node's grandchildren, so one step descends two
+                    // levels and the dependent chain (record -> tests -> next record) that this kernel waits on is half as long.
+                    // Up to three entries are pushed (only while they fit; otherwise the binary step below).
+                    const float4* p = reinterpret_cast<const float4*>(a.quad + cur);
+                    const float4 g0 = p[0], g1 = p[1], g2 = p[2], g3 = p[3], g4 = p[4], g5 = p[5], g6 = p[6], g7 = p[7];
+                    const uint32_t i0 = __float_as_uint(g0.w), i1 = __float_as_uint(g1.w), i2 = __float_as_uint(g2.w), i3 = __float_as_uint(g3.w);
+                    const uint32_t qm = __float_as_uint(g4.w);
+                    uint32_t c0 = child_valid<PRIMARY>(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, r, sx, sy, sz, (qm & 1u) != 0u) ? i0 : RT_SENTINEL;
+                    uint32_t c1 = child_valid<PRIMARY>(g2.x, g2.y, g2.z, g3.x, g3.y, g3.z, r, sx, sy, sz, (qm & 2u) != 0u) ? i1 : RT_SENTINEL;
+                    uint32_t c2 = child_valid<PRIMARY>(g4.x, g4.y, g4.z, g5.x, g5.y, g5.z, r, sx, sy, sz, (qm & 4u) != 0u) ? i2 : RT_SENTINEL;
+                    uint32_t c3 = child_valid<PRIMARY>(g6.x, g6.y, g6.z, g7.x, g7.y, g7.z, r, sx, sy, sz, (qm & 8u) != 0u) ? i3 : RT_SENTINEL;
+                    if (pending == NO_LEAF) {                      // park one reached leaf right away (no stack round trip)
+                        if (c0 != RT_SENTINEL && (c0 & RT_LEAF_FLAG)) { pending = c0 & ~RT_LEAF_FLAG; c0 = RT_SENTINEL; }
+                        else if (c1 != RT_SENTINEL && (c1 & RT_LEAF_FLAG)) { pending = c1 & ~RT_LEAF_FLAG; c1 = RT_SENTINEL; }
+                        else if (c2 != RT_SENTINEL && (c2 & RT_LEAF_FLAG)) { pending = c2 & ~RT_LEAF_FLAG; c2 = RT_SENTINEL; }
+                        else if (c3 != RT_SENTINEL && (c3 & RT_LEAF_FLAG)) { pending = c3 & ~RT_LEAF_FLAG; c3 = RT_SENTINEL; }
+                    }
+                    uint32_t nxt = RT_SENTINEL;
+#define RT_TAKE(c) if (c != RT_SENTINEL) { if (nxt == RT_SENTINEL) nxt = c; else { stack[sp][lane] = c; sp++; } }
+                    RT_TAKE(c0) RT_TAKE(c1) RT_TAKE(c2) RT_TAKE(c3)
+#undef RT_TAKE
+                    if (nxt != RT_SENTINEL) cur = nxt;
+                    else if (sp == 0) cur = RT_SENTINEL;
+                    else { sp--; cur = stack[sp][lane]; }
+                } else if (cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) == 0u) {
                     // inner node: one 64-byte record
                     const float4* p = reinterpret_cast<const float4*>(a.trav + cur);
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
