@@ -167,6 +167,10 @@ class Context:
         self.check(self.lib.rt_ctx_trace_kernel_times(self.h, C.byref(n), C.byref(a), C.byref(b)))
         return dict(launches=n.value, lane_phase_ms=a.value, wave_phase_ms=b.value)
 
+    def get_stream(self) -> int:
+        self.lib.rt_ctx_get_stream.restype = C.c_void_p
+        return int(self.lib.rt_ctx_get_stream(self.h) or 0)
+
     def set_stream(self, stream: int | None):
         self.check(self.lib.rt_ctx_set_stream(self.h, C.c_void_p(stream or 0)))
 
