@@ -214,6 +214,9 @@ int  rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t 
 /* per-kernel device time of the two traversal kernels (lane-per-ray phase, wave-per-ray phase), measured with
  * HIP events recorded around them on the stream they run on; sums over the launches since the last query.   */
 int  rt_ctx_set_profiling(rt_ctx* ctx, int enable);
+/* enable = 2: as 1, and the traversal launches use separately named instances of the same kernels (template tag 2
+ * in rocprofv3's kernel names), so a measurement pass that runs alone on the device can be told apart from
+ * launches that overlap with other streams.                                                                   */
 int  rt_ctx_trace_kernel_times(rt_ctx* ctx, uint64_t* launches, double* lane_phase_ms, double* wave_phase_ms);
 int  rt_timer_create(rt_ctx* ctx, void** timer);
 int  rt_timer_start(rt_ctx* ctx, void* timer);

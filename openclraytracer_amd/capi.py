@@ -159,8 +159,9 @@ class Context:
         self.check(self.lib.rt_ctx_device_info(self.h, C.byref(cu), C.byref(ws), C.byref(lds), name, 64))
         return dict(compute_units=cu.value, wave_size=ws.value, lds_bytes=lds.value, name=name.value.decode())
 
-    def set_profiling(self, on: bool):
-        self.check(self.lib.rt_ctx_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, on):
+        """False/0 off, True/1 HIP events around the traversal kernels, 2 the same with the '<.., 2>' kernel names."""
+        self.check(self.lib.rt_ctx_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))
 
     def trace_kernel_times(self) -> dict:
         n, a, b = C.c_uint64(), C.c_double(), C.c_double()

@@ -483,7 +483,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
-    t.packet = false; t.packet4 = false; t.calibrating = false;
+    t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag;
     t.quad = b->d_quad;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_max_blocks = b->packet_max_blocks;
@@ -536,7 +536,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             if (cand.quad && !b->d_quad) continue;
             t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
-            t.calibrating = true;
+            t.tag = 1;
             // every candidate runs twice unless its first run is hopeless: the first launch of a kernel pays for code and
             // cache warm-up, and one sample of a 0.2 ms frame is too noisy to rank strategies that differ by 10 %
             float ms = 0.f;
@@ -805,6 +805,7 @@ int rt_ctx_set_profiling(rt_ctx* ctx, int enable)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drop_trace_events(ctx);
     ctx->profiling = enable != 0;
+    ctx->profiling_tag = enable == 2 ? 2 : 0;
     return RT_SUCCESS;
 }
 

@@ -80,6 +80,7 @@ struct rt_ctx {
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
     bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
+    int  profiling_tag = 0;       // 2: launches use the <.., 2> kernel instances (isolated measurement pass)
     bool force_packet = false, no_packet = false;   // tuning knobs (env RTMI_PACKET=1 / 0; 4 = the four-wide packet kernel)
     bool force_packet4 = false, no_packet4 = false; // env RTMI_PACKET=4 / RTMI_PACKET4=0 (no four-wide records at all)
     int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
@@ -194,7 +195,8 @@ struct TraceLaunch {
     uint32_t defer_budget;        // 0 = default
     hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
     bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
-    bool calibrating;             // launch belongs to the first-frame calibration (separate kernel names in profiles)
+    int tag;                      // kernel-name tag: 0 steady state, 1 first-frame calibration, 2 isolated measurement pass
+                                  // (rt_ctx_set_profiling(ctx, 2)); same code, separate names in profiles
     bool packet4;                 // with packet: walk the four-wide records
     bool packet;                  // primary rays: packet kernel (one 8x8 block per wave) instead of the two-phase kernels
     uint32_t* packet_spill;       // per-wave overflow area of the packet stack (null when the tree is shallow)

@@ -1075,7 +1075,9 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 template <int PRIMARY>
 static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 {
-    if (t.calibrating) launch_tagged<PRIMARY, 1>(s, t, a); else launch_tagged<PRIMARY, 0>(s, t, a);
+    if (t.tag == 1) launch_tagged<PRIMARY, 1>(s, t, a);
+    else if (t.tag == 2) launch_tagged<PRIMARY, 2>(s, t, a);
+    else launch_tagged<PRIMARY, 0>(s, t, a);
 }
 
 uint32_t trace_packet_stack_entries() { return PACKET_STACK; }

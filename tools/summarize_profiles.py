@@ -40,14 +40,19 @@ for k, c, n, mean, _, _ in rows:
 # frame-launch duration from the kernel-trace stats: must agree with bench.py's live HIP-event figure (roofline.avg_launch_ms)
 ks = list(csv.DictReader(open('profiles/%s_bench_kernel_stats.csv' % R)))
 nm = lambda r: r['Name'].split('(')[0].replace('void ', '')
-st = [r for r in ks if nm(r).startswith(('k_trace', 'k_resolve_split')) and nm(r).endswith('<1, 0>')]
-nfr = sum(int(r['Calls']) for r in st if nm(r).startswith(('k_trace<', 'k_trace_packet<', 'k_trace_packet4<')))
+def launch_summary(tag):
+    st = [r for r in ks if nm(r).startswith(('k_trace', 'k_resolve_split')) and nm(r).endswith('<1, %d>' % tag)]
+    nfr = sum(int(r['Calls']) for r in st if nm(r).startswith(('k_trace<', 'k_trace_packet<', 'k_trace_packet4<')))
+    return {'frame_launches': nfr, 'avg_frame_launch_ms': sum(float(r['TotalDurationNs']) for r in st) / max(nfr, 1) / 1e6}
+iso, conc = launch_summary(2), launch_summary(0)
 summ = {'round': R, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline',
-        'frame_launches': nfr,
-        'avg_frame_launch_ms': sum(float(r['TotalDurationNs']) for r in st) / max(nfr, 1) / 1e6,
+        'isolated_launches_tag_2': iso, 'timed_region_launches_tag_0': conc,
+        'frame_launches': iso['frame_launches'], 'avg_frame_launch_ms': iso['avg_frame_launch_ms'],
+        'note': 'avg_frame_launch_ms = summed duration of the <1, 2> traversal kernels / number of <1, 2> frame launches: the launches '
+                'bench.py times with HIP events for roofline.avg_launch_ms (one scene at a time).  <1, 0> launches overlap on five streams.',
         'kernels': {nm(r): {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3, 'total_ms': float(r['TotalDurationNs']) / 1e6} for r in ks if nm(r).startswith('k_')}}
 json.dump(summ, open('profiles/%s_frame_launch_summary.json' % R, 'w'), indent=1)
-print('avg frame launch ms (rocprof):', summ['avg_frame_launch_ms'], 'over', nfr)
+print('avg frame launch ms (rocprof): isolated', iso, 'timed region', conc)
 try:
     tl = newest("gpurun_out/%s/tlg_stats/*/*_kernel_stats.csv" % R)
     shutil.copy(tl, 'profiles/%s_tlg_config4_kernel_stats.csv' % R)
