@@ -94,8 +94,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    # RTMI_BENCH_FORCE_TILED=1 (tests): the N > 1 code path -- tiled kernels, RCCL gather issued from the frame streams,
+    # untile -- with a process group of ONE rank, i.e. on real RCCL on a one-GPU box
+    force_tiled = world == 1 and os.environ.get('RTMI_BENCH_FORCE_TILED') == '1'
+    if force_tiled:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    tiled = world > 1 or force_tiled
     dist = None
-    if world > 1:
+    if tiled:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # RTMI_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo -- a functional rehearsal of the N > 1 path on a
@@ -135,11 +144,11 @@ def main():
         bvh.build()
         build_ms[name] = (time.perf_counter() - t0) * 1e3 / 2
         cam = demo_camera(buf, *RES)
-        slots = capi.tiles_owned_pixels(cam, rank, world) if world > 1 else npx
+        slots = capi.tiles_owned_pixels(cam, rank, world) if tiled else npx
         item = dict(name=name, ctx=sctx, tstream=tstreams[si], scene=scene, bvh=bvh, cam=cam, slots=slots,
                     contacts=torch.empty(slots * 32, dtype=torch.uint8, device=dev),
                     rgba=torch.empty((slots, 4), dtype=torch.float32, device=dev))
-        if world > 1:
+        if tiled:
             slots0 = capi.tiles_owned_pixels(cam, 0, world)      # rank 0 owns the most tiles: gather slot size
             item['slots0'] = slots0
             item['send'] = torch.zeros((slots0, 4), dtype=torch.float32, device=dev)
@@ -152,7 +161,7 @@ def main():
         pending = []
         for it in work:
             c = it['ctx']
-            if world == 1:
+            if not tiled:
                 it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
                 capi.shade_blinn_phong_d(c, it['scene'], it['cam'], it['contacts'].data_ptr(), npx, it['rgba'].data_ptr())
             else:
@@ -178,7 +187,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if args.check_frames and world > 1:
+    if args.check_frames and tiled:
         if args.warmup == 0:
             step(); fence()
         if rank == 0:
@@ -222,7 +231,7 @@ def main():
         sctx.set_profiling(2)                  # events + the <1, 2> kernel names: launches that had the device to themselves
         tm.start()
         for _ in range(ISOLATED_FRAMES):
-            if world == 1:
+            if not tiled:
                 it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
             else:
                 it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())

@@ -357,3 +357,20 @@ def test_bench_two_rank_rehearsal_assembles_identical_frames():
     out = json.loads(line[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['unit'] == 'Mrays/s' and out['value'] > 0
     assert out['cpu_baseline'] is None and out['roofline']['traffic'] is None      # rank-0-at-N=1-only fields
+
+
+def test_bench_tiled_path_on_rccl_with_one_rank():
+    """The same N > 1 code path on REAL RCCL: a process group of one rank (RTMI_BENCH_FORCE_TILED=1), so the asynchronous
+    gather is issued from the five frame streams (torch ExternalStream over the contexts' HIP streams) on the nccl
+    backend, then untiled and compared with the untiled frames."""
+    import subprocess
+    import sys as _sys
+    env = dict(os.environ, RTMI_BENCH_FORCE_TILED='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT='29533')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--check-frames',
+                        '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'frame check ok: 5 gathered frames equal the untiled ones' in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1 and json.loads(line[0])['value'] > 0
