@@ -206,6 +206,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    issued = time.perf_counter() - t0            # host time to issue the steps (the floor when the device part shrinks)
     fence()
     elapsed = time.perf_counter() - t0
     kt = dict(launches=0, lane_phase_ms=0.0, wave_phase_ms=0.0)
@@ -356,6 +357,7 @@ def main():
                                         '64x64 frame tiles round-robin over %d ranks, one gather of RGBA to rank 0 per frame, '
                                         'the five frames of a step on five HIP streams per rank' % world)),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
+               host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
                roofline=roofline, cpu_baseline=cpu_baseline, per_scene=per_scene)
     print(json.dumps(out))
     if dist is not None:
