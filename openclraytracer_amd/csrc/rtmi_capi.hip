@@ -4,6 +4,7 @@
 #include "rtmi_internal.h"
 
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <sstream>
@@ -108,6 +109,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);
+    if (const char* env = std::getenv("RTMI_PERSISTENT")) ctx->persistent = env[0] == '1';
+    if (const char* env = std::getenv("RTMI_CALIBRATION_LOG")) ctx->calibration_log = env[0] == '1';
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
@@ -483,7 +486,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
-    t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag;
+    t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.persistent = b->ctx->persistent;
     t.quad = b->d_quad;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_max_blocks = b->packet_max_blocks;
@@ -555,6 +558,9 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             uint32_t cand_err = 0;
             if (hipMemcpyAsync(&cand_err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess) { have = false; break; }
+            if (ctx->calibration_log)
+                std::fprintf(stderr, "rtmi calibration: n=%u %ux%u %s budget %u: %.4f ms%s\n", b->n, cam->resX, cam->resY,
+                             cand.packet ? (cand.quad ? "packet4" : "packet") : "lane-per-ray", cand.budget, ms, cand_err ? " (error word set, discarded)" : "");
             if (cand_err) { last_failed = true; continue; }              // e.g. a list too small for this strategy: not a candidate
             last_failed = false;
             if (!have || ms < best_ms) { best = cand.budget; best_packet = cand.packet; best_quad = cand.quad; best_ms = ms; have = true; }

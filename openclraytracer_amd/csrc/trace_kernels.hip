@@ -1022,6 +1022,10 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
     (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
     uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
+    // Grid: one wave per 64-ray block and the hardware dispatcher as the work queue.  A persistent grid (resident waves
+    // pulling blocks from the sharded counters, idle lanes refilled) measured 25-50 % slower on every bundled scene
+    // (Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms); it remains for the packet kernels when the tree is
+    // deep enough to need the per-resident-wave spill area, and behind RTMI_PERSISTENT=1 for comparison.
     // resident blocks per CU: a property of the code object, asked once per kernel (the query costs microseconds of host time)
     static int b1 = 0;
     if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
@@ -1029,7 +1033,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (PRIMARY && t.packet && t.packet4 && t.quad) {
         static int b4 = 0;
         if (b4 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_trace_packet4<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b4 < 1) b4 = 1; }
-        uint32_t grid = (uint32_t)t.compute_units * (uint32_t)b4;
+        uint32_t grid = t.persistent || t.packet_spill ? (uint32_t)t.compute_units * (uint32_t)b4 : need;
         if (grid > need) grid = need;
         if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
         a.n_waves = grid * TRACE_WAVES;
@@ -1042,7 +1046,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (PRIMARY && t.packet) {
         static int bp = 0;
         if (bp == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY, CAL>, TRACE_BLOCK, 0); if (bp < 1) bp = 1; }
-        uint32_t grid = (uint32_t)t.compute_units * (uint32_t)bp;
+        uint32_t grid = t.persistent || t.packet_spill ? (uint32_t)t.compute_units * (uint32_t)bp : need;
         if (grid > need) grid = need;
         if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
         a.n_waves = grid * TRACE_WAVES;
@@ -1060,7 +1064,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     }
     static int b0 = 0;
     if (b0 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b0 < 1) b0 = 1; }
-    uint32_t grid = (uint32_t)t.compute_units * (uint32_t)b0;
+    uint32_t grid = t.persistent ? (uint32_t)t.compute_units * (uint32_t)b0 : need;
     if (grid > need) grid = need;
     a.n_waves = grid * TRACE_WAVES;
     if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);

@@ -21,3 +21,6 @@ find $OUT -name "*.csv" | head -30
 # config 4 (Two-Level Grid build + trace on the atrium-class scene): kernel stats of its own command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tlg_stats -- python3 tools/tlg_config4.py > $OUT/tlg_config4.log 2>&1 || echo "tlg stats pass failed"
 echo "tlg done"
+# config 3 (Bunny-class BVH frame, 1920x1080): kernel stats of its own command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config3_stats -- python3 tools/config_report.py config3 > $OUT/config3.log 2>&1 || echo "config3 stats pass failed"
+echo "config3 done"

@@ -61,3 +61,11 @@ try:
     print(line)
 except Exception as e:
     print('no tlg profile:', e)
+try:
+    c3 = newest("gpurun_out/%s/config3_stats/*/*_kernel_stats.csv" % R)
+    shutil.copy(c3, 'profiles/%s_config3_kernel_stats.csv' % R)
+    t = open('gpurun_out/%s/config3.log' % R).read()
+    open('profiles/%s_config3_line.json' % R, 'w').write(t[t.index('{'):])
+    print(t[t.index('{'):])
+except Exception as e:
+    print('no config3 profile:', e)
