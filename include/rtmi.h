@@ -218,6 +218,9 @@ int  rt_ctx_set_profiling(rt_ctx* ctx, int enable);
  * in rocprofv3's kernel names), so a measurement pass that runs alone on the device can be told apart from
  * launches that overlap with other streams.                                                                   */
 int  rt_ctx_trace_kernel_times(rt_ctx* ctx, uint64_t* launches, double* lane_phase_ms, double* wave_phase_ms);
+/* diagnostic counters of the LAST traversal launch on this context (synchronises): rays handed to the wave-per-ray
+ * kernel, rays whose sub-trees were split between kernels, stack overflow areas the packet kernels took; any pointer may be null */
+int  rt_ctx_last_trace_counters(rt_ctx* ctx, uint32_t* deferred_rays, uint32_t* split_rays, uint32_t* spill_areas_taken);
 int  rt_timer_create(rt_ctx* ctx, void** timer);
 int  rt_timer_start(rt_ctx* ctx, void* timer);
 int  rt_timer_stop(rt_ctx* ctx, void* timer);

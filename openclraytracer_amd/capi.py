@@ -39,7 +39,7 @@ SYMBOLS = [
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba',
-    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times',
+    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
@@ -60,6 +60,9 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    if os.environ.get('RTMI_LIBRARY'):          # tests: the twin with tiny packet stacks (csrc/Makefile), same ABI
+        LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), os.path.basename(os.environ['RTMI_LIBRARY']))
     if not os.path.exists(LIB_PATH):
         raise RtError('librtmi.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
                       'or `make -C openclraytracer_amd/csrc`' % LIB_PATH)
@@ -104,6 +107,7 @@ def load_library() -> C.CDLL:
     L.rt_scan_inclusive_u32.argtypes = [vp, vp, vp, u32]
     L.rt_ctx_set_profiling.argtypes = [vp, i32]
     L.rt_ctx_trace_kernel_times.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rt_ctx_last_trace_counters.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rt_timer_create.argtypes = [vp, pvp]
     L.rt_timer_start.argtypes = [vp, vp]
     L.rt_timer_stop.argtypes = [vp, vp]
@@ -162,6 +166,11 @@ class Context:
     def set_profiling(self, on):
         """False/0 off, True/1 HIP events around the traversal kernels, 2 the same with the '<.., 2>' kernel names."""
         self.check(self.lib.rt_ctx_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))
+
+    def last_trace_counters(self) -> dict:
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.check(self.lib.rt_ctx_last_trace_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(deferred_rays=a.value, split_rays=b.value, spill_areas_taken=c.value)
 
     def trace_kernel_times(self) -> dict:
         n, a, b = C.c_uint64(), C.c_double(), C.c_double()

@@ -469,8 +469,14 @@ int rt_bvh_construct(rt_bvh* b)
         if (need != b->packet_spill_entries) {
             if (b->d_packet_spill) { (void)hipFree(b->d_packet_spill); b->d_packet_spill = nullptr; }
             b->packet_spill_entries = need;
-            b->packet_max_blocks = trace_packet_max_blocks(ctx->prop.multiProcessorCount);
-            if (need) RT_HIP(ctx, hipMalloc((void**)&b->d_packet_spill, (size_t)b->packet_max_blocks * 4u * need * 3u * sizeof(uint32_t)));
+            // one area per wave the device can hold at once (a wave takes one only when its LDS stack overflows)
+            b->packet_spill_slots = ((uint32_t)ctx->prop.multiProcessorCount * (uint32_t)(ctx->prop.maxThreadsPerMultiProcessor / 64) + 31u) & ~31u;
+            if (need) {
+                const size_t bytes = ((size_t)(b->packet_spill_slots >> 5) + (size_t)b->packet_spill_slots * need * 3u) * sizeof(uint32_t);
+                RT_HIP(ctx, hipMalloc((void**)&b->d_packet_spill, bytes));
+                RT_HIP(ctx, hipMemsetAsync(b->d_packet_spill, 0, (size_t)(b->packet_spill_slots >> 5) * sizeof(uint32_t), s));   // all areas free
+                RT_HIP(ctx, hipStreamSynchronize(s));
+            }
         }
     }
     b->frame_initialised = false;
@@ -489,7 +495,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.persistent = b->ctx->persistent;
     t.quad = b->d_quad;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
-    t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_max_blocks = b->packet_max_blocks;
+    t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
     if (b->ctx->profiling) {
         for (int k = 0; k < 3; k++) {
@@ -812,6 +818,19 @@ int rt_ctx_set_profiling(rt_ctx* ctx, int enable)
     drop_trace_events(ctx);
     ctx->profiling = enable != 0;
     ctx->profiling_tag = enable == 2 ? 2 : 0;
+    return RT_SUCCESS;
+}
+
+int rt_ctx_last_trace_counters(rt_ctx* ctx, uint32_t* deferred_rays, uint32_t* split_rays, uint32_t* spill_areas_taken)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t off[3];
+    trace_ctrl_counter_offsets(off);
+    uint32_t* out[3] = { deferred_rays, split_rays, spill_areas_taken };
+    for (int k = 0; k < 3; k++)
+        if (out[k]) RT_HIP(ctx, hipMemcpy(out[k], (const char*)ctx->d_trace_ctrl + off[k], 4, hipMemcpyDeviceToHost));
     return RT_SUCCESS;
 }
 

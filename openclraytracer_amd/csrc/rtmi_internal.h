@@ -117,9 +117,9 @@ struct rt_bvh {
     bool have_search_tree = false;     // d_trav holds 2(n-1) records: reference tree, then the search tree (primary rays)
     uint32_t* d_tree_select = nullptr; // 1 word, bit k: the camera's coordinate k equals a box plane (k_prepare_camera)
     uint32_t search_depth = 0;
-    uint32_t* d_packet_spill = nullptr;   // packet kernel: stack overflow area, sized from the tree depth
+    uint32_t* d_packet_spill = nullptr;   // packet kernels: bitmap + stack overflow areas, sized from the tree depth
     uint32_t packet_spill_entries = 0;
-    uint32_t packet_max_blocks = 0;
+    uint32_t packet_spill_slots = 0;      // overflow areas = resident waves the device can hold (multiple of 32)
     uint32_t max_depth = 0;
     float marked_origin[3] = { 0, 0, 0 };   // camera position the records' inside bits were computed for
     bool marked_valid = false;
@@ -202,12 +202,12 @@ struct TraceLaunch {
                                   // (rt_ctx_set_profiling(ctx, 2)); same code, separate names in profiles
     bool packet4;                 // with packet: walk the four-wide records
     bool packet;                  // primary rays: packet kernel (one 8x8 block per wave) instead of the two-phase kernels
-    uint32_t* packet_spill;       // per-wave overflow area of the packet stack (null when the tree is shallow)
+    uint32_t* packet_spill;       // bitmap + overflow areas of the packet stacks (null when the tree is shallow)
     unsigned long long* keys;     // per work item, split rays only
     uint32_t* split_list;         // long_cap entries
     const uint2* pairs;           // sorted (morton, leaf): position -> leaf
     uint32_t packet_spill_entries;
-    uint32_t packet_max_blocks;   // grid the spill area was sized for
+    uint32_t packet_spill_slots;  // areas behind the bitmap at the start of packet_spill
     int compute_units;
 };
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
@@ -215,9 +215,9 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 size_t trace_ctrl_bytes();
 size_t trace_ctrl_error_offset();
+void trace_ctrl_counter_offsets(size_t out[3]);
 size_t trace_long_record_bytes();
 uint32_t trace_packet_stack_entries();
-uint32_t trace_packet_max_blocks(int compute_units);
 uint32_t trace_lds_stack_entries();
 // tlg_kernels.hip
 struct TlgLaunch {

@@ -71,10 +71,12 @@ struct TraceCtrl {
     uint32_t long_count;  uint32_t p1[31];   // deferred rays
     uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
     uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
+    uint32_t spill_taken; uint32_t p4[31];   // packet kernels: overflow areas taken in this launch (diagnostic)
 };
-static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 3) * 128, "TraceCtrl layout");
+static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 4) * 128, "TraceCtrl layout");
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
+void trace_ctrl_counter_offsets(size_t out[3]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken); }
 size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
 
 // record of a deferred ray (LONG_REC_WORDS words)
@@ -103,8 +105,9 @@ struct TraceArgs {
     unsigned long long* keys;              // (t bits << 32 | position) per work item, used by split rays only
     uint32_t* split_list;                  // work items of split rays (long_cap entries)
     const uint2* __restrict__ pairs;       // position -> leaf
-    uint32_t* packet_spill;                // packet kernel: per-wave overflow of the (node, mask) stack
-    uint32_t packet_spill_entries;
+    uint32_t* packet_spill;                // packet kernels: overflow areas of the (node, mask) stack, handed out on demand;
+    uint32_t packet_spill_entries;         // the first packet_spill_slots / 32 words are the bitmap of areas in use
+    uint32_t packet_spill_slots;
     // primary rays
     rt_camera cam;
     uint32_t rank, nranks, tiles_x;
@@ -512,7 +515,11 @@ __device__ __forceinline__ NodeRec ld_record(const TravNode* trav, uint32_t node
     r.q0 = ld_const4(p); r.q1 = ld_const4(p + 1); r.q2 = ld_const4(p + 2); r.q3 = ld_const4(p + 3);
     return r;
 }
+#ifdef RTMI_TEST_PACKET_STACK
+#define PACKET_STACK RTMI_TEST_PACKET_STACK      // librtmi_teststack.so: every deep block overflows into the global areas
+#else
 #define PACKET_STACK 96u
+#endif
 #define PACKET_LOW_LANES 4u        // "a handful of lanes"
 #define PACKET_LOW_RUN 24u         // consecutive low-occupancy steps before the block sheds sub-trees
 
@@ -539,6 +546,37 @@ __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t l
     }
 }
 
+// Overflow areas of the packet stacks.  One wave per block means far more waves than areas, so a wave takes an area only
+// when its LDS stack overflows (rare) and gives it back when it ends: a bitmap with one bit per area, as many areas as the
+// device can hold resident waves, so a free bit always exists; the search is bounded all the same and reports error 5.
+// Wave-uniform; returns the area or nullptr.
+__device__ __forceinline__ uint32_t* spill_acquire(const TraceArgs& a, uint32_t wave_gid, uint32_t lane, uint32_t& slot)
+{
+    uint32_t got = 0xFFFFFFFFu;
+    if (lane == 0) {
+        const uint32_t words = a.packet_spill_slots >> 5;
+        uint32_t w = (wave_gid * 2654435761u >> 8) % words;
+        for (uint32_t tries = 0; tries < 64u * words && got == 0xFFFFFFFFu; tries++) {
+            const uint32_t used = __hip_atomic_load((gu32*)a.packet_spill + w, RLX_AGENT);
+            if (used != 0xFFFFFFFFu) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(~used);
+                const uint32_t old = __hip_atomic_fetch_or((gu32*)a.packet_spill + w, 1u << bit, RLX_AGENT);
+                if ((old & (1u << bit)) == 0u) { got = (w << 5) + bit; __hip_atomic_fetch_add((gu32*)&a.ctrl->spill_taken, 1u, RLX_AGENT); }
+            } else {
+                w = w + 1u == words ? 0u : w + 1u;
+            }
+        }
+        if (got == 0xFFFFFFFFu) __hip_atomic_store((gu32*)&a.ctrl->error, 5u, RLX_AGENT);
+    }
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+    if (slot == 0xFFFFFFFFu) return nullptr;
+    return a.packet_spill + (a.packet_spill_slots >> 5) + (uint64_t)slot * a.packet_spill_entries * 3u;
+}
+__device__ __forceinline__ void spill_release(const TraceArgs& a, uint32_t lane, uint32_t slot)
+{
+    if (slot != 0xFFFFFFFFu && lane == 0) __hip_atomic_fetch_and((gu32*)a.packet_spill + (slot >> 5), ~(1u << (slot & 31u)), RLX_AGENT);
+}
+
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 {
@@ -549,8 +587,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
     uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
-    // deep stacks spill to a per-wave global area (3 words per entry)
-    uint32_t* spill = a.packet_spill ? a.packet_spill + (uint64_t)wave_gid * a.packet_spill_entries * 3u : nullptr;
+    // deep stacks spill to a global area (3 words per entry), taken on the first overflow
+    uint32_t* spill = nullptr;
+    uint32_t spill_slot = 0xFFFFFFFFu;
 
     const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
     const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;
@@ -628,7 +667,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                         sp--;
                         uint32_t nn, lo, hi;
                         if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
-                        else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                        else if (spill) { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                        else { nn = 0u; lo = 0u; hi = 0u; }                  // the push failed (error word set): an entry nobody wants
                         node = (uint32_t)__builtin_amdgcn_readfirstlane((int)nn);
                         in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
                         cur = ld_record(a.trav, node);
@@ -663,7 +703,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                 // both inner children wanted: B waits on the stack with the lanes that want it
                 if (sp < PACKET_STACK) {
                     if (lane == 0) { st_node[sp] = cb; st_lo[sp] = (uint32_t)mB; st_hi[sp] = (uint32_t)(mB >> 32); }
-                } else if (spill && sp - PACKET_STACK < a.packet_spill_entries) {
+                } else if (a.packet_spill && sp - PACKET_STACK < a.packet_spill_entries && (spill || (spill = spill_acquire(a, wave_gid, lane, spill_slot)))) {
                     if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = cb; e[1] = (uint32_t)mB; e[2] = (uint32_t)(mB >> 32); }
                 } else {
                     if (lane == 0) __hip_atomic_store((gu32*)&a.ctrl->error, 3u, RLX_AGENT);     // frame invalid
@@ -678,7 +718,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                     sp--;
                     uint32_t nn, lo, hi;
                     if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
-                    else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                    else if (spill) { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                        else { nn = 0u; lo = 0u; hi = 0u; }                  // the push failed (error word set): an entry nobody wants
                     node = (uint32_t)__builtin_amdgcn_readfirstlane((int)nn);
                     in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
                     cur = ld_record(a.trav, node);
@@ -707,6 +748,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
         }
         if (blk == 0xFFFFFFFFu) break;
     }
+    spill_release(a, lane, spill_slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -725,7 +767,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
     uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
-    uint32_t* spill = a.packet_spill ? a.packet_spill + (uint64_t)wave_gid * a.packet_spill_entries * 3u : nullptr;
+    uint32_t* spill = nullptr;                           // taken on the first overflow of the LDS stack
+    uint32_t spill_slot = 0xFFFFFFFFu;
 
     const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
     const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;
@@ -790,7 +833,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
                 if (first < 0) { first = k; continue; }
                 if (sp < PACKET_STACK) {
                     if (lane == 0) { st_node[sp] = ids[k]; st_lo[sp] = (uint32_t)m[k]; st_hi[sp] = (uint32_t)(m[k] >> 32); }
-                } else if (spill && sp - PACKET_STACK < a.packet_spill_entries) {
+                } else if (a.packet_spill && sp - PACKET_STACK < a.packet_spill_entries && (spill || (spill = spill_acquire(a, wave_gid, lane, spill_slot)))) {
                     if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
                 } else {
                     if (lane == 0) __hip_atomic_store((gu32*)&a.ctrl->error, 3u, RLX_AGENT);     // frame invalid
@@ -805,7 +848,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
                 sp--;
                 uint32_t nn, lo, hi;
                 if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
-                else { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                else if (spill) { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                        else { nn = 0u; lo = 0u; hi = 0u; }                  // the push failed (error word set): an entry nobody wants
                 node = nn;
                 in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
             }
@@ -827,6 +871,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
         }
         if (blk == 0xFFFFFFFFu) break;
     }
+    spill_release(a, lane, spill_slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1024,8 +1069,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
     // Grid: one wave per 64-ray block and the hardware dispatcher as the work queue.  A persistent grid (resident waves
     // pulling blocks from the sharded counters, idle lanes refilled) measured 25-50 % slower on every bundled scene
-    // (Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms); it remains for the packet kernels when the tree is
-    // deep enough to need the per-resident-wave spill area, and behind RTMI_PERSISTENT=1 for comparison.
+    // (Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms); it remains behind RTMI_PERSISTENT=1 for comparison.
     // resident blocks per CU: a property of the code object, asked once per kernel (the query costs microseconds of host time)
     static int b1 = 0;
     if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
@@ -1033,9 +1077,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (PRIMARY && t.packet && t.packet4 && t.quad) {
         static int b4 = 0;
         if (b4 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_trace_packet4<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b4 < 1) b4 = 1; }
-        uint32_t grid = t.persistent || t.packet_spill ? (uint32_t)t.compute_units * (uint32_t)b4 : need;
+        uint32_t grid = t.persistent ? (uint32_t)t.compute_units * (uint32_t)b4 : need;
         if (grid > need) grid = need;
-        if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
         a.n_waves = grid * TRACE_WAVES;
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
@@ -1046,9 +1089,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (PRIMARY && t.packet) {
         static int bp = 0;
         if (bp == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY, CAL>, TRACE_BLOCK, 0); if (bp < 1) bp = 1; }
-        uint32_t grid = t.persistent || t.packet_spill ? (uint32_t)t.compute_units * (uint32_t)bp : need;
+        uint32_t grid = t.persistent ? (uint32_t)t.compute_units * (uint32_t)bp : need;
         if (grid > need) grid = need;
-        if (grid > t.packet_max_blocks && t.packet_spill) grid = t.packet_max_blocks;
         a.n_waves = grid * TRACE_WAVES;
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         hipLaunchKernelGGL((k_trace_packet<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
@@ -1085,13 +1127,6 @@ static void launch(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 }
 
 uint32_t trace_packet_stack_entries() { return PACKET_STACK; }
-uint32_t trace_packet_max_blocks(int compute_units)
-{
-    int bp = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<1, 0>, TRACE_BLOCK, 0);
-    if (bp < 1) bp = 1;
-    return (uint32_t)compute_units * (uint32_t)bp;
-}
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
@@ -1102,7 +1137,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
     a.n_leaves = t.n_leaves;
-    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries;
+    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots;
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }

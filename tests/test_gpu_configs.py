@@ -90,3 +90,47 @@ def test_config5_atrium_class_4k_tiled_over_8_ranks(gpu_ctx):
         mine = rank_of == r
         assert compact[slot_of[mine]].tobytes() == want[mine].tobytes(), 'rank %d' % r
     gb.close(); sc.close()
+
+
+_OVERFLOW_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'oracle')); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import oracle as orc
+from openclraytracer_amd import capi
+from conftest import as_capi_camera
+buf = open(sys.argv[1], 'rb').read()
+osc = orc.Scene(buf); ob = orc.BVH(osc, 0)
+cam = osc.demo_camera(320, 180)
+want, _ = ob.trace_primary(cam)
+ctx = capi.Context(0)
+sc = capi.DeviceScene(ctx, buf); gb = capi.DeviceBVH(ctx, sc).build()
+taken = []
+for _ in range(2):
+    got = gb.generate_contacts_primary(as_capi_camera(cam))
+    assert got.tobytes() == want.tobytes(), 'contacts differ from the oracle'
+    taken.append(ctx.last_trace_counters()['spill_areas_taken'])
+assert taken[0] > 0 and taken[0] == taken[1], taken
+# areas are given back: many more frames than the bitmap could serve without releases
+frames = min(60, 3 * 8192 // taken[0] + 1)
+for _ in range(frames):
+    got = gb.generate_contacts_primary(as_capi_camera(cam))
+assert got.tobytes() == want.tobytes()
+print('overflow areas per frame %%d, %%d more frames ok' %% (taken[0], frames))
+"""
+
+
+@pytest.mark.parametrize('packet, budget, scene', [('4', '1048576', 'man'), ('1', '1048576', 'man'), ('1', '64', 'tenryuu'),
+                                                   ('4', '1048576', 'synth_atrium')])
+def test_packet_stack_overflow_areas(packet, budget, scene):
+    """Overflow areas of the packet kernels' (node, lane mask) stacks.  With the 96-entry LDS stacks no bundled or synthetic
+    scene overflows (chains of duplicate Morton codes have a leaf on one side), so this runs the test twin of the library
+    (librtmi_teststack.so: same sources, three-entry LDS stacks) in a child process: waves take areas from the bitmap
+    on their first overflow -- one wave per 64-ray block, far more waves than areas -- contacts stay the oracle's, the
+    number of areas taken is the same every frame, and areas are given back (more frames than the bitmap could serve)."""
+    from conftest import packed_scene
+    path = '/tmp/_overflow_%s.bin' % scene
+    open(path, 'wb').write(_synth_scene_bytes(scene) if scene.startswith('synth') else packed_scene(scene))
+    env = dict(os.environ, RTMI_LIBRARY='librtmi_teststack.so', RTMI_PACKET=packet, RTMI_DEFER_BUDGET=budget)
+    r = subprocess.run([sys.executable, '-c', _OVERFLOW_SCRIPT % dict(root=ROOT), path], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert 'more frames ok' in r.stdout
