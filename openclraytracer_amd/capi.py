@@ -107,7 +107,7 @@ def load_library() -> C.CDLL:
     L.rt_scan_inclusive_u32.argtypes = [vp, vp, vp, u32]
     L.rt_ctx_set_profiling.argtypes = [vp, i32]
     L.rt_ctx_trace_kernel_times.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    L.rt_ctx_last_trace_counters.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rt_ctx_last_trace_counters.argtypes = [vp, C.POINTER(C.c_uint32), u32]
     L.rt_timer_create.argtypes = [vp, pvp]
     L.rt_timer_start.argtypes = [vp, vp]
     L.rt_timer_stop.argtypes = [vp, vp]
@@ -168,9 +168,9 @@ class Context:
         self.check(self.lib.rt_ctx_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))
 
     def last_trace_counters(self) -> dict:
-        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        self.check(self.lib.rt_ctx_last_trace_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(deferred_rays=a.value, split_rays=b.value, spill_areas_taken=c.value)
+        out = (C.c_uint32 * 5)()
+        self.check(self.lib.rt_ctx_last_trace_counters(self.h, out, 5))
+        return dict(zip(('deferred_rays', 'split_rays', 'spill_areas_taken', 'wave_per_ray_steps', 'wave_per_ray_steps_max'), list(out)))
 
     def trace_kernel_times(self) -> dict:
         n, a, b = C.c_uint64(), C.c_double(), C.c_double()

@@ -110,6 +110,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_PERSISTENT")) ctx->persistent = env[0] == '1';
+    if (const char* env = std::getenv("RTMI_TRACE_DIAG")) ctx->trace_diagnostics = env[0] == '1';
     if (const char* env = std::getenv("RTMI_CALIBRATION_LOG")) ctx->calibration_log = env[0] == '1';
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
@@ -492,7 +493,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
-    t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.persistent = b->ctx->persistent;
+    t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.persistent = b->ctx->persistent; t.diagnostics = b->ctx->trace_diagnostics;
     t.quad = b->d_quad;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
@@ -821,16 +822,18 @@ int rt_ctx_set_profiling(rt_ctx* ctx, int enable)
     return RT_SUCCESS;
 }
 
-int rt_ctx_last_trace_counters(rt_ctx* ctx, uint32_t* deferred_rays, uint32_t* split_rays, uint32_t* spill_areas_taken)
+int rt_ctx_last_trace_counters(rt_ctx* ctx, uint32_t* out, uint32_t n)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (!out && n) return RT_FAIL(ctx, "counter array is null");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    size_t off[3];
+    size_t off[RT_TRACE_COUNTERS];
     trace_ctrl_counter_offsets(off);
-    uint32_t* out[3] = { deferred_rays, split_rays, spill_areas_taken };
-    for (int k = 0; k < 3; k++)
-        if (out[k]) RT_HIP(ctx, hipMemcpy(out[k], (const char*)ctx->d_trace_ctrl + off[k], 4, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < n; k++) {
+        out[k] = 0;
+        if (k < RT_TRACE_COUNTERS) RT_HIP(ctx, hipMemcpy(&out[k], (const char*)ctx->d_trace_ctrl + off[k], 4, hipMemcpyDeviceToHost));
+    }
     return RT_SUCCESS;
 }
 

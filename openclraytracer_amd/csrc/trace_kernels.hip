@@ -72,11 +72,13 @@ struct TraceCtrl {
     uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
     uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
     uint32_t spill_taken; uint32_t p4[31];   // packet kernels: overflow areas taken in this launch (diagnostic)
+    uint32_t long_steps;  uint32_t long_steps_max; uint32_t p5[30];   // wave-per-ray kernel: pool steps, all records / longest record (diagnostic)
 };
-static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 4) * 128, "TraceCtrl layout");
+static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 5) * 128, "TraceCtrl layout");
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
-void trace_ctrl_counter_offsets(size_t out[3]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken); }
+void trace_ctrl_counter_offsets(size_t out[5]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
+                                                  out[3] = offsetof(TraceCtrl, long_steps); out[4] = offsetof(TraceCtrl, long_steps_max); }
 size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
 
 // record of a deferred ray (LONG_REC_WORDS words)
@@ -108,6 +110,7 @@ struct TraceArgs {
     uint32_t* packet_spill;                // packet kernels: overflow areas of the (node, mask) stack, handed out on demand;
     uint32_t packet_spill_entries;         // the first packet_spill_slots / 32 words are the bitmap of areas in use
     uint32_t packet_spill_slots;
+    uint32_t diagnostics;                  // count the wave-per-ray kernel's pool steps (perturbs its timing)
     // primary rays
     rt_camera cam;
     uint32_t rank, nranks, tiles_x;
@@ -936,7 +939,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             if (rpending != NO_LEAF) { if (lane == 0) leafp[n_leaf] = rpending; n_leaf++; }
         }
 
+        uint32_t pool_steps = 0;
         while (n_inner != 0u || n_leaf != 0u) {
+            pool_steps++;
             // ---- leaves, 64 at a time, when the pool is filling up or nothing else is left ----
             if (n_leaf >= POOL_LEAF - 128u || n_inner == 0u) {
                 uint32_t k = n_leaf < 64u ? n_leaf : 64u;
@@ -1002,6 +1007,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             n_leaf += nal + nbl;
         }
 
+        if (a.diagnostics && lane == 0) {       // same-address atomics cost ~11 ns each: only on request (RTMI_TRACE_DIAG=1)
+            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_steps, pool_steps, RLX_AGENT);
+            __hip_atomic_fetch_max((gu32*)&a.ctrl->long_steps_max, pool_steps, RLX_AGENT);
+        }
         // ---- wave-wide lexicographic min of (t, position) ----
         unsigned long long key = 0xFFFFFFFFFFFFFFFFull;
         if (r.best_leaf != NO_LEAF) key = ((unsigned long long)__float_as_uint(r.best_t) << 32) | a.pos[r.best_leaf];
@@ -1137,7 +1146,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
     a.n_leaves = t.n_leaves;
-    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots;
+    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u;
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
