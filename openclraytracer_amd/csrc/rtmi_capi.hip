@@ -142,7 +142,7 @@ void* rt_ctx_get_stream(const rt_ctx* ctx) { return ctx ? (void*)ctx->stream : n
 int rt_ctx_synchronize(rt_ctx* ctx)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return check_trace_error(ctx);
 }
@@ -165,7 +165,7 @@ int rt_buf_alloc(rt_ctx* ctx, uint64_t bytes, void** d_out)
 {
     if (!ctx || !d_out) return RT_FAIL(ctx, "null argument");
     *d_out = nullptr;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
     return RT_SUCCESS;
 }
@@ -174,7 +174,7 @@ int rt_buf_free(rt_ctx* ctx, void* d_ptr)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
     if (!d_ptr) return RT_SUCCESS;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RT_HIP(ctx, hipFree(d_ptr));
     return RT_SUCCESS;
@@ -184,7 +184,7 @@ int rt_buf_upload(rt_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!d_dst || !h_src))) return RT_FAIL(ctx, "null argument");
     if (!bytes) return RT_SUCCESS;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the host buffer may be reused on return
     return RT_SUCCESS;
@@ -194,7 +194,7 @@ int rt_buf_download(rt_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!h_dst || !d_src))) return RT_FAIL(ctx, "null argument");
     if (!bytes) return RT_SUCCESS;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return check_trace_error(ctx);
@@ -211,7 +211,7 @@ int rt_buf_fill_u32(rt_ctx* ctx, void* d_dst, uint32_t pattern, uint64_t count)
 {
     if (!ctx || (count && !d_dst)) return RT_FAIL(ctx, "null argument");
     if (!count) return RT_SUCCESS;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     uint64_t blocks = (count + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (uint32_t*)d_dst, pattern, count);
@@ -273,6 +273,7 @@ int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_
     if (tri_acc != nTris) { delete sc; return RT_FAIL(ctx, "SceneHeader.totalNumberOfTriangles does not match the meshes"); }
 
     hipError_t e = hipSetDevice(ctx->device);
+    (void)hipGetLastError();                       // see RT_ENTER
     size_t tri_bytes = (size_t)nTris * (6 * sizeof(float4) + sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc(&sc->d_bytes, bytes);
     if (e == hipSuccess) e = hipMalloc(&sc->d_meshes, sizeof(MeshEntry) * (sc->h_meshes.size() + 1));
@@ -379,7 +380,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
 {
     if (!b) return RT_FAIL(nullptr, "bvh is null");
     rt_ctx* ctx = b->ctx;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     uint32_t n = b->scene->d.n_tris;
     if (n < 2) return RT_FAIL(ctx, "a BVH needs at least two triangles");
     uint32_t N = morton_buffer_items(n);
@@ -411,7 +412,7 @@ int rt_bvh_construct(rt_bvh* b)
     if (!b) return RT_FAIL(nullptr, "bvh is null");
     rt_ctx* ctx = b->ctx;
     if (!b->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const DeviceScene& sc = b->scene->d;
     launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
@@ -543,7 +544,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             if (cand.packet && ctx->no_packet) continue;
             if (!cand.packet && ctx->force_packet) continue;
             TraceLaunch t = make_launch(b, cam);
-            if (cand.quad && !b->d_quad) continue;
+            if (cand.quad && (!b->d_quad || !b->have_search_tree)) continue;    // four-wide records are sound on the search tree only
             t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
             t.tag = 1;
@@ -602,7 +603,7 @@ int rt_bvh_generate_contacts_primary(rt_bvh* b, const rt_camera* cam, void* d_co
     if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (!d_contacts) return RT_FAIL(ctx, "contacts buffer is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, 0, 1))) return RT_ERROR;
     return trace_primary_tuned(b, cam, 0, 1, false, (rt_contact*)d_contacts);
 }
@@ -616,7 +617,7 @@ int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint
     if (!d_contacts_compact) return RT_FAIL(ctx, "contacts buffer is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
     return trace_primary_tuned(b, cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
 }
@@ -628,7 +629,7 @@ int rt_bvh_generate_contacts_rays(rt_bvh* b, const void* d_rays, uint32_t ray_co
     if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (ray_count == 0) return RT_SUCCESS;
     if (!d_rays || !d_contacts) return RT_FAIL(ctx, "null buffer");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     if (ensure_long_list(ctx, ray_count)) return RT_ERROR;
     launch_trace_rays(ctx->stream, make_launch(b), (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts);
     RT_HIP(ctx, hipGetLastError());
@@ -670,7 +671,7 @@ int rt_bvh_search_tree(const rt_bvh* b, uint32_t* depth, int* used_by_last_camer
         *used_by_last_camera = 0;
         if (b->have_search_tree && b->built && b->marked_valid) {
             uint32_t sel = 7;
-            RT_HIP(ctx, hipSetDevice(ctx->device));
+            RT_ENTER(ctx);
             RT_HIP(ctx, hipMemcpyAsync(&sel, b->d_tree_select, 4, hipMemcpyDeviceToHost, ctx->stream));
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             *used_by_last_camera = sel == 0u ? 1 : 2;      // 2: only rays without a zero direction component on the camera's plane axes
@@ -697,7 +698,7 @@ int rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* ca
     if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (!d_rgba || (contact_count && !d_contacts)) return RT_FAIL(ctx, "null buffer");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     if (contact_count == 0) {
         RT_HIP(ctx, hipMemsetAsync(d_rgba, 0, (size_t)cam->resX * cam->resY * sizeof(float4), ctx->stream));
         return RT_SUCCESS;
@@ -721,7 +722,7 @@ int rt_shade_blinn_phong_tiled(rt_ctx* ctx, const rt_scene* scene, const rt_came
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
     if (!d_contacts_compact || !d_rgba_compact) return RT_FAIL(ctx, "null buffer");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     uint32_t count = rt_tiles_owned_pixels(cam, rank, nranks);
     launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts_compact, count, (float4*)d_rgba_compact, true,
                  rank, nranks);
@@ -736,7 +737,7 @@ int rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const voi
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || !d_rgba_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
     if (slots_per_rank < rt_tiles_owned_pixels(cam, 0, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     launch_untile_rgba(ctx->stream, *cam, nranks, (const float4*)d_rgba_gathered, slots_per_rank, (float4*)d_rgba_frame);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -749,7 +750,7 @@ int rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2)
 {
     if (!ctx || !d_pairs) return RT_FAIL(ctx, "null argument");
     if (n_pow2 == 0 || (n_pow2 & (n_pow2 - 1))) return RT_FAIL(ctx, "item count must be a power of two");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     launch_bitonic_sort(ctx->stream, (uint2*)d_pairs, n_pow2);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -760,7 +761,7 @@ int rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
     if (n == 0) return RT_SUCCESS;
     if (!d_in || !d_out) return RT_FAIL(ctx, "null buffer");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     uint32_t* scratch = nullptr;
     RT_HIP(ctx, hipMalloc((void**)&scratch, scan_scratch_words(n) * sizeof(uint32_t)));
     launch_scan_inclusive(ctx->stream, (const uint32_t*)d_in, (uint32_t*)d_out, n, scratch);
@@ -782,7 +783,7 @@ int rt_generate_secondary_rays(rt_ctx* ctx, const rt_camera* cam, const void* d_
     if (kind != RT_RAYS_SHADOW && kind != RT_RAYS_REFLECT) return RT_FAIL(ctx, "unknown ray kind");
     if (kind == RT_RAYS_SHADOW && !target) return RT_FAIL(ctx, "shadow rays need a target");
     if (cam && rt_check_camera(ctx, cam)) return RT_ERROR;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     uint32_t* tmp = nullptr;
     const size_t words = 2 * (size_t)count + scan_scratch_words(count);
     RT_HIP(ctx, hipMalloc((void**)&tmp, words * sizeof(uint32_t)));
@@ -814,7 +815,7 @@ static void drop_trace_events(rt_ctx* ctx)
 int rt_ctx_set_profiling(rt_ctx* ctx, int enable)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drop_trace_events(ctx);
     ctx->profiling = enable != 0;
@@ -826,7 +827,7 @@ int rt_ctx_last_trace_counters(rt_ctx* ctx, uint32_t* out, uint32_t n)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
     if (!out && n) return RT_FAIL(ctx, "counter array is null");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     size_t off[RT_TRACE_COUNTERS];
     trace_ctrl_counter_offsets(off);
@@ -840,7 +841,7 @@ int rt_ctx_last_trace_counters(rt_ctx* ctx, uint32_t* out, uint32_t n)
 int rt_ctx_trace_kernel_times(rt_ctx* ctx, uint64_t* launches, double* lane_phase_ms, double* wave_phase_ms)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t n = 0; double a = 0.0, b = 0.0;
     for (size_t i = 0; i + 2 < ctx->trace_events.size(); i += 3) {
@@ -865,7 +866,7 @@ struct rt_timer { hipEvent_t start, stop; };
 int rt_timer_create(rt_ctx* ctx, void** timer)
 {
     if (!ctx || !timer) return RT_FAIL(ctx, "null argument");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     rt_timer* t = new (std::nothrow) rt_timer();
     if (!t) return RT_FAIL(ctx, "out of host memory");
     if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) {

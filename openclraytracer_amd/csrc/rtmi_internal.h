@@ -167,6 +167,15 @@ extern "C" __attribute__((visibility("hidden"))) int rt_check_camera(rt_ctx* ctx
             return RT_FAIL((ctx), std::string(#expr) + ": " + hipGetErrorString(e__));         \
     } while (0)
 
+// Entry of every API call that launches work: select the device and drop whatever error an earlier runtime call of this
+// thread left behind (hipGetLastError is per thread and sticky, and the host application -- torch, RCCL -- makes calls of its
+// own between ours: a stale "invalid resource handle" of theirs was once reported as a failed trace launch).
+#define RT_ENTER(ctx)                                                                           \
+    do {                                                                                        \
+        RT_HIP((ctx), hipSetDevice((ctx)->device));                                             \
+        (void)hipGetLastError();                                                                \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------
 // kernel launchers (one translation unit per family)
 // ---------------------------------------------------------------------------------------

@@ -96,7 +96,7 @@ int rt_tlg_initialize_frame(rt_tlg* g)
 {
     if (!g) return RT_FAIL(nullptr, "tlg is null");
     rt_ctx* ctx = g->ctx;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     g->n = g->scene->d.n_tris;
     if (g->n == 0) return RT_FAIL(ctx, "the scene has no triangles");
     if (calculate_grid_data(g)) return RT_ERROR;
@@ -137,7 +137,7 @@ int rt_tlg_construct(rt_tlg* g)
     if (!g) return RT_FAIL(nullptr, "tlg is null");
     rt_ctx* ctx = g->ctx;
     if (!g->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const DeviceScene& sc = g->scene->d;
     const rt_grid_data& G = g->grid;
@@ -211,7 +211,7 @@ int rt_tlg_generate_contacts_primary(rt_tlg* g, const rt_camera* cam, void* d_co
     if (!g->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (!d_contacts) return RT_FAIL(ctx, "contacts buffer is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     launch_tlg_trace_primary(ctx->stream, make_tlg_launch(g), *cam, 0, 1, false, (rt_contact*)d_contacts);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -225,7 +225,7 @@ int rt_tlg_generate_contacts_primary_tiled(rt_tlg* g, const rt_camera* cam, uint
     if (!d_contacts_compact) return RT_FAIL(ctx, "contacts buffer is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     launch_tlg_trace_primary(ctx->stream, make_tlg_launch(g), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -238,7 +238,7 @@ int rt_tlg_generate_contacts_rays(rt_tlg* g, const void* d_rays, uint32_t ray_co
     if (!g->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (ray_count == 0) return RT_SUCCESS;
     if (!d_rays || !d_contacts) return RT_FAIL(ctx, "null buffer");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     launch_tlg_trace_rays(ctx->stream, make_tlg_launch(g), (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -276,7 +276,7 @@ int rt_tlg_read(const rt_tlg* g, int what, void* h_dst, uint64_t bytes)
     }
     if (bytes != want) return RT_FAIL(ctx, "size mismatch");
     if (want == 0) return RT_SUCCESS;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_ENTER(ctx);
     RT_HIP(ctx, hipMemcpyAsync(h_dst, src, want, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_SUCCESS;

@@ -386,9 +386,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
             uint32_t extra = RT_SENTINEL;     // child that did not fit on the stack (forces a deferral)
             if (active) {
                 iters++;
-                if (cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) == 0u && a.quad != nullptr && sp + 3u <= LDS_STACK) {
+                if (cur != RT_SENTINEL && (cur & RT_LEAF_FLAG) == 0u && a.quad != nullptr && cur >= a.search_root && sp + 3u <= LDS_STACK) {
                     // inner node, four-wide: the 128-byte record holds the node's grandchildren, so one step descends two
                     // levels and the dependent chain (record -> tests -> next record) that this kernel waits on is half as long.
+                    // Skipping the inner children's own boxes changes nothing only where the search-tree argument holds
+                    // (DESIGN.md section 2), so this step is taken on search-tree records alone: rays that ray_root sent to the
+                    // reference tree (a slab product could be 0 * inf) walk it record by record, box by box.
                     // Up to three entries are pushed (only while they fit; otherwise the binary step below).
                     const float4* p = reinterpret_cast<const float4*>(a.quad + cur);
                     const float4 g0 = p[0], g1 = p[1], g2 = p[2], g3 = p[3], g4 = p[4], g5 = p[5], g6 = p[6], g7 = p[7];
@@ -792,20 +795,31 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
             o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        bool in = ok;
         uint32_t sp = 0;
-        uint32_t node = 0;
-        if (PRIMARY && a.search_root != 0u) {
-            const bool on_ref = ok && ray_root<PRIMARY>(a, r, plane_bits) == 0u;
-            const uint64_t m_ref = __ballot(on_ref), m_search = __ballot(ok && !on_ref);
-            if (m_search != 0ull) {
-                node = a.search_root; in = ok && !on_ref;
-                if (m_ref != 0ull) {
-                    if (lane == 0) { st_node[0] = 0u; st_lo[0] = (uint32_t)m_ref; st_hi[0] = (uint32_t)(m_ref >> 32); }
-                    sp = 1;
+        // The four-wide records skip the boxes of a node's inner children, which is sound on the search tree only (the host
+        // launches this kernel only when there is one).  A ray that must walk the reference tree box by box (ray_root: a slab
+        // product could be 0 * inf -- the camera on a box plane and a zero direction component) is handed, whole, to the
+        // wave-per-ray kernel, which walks binary records.
+        const bool on_ref = ok && ray_root<PRIMARY>(a, r, plane_bits) == 0u;
+        const uint64_t m_ref = __ballot(on_ref);
+        if (m_ref != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&a.ctrl->long_count, (uint32_t)__popcll(m_ref), RLX_AGENT);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (on_ref) {
+                const uint32_t idx = base + lane_rank(m_ref);
+                if (idx < a.long_cap) {
+                    uint32_t* rec = a.long_list + (uint64_t)idx * LONG_REC_WORDS;
+                    rec[LR_WORK] = w; rec[LR_CUR] = 0u; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
+                    rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF; rec[LR_PARTIAL] = 0u;
+                } else {
+                    __hip_atomic_store((gu32*)&a.ctrl->error, 1u, RLX_AGENT);          // nowhere to put the ray: frame invalid
                 }
             }
+            ok = ok && !on_ref;                                                         // their contacts are written there
         }
+        bool in = ok;
+        uint32_t node = a.search_root;
         bool walking = __ballot(in) != 0ull;
         while (walking) {
             const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
@@ -1083,7 +1097,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     static int b1 = 0;
     if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
-    if (PRIMARY && t.packet && t.packet4 && t.quad) {
+    if (PRIMARY && t.packet && t.packet4 && t.quad && t.search_root) {
         static int b4 = 0;
         if (b4 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_trace_packet4<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b4 < 1) b4 = 1; }
         uint32_t grid = t.persistent ? (uint32_t)t.compute_units * (uint32_t)b4 : need;
@@ -1092,6 +1106,10 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
+        // rays the four-wide records may not be used for (see the kernel) wait on the deferred list: normally none, and the
+        // wave-per-ray kernel returns at once
+        a.n_waves = grid1 * TRACE_WAVES;
+        hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
@@ -1139,7 +1157,7 @@ uint32_t trace_packet_stack_entries() { return PACKET_STACK; }
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
-    a.trav = t.trav; a.quad = t.quad; a.search_root = t.search_root; a.tree_select = t.tree_select;
+    a.trav = t.trav; a.quad = t.search_root ? t.quad : nullptr; a.search_root = t.search_root; a.tree_select = t.tree_select;
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
     a.pos = t.pos;
     a.ctrl = (TraceCtrl*)t.ctrl;

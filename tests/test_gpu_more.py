@@ -306,6 +306,35 @@ def test_camera_on_a_box_plane_falls_back_to_the_reference_tree(gpu_ctx, name):
     assert gb.search_tree()['used_by_last_camera'] == 1
 
 
+@pytest.mark.parametrize('packet, budget', [('4', '1048576'), ('0', '1048576'), ('0', '64'), ('1', '256')])
+@pytest.mark.parametrize('name', ['man', 'clumsydragon'])
+def test_camera_on_a_box_plane_with_every_kernel(name, packet, budget, monkeypatch):
+    """the same camera (x on a plane of leaf boxes, a pixel column with direction.x == 0) under every forced strategy: the
+    four-wide records skip the boxes of inner children, which is sound on the search tree only, so the four-wide packet
+    kernel hands such rays to the wave-per-ray kernel and the lane-per-ray kernel walks them with binary steps."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    monkeypatch.setenv('RTMI_PACKET', packet)
+    monkeypatch.setenv('RTMI_DEFER_BUDGET', budget)
+    osc, ob = oracle_bvh(name)
+    cam = osc.demo_camera(160, 120).copy()
+    cam['m'][0][3] = 0.0
+    want, _ = ob.trace_primary(cam)
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        for _ in range(2):
+            got = gb.generate_contacts_primary(as_capi_camera(cam))
+            assert got.tobytes() == want.tobytes()
+        assert gb.search_tree()['used_by_last_camera'] == 2
+        if packet == '4':
+            assert ctx.last_trace_counters()['deferred_rays'] == 120          # exactly the pixel column with direction.x == 0
+        gb.close(); sc.close()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize('name,res', [('gardenlight', (160, 120)), ('tenryuu', (320, 240))])
 def test_secondary_rays_two_bounces(gpu_ctx, name, res):
     """rt_generate_secondary_rays (extension, reference TODO 2.2): shadow rays from the primary contacts and reflections of
