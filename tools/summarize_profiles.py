@@ -64,8 +64,10 @@ except Exception as e:
 try:
     c3 = newest("gpurun_out/%s/config3_stats/*/*_kernel_stats.csv" % R)
     shutil.copy(c3, 'profiles/%s_config3_kernel_stats.csv' % R)
-    t = open('gpurun_out/%s/config3.log' % R).read()
-    open('profiles/%s_config3_line.json' % R, 'w').write(t[t.index('{'):])
-    print(t[t.index('{'):])
+    ls = open('gpurun_out/%s/config3.log' % R).read().splitlines()
+    a = ls.index('{'); b = ls.index('}', a)
+    t = '\n'.join(ls[a:b + 1]) + '\n'
+    open('profiles/%s_config3_line.json' % R, 'w').write(t)
+    print(t)
 except Exception as e:
     print('no config3 profile:', e)
