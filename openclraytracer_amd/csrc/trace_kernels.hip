@@ -110,6 +110,7 @@ struct TraceArgs {
     uint32_t* packet_spill;                // packet kernels: overflow areas of the (node, mask) stack, handed out on demand;
     uint32_t packet_spill_entries;         // the first packet_spill_slots / 32 words are the bitmap of areas in use
     uint32_t packet_spill_slots;
+    uint32_t persistent;                   // resident waves pull blocks from the work counters (RTMI_PERSISTENT=1)
     uint32_t diagnostics;                  // count the wave-per-ray kernel's pool steps (perturbs its timing)
     // primary rays
     rt_camera cam;
@@ -485,9 +486,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
             uint32_t n_active = (uint32_t)__popcll(__ballot(active));
             if (n_active == 0u) break;
             if (!exhausted && n_active <= 64u - REFILL_MIN_IDLE) break;
-            if (exhausted) {
-                // nothing left to refill with: the emptier the wave, the less a lane-per-ray step is worth, so the
-                // budget shrinks with the number of busy lanes and stragglers move to the wave-per-ray phase early
+            if (exhausted && a.persistent) {
+                // persistent grid, nothing left to refill with: the emptier the wave, the less a lane-per-ray step is worth, so
+                // the budget shrinks with the number of busy lanes and stragglers move to the wave-per-ray phase early.
+                // (One wave per block: every lane starts at step 0 together, so the budget is simply the step at which
+                // whatever is still walking is handed over; measured better than any scaling, and finer budgets are calibrated.)
                 uint32_t b = (a.defer_budget * n_active) >> 6;
                 drain_budget = b < STRAGGLER_BUDGET ? STRAGGLER_BUDGET : b;
             }
@@ -1164,7 +1167,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
     a.n_leaves = t.n_leaves;
-    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u;
+    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u; a.persistent = t.persistent ? 1u : 0u;
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
