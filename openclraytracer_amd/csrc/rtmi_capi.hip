@@ -237,7 +237,8 @@ int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_
     if (nLights > bytes || nSpheres > bytes || nMaterials > bytes) return RT_FAIL(ctx, "corrupt scene header counts");
     uint64_t off = 96 + 16 * nLights + 16 * nSpheres + 96 * nMaterials;        // MODEL_BUFFER_PTR, :69-74
     if (off > bytes) return RT_FAIL(ctx, "scene header counts exceed the buffer");
-    if (nTris >= 0x7FFFFFFFull) return RT_FAIL(ctx, "too many triangles");
+    // record and leaf ids carry a ray slot in their top four bits inside the wave-per-ray kernel (2 (n-1) records < 2^28)
+    if (nTris > (1ull << 27)) return RT_FAIL(ctx, "too many triangles (more than 2^27)");
 
     rt_scene* sc = new (std::nothrow) rt_scene();
     if (!sc) return RT_FAIL(ctx, "out of host memory");

@@ -226,7 +226,7 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 size_t trace_ctrl_bytes();
 size_t trace_ctrl_error_offset();
-void trace_ctrl_counter_offsets(size_t out[5]);
+void trace_ctrl_counter_offsets(size_t out[6]);
 size_t trace_long_record_bytes();
 uint32_t trace_packet_stack_entries();
 uint32_t trace_lds_stack_entries();

@@ -72,13 +72,13 @@ struct TraceCtrl {
     uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
     uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
     uint32_t spill_taken; uint32_t p4[31];   // packet kernels: overflow areas taken in this launch (diagnostic)
-    uint32_t long_steps;  uint32_t long_steps_max; uint32_t p5[30];   // wave-per-ray kernel: pool steps, all records / longest record (diagnostic)
+    uint32_t long_steps;  uint32_t long_steps_max; uint32_t long_nodes; uint32_t p5[29];   // wave-per-ray kernel: pool steps, all records / longest record (diagnostic)
 };
 static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 5) * 128, "TraceCtrl layout");
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
-void trace_ctrl_counter_offsets(size_t out[5]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
-                                                  out[3] = offsetof(TraceCtrl, long_steps); out[4] = offsetof(TraceCtrl, long_steps_max); }
+void trace_ctrl_counter_offsets(size_t out[6]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
+                                                  out[3] = offsetof(TraceCtrl, long_steps); out[4] = offsetof(TraceCtrl, long_steps_max); out[5] = offsetof(TraceCtrl, long_nodes); }
 size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
 
 // record of a deferred ray (LONG_REC_WORDS words)
@@ -895,74 +895,132 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// phase 1: one deferred ray per wave, 64 lanes walk its sub-trees together
+// phase 1: LONG_BATCH deferred rays per wave, 64 lanes walk their sub-trees together
 // ------------------------------------------------------------------------------------------------
+// One deferred ray keeps 16-37 of 64 lanes busy per pool step (ClumsyDragon / Tenryuu, RTMI_TRACE_DIAG=1) and the kernel is
+// bound by instruction issue, so a wave takes LONG_BATCH records at once: pool entries carry the ray's slot in their top
+// bits, the rays live in LDS (two 16-byte reads per lane and step instead of registers), and hits meet in a 64-bit
+// (t bits, position) key per slot through an LDS atomic min -- the same lexicographic minimum the one-ray version reduced
+// at the end, so results do not depend on which rays share a wave.
+#define LONG_BATCH 4u
+#define LONG_SLOT_SHIFT 28u                     // ids below 2^28: rt_bvh_construct refuses more than 2^27 triangles
+#define LONG_ID_MASK 0x0FFFFFFFu
+#define LONG_LIVE 1u
+#define LONG_PARTIAL 2u
+
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
 {
     __shared__ uint32_t s_inner[TRACE_WAVES][POOL_INNER];
     __shared__ uint32_t s_leaf[TRACE_WAVES][POOL_LEAF];
+    // per slot: (o.xyz, signs) (d.xyz, work) (inv.xyz, flags) (out_index, pixel, -, -)
+    __shared__ float4 s_ray[TRACE_WAVES][LONG_BATCH][4];
+    __shared__ unsigned long long s_key[TRACE_WAVES][LONG_BATCH];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t* inner = s_inner[wave];
     uint32_t* leafp = s_leaf[wave];
+    float4 (*ray)[4] = s_ray[wave];
+    unsigned long long* keys = s_key[wave];
     const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
     gu32* error_word = (gu32*)&a.ctrl->error;
     uint32_t count = a.ctrl->long_count;                  // written by the previous kernel
     if (count > a.long_cap) count = a.long_cap;
+    const uint32_t n_batches = (count + LONG_BATCH - 1u) / LONG_BATCH;
 
-    // deferred rays differ in length by an order of magnitude: the first task of a wave is static (its own index),
-    // further tasks are pulled from sharded counters, as in phase 0
-    uint32_t i = wave_gid;
+    // deferred rays differ in length by an order of magnitude: the first batch of a wave is static (its own index),
+    // further batches are pulled from sharded counters
+    uint32_t bi = wave_gid;
     uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
     for (;;) {
-        if (i >= count) break;
-        const uint32_t* rec = a.long_list + (uint64_t)i * LONG_REC_WORDS;
-        // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
-        uint32_t work = rec[LR_WORK], rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
-        const bool partial = rec[LR_PARTIAL] != 0u;      // a sub-tree of a ray the packet kernel keeps walking elsewhere
-        bool void_record = work == 0xFFFFFFFFu;           // reserved by a block that found the list full
-        {   // a record that does not describe a task of this launch must never be walked (it would read anywhere):
-            // report it through the error word and skip it
-            const uint32_t n_leaves = a.n_leaves;
-            auto bad_id = [&](uint32_t id) {
-                return id != RT_SENTINEL && ((id & RT_LEAF_FLAG) ? (id & ~RT_LEAF_FLAG) >= n_leaves : id >= a.n_records);
-            };
-            const bool bad = !void_record && (work >= a.total_work || rsp > LDS_STACK || bad_id(rcur) || bad_id(rextra) ||
-                                              (rpending != NO_LEAF && rpending >= n_leaves) ||
-                                              (rec[LR_BEST_LEAF] != NO_LEAF && rec[LR_BEST_LEAF] >= n_leaves));
-            if (bad) { if (lane == 0) __hip_atomic_store(error_word, 4u, RLX_AGENT); void_record = true; }
+        if (bi >= n_batches) break;
+        // ---------------- set the batch up: lane s < LONG_BATCH prepares slot s ----------------
+        if (lane < LONG_BATCH) {
+            const uint32_t i = bi * LONG_BATCH + lane;
+            bool live = i < count;
+            const uint32_t* rec = a.long_list + (uint64_t)(live ? i : 0u) * LONG_REC_WORDS;
+            uint32_t work = live ? rec[LR_WORK] : 0xFFFFFFFFu;
+            if (work == 0xFFFFFFFFu) live = false;       // reserved by a block that found the list full
+            if (live) {
+                // a record that does not describe a task of this launch must never be walked (it would read anywhere):
+                // report it through the error word and skip it
+                const uint32_t n_leaves = a.n_leaves;
+                auto bad_id = [&](uint32_t id) {
+                    return id != RT_SENTINEL && ((id & RT_LEAF_FLAG) ? (id & ~RT_LEAF_FLAG) >= n_leaves : id >= a.n_records);
+                };
+                const bool bad = work >= a.total_work || rec[LR_SP] > LDS_STACK || bad_id(rec[LR_CUR]) || bad_id(rec[LR_EXTRA]) ||
+                                 (rec[LR_PENDING] != NO_LEAF && rec[LR_PENDING] >= n_leaves) ||
+                                 (rec[LR_BEST_LEAF] != NO_LEAF && rec[LR_BEST_LEAF] >= n_leaves);
+                if (bad) { __hip_atomic_store(error_word, 4u, RLX_AGENT); live = false; }
+            }
+            RayState r;
+            bool sx, sy, sz;
+            load_ray<PRIMARY>(a, live ? work : 0u, r, sx, sy, sz);
+            const uint32_t signs = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
+            const uint32_t flags = (live ? LONG_LIVE : 0u) | (live && rec[LR_PARTIAL] != 0u ? LONG_PARTIAL : 0u);
+            ray[lane][0] = make_float4(r.o.x, r.o.y, r.o.z, __uint_as_float(signs));
+            ray[lane][1] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(work));
+            ray[lane][2] = make_float4(r.inv.x, r.inv.y, r.inv.z, __uint_as_float(flags));
+            ray[lane][3] = make_float4(__uint_as_float(r.out_index), __uint_as_float(r.pixel), 0.0f, 0.0f);
+            unsigned long long key = KEY_NONE;            // the best hit found in phase 0
+            if (live && rec[LR_BEST_LEAF] != NO_LEAF) key = ((unsigned long long)rec[LR_BEST_T] << 32) | a.pos[rec[LR_BEST_LEAF]];
+            keys[lane] = key;
         }
-        RayState r;
-        bool sx, sy, sz;
-        load_ray<PRIMARY>(a, void_record ? 0u : work, r, sx, sy, sz);        // same ray in every lane
-        if (lane == 0 && !void_record) {                  // lane 0 carries the best hit found in phase 0
-            r.best_leaf = rec[LR_BEST_LEAF];
-            r.best_t = __uint_as_float(rec[LR_BEST_T]);
-        }
-        // seed the pools: lanes 0..sp-1 take the stack, lanes 62/63 the current node and the extra child
-        uint32_t seed = RT_SENTINEL;
-        if (!void_record && lane < rsp) seed = rec[LR_STACK + lane];
-        if (!void_record && lane == 62) seed = rcur;
-        if (!void_record && lane == 63) seed = rextra;
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- seed the pools, slot by slot: lanes 0..sp-1 take the stack, lanes 62/63 the current node and the extra child
         uint32_t n_inner = 0, n_leaf = 0;
-        if (!void_record) {
-            bool is_in = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) == 0u;
-            bool is_lf = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) != 0u;
-            uint64_t mi = __ballot(is_in), ml = __ballot(is_lf);
-            if (is_in) inner[lane_rank(mi)] = seed;
-            if (is_lf) leafp[lane_rank(ml)] = seed & ~RT_LEAF_FLAG;
-            n_inner = (uint32_t)__popcll(mi); n_leaf = (uint32_t)__popcll(ml);
-            if (rpending != NO_LEAF) { if (lane == 0) leafp[n_leaf] = rpending; n_leaf++; }
+        for (uint32_t sl = 0; sl < LONG_BATCH; sl++) {
+            if ((__float_as_uint(ray[sl][2].w) & LONG_LIVE) == 0u) continue;                 // wave-uniform
+            const uint32_t* rec = a.long_list + (uint64_t)(bi * LONG_BATCH + sl) * LONG_REC_WORDS;
+            // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
+            const uint32_t rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
+            uint32_t seed = RT_SENTINEL;
+            if (lane < rsp) seed = rec[LR_STACK + lane];
+            if (lane == 62) seed = rcur;
+            if (lane == 63) seed = rextra;
+            const bool is_in = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) == 0u;
+            const bool is_lf = seed != RT_SENTINEL && (seed & RT_LEAF_FLAG) != 0u;
+            const uint64_t mi = __ballot(is_in), ml = __ballot(is_lf);
+            const uint32_t tag = sl << LONG_SLOT_SHIFT;
+            if (is_in) inner[n_inner + lane_rank(mi)] = seed | tag;
+            if (is_lf) leafp[n_leaf + lane_rank(ml)] = (seed & ~RT_LEAF_FLAG) | tag;
+            n_inner += (uint32_t)__popcll(mi); n_leaf += (uint32_t)__popcll(ml);
+            if (rpending != NO_LEAF) { if (lane == 0) leafp[n_leaf] = rpending | tag; n_leaf++; }
         }
 
-        uint32_t pool_steps = 0;
+        uint32_t pool_steps = 0, pool_nodes = 0;
         while (n_inner != 0u || n_leaf != 0u) {
             pool_steps++;
             // ---- leaves, 64 at a time, when the pool is filling up or nothing else is left ----
             if (n_leaf >= POOL_LEAF - 128u || n_inner == 0u) {
                 uint32_t k = n_leaf < 64u ? n_leaf : 64u;
-                if (lane < k) leaf_test(a, leafp[n_leaf - 1u - lane], r);
+                if (lane < k) {
+                    // triangleIntersect, Triangle.h:66-107, as in leaf_test; the hit goes into the slot's key
+                    const uint32_t e = leafp[n_leaf - 1u - lane];
+                    const uint32_t sl = e >> LONG_SLOT_SHIFT, leaf = e & LONG_ID_MASK;
+                    const float4 ro = ray[sl][0], rd = ray[sl][1];
+                    const f3 o = f3{ ro.x, ro.y, ro.z }, d = f3{ rd.x, rd.y, rd.z };
+                    float4 v0 = a.v0[leaf], E1 = a.e1[leaf], E2 = a.e2[leaf];
+                    f3 vert0 = f3_from4(v0), edge1 = f3_from4(E1), edge2 = f3_from4(E2);
+                    f3 pvec = f3_cross(d, edge2);
+                    float det = f3_dot(edge1, pvec);
+                    bool flag = fabsf(det) >= FLT_EPSILON;
+                    float inv_det = 1.0f / det;
+                    f3 tvec = f3_sub(o, vert0);
+                    float u = f3_dot(tvec, pvec) * inv_det;
+                    flag = flag & (u < 1.0f);
+                    flag = flag & (u >= 0.0f);
+                    f3 qvec = f3_cross(tvec, edge1);
+                    float v = f3_dot(d, qvec) * inv_det;
+                    flag = flag & ((u + v) <= 1.0f);
+                    flag = flag & (v >= 0.0f);
+                    float t = f3_dot(edge2, qvec) * inv_det;
+                    // a hit replaces the best only if t < best (BVH.h:392), and the best starts at FLT_MAX
+                    if (flag & (t > 0.0f) & (t < FLT_MAX)) {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | a.pos[leaf];
+                        if (key < keys[sl]) __hip_atomic_fetch_min(&keys[sl], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
                 n_leaf -= k;
                 continue;
             }
@@ -977,17 +1035,26 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             // only if every record before it is valid-B and links to its successor (prefix AND through a ballot),
             // so exactly the reached nodes contribute -- up to 64 chain nodes per step instead of one.
             // lanes 0..k-1 take the k popped nodes (lane 0 the top one); lanes k..63 run ahead along the chain below
-            // the top node: lane k+j-1 speculatively takes record top+j
-            const uint32_t top = inner[n_inner - 1u];
+            // the top node, for the top node's ray: lane k+j-1 speculatively takes record top+j
+            const uint32_t top_e = inner[n_inner - 1u];
+            const uint32_t top = top_e & LONG_ID_MASK;
             const bool spec_lane = lane >= k;
             const uint32_t seq_j = spec_lane ? lane - k + 1u : 0u;          // position in the sequence top, top+1, ...
-            uint32_t node = spec_lane ? top + seq_j : inner[n_inner - 1u - (lane < k ? lane : 0u)];
+            const uint32_t e = spec_lane ? top_e : inner[n_inner - 1u - (lane < k ? lane : 0u)];
+            const uint32_t sl = e >> LONG_SLOT_SHIFT;
+            const uint32_t tag = sl << LONG_SLOT_SHIFT;
+            uint32_t node = spec_lane ? top + seq_j : (e & LONG_ID_MASK);
             bool mine = spec_lane ? node < a.n_records : true;
             n_inner -= k;
             bool aIn = false, aLf = false, bIn = false, bLf = false;
             uint32_t ca = 0, cb = 0;
             bool bValid = false;
             if (mine) {
+                const float4 ro = ray[sl][0], ri = ray[sl][2];
+                RayState r;
+                r.o = f3{ ro.x, ro.y, ro.z }; r.inv = f3{ ri.x, ri.y, ri.z };
+                const uint32_t signs = __float_as_uint(ro.w);
+                const bool sx = (signs & 1u) != 0u, sy = (signs & 2u) != 0u, sz = (signs & 4u) != 0u;
                 const float4* p = reinterpret_cast<const float4*>(a.trav + node);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 ca = __float_as_uint(q0.w); cb = __float_as_uint(q1.w);
@@ -1003,6 +1070,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
                 uint64_t seq = (lk & 1ull) | (k < 64u ? ((lk >> k) << 1) : 0ull);          // links in sequence order
                 uint32_t reached = (uint32_t)__ffsll((unsigned long long)~seq);           // reached sequence elements
                 if (reached == 0u || reached > 65u - k) reached = 65u - k;
+                pool_nodes += k + reached - 1u;
                 bool in_prefix = !spec_lane || seq_j < reached;
                 bool emits_b = spec_lane ? (seq_j + 1u == reached) : (lane == 0u ? reached == 1u : true);
                 aIn = aIn & in_prefix; aLf = aLf & in_prefix;
@@ -1016,10 +1084,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
                 n_inner = 0; n_leaf = 0;
                 break;
             }
-            if (aIn) inner[n_inner + lane_rank(mai)] = ca;
-            if (bIn) inner[n_inner + nai + lane_rank(mbi)] = cb;
-            if (aLf) leafp[n_leaf + lane_rank(mal)] = ca & ~RT_LEAF_FLAG;
-            if (bLf) leafp[n_leaf + nal + lane_rank(mbl)] = cb & ~RT_LEAF_FLAG;
+            if (aIn) inner[n_inner + lane_rank(mai)] = ca | tag;
+            if (bIn) inner[n_inner + nai + lane_rank(mbi)] = cb | tag;
+            if (aLf) leafp[n_leaf + lane_rank(mal)] = (ca & ~RT_LEAF_FLAG) | tag;
+            if (bLf) leafp[n_leaf + nal + lane_rank(mbl)] = (cb & ~RT_LEAF_FLAG) | tag;
             n_inner += nai + nbi;
             n_leaf += nal + nbl;
         }
@@ -1027,39 +1095,40 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         if (a.diagnostics && lane == 0) {       // same-address atomics cost ~11 ns each: only on request (RTMI_TRACE_DIAG=1)
             __hip_atomic_fetch_add((gu32*)&a.ctrl->long_steps, pool_steps, RLX_AGENT);
             __hip_atomic_fetch_max((gu32*)&a.ctrl->long_steps_max, pool_steps, RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_nodes, pool_nodes, RLX_AGENT);
         }
-        // ---- wave-wide lexicographic min of (t, position) ----
-        unsigned long long key = 0xFFFFFFFFFFFFFFFFull;
-        if (r.best_leaf != NO_LEAF) key = ((unsigned long long)__float_as_uint(r.best_t) << 32) | a.pos[r.best_leaf];
-        uint32_t leaf = r.best_leaf;
-        for (int off = 32; off > 0; off >>= 1) {
-            unsigned long long ok = (unsigned long long)__shfl_xor((long long)key, off, 64);
-            uint32_t ol = (uint32_t)__shfl_xor((int)leaf, off, 64);
-            if (ok < key) { key = ok; leaf = ol; }
-        }
-        if (lane == 0 && !void_record) {
-            if (partial) {
-                if (leaf != NO_LEAF) __hip_atomic_fetch_min((gu64*)a.keys + work, key, RLX_AGENT);   // meets the other parts in k_resolve_split
-            } else {
-                float t = leaf != NO_LEAF ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
-                store_contact(a, r.out_index, r.pixel, t, leaf);
+        // ---------------- results: lane s < LONG_BATCH finishes slot s ----------------
+        __builtin_amdgcn_wave_barrier();
+        if (lane < LONG_BATCH) {
+            const uint32_t flags = __float_as_uint(ray[lane][2].w);
+            if (flags & LONG_LIVE) {
+                const unsigned long long key = keys[lane];
+                const uint32_t work = __float_as_uint(ray[lane][1].w);
+                if (flags & LONG_PARTIAL) {
+                    if (key != KEY_NONE) __hip_atomic_fetch_min((gu64*)a.keys + work, key, RLX_AGENT);   // meets the other parts in k_resolve_split
+                } else {
+                    const uint32_t leaf = key != KEY_NONE ? a.pairs[(uint32_t)key].y : NO_LEAF;
+                    const float t = key != KEY_NONE ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
+                    store_contact(a, __float_as_uint(ray[lane][3].x), __float_as_uint(ray[lane][3].y), t, leaf);
+                }
             }
         }
-        // next task
-        i = 0xFFFFFFFFu;
-        uint32_t dyn = count > a.n_waves ? count - a.n_waves : 0u;
+        __builtin_amdgcn_wave_barrier();
+        // next batch
+        bi = 0xFFFFFFFFu;
+        uint32_t dyn = n_batches > a.n_waves ? n_batches - a.n_waves : 0u;
         uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
-        while (i == 0xFFFFFFFFu && shards_tried < WORK_SHARDS) {
+        while (bi == 0xFFFFFFFFu && shards_tried < WORK_SHARDS) {
             uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
             uint32_t got = 0xFFFFFFFFu;
             if (lo < hi) {
                 if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->lshard[shard].next, 1u, RLX_AGENT);
                 got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             }
-            if (lo < hi && got < hi - lo) i = a.n_waves + lo + got;
+            if (lo < hi && got < hi - lo) bi = a.n_waves + lo + got;
             else { shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u; shards_tried++; }
         }
-        if (i == 0xFFFFFFFFu) break;
+        if (bi == 0xFFFFFFFFu) break;
     }
 }
 
