@@ -110,6 +110,7 @@ struct TraceArgs {
     uint32_t* packet_spill;                // packet kernels: overflow areas of the (node, mask) stack, handed out on demand;
     uint32_t packet_spill_entries;         // the first packet_spill_slots / 32 words are the bitmap of areas in use
     uint32_t packet_spill_slots;
+    uint32_t long_batch;                   // experiment knob: rays per wave in the wave-per-ray kernel (0 = by count)
     uint32_t persistent;                   // resident waves pull blocks from the work counters (RTMI_PERSISTENT=1)
     uint32_t diagnostics;                  // count the wave-per-ray kernel's pool steps (perturbs its timing)
     // primary rays
@@ -895,14 +896,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// phase 1: LONG_BATCH deferred rays per wave, 64 lanes walk their sub-trees together
+// phase 1: up to LONG_BATCH deferred rays per wave, 64 lanes walk their sub-trees together
 // ------------------------------------------------------------------------------------------------
 // One deferred ray keeps 16-37 of 64 lanes busy per pool step (ClumsyDragon / Tenryuu, RTMI_TRACE_DIAG=1) and the kernel is
-// bound by instruction issue, so a wave takes LONG_BATCH records at once: pool entries carry the ray's slot in their top
+// bound by instruction issue, so a wave takes several records at once: pool entries carry the ray's slot in their top
 // bits, the rays live in LDS (two 16-byte reads per lane and step instead of registers), and hits meet in a 64-bit
 // (t bits, position) key per slot through an LDS atomic min -- the same lexicographic minimum the one-ray version reduced
 // at the end, so results do not depend on which rays share a wave.
-#define LONG_BATCH 4u
+#define LONG_BATCH 4u                          // most rays per wave; the kernel takes 1, 2 or 4 (see `batch`)
 #define LONG_SLOT_SHIFT 28u                     // ids below 2^28: rt_bvh_construct refuses more than 2^27 triangles
 #define LONG_ID_MASK 0x0FFFFFFFu
 #define LONG_LIVE 1u
@@ -926,7 +927,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
     gu32* error_word = (gu32*)&a.ctrl->error;
     uint32_t count = a.ctrl->long_count;                  // written by the previous kernel
     if (count > a.long_cap) count = a.long_cap;
-    const uint32_t n_batches = (count + LONG_BATCH - 1u) / LONG_BATCH;
+    // rays per wave: sharing a wave pays only while there are more records than resident waves (a frame with few deferred
+    // rays is latency bound, and four rays in one wave are then four times the latency: ClumsyDragon 0.11 -> 0.15 ms)
+    // (Tenryuu, 63 k / 110 k records on ~6 k resident waves: 0.47 / 0.73 ms alone, 0.36 / 0.50 in pairs, 0.37 / 0.46 in fours,
+    // 0.48 / 0.56 in eights)
+    const uint32_t batch = a.long_batch ? a.long_batch : count >= 4u * a.n_waves ? 4u : count >= a.n_waves ? 2u : 1u;
+    const uint32_t n_batches = (count + batch - 1u) / batch;
 
     // deferred rays differ in length by an order of magnitude: the first batch of a wave is static (its own index),
     // further batches are pulled from sharded counters
@@ -934,9 +940,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
     uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
     for (;;) {
         if (bi >= n_batches) break;
-        // ---------------- set the batch up: lane s < LONG_BATCH prepares slot s ----------------
-        if (lane < LONG_BATCH) {
-            const uint32_t i = bi * LONG_BATCH + lane;
+        // ---------------- set the batch up: lane s < batch prepares slot s ----------------
+        if (lane < batch) {
+            const uint32_t i = bi * batch + lane;
             bool live = i < count;
             const uint32_t* rec = a.long_list + (uint64_t)(live ? i : 0u) * LONG_REC_WORDS;
             uint32_t work = live ? rec[LR_WORK] : 0xFFFFFFFFu;
@@ -969,9 +975,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         __builtin_amdgcn_wave_barrier();
         // ---------------- seed the pools, slot by slot: lanes 0..sp-1 take the stack, lanes 62/63 the current node and the extra child
         uint32_t n_inner = 0, n_leaf = 0;
-        for (uint32_t sl = 0; sl < LONG_BATCH; sl++) {
+        for (uint32_t sl = 0; sl < batch; sl++) {
             if ((__float_as_uint(ray[sl][2].w) & LONG_LIVE) == 0u) continue;                 // wave-uniform
-            const uint32_t* rec = a.long_list + (uint64_t)(bi * LONG_BATCH + sl) * LONG_REC_WORDS;
+            const uint32_t* rec = a.long_list + (uint64_t)(bi * batch + sl) * LONG_REC_WORDS;
             // header words are read by every lane (same address: one broadcast fetch of the 128-byte record)
             const uint32_t rcur = rec[LR_CUR], rsp = rec[LR_SP], rextra = rec[LR_EXTRA], rpending = rec[LR_PENDING];
             uint32_t seed = RT_SENTINEL;
@@ -1097,9 +1103,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             __hip_atomic_fetch_max((gu32*)&a.ctrl->long_steps_max, pool_steps, RLX_AGENT);
             __hip_atomic_fetch_add((gu32*)&a.ctrl->long_nodes, pool_nodes, RLX_AGENT);
         }
-        // ---------------- results: lane s < LONG_BATCH finishes slot s ----------------
+        // ---------------- results: lane s < batch finishes slot s ----------------
         __builtin_amdgcn_wave_barrier();
-        if (lane < LONG_BATCH) {
+        if (lane < batch) {
             const uint32_t flags = __float_as_uint(ray[lane][2].w);
             if (flags & LONG_LIVE) {
                 const unsigned long long key = keys[lane];
@@ -1237,6 +1243,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
     a.n_leaves = t.n_leaves;
     a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u; a.persistent = t.persistent ? 1u : 0u;
+    { static int lb = -1; if (lb < 0) { const char* e = getenv("RTMI_LONG_BATCH"); lb = e ? atoi(e) : 0; if (lb < 0 || lb > (int)LONG_BATCH) lb = 0; } a.long_batch = (uint32_t)lb; }
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
