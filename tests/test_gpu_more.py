@@ -249,6 +249,42 @@ def test_forced_trace_strategies_and_full_deferred_list(packet, budget, list_max
         ctx.close()
 
 
+@pytest.mark.parametrize('batch', ['1', '2', '4'])
+def test_wave_per_ray_kernel_with_one_two_and_four_rays_per_wave(batch, monkeypatch):
+    """The wave-per-ray kernel walks 1, 2 or 4 deferred rays per wave (chosen from the number of deferred rays per resident
+    wave; forced here with RTMI_LONG_BATCH): pool entries carry the ray's slot, hits meet in an LDS atomic min on
+    (t, position).  Small hand-over budgets send most rays through it -- whole rays from the lane-per-ray kernel, partial
+    rays (sub-trees) from the packet kernel -- and the contacts are the oracle's for every batch size, primary rays and
+    ray buffers alike."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    import oracle as orc
+    monkeypatch.setenv('RTMI_LONG_BATCH', batch)
+    monkeypatch.setenv('RTMI_POISON', '7')
+    for packet, budget in (('0', '8'), ('1', '64')):
+        monkeypatch.setenv('RTMI_PACKET', packet)
+        monkeypatch.setenv('RTMI_DEFER_BUDGET', budget)
+        ctx = capi.Context(0)
+        try:
+            for name, res in (('tenryuu', (320, 240)), ('man', (200, 150)), ('clumsydragon', (256, 192))):
+                osc, ob = oracle_bvh(name)
+                sc = capi.DeviceScene(ctx, packed_scene(name))
+                gb = capi.DeviceBVH(ctx, sc).build()
+                cam = osc.demo_camera(*res)
+                want, _ = ob.trace_primary(cam)
+                for _ in range(2):
+                    got = gb.generate_contacts_primary(as_capi_camera(cam))
+                    assert got.tobytes() == want.tobytes(), (name, packet, budget, batch)
+                assert ctx.last_trace_counters()['deferred_rays'] > 200
+                if packet == '0':
+                    rays = orc.generate_rays(cam)[::3].copy()                      # a ragged ray buffer through the same kernels
+                    want_r, _ = ob.trace_rays(rays)
+                    assert gb.generate_contacts_rays(rays).tobytes() == want_r.tobytes()
+                gb.close(); sc.close()
+        finally:
+            ctx.close()
+
+
 def test_search_tree_is_an_implementation_detail(monkeypatch):
     """primary rays walk the search tree by default and the reference tree with RTMI_SEARCH_TREE=0: same bytes, and both
     are the oracle's (which walks the reference tree in the reference's order)"""

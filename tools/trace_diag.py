@@ -1,4 +1,5 @@
-"""experiment: wave-per-ray phase diagnostics per bundled scene at 1920x1080"""
+"""Diagnostics of the two traversal phases per bundled scene at 1920x1080: strategy, deferred rays, pool steps and nodes of the
+wave-per-ray kernel (RTMI_TRACE_DIAG=1 for the last two; the counting perturbs the timings printed beside them)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
