@@ -298,6 +298,9 @@ def main():
                     concurrent_streams=len(SCENES),
                     timed_region_launch_span_ms=round(trace_ms_concurrent, 4),
                     achieved_all_streams=round(achieved_device, 1),
+                    measured_hbm_gbps=(round(traffic / (trace_ms_avg * 1e-3) / 1e9, 1) if traffic else None),
+                    measured_hbm_frac=(round(traffic / (trace_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None),
+                    binds='instruction issue (VALU / SALU) on cache-resident records, not HBM: frac > 1 and measured_hbm_frac say so',
                     algorithmic_bytes_per_launch=int(walked_per_launch),
                     reference_algorithm_bytes_per_launch=int(alg_per_launch),
                     achieved_reference_algorithm=round(achieved_ref, 1),
@@ -309,7 +312,8 @@ def main():
                          'device as a whole (the walked records are L2-resident for the small scenes, hence above the HBM peak).  '
                          'Bytes: 56 B per inner record + 40 B per triangle + 32 B contact of the hierarchy actually '
                          'walked (search tree over the reference leaves); *_reference_algorithm is the same time against the bytes '
-                         'the reference traversal order would touch (SURVEY.md 8(d)); traffic = measured HBM bytes per launch')
+                         'the reference traversal order would touch (SURVEY.md 8(d)); traffic = measured HBM bytes per launch (rocprofv3 FETCH_SIZE / '
+                         'WRITE_SIZE passes, profiles/traffic_latest.json), measured_hbm_* = that traffic over the same launch duration')
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
