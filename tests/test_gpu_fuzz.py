@@ -136,3 +136,55 @@ def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
             gg.close()
     finally:
         gb.close(); sc.close()
+
+
+@pytest.mark.parametrize('knobs', [dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='1048576'),
+                                   dict(RTMI_PACKET='1', RTMI_DEFER_BUDGET='16'),
+                                   dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='4', RTMI_LONG_BATCH='4'),
+                                   dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='4', RTMI_LONG_BATCH='2'),
+                                   dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='1048576')],
+                         ids=['packet4', 'packet16', 'lane4-batch4', 'lane4-batch2', 'lane-inf'])
+@pytest.mark.parametrize('seed,kind,n', [(21, 'uniform', 700), (22, 'clustered', 1200), (23, 'lattice', 200), (24, 'degenerate', 900),
+                                         (25, 'lattice', 24), (26, 'uniform', 3)])
+def test_random_scene_under_every_forced_strategy(tmp_path, monkeypatch, seed, kind, n, knobs):
+    """the same kind of soups and cameras (outside, inside, on a box plane, rotated) with the first-phase kernel and the
+    hand-over budget forced: four-wide packet kernel (unsafe rays go to the wave-per-ray kernel), binary packet kernel that
+    sheds almost everything as partial rays, lane-per-ray kernel that hands nearly every ray over after four steps (wave-
+    per-ray kernel with two and four rays per wave), lane-per-ray kernel alone.  Primary rays and a ray buffer."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv('RTMI_POISON', '7')
+    rng = np.random.default_rng(seed)
+    tris = _soup(rng, n, kind)
+    buf = _write_scene(tmp_path, 'fuzz%d' % seed, tris)
+    osc = orc.Scene(buf)
+    ob = orc.BVH(osc, 0)
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, buf)
+        gb = capi.DeviceBVH(ctx, sc).build()
+        res = (104, 72)
+        for k, cam in enumerate(_cameras(orc, osc, res, rng, tris)):
+            want, _ = ob.trace_primary(cam)
+            for _ in range(2):
+                got = gb.generate_contacts_primary(as_capi_camera(cam))
+                assert got.tobytes() == want.tobytes(), ('bvh', kind, seed, k, knobs, gb.search_tree())
+        m = 1501
+        rays = np.zeros(m, dtype=orc.RAY)
+        rays['idx'] = np.arange(m)
+        lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+        rays['origin'][:, :3] = rng.uniform(lo - 1.0, hi + 1.0, size=(m, 3)).astype(np.float32)
+        rays['origin'][::5, :3] = tris.reshape(-1, 3)[rng.integers(0, len(tris) * 3, size=len(rays[::5]))]
+        dd = rng.normal(size=(m, 3)).astype(np.float32)
+        dd /= np.linalg.norm(dd, axis=1, keepdims=True).astype(np.float32)
+        dd[::7] *= np.float32(1000.0)
+        dd[1::11, 0] = 0.0
+        dd[2::13, 1] = 0.0
+        rays['direction'][:, :3] = dd
+        want, _ = ob.trace_rays(rays)
+        assert gb.generate_contacts_rays(rays.view(capi.RAY)).tobytes() == want.tobytes(), ('bvh rays', kind, seed, knobs)
+        gb.close(); sc.close()
+    finally:
+        ctx.close()
