@@ -364,6 +364,11 @@ static void free_build_buffers(rt_bvh* b)
     b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
     if (b->d_tree_select) (void)hipFree(b->d_tree_select);
     b->d_tree_select = nullptr; b->have_search_tree = false;
+    if (b->s_nodes) (void)hipFree(b->s_nodes);
+    if (b->s_pairs) (void)hipFree(b->s_pairs);
+    if (b->s_counters) (void)hipFree(b->s_counters);
+    if (b->s_pos) (void)hipFree(b->s_pos);
+    b->s_nodes = nullptr; b->s_pairs = nullptr; b->s_counters = nullptr; b->s_pos = nullptr;
     b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
     b->d_depth = nullptr; b->d_pos = nullptr;
 }
@@ -397,6 +402,12 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         RT_HIP(ctx, hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t)));
         RT_HIP(ctx, hipMalloc((void**)&b->d_tree_select, 256));
         if (!ctx->no_packet4) RT_HIP(ctx, hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * (ctx->no_search_tree ? 1u : 2u)));
+        if (!ctx->no_search_tree) {                   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
+            RT_HIP(ctx, hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node)));
+            RT_HIP(ctx, hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2)));
+            RT_HIP(ctx, hipMalloc((void**)&b->s_counters, (size_t)n * sizeof(uint32_t) + 256));
+            RT_HIP(ctx, hipMalloc((void**)&b->s_pos, (size_t)n * sizeof(uint32_t)));
+        }
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -424,43 +435,27 @@ int rt_bvh_construct(rt_bvh* b)
     RT_HIP(ctx, hipGetLastError());
     uint32_t depth = 0;
     RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
-    // search tree for primary rays: same leaves, better order.  Working buffers are temporary.
-    rt_bvh_node* s_nodes = nullptr; uint2* s_pairs = nullptr; uint32_t* s_counters = nullptr; uint32_t* s_pos = nullptr;
+    // search tree for primary rays: same leaves, better order
     uint32_t search_depth = 0;
     b->have_search_tree = false;
     if (!ctx->no_search_tree) {
         const uint32_t n = b->n, N = b->N;
-        hipError_t e = hipMalloc((void**)&s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
-        if (e == hipSuccess) e = hipMalloc((void**)&s_pairs, (size_t)N * sizeof(uint2));
-        if (e == hipSuccess) e = hipMalloc((void**)&s_counters, (size_t)n * sizeof(uint32_t) + 256);
-        if (e == hipSuccess) e = hipMalloc((void**)&s_pos, (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess) {
-            (void)hipMemsetAsync(s_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s);
-            (void)hipMemcpyAsync(s_nodes, b->d_nodes, (size_t)n * sizeof(rt_bvh_node), hipMemcpyDeviceToDevice, s);   // the leaves
-            (void)hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s);
-            (void)hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s);
-            launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
-            launch_bitonic_sort(s, s_pairs, N);
-            launch_radix_tree(s, s_nodes, s_pairs, n);
-            launch_refit(s, s_nodes, s_counters, n);
-            uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
-            launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, s_depth, n - 1);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s);
-        }
-        if (e != hipSuccess) {
-            (void)hipStreamSynchronize(s);
-            if (s_nodes) (void)hipFree(s_nodes); if (s_pairs) (void)hipFree(s_pairs);
-            if (s_counters) (void)hipFree(s_counters); if (s_pos) (void)hipFree(s_pos);
-            return RT_FAIL(ctx, std::string("search tree build failed: ") + hipGetErrorString(e));
-        }
+        rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
+        RT_HIP(ctx, hipMemsetAsync(s_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
+        RT_HIP(ctx, hipMemcpyAsync(s_nodes, b->d_nodes, (size_t)n * sizeof(rt_bvh_node), hipMemcpyDeviceToDevice, s));   // the leaves
+        RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));
+        RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
+        launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
+        launch_bitonic_sort(s, s_pairs, N);
+        launch_radix_tree(s, s_nodes, s_pairs, n);
+        launch_refit(s, s_nodes, s_counters, n);
+        uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
+        launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, s_depth, n - 1);
+        RT_HIP(ctx, hipGetLastError());
+        RT_HIP(ctx, hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s));
     }
     if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (ctx->no_search_tree ? 1u : 2u));
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
-    if (s_nodes) (void)hipFree(s_nodes);
-    if (s_pairs) (void)hipFree(s_pairs);
-    if (s_counters) (void)hipFree(s_counters);
-    if (s_pos) (void)hipFree(s_pos);
     b->max_depth = depth;
     b->search_depth = search_depth;
     // (a degenerate model -- thousands of coincident box centres -- makes this tree as deep as the reference's: no gain then,

@@ -118,6 +118,10 @@ struct rt_bvh {
     bool have_search_tree = false;     // d_trav holds 2(n-1) records: reference tree, then the search tree (primary rays)
     uint32_t* d_tree_select = nullptr; // 1 word, bit k: the camera's coordinate k equals a box plane (k_prepare_camera)
     uint32_t search_depth = 0;
+    rt_bvh_node* s_nodes = nullptr;    // working set of the search-tree build (kept between builds)
+    uint2* s_pairs = nullptr;
+    uint32_t* s_counters = nullptr;
+    uint32_t* s_pos = nullptr;
     uint32_t* d_packet_spill = nullptr;   // packet kernels: bitmap + stack overflow areas, sized from the tree depth
     uint32_t packet_spill_entries = 0;
     uint32_t packet_spill_slots = 0;      // overflow areas = resident waves the device can hold (multiple of 32)
