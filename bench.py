@@ -151,9 +151,10 @@ def main():
         if tiled:
             slots0 = capi.tiles_owned_pixels(cam, 0, world)      # rank 0 owns the most tiles: gather slot size
             item['slots0'] = slots0
-            item['send'] = torch.zeros((slots0, 4), dtype=torch.float32, device=dev)
+            # 12-byte wire format: three float planes per rank, hit flag in the sign bit of red (rt_shade_blinn_phong_tiled_packed)
+            item['send'] = torch.zeros((3, slots0), dtype=torch.float32, device=dev)
             if rank == 0:
-                item['gathered'] = torch.empty((world, slots0, 4), dtype=torch.float32, device=dev)
+                item['gathered'] = torch.empty((world, 3, slots0), dtype=torch.float32, device=dev)
                 item['frame'] = torch.empty((npx, 4), dtype=torch.float32, device=dev)
         work.append(item)
 
@@ -167,8 +168,8 @@ def main():
             else:
                 it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
                 # shade straight into the fixed-size send buffer (ranks own slots <= slots0)
-                capi.shade_blinn_phong_tiled_d(c, it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
-                                               it['send'].data_ptr())
+                capi.shade_blinn_phong_tiled_packed_d(c, it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
+                                                      it['send'].data_ptr(), it['slots0'])
                 # the one collective of a frame: issued from the frame's stream, runs on the communicator's stream
                 with torch.cuda.stream(it['tstream']):
                     _, w = frame_tiles.gather_to_root(it['send'], world, rank, out=it.get('gathered'), async_op=True)
@@ -177,7 +178,7 @@ def main():
             with torch.cuda.stream(it['tstream']):
                 w.wait()                               # orders the frame's stream behind its gather
             if rank == 0:
-                capi.untile_rgba_d(it['ctx'], it['cam'], world, it['gathered'].data_ptr(), it['slots0'], it['frame'].data_ptr())
+                capi.untile_rgba_packed_d(it['ctx'], it['cam'], world, it['gathered'].data_ptr(), it['slots0'], it['frame'].data_ptr())
 
     def fence():
         if dist is not None:
@@ -363,7 +364,7 @@ def main():
                config=dict(workload='5 bundled TestModels scenes x 1920x1080 primary rays, BVH traversal + Blinn-Phong shading',
                            rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES,
                            parallelism=('single GPU, the five frames of a step on five HIP streams' if world == 1 else
-                                        '64x64 frame tiles round-robin over %d ranks, one gather of RGBA to rank 0 per frame, '
+                                        '64x64 frame tiles round-robin over %d ranks, one gather of RGBA (12 B per pixel on the wire) to rank 0 per frame, '
                                         'the five frames of a step on five HIP streams per rank' % world)),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),

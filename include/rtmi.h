@@ -202,6 +202,15 @@ int  rt_shade_blinn_phong_tiled(rt_ctx* ctx, const rt_scene* scene, const rt_cam
                                 uint32_t nranks, const void* d_contacts_compact, void* d_rgba_compact);
 int  rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgba_gathered,
                     uint32_t slots_per_rank, void* d_rgba_frame);
+/* The same pair with a 12-byte-per-slot wire format for the gather (the links into the root bound a tiled frame): the
+ * compact buffer is three float planes of slots_per_rank slots each -- red, green, blue -- and the hit flag (alpha is 1 for
+ * a hit, 0 for a miss, colours are clamped to [0, 1]) travels in the sign bit of the red plane.  rt_untile_rgba_packed
+ * takes nranks such buffers back to back and writes the same RGBA frame, bit for bit, as the 16-byte pair above.     */
+int  rt_shade_blinn_phong_tiled_packed(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint32_t rank,
+                                       uint32_t nranks, const void* d_contacts_compact, void* d_rgb_planes,
+                                       uint32_t slots_per_rank);
+int  rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgb_planes_gathered,
+                           uint32_t slots_per_rank, void* d_rgba_frame);
 
 /* ---- parallel primitives used by the builders ------------------------------------------- */
 /* BitonicSort::sort (Include/Algorithms/Sorting.h:77, BitonicSort.cpp:118-189): uint2 pairs, key = .x,

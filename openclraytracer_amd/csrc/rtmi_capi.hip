@@ -777,6 +777,35 @@ int rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const voi
     return RT_SUCCESS;
 }
 
+int rt_shade_blinn_phong_tiled_packed(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks,
+                                      const void* d_contacts_compact, void* d_rgb_planes, uint32_t slots_per_rank)
+{
+    if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (!d_contacts_compact || !d_rgb_planes) return RT_FAIL(ctx, "null buffer");
+    uint32_t count = rt_tiles_owned_pixels(cam, rank, nranks);
+    if (slots_per_rank < count || slots_per_rank == 0) return RT_FAIL(ctx, "slots_per_rank too small");
+    RT_ENTER(ctx);
+    launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts_compact, count, (float4*)d_rgb_planes, true,
+                 rank, nranks, slots_per_rank);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgb_planes_gathered,
+                          uint32_t slots_per_rank, void* d_rgba_frame)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (nranks == 0 || !d_rgb_planes_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
+    if (slots_per_rank < rt_tiles_owned_pixels(cam, 0, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
+    RT_ENTER(ctx);
+    launch_untile_rgba_packed(ctx->stream, *cam, nranks, (const float*)d_rgb_planes_gathered, slots_per_rank, (float4*)d_rgba_frame);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
 // ---------------------------------------------------------------------------------------
 // primitives
 // ---------------------------------------------------------------------------------------

@@ -260,9 +260,11 @@ void launch_secondary_emit(hipStream_t s, const rt_camera* cam, const rt_ray* ra
                            const uint32_t* scan, int kind, const float target[3], float eps, rt_ray* out);
 // shade_kernels.hip
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,
-                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks);
+                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks, uint32_t plane_stride = 0);
 void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,
                         uint32_t slots_per_rank, float4* frame);
+void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* gathered,
+                               uint32_t slots_per_rank, float4* frame);
 
 // tiling helpers shared by host and device (64x64-pixel tiles dealt round-robin)
 #define RT_TILE 64u

@@ -16,6 +16,7 @@ struct ShadeArgs {
     uint32_t count;
     float4* __restrict__ rgba;
     uint32_t tiled, rank, nranks, tiles_x;
+    uint32_t plane_stride;                     // != 0: three float planes (r with the hit flag in its sign bit, g, b) of this many slots
 };
 
 __device__ __forceinline__ float light_energy_percentage(float distance, float lightEnergy)
@@ -88,12 +89,24 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
     // untiled: exactly RTFrame -- the frame was cleared by the launcher (memset at :298) and only hits are
     //          stored, at colors[contact.pixelIndex] (:305-311);
     // tiled  : compact slot i keeps its slot, misses and out-of-frame slots store zeros.
+    if (a.plane_stride) {
+        // packed compact buffer for the gather: 12 bytes per slot instead of 16.  Alpha is 1 for a hit and 0 for a miss
+        // (Shading.h:164 / the cleared frame) and colours are clamped to [0, 1], so the hit flag travels in the sign bit of
+        // the red plane (a hit with red 0 is -0.0f) and rt_untile_rgba_packed restores RGBA bit for bit.
+        float* planes = reinterpret_cast<float*>(a.rgba);
+        float4 col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (nt.w > 0.0f) { col = shade_one(a, c); col.x = __uint_as_float(__float_as_uint(col.x) | 0x80000000u); }
+        planes[i] = col.x;
+        planes[(size_t)a.plane_stride + i] = col.y;
+        planes[2u * (size_t)a.plane_stride + i] = col.z;
+        return;
+    }
     if (nt.w > 0.0f) a.rgba[a.tiled ? i : c.pixelIndex] = shade_one(a, c);
     else if (a.tiled) a.rgba[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,
-                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks)
+                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks, uint32_t plane_stride)
 {
     if (!count) return;
     ShadeArgs a{};
@@ -101,7 +114,7 @@ void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, co
     a.n_lights = sc.n_lights; a.n_spheres = sc.n_spheres; a.n_materials = sc.n_materials;
     a.cam = cam;
     a.contacts = contacts; a.count = count; a.rgba = rgba;
-    a.tiled = tiled ? 1u : 0u; a.rank = rank; a.nranks = nranks; a.tiles_x = rt_tiles_x(cam.resX);
+    a.tiled = tiled ? 1u : 0u; a.rank = rank; a.nranks = nranks; a.tiles_x = rt_tiles_x(cam.resX); a.plane_stride = plane_stride;
     if (!tiled) (void)hipMemsetAsync(rgba, 0, (size_t)cam.resX * cam.resY * sizeof(float4), s);   // memset(colors,0), :298
     hipLaunchKernelGGL(k_shade, dim3((count + 255) / 256), dim3(256), 0, s, a);
 }
@@ -118,6 +131,30 @@ __global__ __launch_bounds__(256) void k_untile_rgba(rt_camera cam, uint32_t nra
     uint32_t rank = tile % nranks, ordinal = tile / nranks;
     uint32_t slot = ordinal * (RT_TILE * RT_TILE) + (y - ty * RT_TILE) * RT_TILE + (x - tx * RT_TILE);
     frame[pixel] = gathered[(uint64_t)rank * slots_per_rank + slot];
+}
+
+// the same from the packed planes of rt_shade_blinn_phong_tiled_packed: gathered[r][plane][slot]
+__global__ __launch_bounds__(256) void k_untile_rgba_packed(rt_camera cam, uint32_t nranks, const float* __restrict__ gathered,
+                                                            uint32_t slots_per_rank, float4* __restrict__ frame)
+{
+    uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixel >= cam.resX * cam.resY) return;
+    uint32_t y = pixel / cam.resX, x = pixel - y * cam.resX;
+    uint32_t tx = x / RT_TILE, ty = y / RT_TILE;
+    uint32_t tile = ty * rt_tiles_x(cam.resX) + tx;
+    uint32_t rank = tile % nranks, ordinal = tile / nranks;
+    uint32_t slot = ordinal * (RT_TILE * RT_TILE) + (y - ty * RT_TILE) * RT_TILE + (x - tx * RT_TILE);
+    const float* g = gathered + (uint64_t)rank * 3u * slots_per_rank + slot;
+    const uint32_t r = __float_as_uint(g[0]);
+    frame[pixel] = make_float4(__uint_as_float(r & 0x7FFFFFFFu), g[slots_per_rank], g[2u * (uint64_t)slots_per_rank],
+                               (r & 0x80000000u) ? 1.0f : 0.0f);
+}
+
+void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* gathered,
+                               uint32_t slots_per_rank, float4* frame)
+{
+    uint32_t n = cam.resX * cam.resY;
+    hipLaunchKernelGGL(k_untile_rgba_packed, dim3((n + 255) / 256), dim3(256), 0, s, cam, nranks, gathered, slots_per_rank, frame);
 }
 
 void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,

@@ -49,6 +49,36 @@ def untile_host(gathered: np.ndarray, resx: int, resy: int) -> np.ndarray:
     return gathered[r, s]
 
 
+def pack_planes(rgba: np.ndarray) -> np.ndarray:
+    """== what rt_shade_blinn_phong_tiled_packed writes for a compact RGBA buffer: three float planes, 12 bytes per slot
+    instead of 16; alpha (1 for a hit, 0 for a miss) travels in the sign bit of the red plane (colours are in [0, 1])."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.ascontiguousarray(rgba[:, :3].T).copy()
+    red = out[0].view(np.uint32)
+    red |= np.where(rgba[:, 3] != 0.0, np.uint32(0x80000000), np.uint32(0))
+    return out
+
+
+def unpack_planes(planes: np.ndarray) -> np.ndarray:
+    """inverse of pack_planes: [3, slots] -> [slots, 4]"""
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    bits = planes[0].view(np.uint32)
+    out = np.empty((planes.shape[1], 4), dtype=np.float32)
+    out[:, 0] = (bits & np.uint32(0x7FFFFFFF)).view(np.float32)
+    out[:, 1] = planes[1]
+    out[:, 2] = planes[2]
+    out[:, 3] = np.where(bits & np.uint32(0x80000000), np.float32(1.0), np.float32(0.0))
+    return out
+
+
+def untile_host_packed(gathered: np.ndarray, resx: int, resy: int) -> np.ndarray:
+    """== rt_untile_rgba_packed: gathered[rank, plane, slot] -> frame[pixel, rgba]"""
+    nranks = gathered.shape[0]
+    r, s = slot_map(resx, resy, nranks)
+    per_rank = np.stack([unpack_planes(gathered[k]) for k in range(nranks)])
+    return per_rank[r, s]
+
+
 def gather_to_root(send, world: int, rank: int, out=None, async_op: bool = False):
     """THE collective of the path: one gather of equally sized compact buffers to rank 0
     (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU).

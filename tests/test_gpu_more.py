@@ -99,6 +99,8 @@ def test_tiled_frame_equals_untiled(gpu_ctx, nranks):
     full_rgba = capi.shade_blinn_phong(gpu_ctx, sc, cam, full)
     slots0 = capi.tiles_owned_pixels(cam, 0, nranks)
     gathered = np.zeros((nranks, slots0, 4), dtype=np.float32)
+    packed = np.zeros((nranks, 3, slots0), dtype=np.float32)
+    from openclraytracer_amd import frame_tiles as ft
     rank_of, slot_of = capi.tile_slot_map(res[0], res[1], nranks)
     for r in range(nranks):
         slots = capi.tiles_owned_pixels(cam, r, nranks)
@@ -114,13 +116,26 @@ def test_tiled_frame_equals_untiled(gpu_ctx, nranks):
         other[slot_of[mine]] = False
         assert (compact[other]['normalAndDistance'][:, 3] == 0).all()          # slots outside the frame
         gathered[r, :slots] = rgba
-        gpu_ctx.free(dc); gpu_ctx.free(dr)
+        # the 12-byte wire format of the same buffer: three planes, hit flag in the sign bit of red
+        dp = gpu_ctx.alloc(slots0 * 12)
+        gpu_ctx.fill_u32(dp, 0xDEADBEEF, slots0 * 3)
+        capi.shade_blinn_phong_tiled_packed_d(gpu_ctx, sc, cam, r, nranks, dc, dp, slots0)
+        planes = gpu_ctx.download(dp, slots0 * 3, np.float32).reshape(3, slots0)
+        assert planes[:, :slots].tobytes() == ft.pack_planes(rgba).tobytes()
+        packed[r, :, :slots] = planes[:, :slots]
+        gpu_ctx.free(dc); gpu_ctx.free(dr); gpu_ctx.free(dp)
     dg, df = gpu_ctx.alloc(gathered.nbytes), gpu_ctx.alloc(npx * 16)
     gpu_ctx.upload(dg, gathered)
     capi.untile_rgba_d(gpu_ctx, cam, nranks, dg, slots0, df)
     frame = gpu_ctx.download(df, npx * 4, np.float32).reshape(npx, 4)
+    assert frame.tobytes() == full_rgba.tobytes()
+    gpu_ctx.upload(dg, packed)
+    gpu_ctx.fill_u32(df, 0xDEADBEEF, npx * 4)
+    capi.untile_rgba_packed_d(gpu_ctx, cam, nranks, dg, slots0, df)
+    frame = gpu_ctx.download(df, npx * 4, np.float32).reshape(npx, 4)
     gpu_ctx.free(dg); gpu_ctx.free(df)
     assert frame.tobytes() == full_rgba.tobytes()
+    assert ft.untile_host_packed(packed, res[0], res[1]).tobytes() == full_rgba.tobytes()      # the host statement agrees
 
 
 def test_sort_and_scan_primitives(gpu_ctx):

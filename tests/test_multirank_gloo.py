@@ -45,9 +45,14 @@ def _worker(rank, world, port, res, name, ret):
         out_sync = ft.gather_to_root(torch.from_numpy(send), world, rank)
         if rank == 0:
             assert torch.equal(out, out_sync)
+        # the 12-byte wire format bench.py gathers: three planes per rank, hit flag in the sign bit of red
+        planes = np.zeros((3, slots0), dtype=np.float32)
+        planes[:, :mine] = ft.pack_planes(send[:mine])
+        outp = ft.gather_to_root(torch.from_numpy(planes), world, rank)
         if rank == 0:
             got = ft.untile_host(out.numpy(), res[0], res[1])
-            ret['equal'] = bool(np.array_equal(got, frame))
+            gotp = ft.untile_host_packed(outp.numpy(), res[0], res[1])
+            ret['equal'] = bool(np.array_equal(got, frame)) and gotp.tobytes() == frame.tobytes()
             ret['hits'] = int((frame[:, 3] > 0).sum())
     finally:
         dist.destroy_process_group()
