@@ -149,36 +149,52 @@ def main():
                     contacts=torch.empty(slots * 32, dtype=torch.uint8, device=dev),
                     rgba=torch.empty((slots, 4), dtype=torch.float32, device=dev))
         if tiled:
-            slots0 = capi.tiles_owned_pixels(cam, 0, world)      # rank 0 owns the most tiles: gather slot size
-            item['slots0'] = slots0
-            # 12-byte wire format: three float planes per rank, hit flag in the sign bit of red (rt_shade_blinn_phong_tiled_packed)
-            item['send'] = torch.zeros((3, slots0), dtype=torch.float32, device=dev)
+            item['slots0'] = capi.tiles_owned_pixels(cam, 0, world)      # rank 0 owns the most tiles: gather slot size
             if rank == 0:
-                item['gathered'] = torch.empty((world, 3, slots0), dtype=torch.float32, device=dev)
                 item['frame'] = torch.empty((npx, 4), dtype=torch.float32, device=dev)
         work.append(item)
 
+    if tiled:
+        # The frames of a step travel in ONE gather (fewer, larger collectives: a gather costs ~50 us of host time and the
+        # links into rank 0 are the bound).  12-byte wire format: three float planes per frame and rank,
+        # hit flag in the sign bit of red (rt_shade_blinn_phong_tiled_packed).  The send buffer is double buffered: step k
+        # shades into buffer k & 1 while the gather of step k - 1 may still be reading the other one.
+        slots0 = work[0]['slots0']
+        assert all(it['slots0'] == slots0 for it in work)
+        send = [torch.zeros((len(SCENES), 3, slots0), dtype=torch.float32, device=dev) for _ in range(2)]
+        gathered = torch.empty((world, len(SCENES), 3, slots0), dtype=torch.float32, device=dev) if rank == 0 else None
+        gctx = capi.Context(local_rank)                    # gather + untile stream, ordered behind the five frame streams
+        gstream = torch.cuda.ExternalStream(gctx.get_stream(), device=dev)
+        gather_done = [None, None]                         # event behind the gather that last read send[b]
+        step_no = [0]
+
     def step():
-        pending = []
-        for it in work:
-            c = it['ctx']
-            if not tiled:
+        if not tiled:
+            for it in work:
                 it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
-                capi.shade_blinn_phong_d(c, it['scene'], it['cam'], it['contacts'].data_ptr(), npx, it['rgba'].data_ptr())
-            else:
-                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
-                # shade straight into the fixed-size send buffer (ranks own slots <= slots0)
-                capi.shade_blinn_phong_tiled_packed_d(c, it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
-                                                      it['send'].data_ptr(), it['slots0'])
-                # the one collective of a frame: issued from the frame's stream, runs on the communicator's stream
-                with torch.cuda.stream(it['tstream']):
-                    _, w = frame_tiles.gather_to_root(it['send'], world, rank, out=it.get('gathered'), async_op=True)
-                pending.append((it, w))
-        for it, w in pending:
-            with torch.cuda.stream(it['tstream']):
-                w.wait()                               # orders the frame's stream behind its gather
-            if rank == 0:
-                capi.untile_rgba_packed_d(it['ctx'], it['cam'], world, it['gathered'].data_ptr(), it['slots0'], it['frame'].data_ptr())
+                capi.shade_blinn_phong_d(it['ctx'], it['scene'], it['cam'], it['contacts'].data_ptr(), npx, it['rgba'].data_ptr())
+            return
+        b = step_no[0] & 1
+        step_no[0] += 1
+        for i, it in enumerate(work):
+            if gather_done[b] is not None:
+                it['tstream'].wait_event(gather_done[b])            # send[b] is free again
+            it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
+            # shade straight into this frame's planes of the send buffer (ranks own slots <= slots0)
+            capi.shade_blinn_phong_tiled_packed_d(it['ctx'], it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
+                                                  send[b][i].data_ptr(), slots0)
+            gstream.wait_stream(it['tstream'])
+        with torch.cuda.stream(gstream):
+            # the one collective of a step: issued behind all five frames, runs on the communicator's stream
+            _, w = frame_tiles.gather_to_root(send[b], world, rank, out=gathered, async_op=True)
+            w.wait()                                                 # orders the gather stream behind the gather
+            ev = torch.cuda.Event()
+            ev.record(gstream)
+            gather_done[b] = ev
+        if rank == 0:
+            for i, it in enumerate(work):
+                capi.untile_rgba_packed_d(gctx, it['cam'], world, gathered[0, i].data_ptr(), slots0, it['frame'].data_ptr(),
+                                          rank_stride_floats=len(SCENES) * 3 * slots0)
 
     def fence():
         if dist is not None:
@@ -188,9 +204,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if args.check_frames and tiled:
-        if args.warmup == 0:
-            step(); fence()
+    def check_frames(when):
+        # rank 0 traces and shades every frame untiled and compares it with the one the ranks assembled
         if rank == 0:
             for it in work:
                 full_c = torch.empty(npx * 32, dtype=torch.uint8, device=dev)
@@ -199,9 +214,14 @@ def main():
                 capi.shade_blinn_phong_d(it['ctx'], it['scene'], it['cam'], full_c.data_ptr(), npx, full_rgba.data_ptr())
                 torch.cuda.synchronize(dev)
                 if not torch.equal(full_rgba, it['frame']):
-                    raise SystemExit('frame check failed for %s: the gathered frame differs from the untiled one' % it['name'])
-            print('frame check ok: %d gathered frames equal the untiled ones' % len(work), file=sys.stderr)
+                    raise SystemExit('frame check failed for %s (%s): the gathered frame differs from the untiled one' % (it['name'], when))
+            print('frame check ok (%s): %d gathered frames equal the untiled ones' % (when, len(work)), file=sys.stderr)
         fence()
+
+    if args.check_frames and tiled:
+        if args.warmup == 0:
+            step(); fence()
+        check_frames('after the warm-up')
     for c in ctxs:
         c.set_profiling(True)
     t0 = time.perf_counter()
@@ -210,6 +230,8 @@ def main():
     issued = time.perf_counter() - t0            # host time to issue the steps (the floor when the device part shrinks)
     fence()
     elapsed = time.perf_counter() - t0
+    if args.check_frames and tiled:
+        check_frames('after the timed steps')     # the frames of the last, fully overlapped step
     kt = dict(launches=0, lane_phase_ms=0.0, wave_phase_ms=0.0)
     for c in ctxs:
         k1 = c.trace_kernel_times()

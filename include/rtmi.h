@@ -205,12 +205,13 @@ int  rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const vo
 /* The same pair with a 12-byte-per-slot wire format for the gather (the links into the root bound a tiled frame): the
  * compact buffer is three float planes of slots_per_rank slots each -- red, green, blue -- and the hit flag (alpha is 1 for
  * a hit, 0 for a miss, colours are clamped to [0, 1]) travels in the sign bit of the red plane.  rt_untile_rgba_packed
- * takes nranks such buffers back to back and writes the same RGBA frame, bit for bit, as the 16-byte pair above.     */
+ * takes nranks such buffers, rank r's at d_rgb_planes_gathered + r * rank_stride_floats floats (0 = back to back; a larger
+ * stride lets several frames travel in one gather), and writes the same RGBA frame, bit for bit, as the 16-byte pair. */
 int  rt_shade_blinn_phong_tiled_packed(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint32_t rank,
                                        uint32_t nranks, const void* d_contacts_compact, void* d_rgb_planes,
                                        uint32_t slots_per_rank);
 int  rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgb_planes_gathered,
-                           uint32_t slots_per_rank, void* d_rgba_frame);
+                           uint32_t slots_per_rank, uint64_t rank_stride_floats, void* d_rgba_frame);
 
 /* ---- parallel primitives used by the builders ------------------------------------------- */
 /* BitonicSort::sort (Include/Algorithms/Sorting.h:77, BitonicSort.cpp:118-189): uint2 pairs, key = .x,

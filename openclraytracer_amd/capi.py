@@ -104,7 +104,7 @@ def load_library() -> C.CDLL:
     L.rt_shade_blinn_phong_tiled.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.rt_untile_rgba.argtypes = [vp, vp, u32, vp, u32, vp]
     L.rt_shade_blinn_phong_tiled_packed.argtypes = [vp, vp, vp, u32, u32, vp, vp, u32]
-    L.rt_untile_rgba_packed.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.rt_untile_rgba_packed.argtypes = [vp, vp, u32, vp, u32, u64, vp]
     L.rt_sort_pairs_bitonic.argtypes = [vp, vp, u32]
     L.rt_scan_inclusive_u32.argtypes = [vp, vp, vp, u32]
     L.rt_ctx_set_profiling.argtypes = [vp, i32]
@@ -469,9 +469,9 @@ def shade_blinn_phong_tiled_packed_d(ctx, scene, cam, rank, nranks, d_contacts, 
                                                         C.c_void_p(d_planes), slots_per_rank))
 
 
-def untile_rgba_packed_d(ctx, cam, nranks, d_gathered, slots_per_rank, d_frame):
+def untile_rgba_packed_d(ctx, cam, nranks, d_gathered, slots_per_rank, d_frame, rank_stride_floats=0):
     ctx.check(ctx.lib.rt_untile_rgba_packed(ctx.h, _p(cam), nranks, C.c_void_p(d_gathered), slots_per_rank,
-                                            C.c_void_p(d_frame)))
+                                            rank_stride_floats, C.c_void_p(d_frame)))
 
 
 def untile_rgba_d(ctx, cam, nranks, d_gathered, slots_per_rank, d_frame):

@@ -794,14 +794,17 @@ int rt_shade_blinn_phong_tiled_packed(rt_ctx* ctx, const rt_scene* scene, const 
 }
 
 int rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgb_planes_gathered,
-                          uint32_t slots_per_rank, void* d_rgba_frame)
+                          uint32_t slots_per_rank, uint64_t rank_stride_floats, void* d_rgba_frame)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (nranks == 0 || !d_rgb_planes_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
     if (slots_per_rank < rt_tiles_owned_pixels(cam, 0, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
+    if (rank_stride_floats == 0) rank_stride_floats = 3ull * slots_per_rank;
+    if (rank_stride_floats < 3ull * slots_per_rank) return RT_FAIL(ctx, "rank stride smaller than one rank's planes");
     RT_ENTER(ctx);
-    launch_untile_rgba_packed(ctx->stream, *cam, nranks, (const float*)d_rgb_planes_gathered, slots_per_rank, (float4*)d_rgba_frame);
+    launch_untile_rgba_packed(ctx->stream, *cam, nranks, (const float*)d_rgb_planes_gathered, slots_per_rank, rank_stride_floats,
+                              (float4*)d_rgba_frame);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }

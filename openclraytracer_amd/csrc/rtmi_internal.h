@@ -264,7 +264,7 @@ void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, co
 void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,
                         uint32_t slots_per_rank, float4* frame);
 void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* gathered,
-                               uint32_t slots_per_rank, float4* frame);
+                               uint32_t slots_per_rank, uint64_t rank_stride, float4* frame);
 
 // tiling helpers shared by host and device (64x64-pixel tiles dealt round-robin)
 #define RT_TILE 64u

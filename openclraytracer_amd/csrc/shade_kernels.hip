@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_untile_rgba(rt_camera cam, uint32_t nra
 
 // the same from the packed planes of rt_shade_blinn_phong_tiled_packed: gathered[r][plane][slot]
 __global__ __launch_bounds__(256) void k_untile_rgba_packed(rt_camera cam, uint32_t nranks, const float* __restrict__ gathered,
-                                                            uint32_t slots_per_rank, float4* __restrict__ frame)
+                                                            uint32_t slots_per_rank, uint64_t rank_stride, float4* __restrict__ frame)
 {
     uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
     if (pixel >= cam.resX * cam.resY) return;
@@ -144,17 +144,17 @@ __global__ __launch_bounds__(256) void k_untile_rgba_packed(rt_camera cam, uint3
     uint32_t tile = ty * rt_tiles_x(cam.resX) + tx;
     uint32_t rank = tile % nranks, ordinal = tile / nranks;
     uint32_t slot = ordinal * (RT_TILE * RT_TILE) + (y - ty * RT_TILE) * RT_TILE + (x - tx * RT_TILE);
-    const float* g = gathered + (uint64_t)rank * 3u * slots_per_rank + slot;
+    const float* g = gathered + (uint64_t)rank * rank_stride + slot;
     const uint32_t r = __float_as_uint(g[0]);
     frame[pixel] = make_float4(__uint_as_float(r & 0x7FFFFFFFu), g[slots_per_rank], g[2u * (uint64_t)slots_per_rank],
                                (r & 0x80000000u) ? 1.0f : 0.0f);
 }
 
 void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* gathered,
-                               uint32_t slots_per_rank, float4* frame)
+                               uint32_t slots_per_rank, uint64_t rank_stride, float4* frame)
 {
     uint32_t n = cam.resX * cam.resY;
-    hipLaunchKernelGGL(k_untile_rgba_packed, dim3((n + 255) / 256), dim3(256), 0, s, cam, nranks, gathered, slots_per_rank, frame);
+    hipLaunchKernelGGL(k_untile_rgba_packed, dim3((n + 255) / 256), dim3(256), 0, s, cam, nranks, gathered, slots_per_rank, rank_stride, frame);
 }
 
 void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,

@@ -428,10 +428,11 @@ def test_bench_two_rank_rehearsal_assembles_identical_frames():
     import sys as _sys
     env = dict(os.environ, RTMI_BENCH_REHEARSAL='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([_sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
                         '--check-frames'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert 'frame check ok: 5 gathered frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the warm-up): 5 gathered frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the timed steps): 5 gathered frames equal the untiled ones' in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1
     out = json.loads(line[0])
@@ -448,9 +449,10 @@ def test_bench_tiled_path_on_rccl_with_one_rank():
     env = dict(os.environ, RTMI_BENCH_FORCE_TILED='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT='29533')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
-    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--check-frames',
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '7', '--warmup', '2', '--check-frames',
                         '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert 'frame check ok: 5 gathered frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the warm-up): 5 gathered frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the timed steps): 5 gathered frames equal the untiled ones' in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1 and json.loads(line[0])['value'] > 0
