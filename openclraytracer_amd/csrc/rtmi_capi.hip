@@ -109,7 +109,6 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);
-    if (const char* env = std::getenv("RTMI_PERSISTENT")) ctx->persistent = env[0] == '1';
     if (const char* env = std::getenv("RTMI_TRACE_DIAG")) ctx->trace_diagnostics = env[0] == '1';
     if (const char* env = std::getenv("RTMI_CALIBRATION_LOG")) ctx->calibration_log = env[0] == '1';
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
@@ -491,7 +490,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
-    t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.persistent = b->ctx->persistent; t.diagnostics = b->ctx->trace_diagnostics;
+    t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;
     t.quad = b->d_quad;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;

@@ -85,7 +85,6 @@ struct rt_ctx {
     bool force_packet4 = false, no_packet4 = false; // env RTMI_PACKET=4 / RTMI_PACKET4=0 (no four-wide records at all)
     int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
     bool no_search_tree = false;  // knob (env RTMI_SEARCH_TREE=0): primary rays walk the reference tree
-    bool persistent = false;      // knob (env RTMI_PERSISTENT=1): persistent grids + work counters instead of one wave per block
     bool trace_diagnostics = false; // knob (env RTMI_TRACE_DIAG=1)
     bool calibration_log = false; // knob (env RTMI_CALIBRATION_LOG=1): one stderr line per calibration candidate
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
@@ -212,7 +211,6 @@ struct TraceLaunch {
     hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
     bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
     bool diagnostics;             // knob RTMI_TRACE_DIAG=1: the wave-per-ray kernel counts its pool steps
-    bool persistent;              // resident waves pull blocks from the work counters (old scheme, knob)
     int tag;                      // kernel-name tag: 0 steady state, 1 first-frame calibration, 2 isolated measurement pass
                                   // (rt_ctx_set_profiling(ctx, 2)); same code, separate names in profiles
     bool packet4;                 // with packet: walk the four-wide records

@@ -19,30 +19,30 @@
 //
 // Machine mapping (MI355X, wave64, 256 CUs).  A frame is one first-phase kernel plus, when work was handed over,
 // k_trace_long (+ k_resolve_split); which first-phase kernel and which budget is calibrated per BVH on the first frame
-// (rtmi_capi.hip, trace_primary_tuned):
-//  k_trace, one ray per lane, persistent waves:
-//   * the grid is sized to what is resident; a wave's first 8x8-pixel block is static, further blocks come from 16
-//     sharded counters (one atomic per 64 rays); lanes whose ray has finished are refilled (ballot + prefix-popcount
-//     packing) instead of idling until the slowest ray of the block is done;
+// (rtmi_capi.hip, trace_primary_tuned).  The first-phase kernels run one wave per 64-ray block (8x8 pixels of a primary
+// frame) with the hardware dispatcher as the work queue.
+//  k_trace, one ray per lane:
 //   * the per-lane traversal stack lives in LDS ([level][lane]: one bank per lane, no conflicts);
 //   * one inner-node visit = one 64-byte record holding both child boxes and both child ids (TravNode)
-//     instead of a 48-byte node + two dependent 32-byte box fetches (BVH.h:359-364);
+//     instead of a 48-byte node + two dependent 32-byte box fetches (BVH.h:359-364) -- or, on search-tree records, one
+//     128-byte record holding the node's up to four grandchildren (QuadNode): half the dependent fetches;
 //   * leaves read an SoA triangle table (v0, e1, e2 as float4) instead of chasing ModelHeader /
 //     MeshHeader.dataSize chains and ushort indices (SceneBufferParser.h:175-217); edges and the
 //     geometric normal are ray independent and precomputed with the same operations;
 //   * leaf tests are postponed: a lane parks one reached leaf and keeps walking inner nodes; the wave
 //     runs the triangle code only when a lane needs its slot again or is about to finish;
-//   * a ray that exceeds the iteration budget, or whose stack is full, is DEFERRED: its state (pending
+//   * a ray that is still walking after `defer_budget` steps, or whose stack is full, is DEFERRED: its state (pending
 //     sub-trees, best hit so far) goes to a compact list.  A few rays visit thousands of nodes while most
 //     visit a handful; walked by one lane each they would set the frame time.
 //  k_trace_packet, one 8x8-pixel block per wave: the node is wave-uniform, its record comes through the scalar path
 //     and stays in registers, both children's records are requested before the box tests; (node, lane mask) pairs wait
 //     on an LDS stack; sub-trees only a handful of lanes still want, or everything left once a budget is spent, go to
 //     the deferred list as per-ray partial records whose results meet in a 64-bit atomicMin on (t, position).
-//  k_trace_long, one deferred record per WAVE: the 64 lanes walk the ray's sub-trees together out of an LDS node pool
-//     (64 nodes per step, children appended with ballot/prefix-popcount compaction, spare lanes running ahead along
-//     duplicate-code chains, leaves collected in a second pool and tested 64 at a time), then reduce their
-//     (t, position) candidates with a wave-wide lexicographic min.
+//  k_trace_packet4, the same on the four-wide records of the search tree (two levels per step, nothing handed over).
+//  k_trace_long, one, two or four deferred records per WAVE: the 64 lanes walk the rays' sub-trees together out of an LDS
+//     node pool (64 nodes per step, children appended with ballot/prefix-popcount compaction, spare lanes running ahead
+//     along duplicate-code chains, leaves collected in a second pool and tested 64 at a time); hits meet in a 64-bit
+//     (t, position) key per ray through an LDS atomic min.
 //  k_prepare_camera, per camera position: "camera inside child box" bits of every record and the camera-on-a-plane bits.
 #include "rtmi_internal.h"
 #include "device_math.h"
@@ -51,9 +51,7 @@
 #define TRACE_WAVES (TRACE_BLOCK / 64u)
 #define LDS_STACK 24u            // stack entries per lane in k_trace (observed need at 1080p: <= 18)
 #define NO_LEAF 0xFFFFFFFEu
-#define REFILL_MIN_IDLE 16u      // refill a wave once this many lanes are idle
 #define DEFER_BUDGET_DEFAULT 1024u  // k_trace iterations after which a ray moves to the deferred list (default when nothing was calibrated)
-#define STRAGGLER_BUDGET 96u     // smallest deferral budget of a nearly empty wave once the primary work is gone
 #define LONG_REC_WORDS 32u       // 128-byte record per deferred ray
 #define POOL_INNER 1024u         // phase-1 LDS pool of pending inner nodes (per wave)
 #define POOL_LEAF 256u           // phase-1 LDS pool of pending leaves (per wave)
@@ -66,15 +64,14 @@ uint32_t trace_lds_stack_entries() { return LDS_STACK; }
 // control block, zeroed before every launch; every word on its own 128-byte line
 #define WORK_SHARDS 16u
 struct TraceCtrl {
-    struct { uint32_t next; uint32_t pad[31]; } shard[WORK_SHARDS];   // dynamic primary work: next 64-ray block per shard
-    struct { uint32_t next; uint32_t pad[31]; } lshard[WORK_SHARDS];  // phase 1: next deferred ray per shard
+    struct { uint32_t next; uint32_t pad[31]; } lshard[WORK_SHARDS];  // wave-per-ray kernel: next batch of deferred rays per shard
     uint32_t long_count;  uint32_t p1[31];   // deferred rays
     uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
     uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
     uint32_t spill_taken; uint32_t p4[31];   // packet kernels: overflow areas taken in this launch (diagnostic)
     uint32_t long_steps;  uint32_t long_steps_max; uint32_t long_nodes; uint32_t p5[29];   // wave-per-ray kernel: pool steps, all records / longest record (diagnostic)
 };
-static_assert(sizeof(TraceCtrl) == (2 * WORK_SHARDS + 5) * 128, "TraceCtrl layout");
+static_assert(sizeof(TraceCtrl) == (WORK_SHARDS + 5) * 128, "TraceCtrl layout");
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
 void trace_ctrl_counter_offsets(size_t out[6]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
@@ -111,7 +108,6 @@ struct TraceArgs {
     uint32_t packet_spill_entries;         // the first packet_spill_slots / 32 words are the bitmap of areas in use
     uint32_t packet_spill_slots;
     uint32_t long_batch;                   // experiment knob: rays per wave in the wave-per-ray kernel (0 = by count)
-    uint32_t persistent;                   // resident waves pull blocks from the work counters (RTMI_PERSISTENT=1)
     uint32_t diagnostics;                  // count the wave-per-ray kernel's pool steps (perturbs its timing)
     // primary rays
     rt_camera cam;
@@ -326,64 +322,25 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
     bool active = false;
     bool may_defer = true;            // false once the long-ray list turned out to be full
 
-    const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;          // 8x8 blocks (or 64-ray chunks)
-    uint32_t res_next = wave_gid << 6, res_end = res_next + 64u;   // reserved work items [res_next, res_end)
-    bool exhausted = wave_gid >= n_blocks8;                        // wave-uniform: no primary work left
-    uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;     // wave-uniform: position in the shard walk
-    uint32_t drain_budget = a.defer_budget;                        // wave-uniform: current deferral budget
-
-    for (;;) {
-        // ---------------- refill idle lanes (wavefront ballot / compaction) ----------------
-        if (!exhausted) {
-            uint64_t idle = __ballot(!active);
-            uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (n_idle >= REFILL_MIN_IDLE) {
-                while (res_next == res_end && !exhausted) {
-                    // dynamic blocks [n_waves, n_blocks8) are cut into WORK_SHARDS contiguous shards, each with its
-                    // own counter line (one word saturates near 88 atomics/us: 26 k atomics were the whole frame time
-                    // of the easy scenes); a wave drains its home shard first and then walks the others
-                    uint32_t dyn = n_blocks8 > a.n_waves ? n_blocks8 - a.n_waves : 0u;
-                    uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
-                    uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
-                    uint32_t got = 0xFFFFFFFFu;
-                    if (lo < hi) {
-                        if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->shard[shard].next, 1u, RLX_AGENT);
-                        got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                    }
-                    if (lo < hi && got < hi - lo) {
-                        res_next = (a.n_waves + lo + got) << 6; res_end = res_next + 64u;
-                    } else {
-                        shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u;
-                        if (++shards_tried >= WORK_SHARDS) exhausted = true;
-                    }
-                }
-                if (!exhausted) {
-                    uint32_t w = res_next + lane_rank(idle);
-                    if (!active && w < res_end && w < a.total_work) {
-                        if (load_ray<PRIMARY>(a, w, r, sx, sy, sz)) {
-                            cur = ray_root<PRIMARY>(a, r, plane_bits);    // record 0 = the reference root (node n), or the search tree's root
-                            sp = 0; pending = NO_LEAF; iters = 0;
-                            active = true;
-                        } else if (PRIMARY && a.compact) {
-                            // slot of a border tile that lies outside the frame: defined as "no contact"
-                            uint32_t x, y, slot;
-                            work_to_pixel(a, w, x, y, slot);
-                            float4* o = reinterpret_cast<float4*>(a.out + slot);
-                            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        }
-                    }
-                    uint32_t left = res_end - res_next;
-                    res_next += n_idle < left ? n_idle : left;
-                }
+    // one wave per 64-ray block (an 8x8-pixel block of a primary frame): the hardware dispatcher is the work queue
+    {
+        const uint32_t w = (wave_gid << 6) + lane;
+        if (w < a.total_work) {
+            if (load_ray<PRIMARY>(a, w, r, sx, sy, sz)) {
+                cur = ray_root<PRIMARY>(a, r, plane_bits);    // record 0 = the reference root (node n), or the search tree's root
+                active = true;
+            } else if (PRIMARY && a.compact) {
+                // slot of a border tile that lies outside the frame: defined as "no contact"
+                uint32_t x, y, slot;
+                work_to_pixel(a, w, x, y, slot);
+                float4* o = reinterpret_cast<float4*>(a.out + slot);
+                o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         }
-        if (__ballot(active) == 0ull) {
-            if (exhausted) break;
-            continue;                 // every pulled slot was outside the frame: pull again
-        }
-
-        // ---------------- traversal steps until enough lanes have drained ----------------
+    }
+    if (__ballot(active) != 0ull) {
+        // ---------------- traversal steps until every ray of the block has finished or moved on ----------------
         for (;;) {
             uint32_t extra = RT_SENTINEL;     // child that did not fit on the stack (forces a deferral)
             if (active) {
@@ -455,7 +412,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
 
             // ---- defer long rays to phase 1 (budget exceeded, or stack full) ----
             bool want_defer = active && cur != RT_SENTINEL &&
-                              (extra != RT_SENTINEL || (may_defer && iters >= drain_budget));
+                              (extra != RT_SENTINEL || (may_defer && iters >= a.defer_budget));
             uint64_t deferring = __ballot(want_defer);
             if (deferring != 0ull) {
                 uint32_t base = 0;
@@ -484,17 +441,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                 store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
                 active = false;
             }
-            uint32_t n_active = (uint32_t)__popcll(__ballot(active));
-            if (n_active == 0u) break;
-            if (!exhausted && n_active <= 64u - REFILL_MIN_IDLE) break;
-            if (exhausted && a.persistent) {
-                // persistent grid, nothing left to refill with: the emptier the wave, the less a lane-per-ray step is worth, so
-                // the budget shrinks with the number of busy lanes and stragglers move to the wave-per-ray phase early.
-                // (One wave per block: every lane starts at step 0 together, so the budget is simply the step at which
-                // whatever is still walking is handed over; measured better than any scaling, and finer budgets are calibrated.)
-                uint32_t b = (a.defer_budget * n_active) >> 6;
-                drain_budget = b < STRAGGLER_BUDGET ? STRAGGLER_BUDGET : b;
-            }
+            if (__ballot(active) == 0ull) break;
         }
     }
 }
@@ -602,12 +549,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
     uint32_t spill_slot = 0xFFFFFFFFu;
 
     const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
-    const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;
-    uint32_t blk = wave_gid;
-    uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
-    for (;;) {
-        if (blk >= n_blocks8) break;
-        const uint32_t w = (blk << 6) + lane;
+    // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
+    if ((wave_gid << 6) < a.total_work) {
+        const uint32_t w = (wave_gid << 6) + lane;
         RayState r;
         bool sx = false, sy = false, sz = false;
         r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
@@ -742,21 +686,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                 __hip_atomic_fetch_min((gu64*)a.keys + w, ((unsigned long long)__float_as_uint(r.best_t) << 32) | a.pos[r.best_leaf], RLX_AGENT);
         }
 
-        // next block: dynamic, sharded (as in k_trace)
-        blk = 0xFFFFFFFFu;
-        uint32_t dyn = n_blocks8 > a.n_waves ? n_blocks8 - a.n_waves : 0u;
-        uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
-        while (blk == 0xFFFFFFFFu && shards_tried < WORK_SHARDS) {
-            uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
-            uint32_t got = 0xFFFFFFFFu;
-            if (lo < hi) {
-                if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->shard[shard].next, 1u, RLX_AGENT);
-                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            }
-            if (lo < hi && got < hi - lo) blk = a.n_waves + lo + got;
-            else { shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u; shards_tried++; }
-        }
-        if (blk == 0xFFFFFFFFu) break;
     }
     spill_release(a, lane, spill_slot);
 }
@@ -781,12 +710,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
     uint32_t spill_slot = 0xFFFFFFFFu;
 
     const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
-    const uint32_t n_blocks8 = (a.total_work + 63u) >> 6;
-    uint32_t blk = wave_gid;
-    uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
-    for (;;) {
-        if (blk >= n_blocks8) break;
-        const uint32_t w = (blk << 6) + lane;
+    // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
+    if ((wave_gid << 6) < a.total_work) {
+        const uint32_t w = (wave_gid << 6) + lane;
         RayState r;
         bool sx = false, sy = false, sz = false;
         r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
@@ -877,20 +803,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
         }
         if (ok) store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
 
-        blk = 0xFFFFFFFFu;
-        uint32_t dyn = n_blocks8 > a.n_waves ? n_blocks8 - a.n_waves : 0u;
-        uint32_t per = (dyn + WORK_SHARDS - 1u) / WORK_SHARDS;
-        while (blk == 0xFFFFFFFFu && shards_tried < WORK_SHARDS) {
-            uint32_t lo = shard * per, hi = lo + per < dyn ? lo + per : dyn;
-            uint32_t got = 0xFFFFFFFFu;
-            if (lo < hi) {
-                if (lane == 0) got = __hip_atomic_fetch_add((gu32*)&a.ctrl->shard[shard].next, 1u, RLX_AGENT);
-                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            }
-            if (lo < hi && got < hi - lo) blk = a.n_waves + lo + got;
-            else { shard = shard + 1u == WORK_SHARDS ? 0u : shard + 1u; shards_tried++; }
-        }
-        if (blk == 0xFFFFFFFFu) break;
     }
     spill_release(a, lane, spill_slot);
 }
@@ -1167,58 +1079,42 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (a.total_work == 0) return;
     // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
     (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
-    uint32_t need = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
-    // Grid: one wave per 64-ray block and the hardware dispatcher as the work queue.  A persistent grid (resident waves
-    // pulling blocks from the sharded counters, idle lanes refilled) measured 25-50 % slower on every bundled scene
-    // (Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms); it remains behind RTMI_PERSISTENT=1 for comparison.
-    // resident blocks per CU: a property of the code object, asked once per kernel (the query costs microseconds of host time)
+    // First-phase kernels: one wave per 64-ray block and the hardware dispatcher as the work queue.  (A persistent grid --
+    // resident waves pulling blocks from sharded counters, idle lanes refilled -- measured 25-50 % slower on every bundled
+    // scene: Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms)
+    const uint32_t grid = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
+    // The wave-per-ray kernel does not know its work on the host: resident waves pull batches of deferred rays.  Resident
+    // blocks per CU are a property of the code object, asked once (the query costs microseconds of host time).
     static int b1 = 0;
     if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
+    a.n_waves = grid1 * TRACE_WAVES;                     // resident waves of the wave-per-ray kernel
     if (PRIMARY && t.packet && t.packet4 && t.quad && t.search_root) {
-        static int b4 = 0;
-        if (b4 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_trace_packet4<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b4 < 1) b4 = 1; }
-        uint32_t grid = t.persistent ? (uint32_t)t.compute_units * (uint32_t)b4 : need;
-        if (grid > need) grid = need;
-        a.n_waves = grid * TRACE_WAVES;
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // rays the four-wide records may not be used for (see the kernel) wait on the deferred list: normally none, and the
         // wave-per-ray kernel returns at once
-        a.n_waves = grid1 * TRACE_WAVES;
         hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
     if (PRIMARY && t.packet) {
-        static int bp = 0;
-        if (bp == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_trace_packet<PRIMARY, CAL>, TRACE_BLOCK, 0); if (bp < 1) bp = 1; }
-        uint32_t grid = t.persistent ? (uint32_t)t.compute_units * (uint32_t)bp : need;
-        if (grid > need) grid = need;
-        a.n_waves = grid * TRACE_WAVES;
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         hipLaunchKernelGGL((k_trace_packet<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // without a budget the packet kernel hands nothing over: the wave-per-ray and resolve kernels would find empty lists
         if (a.defer_budget < (1u << 20)) {
-            a.n_waves = grid1 * TRACE_WAVES;
             hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
             hipLaunchKernelGGL((k_resolve_split<PRIMARY, CAL>), dim3(64), dim3(256), 0, s, a);
         }
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
-    static int b0 = 0;
-    if (b0 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, k_trace<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b0 < 1) b0 = 1; }
-    uint32_t grid = t.persistent ? (uint32_t)t.compute_units * (uint32_t)b0 : need;
-    if (grid > need) grid = need;
-    a.n_waves = grid * TRACE_WAVES;
     if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
     hipLaunchKernelGGL((k_trace<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
     if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
     // wave-per-ray phase: the number of deferred rays lives on the device; a fixed grid pulls from the list
-    a.n_waves = grid1 * TRACE_WAVES;
     hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
     if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
 }
@@ -1242,7 +1138,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
     a.n_leaves = t.n_leaves;
-    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u; a.persistent = t.persistent ? 1u : 0u;
+    a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u;
     { static int lb = -1; if (lb < 0) { const char* e = getenv("RTMI_LONG_BATCH"); lb = e ? atoi(e) : 0; if (lb < 0 || lb > (int)LONG_BATCH) lb = 0; } a.long_batch = (uint32_t)lb; }
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
