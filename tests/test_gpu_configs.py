@@ -134,3 +134,68 @@ def test_packet_stack_overflow_areas(packet, budget, scene):
     r = subprocess.run([sys.executable, '-c', _OVERFLOW_SCRIPT % dict(root=ROOT), path], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert 'more frames ok' in r.stdout
+
+
+def _terrain_scene_bytes(n=708, rows_per_shape=44, seed=5):
+    """a height field of n x n quads (1 002 528 triangles for n = 708) facing the demo camera, cut into shapes of fewer
+    than 65 536 vertices (ushort indices); packed by the product's C++ loader"""
+    d = '/tmp/_terrain_%d' % n
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-50, 50, n + 1, dtype=np.float64)
+    H = (np.sin(xs[:, None] * 0.21) * np.cos(xs[None, :] * 0.17) * 6.0 + rng.normal(scale=0.35, size=(n + 1, n + 1))).astype(np.float32)
+    out, base = [], 1
+    for r0 in range(0, n, rows_per_shape):
+        r1 = min(n, r0 + rows_per_shape)
+        rr = np.arange(r0, r1 + 1)
+        X, Z = np.meshgrid(xs, xs[rr], indexing='xy')
+        V = np.stack([X, Z, H[rr]], axis=-1).reshape(-1, 3)
+        out.append('o strip%d\n' % r0)
+        out.append(''.join('v %.6f %.6f %.6f\n' % tuple(v) for v in V))
+        w = n + 1
+        i, j = np.meshgrid(np.arange(r1 - r0), np.arange(n), indexing='ij')
+        a = base + i * w + j; b = a + 1; c = a + w; e = c + 1
+        F = np.concatenate([np.stack([a, c, b], -1).reshape(-1, 3), np.stack([b, c, e], -1).reshape(-1, 3)])
+        out.append(''.join('f %d %d %d\n' % tuple(f) for f in F))
+        base += len(V)
+    open(os.path.join(d, 'terrain.obj'), 'w').write(''.join(out))
+    open(os.path.join(d, 'terrain.txt'), 'w').write('LIGHT 0.0 60.0 -130.0 1000.0\nMESH %s' % os.path.join(d, 'terrain.obj'))
+    subprocess.check_call([os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool'), os.path.join(d, 'terrain.txt'),
+                           os.path.join(d, 'terrain.bin')], cwd=ROOT)
+    return open(os.path.join(d, 'terrain.bin'), 'rb').read()
+
+
+def test_one_million_triangles(gpu_ctx):
+    """Four times the largest BASELINE configuration: 1 002 528 triangles in 17 meshes (N = 2^20 Morton pairs, 2 004 054
+    records per tree kind).  Build products (sorted pairs, every node byte) and every contact of a primary frame and of a
+    ray buffer equal the oracle's."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    buf = _terrain_scene_bytes()
+    osc = orc.Scene(buf)
+    assert osc.n_tris == 1002528
+    ob = orc.BVH(osc, 0)
+    sc = capi.DeviceScene(gpu_ctx, buf)
+    gb = capi.DeviceBVH(gpu_ctx, sc).build()
+    try:
+        assert gb.read_morton_pairs().tobytes() == ob.pairs.tobytes()
+        assert gb.read_nodes().tobytes() == ob.nodes.tobytes()
+        cam = osc.demo_camera(192, 108)
+        want, st = ob.trace_primary(cam)
+        got = gb.generate_contacts_primary(as_capi_camera(cam))
+        assert got.tobytes() == want.tobytes()
+        assert st.hits == 192 * 108                               # the terrain fills the frame
+        rng = np.random.default_rng(77)
+        m = 3001
+        rays = np.zeros(m, dtype=orc.RAY)
+        rays['idx'] = np.arange(m)
+        rays['origin'][:, :3] = rng.uniform([-60, -60, -40], [60, 60, -10], size=(m, 3)).astype(np.float32)
+        dd = rng.normal(size=(m, 3)).astype(np.float32)
+        dd[:, 2] = np.abs(dd[:, 2]) + 0.2
+        dd /= np.linalg.norm(dd, axis=1, keepdims=True).astype(np.float32)
+        dd[::9, 0] = 0.0                                          # zero components: those rays walk the reference tree
+        rays['direction'][:, :3] = dd
+        want_r, _ = ob.trace_rays(rays)
+        assert gb.generate_contacts_rays(rays.view(capi.RAY)).tobytes() == want_r.tobytes()
+    finally:
+        gb.close(); sc.close()
