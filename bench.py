@@ -103,6 +103,10 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
     tiled = world > 1 or force_tiled
+    # RT_TILING word: with N > 1 rank 0, which gathers the frame, owns `root_extra` more tiles per period of N + root_extra
+    # tiles (default 1: two tiles of three at N = 2), so less of the frame has to cross its links
+    root_extra = int(os.environ.get('RTMI_BENCH_ROOT_EXTRA', '1' if world > 1 else '0'))
+    tiling = capi.tiling(world, root_extra)
     dist = None
     if tiled:
         import torch.distributed as dist
@@ -144,12 +148,12 @@ def main():
         bvh.build()
         build_ms[name] = (time.perf_counter() - t0) * 1e3 / 2
         cam = demo_camera(buf, *RES)
-        slots = capi.tiles_owned_pixels(cam, rank, world) if tiled else npx
+        slots = capi.tiles_owned_pixels(cam, rank, tiling) if tiled else npx
         item = dict(name=name, ctx=sctx, tstream=tstreams[si], scene=scene, bvh=bvh, cam=cam, slots=slots,
                     contacts=torch.empty(slots * 32, dtype=torch.uint8, device=dev),
                     rgba=torch.empty((slots, 4), dtype=torch.float32, device=dev))
         if tiled:
-            item['slots0'] = capi.tiles_owned_pixels(cam, 0, world)      # rank 0 owns the most tiles: gather slot size
+            item['slots0'] = capi.tiles_owned_pixels(cam, 0, tiling)      # rank 0 owns the most tiles: gather slot size
             if rank == 0:
                 item['frame'] = torch.empty((npx, 4), dtype=torch.float32, device=dev)
         work.append(item)
@@ -179,9 +183,9 @@ def main():
         for i, it in enumerate(work):
             if gather_done[b] is not None:
                 it['tstream'].wait_event(gather_done[b])            # send[b] is free again
-            it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
+            it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
             # shade straight into this frame's planes of the send buffer (ranks own slots <= slots0)
-            capi.shade_blinn_phong_tiled_packed_d(it['ctx'], it['scene'], it['cam'], rank, world, it['contacts'].data_ptr(),
+            capi.shade_blinn_phong_tiled_packed_d(it['ctx'], it['scene'], it['cam'], rank, tiling, it['contacts'].data_ptr(),
                                                   send[b][i].data_ptr(), slots0)
             gstream.wait_stream(it['tstream'])
         with torch.cuda.stream(gstream):
@@ -193,7 +197,7 @@ def main():
             gather_done[b] = ev
         if rank == 0:
             for i, it in enumerate(work):
-                capi.untile_rgba_packed_d(gctx, it['cam'], world, gathered[0, i].data_ptr(), slots0, it['frame'].data_ptr(),
+                capi.untile_rgba_packed_d(gctx, it['cam'], tiling, gathered[0, i].data_ptr(), slots0, it['frame'].data_ptr(),
                                           rank_stride_floats=len(SCENES) * 3 * slots0)
 
     def fence():
@@ -256,14 +260,14 @@ def main():
             if not tiled:
                 it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
             else:
-                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
+                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
         sctx.set_profiling(2)                  # events + the <1, 2> kernel names: launches that had the device to themselves
         tm.start()
         for _ in range(ISOLATED_FRAMES):
             if not tiled:
                 it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
             else:
-                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, world, it['contacts'].data_ptr())
+                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
         tm.stop()
         ms = tm.elapsed_ms() / ISOLATED_FRAMES
         k = sctx.trace_kernel_times()
@@ -295,8 +299,9 @@ def main():
     launches = max(kt['launches'], 1)
     trace_ms_concurrent = (kt['lane_phase_ms'] + kt['wave_phase_ms']) / launches   # timed region: launches overlap on five streams
     alg_total = sum(per_scene[n]['algorithmic_bytes'] for n in SCENES)
-    alg_per_launch = alg_total / len(SCENES) / world                                # this rank's share of an average frame
-    walked_per_launch = sum(per_scene[n]['walked_bytes'] for n in SCENES) / len(SCENES) / world
+    share = (work[0]['slots'] / float(sum(capi.tiles_owned_pixels(work[0]['cam'], r, tiling) for r in range(world)))) if tiled else 1.0
+    alg_per_launch = alg_total / len(SCENES) * share                                # this rank's share of an average frame
+    walked_per_launch = sum(per_scene[n]['walked_bytes'] for n in SCENES) / len(SCENES) * share
     # The five frames of a step run side by side on five streams, so in the timed region a launch's HIP-event span contains
     # the time it shared the device with four others (and queued behind them): it is not a kernel duration any more and
     # rocprofv3's per-kernel durations of those launches are stretched the same way.  The roofline figure of the kernel is
@@ -386,8 +391,9 @@ def main():
                config=dict(workload='5 bundled TestModels scenes x 1920x1080 primary rays, BVH traversal + Blinn-Phong shading',
                            rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES,
                            parallelism=('single GPU, the five frames of a step on five HIP streams' if world == 1 else
-                                        '64x64 frame tiles round-robin over %d ranks, one gather of RGBA (12 B per pixel on the wire) to rank 0 per frame, '
-                                        'the five frames of a step on five HIP streams per rank' % world)),
+                                        ('64x64 frame tiles dealt over %d ranks (rank 0 owns %d extra per period of %d tiles), one gather of RGBA '
+                                         '(12 B per pixel on the wire) to rank 0 per step, the five frames of a step on five HIP streams per rank'
+                                         % (world, root_extra, world + root_extra)))),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
                roofline=roofline, cpu_baseline=cpu_baseline, per_scene=per_scene)

@@ -195,6 +195,10 @@ int  rt_generate_secondary_rays(rt_ctx* ctx, const rt_camera* cam, const void* d
  * `nranks` owns tiles r, r+nranks, ...  The compact per-rank buffers are ordered by
  * (owned tile ordinal, pixel within tile) so that one gather of contiguous buffers assembles
  * the frame; rt_untile_* scatters a gathered buffer back to pixel order on the root.           */
+/* `nranks` of every tiled entry point is a word: low 16 bits = number of ranks N; high 16 bits = e, the extra tiles per
+ * period of N + e tiles that rank 0 owns (0 = plain round robin).  The rank that gathers the frame then traces more of it
+ * itself and receives less over its links: in a period, tiles 0..e belong to rank 0 and tile e + r to rank r.          */
+#define RT_TILING(nranks, root_extra) ((uint32_t)(nranks) | ((uint32_t)(root_extra) << 16))
 uint32_t rt_tiles_owned_pixels(const rt_camera* cam, uint32_t rank, uint32_t nranks); /* slots in the compact buffer */
 int  rt_bvh_generate_contacts_primary_tiled(rt_bvh* bvh, const rt_camera* cam, uint32_t rank, uint32_t nranks,
                                             void* d_contacts_compact);

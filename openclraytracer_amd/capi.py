@@ -479,14 +479,22 @@ def untile_rgba_d(ctx, cam, nranks, d_gathered, slots_per_rank, d_frame):
                                      C.c_void_p(d_frame)))
 
 
+def tiling(nranks: int, root_extra: int = 0) -> int:
+    """RT_TILING of include/rtmi.h: the `nranks` word of the tiled entry points"""
+    return int(nranks) | (int(root_extra) << 16)
+
+
 def tile_slot_map(resx: int, resy: int, nranks: int):
-    """Host statement of the tiling contract of include/rtmi.h: for every pixel, (rank, slot)."""
+    """Host statement of the tiling contract of include/rtmi.h: for every pixel, (rank, slot).  `nranks` is the word of
+    the C ABI (low 16 bits N, high 16 bits e = extra tiles per period of N + e tiles for rank 0)."""
     T = 64
+    n, e = nranks & 0xFFFF, nranks >> 16
     tiles_x = (resx + T - 1) // T
     y, x = np.divmod(np.arange(resx * resy, dtype=np.int64), resx)
     tx, ty = x // T, y // T
     tile = ty * tiles_x + tx
-    rank = tile % nranks
-    ordinal = tile // nranks
+    q, p = np.divmod(tile, n + e)
+    rank = np.where(p <= e, 0, p - e)
+    ordinal = np.where(p <= e, q * (e + 1) + p, q)
     slot = ordinal * (T * T) + (y - ty * T) * T + (x - tx * T)
     return rank.astype(np.int64), slot.astype(np.int64)

@@ -649,7 +649,7 @@ int rt_bvh_generate_contacts_primary_tiled(rt_bvh* b, const rt_camera* cam, uint
     if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (!d_contacts_compact) return RT_FAIL(ctx, "contacts buffer is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return RT_FAIL(ctx, "rank/nranks invalid");
     RT_ENTER(ctx);
     if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
     return trace_primary_tuned(b, cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
@@ -743,7 +743,7 @@ int rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* ca
 
 uint32_t rt_tiles_owned_pixels(const rt_camera* cam, uint32_t rank, uint32_t nranks)
 {
-    if (!cam || nranks == 0 || rank >= nranks) return 0;
+    if (!cam || rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return 0;
     uint32_t total = rt_tiles_x(cam->resX) * rt_tiles_y(cam->resY);
     return rt_owned_tiles(total, rank, nranks) * RT_TILE * RT_TILE;
 }
@@ -753,7 +753,7 @@ int rt_shade_blinn_phong_tiled(rt_ctx* ctx, const rt_scene* scene, const rt_came
 {
     if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return RT_FAIL(ctx, "rank/nranks invalid");
     if (!d_contacts_compact || !d_rgba_compact) return RT_FAIL(ctx, "null buffer");
     RT_ENTER(ctx);
     uint32_t count = rt_tiles_owned_pixels(cam, rank, nranks);
@@ -768,7 +768,7 @@ int rt_untile_rgba(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const voi
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    if (nranks == 0 || !d_rgba_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
+    if (rt_nranks(nranks) == 0 || !d_rgba_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
     if (slots_per_rank < rt_tiles_owned_pixels(cam, 0, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
     RT_ENTER(ctx);
     launch_untile_rgba(ctx->stream, *cam, nranks, (const float4*)d_rgba_gathered, slots_per_rank, (float4*)d_rgba_frame);
@@ -781,7 +781,7 @@ int rt_shade_blinn_phong_tiled_packed(rt_ctx* ctx, const rt_scene* scene, const 
 {
     if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return RT_FAIL(ctx, "rank/nranks invalid");
     if (!d_contacts_compact || !d_rgb_planes) return RT_FAIL(ctx, "null buffer");
     uint32_t count = rt_tiles_owned_pixels(cam, rank, nranks);
     if (slots_per_rank < count || slots_per_rank == 0) return RT_FAIL(ctx, "slots_per_rank too small");
@@ -797,7 +797,7 @@ int rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, co
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    if (nranks == 0 || !d_rgb_planes_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
+    if (rt_nranks(nranks) == 0 || !d_rgb_planes_gathered || !d_rgba_frame) return RT_FAIL(ctx, "invalid argument");
     if (slots_per_rank < rt_tiles_owned_pixels(cam, 0, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
     if (rank_stride_floats == 0) rank_stride_floats = 3ull * slots_per_rank;
     if (rank_stride_floats < 3ull * slots_per_rank) return RT_FAIL(ctx, "rank stride smaller than one rank's planes");

@@ -268,7 +268,29 @@ void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nra
 #define RT_TILE 64u
 __host__ __device__ inline uint32_t rt_tiles_x(uint32_t resX) { return (resX + RT_TILE - 1) / RT_TILE; }
 __host__ __device__ inline uint32_t rt_tiles_y(uint32_t resY) { return (resY + RT_TILE - 1) / RT_TILE; }
-__host__ __device__ inline uint32_t rt_owned_tiles(uint32_t total_tiles, uint32_t rank, uint32_t nranks)
+// Who owns which tile.  `nranks` is the word of the C ABI: low 16 bits = number of ranks N, high 16 bits = e, the extra tiles
+// per period of N + e tiles that go to rank 0 (RT_TILING in rtmi.h; e = 0 is plain round robin).  With e > 0 the rank that
+// gathers the frame traces more of it itself and receives less over its links.
+//   position p = tile % (N + e) in its period q = tile / (N + e):  p <= e -> rank 0, ordinal q (e + 1) + p;  else rank p - e, ordinal q
+__host__ __device__ inline uint32_t rt_nranks(uint32_t nranks_word) { return nranks_word & 0xFFFFu; }
+__host__ __device__ inline uint32_t rt_root_extra(uint32_t nranks_word) { return nranks_word >> 16; }
+__host__ __device__ inline void rt_tile_owner(uint32_t tile, uint32_t nranks_word, uint32_t& rank, uint32_t& ordinal)
 {
-    return total_tiles > rank ? (total_tiles - rank + nranks - 1) / nranks : 0u;
+    const uint32_t e = rt_root_extra(nranks_word), period = rt_nranks(nranks_word) + e;
+    const uint32_t q = tile / period, p = tile - q * period;
+    if (p <= e) { rank = 0u; ordinal = q * (e + 1u) + p; }
+    else { rank = p - e; ordinal = q; }
+}
+__host__ __device__ inline uint32_t rt_tile_of(uint32_t rank, uint32_t ordinal, uint32_t nranks_word)
+{
+    const uint32_t e = rt_root_extra(nranks_word), period = rt_nranks(nranks_word) + e;
+    if (rank == 0u) { const uint32_t q = ordinal / (e + 1u); return q * period + (ordinal - q * (e + 1u)); }
+    return ordinal * period + rank + e;
+}
+__host__ __device__ inline uint32_t rt_owned_tiles(uint32_t total_tiles, uint32_t rank, uint32_t nranks_word)
+{
+    const uint32_t e = rt_root_extra(nranks_word), period = rt_nranks(nranks_word) + e;
+    const uint32_t q = total_tiles / period, rem = total_tiles - q * period;
+    if (rank == 0u) return q * (e + 1u) + (rem < e + 1u ? rem : e + 1u);
+    return q + (rem > rank + e ? 1u : 0u);
 }

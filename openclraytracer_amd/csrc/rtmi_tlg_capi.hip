@@ -224,7 +224,7 @@ int rt_tlg_generate_contacts_primary_tiled(rt_tlg* g, const rt_camera* cam, uint
     if (!g->built) return RT_FAIL(ctx, "construct must precede generateContacts");
     if (!d_contacts_compact) return RT_FAIL(ctx, "contacts buffer is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
-    if (nranks == 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return RT_FAIL(ctx, "rank/nranks invalid");
     RT_ENTER(ctx);
     launch_tlg_trace_primary(ctx->stream, make_tlg_launch(g), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
     RT_HIP(ctx, hipGetLastError());

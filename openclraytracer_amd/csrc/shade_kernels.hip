@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void k_untile_rgba(rt_camera cam, uint32_t nra
     uint32_t y = pixel / cam.resX, x = pixel - y * cam.resX;
     uint32_t tx = x / RT_TILE, ty = y / RT_TILE;
     uint32_t tile = ty * rt_tiles_x(cam.resX) + tx;
-    uint32_t rank = tile % nranks, ordinal = tile / nranks;
+    uint32_t rank, ordinal;
+    rt_tile_owner(tile, nranks, rank, ordinal);
     uint32_t slot = ordinal * (RT_TILE * RT_TILE) + (y - ty * RT_TILE) * RT_TILE + (x - tx * RT_TILE);
     frame[pixel] = gathered[(uint64_t)rank * slots_per_rank + slot];
 }
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(256) void k_untile_rgba_packed(rt_camera cam, uint3
     uint32_t y = pixel / cam.resX, x = pixel - y * cam.resX;
     uint32_t tx = x / RT_TILE, ty = y / RT_TILE;
     uint32_t tile = ty * rt_tiles_x(cam.resX) + tx;
-    uint32_t rank = tile % nranks, ordinal = tile / nranks;
+    uint32_t rank, ordinal;
+    rt_tile_owner(tile, nranks, rank, ordinal);
     uint32_t slot = ordinal * (RT_TILE * RT_TILE) + (y - ty * RT_TILE) * RT_TILE + (x - tx * RT_TILE);
     const float* g = gathered + (uint64_t)rank * rank_stride + slot;
     const uint32_t r = __float_as_uint(g[0]);

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
     if (PRIMARY) {
         // work item -> pixel: this rank's 64x64 tiles, inside a tile 8x8 blocks (one wave = one block), as in trace_kernels.hip
         const uint32_t ordinal = w >> 12, within = w & 4095u;
-        const uint32_t tile = ordinal * a.nranks + a.rank;
+        const uint32_t tile = rt_tile_of(a.rank, ordinal, a.nranks);
         const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const uint32_t blk = within >> 6, lp = within & 63u;
         const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3), lx = ((blk & 7u) << 3) + (lp & 7u);

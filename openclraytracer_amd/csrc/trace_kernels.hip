@@ -221,7 +221,7 @@ __device__ __forceinline__ bool work_to_pixel(const TraceArgs& a, uint32_t w, ui
 {
     uint32_t ordinal = w >> 12;                 // owned tile ordinal (4096 px per tile)
     uint32_t within = w & 4095u;
-    uint32_t tile = ordinal * a.nranks + a.rank;
+    uint32_t tile = rt_tile_of(a.rank, ordinal, a.nranks);
     uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     uint32_t blk = within >> 6, lp = within & 63u;
     uint32_t ly = ((blk >> 3) << 3) + (lp >> 3);

@@ -15,21 +15,38 @@ def tiles_xy(resx: int, resy: int):
     return (resx + TILE - 1) // TILE, (resy + TILE - 1) // TILE
 
 
+def tiling(nranks: int, root_extra: int = 0) -> int:
+    """== RT_TILING: the `nranks` word of the tiled entry points (low 16 bits N, high 16 bits the extra tiles per period of
+    N + e tiles that rank 0 owns; 0 = plain round robin)"""
+    return int(nranks) | (int(root_extra) << 16)
+
+
+def _decode(nranks: int):
+    return nranks & 0xFFFF, nranks >> 16
+
+
 def owned_slots(resx: int, resy: int, rank: int, nranks: int) -> int:
     """== rt_tiles_owned_pixels"""
+    n, e = _decode(nranks)
     tx, ty = tiles_xy(resx, resy)
     total = tx * ty
-    return ((total - rank + nranks - 1) // nranks) * TILE * TILE if total > rank else 0
+    period = n + e
+    q, rem = divmod(total, period)
+    tiles = q * (e + 1) + min(rem, e + 1) if rank == 0 else q + (1 if rem > rank + e else 0)
+    return tiles * TILE * TILE
 
 
 def slot_map(resx: int, resy: int, nranks: int):
     """for every pixel (row-major): owning rank and slot in that rank's compact buffer"""
+    n, e = _decode(nranks)
     tx, _ = tiles_xy(resx, resy)
     y, x = np.divmod(np.arange(resx * resy, dtype=np.int64), resx)
     px, py = x // TILE, y // TILE
     tile = py * tx + px
-    rank = tile % nranks
-    slot = (tile // nranks) * (TILE * TILE) + (y - py * TILE) * TILE + (x - px * TILE)
+    q, p = np.divmod(tile, n + e)
+    rank = np.where(p <= e, 0, p - e)
+    ordinal = np.where(p <= e, q * (e + 1) + p, q)
+    slot = ordinal * (TILE * TILE) + (y - py * TILE) * TILE + (x - px * TILE)
     return rank, slot
 
 
@@ -42,10 +59,9 @@ def compact_from_frame(frame: np.ndarray, resx: int, resy: int, rank: int, nrank
     return out
 
 
-def untile_host(gathered: np.ndarray, resx: int, resy: int) -> np.ndarray:
+def untile_host(gathered: np.ndarray, resx: int, resy: int, nranks: int = None) -> np.ndarray:
     """== rt_untile_rgba: gathered[rank, slot] -> frame[pixel]"""
-    nranks = gathered.shape[0]
-    r, s = slot_map(resx, resy, nranks)
+    r, s = slot_map(resx, resy, nranks if nranks is not None else gathered.shape[0])
     return gathered[r, s]
 
 
@@ -71,11 +87,10 @@ def unpack_planes(planes: np.ndarray) -> np.ndarray:
     return out
 
 
-def untile_host_packed(gathered: np.ndarray, resx: int, resy: int) -> np.ndarray:
+def untile_host_packed(gathered: np.ndarray, resx: int, resy: int, nranks: int = None) -> np.ndarray:
     """== rt_untile_rgba_packed: gathered[rank, plane, slot] -> frame[pixel, rgba]"""
-    nranks = gathered.shape[0]
-    r, s = slot_map(resx, resy, nranks)
-    per_rank = np.stack([unpack_planes(gathered[k]) for k in range(nranks)])
+    r, s = slot_map(resx, resy, nranks if nranks is not None else gathered.shape[0])
+    per_rank = np.stack([unpack_planes(gathered[k]) for k in range(gathered.shape[0])])
     return per_rank[r, s]
 
 

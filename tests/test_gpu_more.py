@@ -86,10 +86,12 @@ def test_shade_empty_contact_list_clears_frame(gpu_ctx):
     assert (out == 0).all()
 
 
-@pytest.mark.parametrize('nranks', [2, 3, 8])
-def test_tiled_frame_equals_untiled(gpu_ctx, nranks):
-    """every rank's compact buffers, gathered and untiled, equal the single-GPU frame (contacts bit-exact, RGBA too)."""
+@pytest.mark.parametrize('n_ranks, root_extra', [(2, 0), (3, 0), (8, 0), (2, 1), (4, 1), (8, 2), (3, 5)])
+def test_tiled_frame_equals_untiled(gpu_ctx, n_ranks, root_extra):
+    """every rank's compact buffers, gathered and untiled, equal the single-GPU frame (contacts bit-exact, RGBA too), for
+    plain round robin and for tilings in which rank 0 owns extra tiles per period (RT_TILING)."""
     from openclraytracer_amd import capi
+    nranks = capi.tiling(n_ranks, root_extra)
     osc, _ = oracle_bvh('gardenlight')
     sc, gb = gpu_bvh(gpu_ctx, 'gardenlight')
     res = (333, 200)
@@ -98,11 +100,13 @@ def test_tiled_frame_equals_untiled(gpu_ctx, nranks):
     full = gb.generate_contacts_primary(cam)
     full_rgba = capi.shade_blinn_phong(gpu_ctx, sc, cam, full)
     slots0 = capi.tiles_owned_pixels(cam, 0, nranks)
-    gathered = np.zeros((nranks, slots0, 4), dtype=np.float32)
-    packed = np.zeros((nranks, 3, slots0), dtype=np.float32)
+    gathered = np.zeros((n_ranks, slots0, 4), dtype=np.float32)
+    packed = np.zeros((n_ranks, 3, slots0), dtype=np.float32)
+    assert all(capi.tiles_owned_pixels(cam, r, nranks) <= slots0 for r in range(n_ranks))      # rank 0 sizes the gather
+    assert sum(capi.tiles_owned_pixels(cam, r, nranks) for r in range(n_ranks)) == 6 * 4 * 4096     # every tile has one owner
     from openclraytracer_amd import frame_tiles as ft
     rank_of, slot_of = capi.tile_slot_map(res[0], res[1], nranks)
-    for r in range(nranks):
+    for r in range(n_ranks):
         slots = capi.tiles_owned_pixels(cam, r, nranks)
         dc, dr = gpu_ctx.alloc(max(slots, 1) * 32), gpu_ctx.alloc(max(slots, 1) * 16)
         gpu_ctx.fill_u32(dc, 0xDEADBEEF, max(slots, 1) * 8)
@@ -135,7 +139,8 @@ def test_tiled_frame_equals_untiled(gpu_ctx, nranks):
     frame = gpu_ctx.download(df, npx * 4, np.float32).reshape(npx, 4)
     gpu_ctx.free(dg); gpu_ctx.free(df)
     assert frame.tobytes() == full_rgba.tobytes()
-    assert ft.untile_host_packed(packed, res[0], res[1]).tobytes() == full_rgba.tobytes()      # the host statement agrees
+    assert ft.untile_host_packed(packed, res[0], res[1], nranks).tobytes() == full_rgba.tobytes()      # the host statement agrees
+    assert ft.untile_host(gathered, res[0], res[1], nranks).tobytes() == full_rgba.tobytes()
 
 
 def test_sort_and_scan_primitives(gpu_ctx):

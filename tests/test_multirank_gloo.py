@@ -34,10 +34,11 @@ def _worker(rank, world, port, res, name, ret):
         # every rank holds the replicated scene; the checker computes the frame, the rank keeps only its tiles
         c, _ = b.trace_primary(cam, nthreads=2)
         frame = orc.shade_frame(osc, cam, c, nthreads=2)
-        slots0 = ft.owned_slots(res[0], res[1], 0, world)
-        mine = ft.owned_slots(res[0], res[1], rank, world)
+        til = ft.tiling(world, 1)                          # rank 0 owns two tiles of every three (bench.py's default for N > 1)
+        slots0 = ft.owned_slots(res[0], res[1], 0, til)
+        mine = ft.owned_slots(res[0], res[1], rank, til)
         send = np.zeros((slots0, 4), dtype=np.float32)
-        send[:mine] = ft.compact_from_frame(frame, res[0], res[1], rank, world, mine)
+        send[:mine] = ft.compact_from_frame(frame, res[0], res[1], rank, til, mine)
         # bench.py's pattern: the gather is issued asynchronously (the next frame's kernels overlap it on the GPU) and
         # waited for before the frame is untiled; the synchronous form must give the same buffer
         out, work_handle = ft.gather_to_root(torch.from_numpy(send), world, rank, async_op=True)
@@ -50,8 +51,8 @@ def _worker(rank, world, port, res, name, ret):
         planes[:, :mine] = ft.pack_planes(send[:mine])
         outp = ft.gather_to_root(torch.from_numpy(planes), world, rank)
         if rank == 0:
-            got = ft.untile_host(out.numpy(), res[0], res[1])
-            gotp = ft.untile_host_packed(outp.numpy(), res[0], res[1])
+            got = ft.untile_host(out.numpy(), res[0], res[1], til)
+            gotp = ft.untile_host_packed(outp.numpy(), res[0], res[1], til)
             ret['equal'] = bool(np.array_equal(got, frame)) and gotp.tobytes() == frame.tobytes()
             ret['hits'] = int((frame[:, 3] > 0).sum())
     finally:
@@ -77,11 +78,19 @@ def test_two_rank_gather_reassembles_the_frame(res):
 
 def test_slot_contract_matches_c_abi():
     from openclraytracer_amd import capi, frame_tiles as ft
-    for (w, h, n) in [(1920, 1080, 8), (1920, 1080, 4), (640, 480, 2), (63, 65, 3)]:
+    for (w, h, ranks, extra) in [(1920, 1080, 8, 0), (1920, 1080, 4, 0), (640, 480, 2, 0), (63, 65, 3, 0),
+                                 (1920, 1080, 2, 1), (1920, 1080, 4, 1), (1920, 1080, 8, 1), (3840, 2160, 8, 3), (333, 200, 3, 5)]:
+        n = ft.tiling(ranks, extra)                       # == RT_TILING: rank 0 owns `extra` more tiles per period
+        assert n == capi.tiling(ranks, extra)
         cam = np.zeros(1, dtype=capi.CAMERA)
         cam['resX'], cam['resY'] = w, h
-        for r in range(n):
+        for r in range(ranks):
             assert capi.tiles_owned_pixels(cam, r, n) == ft.owned_slots(w, h, r, n)
         a = capi.tile_slot_map(w, h, n)
         b = ft.slot_map(w, h, n)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # every pixel has exactly one (rank, slot), slots of a rank are distinct and below its count
+        for r in range(ranks):
+            mine = b[1][b[0] == r]
+            assert len(np.unique(mine)) == len(mine) and (len(mine) == 0 or mine.max() < ft.owned_slots(w, h, r, n))
+        assert ft.owned_slots(w, h, 0, n) == max(ft.owned_slots(w, h, r, n) for r in range(ranks))   # rank 0 sizes the gather
