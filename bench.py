@@ -79,8 +79,8 @@ ISOLATED_FRAMES = 10         # frames per scene of the isolated (one scene at a 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--check-frames', action='store_true',
                     help='N > 1: after the warm-up, rank 0 also traces every frame untiled and compares it with the gathered one')
