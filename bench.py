@@ -176,7 +176,7 @@ def main():
         if not tiled:
             for it in work:
                 it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
-                capi.shade_blinn_phong_d(it['ctx'], it['scene'], it['cam'], it['contacts'].data_ptr(), npx, it['rgba'].data_ptr())
+                capi.shade_blinn_phong_frame_d(it['ctx'], it['scene'], it['cam'], it['contacts'].data_ptr(), it['rgba'].data_ptr())
             return
         b = step_no[0] & 1
         step_no[0] += 1

@@ -177,6 +177,11 @@ float rt_tlg_pow_third(float x);
  *      d_rgba holds resX*resY float4; pixels without a hit are written (0,0,0,0).               */
 int  rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
                           const void* d_contacts, uint32_t contact_count, void* d_rgba);
+/* The same for the PRIMARY contact buffer of `cam` (what rt_bvh / rt_tlg_generate_contacts_primary filled: contact i belongs
+ * to pixel i, BVHKernels.cl:95): every pixel is written by its own thread, a miss as (0,0,0,0), so the frame needs no
+ * clearing pass.  Same RGBA, bit for bit.                                                                              */
+int  rt_shade_blinn_phong_frame(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const void* d_primary_contacts,
+                                void* d_rgba);
 
 /* ---- secondary rays (EXTENSION; the reference plans it, KNOWN_ISSUES_AND_TODO.txt 2.2: "generating rays from viewing
  *      rays-scene contacts, and execute ray tracing kernel in loop") ---------------------------------------------------

@@ -38,7 +38,7 @@ SYMBOLS = [
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
-    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
+    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
     'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
     L.rt_bvh_generate_contacts_primary_tiled.argtypes = [vp, vp, u32, u32, vp]
     L.rt_shade_blinn_phong_tiled.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.rt_untile_rgba.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.rt_shade_blinn_phong_frame.argtypes = [vp, vp, vp, vp, vp]
     L.rt_shade_blinn_phong_tiled_packed.argtypes = [vp, vp, vp, u32, u32, vp, vp, u32]
     L.rt_untile_rgba_packed.argtypes = [vp, vp, u32, vp, u32, u64, vp]
     L.rt_sort_pairs_bitonic.argtypes = [vp, vp, u32]
@@ -462,6 +463,10 @@ def tiles_owned_pixels(cam: np.ndarray, rank: int, nranks: int) -> int:
 def shade_blinn_phong_tiled_d(ctx, scene, cam, rank, nranks, d_contacts, d_rgba):
     ctx.check(ctx.lib.rt_shade_blinn_phong_tiled(ctx.h, scene.h, _p(cam), rank, nranks, C.c_void_p(d_contacts),
                                                  C.c_void_p(d_rgba)))
+
+
+def shade_blinn_phong_frame_d(ctx, scene, cam, d_primary_contacts, d_rgba):
+    ctx.check(ctx.lib.rt_shade_blinn_phong_frame(ctx.h, scene.h, _p(cam), C.c_void_p(d_primary_contacts), C.c_void_p(d_rgba)))
 
 
 def shade_blinn_phong_tiled_packed_d(ctx, scene, cam, rank, nranks, d_contacts, d_planes, slots_per_rank):

@@ -741,6 +741,19 @@ int rt_shade_blinn_phong(rt_ctx* ctx, const rt_scene* scene, const rt_camera* ca
     return RT_SUCCESS;
 }
 
+int rt_shade_blinn_phong_frame(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const void* d_primary_contacts, void* d_rgba)
+{
+    if (!ctx || !scene) return RT_FAIL(ctx, "null argument");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (!d_rgba || !d_primary_contacts) return RT_FAIL(ctx, "null buffer");
+    RT_ENTER(ctx);
+    // contact i belongs to pixel i, so every pixel is written by its own thread (a miss as zeros) and the clearing pass of
+    // rt_shade_blinn_phong -- 33 MB of writes per 1080p frame -- is not needed
+    launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_primary_contacts, cam->resX * cam->resY, (float4*)d_rgba, true, 0, 1);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
 uint32_t rt_tiles_owned_pixels(const rt_camera* cam, uint32_t rank, uint32_t nranks)
 {
     if (!cam || rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return 0;

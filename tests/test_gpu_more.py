@@ -75,6 +75,16 @@ def test_shading_within_tolerance(gpu_ctx, name):
     assert np.array_equal(got[:, 3], want[:, 3])
     miss = contacts['normal_t'][:, 3] <= 0
     assert (got[miss] == 0).all()
+    # the frame variant for a primary contact buffer (contact i = pixel i, no clearing pass): the same RGBA, bit for bit,
+    # also into a buffer full of garbage
+    npx = 320 * 240
+    dc, dr = gpu_ctx.alloc(npx * 32), gpu_ctx.alloc(npx * 16)
+    gpu_ctx.upload(dc, contacts.view(capi.CONTACT))
+    gpu_ctx.fill_u32(dr, 0xDEADBEEF, npx * 4)
+    capi.shade_blinn_phong_frame_d(gpu_ctx, sc, as_capi_camera(cam), dc, dr)
+    frame = gpu_ctx.download(dr, npx * 4, np.float32).reshape(npx, 4)
+    gpu_ctx.free(dc); gpu_ctx.free(dr)
+    assert frame.tobytes() == got.tobytes()
 
 
 def test_shade_empty_contact_list_clears_frame(gpu_ctx):
