@@ -471,3 +471,44 @@ def test_bench_tiled_path_on_rccl_with_one_rank():
     assert 'frame check ok (after the timed steps): 5 gathered frames equal the untiled ones' in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1 and json.loads(line[0])['value'] > 0
+
+
+@pytest.mark.parametrize('knobs', [dict(), dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='1048576'), dict(RTMI_PACKET='1', RTMI_DEFER_BUDGET='32'),
+                                   dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='6', RTMI_LONG_BATCH='4')],
+                         ids=['calibrated', 'packet4', 'packet32', 'lane6-batch4'])
+@pytest.mark.parametrize('name', ['tenryuu', 'man', 'clumsydragon'])
+def test_rotated_cameras_inside_outside_and_on_planes(name, knobs, monkeypatch):
+    """seeded random camera poses (rotation about two axes; position outside, inside and exactly on planes of leaf boxes),
+    odd resolutions, every first-phase kernel: contacts are the oracle's."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    osc, ob = oracle_bvh(name)
+    rng = np.random.default_rng(len(name) * 7 + len(knobs))
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        lo = ob.nodes['lo'][:ob.n, :3].min(0)
+        hi = ob.nodes['hi'][:ob.n, :3].max(0)
+        for pose in range(3):
+            res = (int(rng.integers(40, 280)), int(rng.integers(30, 180)))
+            cam = osc.demo_camera(*res).copy()
+            m = cam['m'][0]
+            a, b = rng.uniform(-0.8, 0.8, 2)
+            ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+            rot = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]]) @ np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
+            for r in range(3):
+                for c in range(3):
+                    m[r * 4 + c] = np.float32(rot[r, c])
+            p = lo + (hi - lo) * rng.uniform(-0.3, 1.3, 3)
+            if pose == 2:
+                p = ob.nodes['lo'][int(rng.integers(0, ob.n)), :3]        # every coordinate on a plane of a leaf box
+            m[3], m[7], m[11] = [np.float32(x) for x in p]
+            want, _ = ob.trace_primary(cam)
+            got = gb.generate_contacts_primary(as_capi_camera(cam))
+            assert got.tobytes() == want.tobytes(), (name, knobs, pose, res)
+        gb.close(); sc.close()
+    finally:
+        ctx.close()
