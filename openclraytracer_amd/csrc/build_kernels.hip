@@ -233,38 +233,62 @@ void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, ui
 //    with an agent-scope release before the counter add and an agent-scope acquire after it
 //    (per-CU L1 and per-XCD L2 are not coherent, MI355X_MICROARCH "inter-workgroup visibility").
 // ----------------------------------------------------------------------------------------
+// mergeBoundingBox (BVH.h:328-334) = merge3 (AABB.h:107-113) on all four lanes: child A, child B, then the node's own box,
+// which still holds what constructNode gave it: (FLT_MAX, FLT_MAX, FLT_MAX, 0) / (FLT_MIN, FLT_MIN, FLT_MIN, 0).  The
+// operand order matters for ties (RMIN / RMAX return their second operand unless the first is strictly smaller / larger).
+__device__ __forceinline__ void refit_merge(float4 alo, float4 ahi, float4 blo, float4 bhi, float4& rlo, float4& rhi)
+{
+    const float4 slo = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.0f), shi = make_float4(FLT_MIN, FLT_MIN, FLT_MIN, 0.0f);
+    float4 t;
+    t.x = RMIN(alo.x, blo.x); t.y = RMIN(alo.y, blo.y); t.z = RMIN(alo.z, blo.z); t.w = RMIN(alo.w, blo.w);
+    rlo.x = RMIN(t.x, slo.x); rlo.y = RMIN(t.y, slo.y); rlo.z = RMIN(t.z, slo.z); rlo.w = RMIN(t.w, slo.w);
+    t.x = RMAX(ahi.x, bhi.x); t.y = RMAX(ahi.y, bhi.y); t.z = RMAX(ahi.z, bhi.z); t.w = RMAX(ahi.w, bhi.w);
+    rhi.x = RMAX(t.x, shi.x); rhi.y = RMAX(t.y, shi.y); rhi.z = RMAX(t.z, shi.z); rhi.w = RMAX(t.w, shi.w);
+}
+
+// One walker per pair of sibling leaves climbs towards the root and carries the box it has just computed in registers.
+//   * a node whose other child is a LEAF is merged on the spot: a leaf's box is final, no hand-shake is needed -- this is
+//     every step along a chain of duplicate Morton codes (node i = leaf + node i+1), the deep part of the reference tree;
+//   * a node whose other child is an INNER node is merged by the second arriver, decided by the counter's return value
+//     (the reference re-reads the counter non-atomically and has no fence); the first arriver leaves its box in memory
+//     behind an agent-scope release, the second reads it after an agent-scope acquire (per-CU L1 and per-XCD L2 are not
+//     coherent, MI355X_MICROARCH "inter-workgroup visibility").
+// Same merges in the same operand order as one walker per leaf with a counter at every node, hence the same bytes.
 __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n)
 {
-    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
-    uint32_t current = nodes[leaf].data[0];
-    bool wrote = false;
-    while (current != UINT_MAX) {
-        if (wrote) {
+    uint32_t current = nodes[leaf].data[0];                // the leaf's parent
+    if (current == UINT_MAX) return;
+    uint32_t ca = nodes[current].data[1], cb = nodes[current].data[2];
+    if (ca != leaf || cb >= n) return;                     // walkers start at (leaf, leaf) nodes, from child A
+    float4 lo, hi;
+    refit_merge(*reinterpret_cast<const float4*>(nodes[ca].boundsMin), *reinterpret_cast<const float4*>(nodes[ca].boundsMax),
+                *reinterpret_cast<const float4*>(nodes[cb].boundsMin), *reinterpret_cast<const float4*>(nodes[cb].boundsMax), lo, hi);
+    for (;;) {
+        *reinterpret_cast<float4*>(nodes[current].boundsMin) = lo;
+        *reinterpret_cast<float4*>(nodes[current].boundsMax) = hi;
+        const uint32_t parent = nodes[current].data[0];
+        if (parent == UINT_MAX) break;
+        ca = nodes[parent].data[1]; cb = nodes[parent].data[2];
+        const bool i_am_a = ca == current;
+        const uint32_t sibling = i_am_a ? cb : ca;
+        if (sibling >= n) {
+            // inner sibling: whoever comes second merges
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t old = atomicAdd(&counters[parent - n], 1u);
+            if (old == 0) break;                           // first arriver leaves; its box is in memory
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        uint32_t old = atomicAdd(&counters[current - n], 1u);
-        if (old == 0) break;                      // first arriver leaves
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        rt_bvh_node* nd = &nodes[current];
-        uint32_t ca = nd->data[1], cb = nd->data[2];
-        float4 alo = *reinterpret_cast<const float4*>(nodes[ca].boundsMin);
-        float4 ahi = *reinterpret_cast<const float4*>(nodes[ca].boundsMax);
-        float4 blo = *reinterpret_cast<const float4*>(nodes[cb].boundsMin);
-        float4 bhi = *reinterpret_cast<const float4*>(nodes[cb].boundsMax);
-        float4 slo = *reinterpret_cast<const float4*>(nd->boundsMin);
-        float4 shi = *reinterpret_cast<const float4*>(nd->boundsMax);
-        float4 rlo, rhi, t;
-        t.x = RMIN(alo.x, blo.x); t.y = RMIN(alo.y, blo.y); t.z = RMIN(alo.z, blo.z); t.w = RMIN(alo.w, blo.w);
-        rlo.x = RMIN(t.x, slo.x); rlo.y = RMIN(t.y, slo.y); rlo.z = RMIN(t.z, slo.z); rlo.w = RMIN(t.w, slo.w);
-        t.x = RMAX(ahi.x, bhi.x); t.y = RMAX(ahi.y, bhi.y); t.z = RMAX(ahi.z, bhi.z); t.w = RMAX(ahi.w, bhi.w);
-        rhi.x = RMAX(t.x, shi.x); rhi.y = RMAX(t.y, shi.y); rhi.z = RMAX(t.z, shi.z); rhi.w = RMAX(t.w, shi.w);
-        *reinterpret_cast<float4*>(nd->boundsMin) = rlo;
-        *reinterpret_cast<float4*>(nd->boundsMax) = rhi;
-        wrote = true;
-        current = nd->data[0];
+        const float4 slo = *reinterpret_cast<const float4*>(nodes[sibling].boundsMin);
+        const float4 shi = *reinterpret_cast<const float4*>(nodes[sibling].boundsMax);
+        float4 rlo, rhi;
+        if (i_am_a) refit_merge(lo, hi, slo, shi, rlo, rhi);
+        else refit_merge(slo, shi, lo, hi, rlo, rhi);
+        lo = rlo; hi = rhi;
+        current = parent;
     }
 }
 
