@@ -216,7 +216,7 @@ __device__ __forceinline__ void leaf_test(const TraceArgs& a, uint32_t leaf, Ray
 }
 
 // work item -> pixel.  Work items enumerate this rank's 64x64 tiles; inside a tile the 64 8x8
-// blocks, inside a block the 64 pixels (one wave refill batch ~ one 8x8 block).
+// blocks, inside a block the 64 pixels (one wave = one 8x8 block).
 __device__ __forceinline__ bool work_to_pixel(const TraceArgs& a, uint32_t w, uint32_t& x, uint32_t& y, uint32_t& slot)
 {
     uint32_t ordinal = w >> 12;                 // owned tile ordinal (4096 px per tile)
