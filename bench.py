@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='issue every frame eagerly instead of replaying a HIP graph per frame')
     ap.add_argument('--check-frames', action='store_true',
                     help='N > 1: after the warm-up, rank 0 also traces every frame untiled and compares it with the gathered one')
     args = ap.parse_args()
@@ -170,35 +171,66 @@ def main():
         gctx = capi.Context(local_rank)                    # gather + untile stream, ordered behind the five frame streams
         gstream = torch.cuda.ExternalStream(gctx.get_stream(), device=dev)
         gather_done = [None, None]                         # event behind the gather that last read send[b]
+        gather_events = [torch.cuda.Event(), torch.cuda.Event()]
         step_no = [0]
+        # per-step Python work is the bound for N >= 4: everything that can be prepared once is
+        gather_out = list(gathered.unbind(0)) if rank == 0 else None
+        frame_ptrs = [it['frame'].data_ptr() for it in work] if rank == 0 else None
+        gathered_ptrs = [gathered[0, i].data_ptr() for i in range(len(SCENES))] if rank == 0 else None
+        rank_stride = len(SCENES) * 3 * slots0
+        native_gather = dist.get_backend() != 'gloo'      # gloo (rehearsal on one GPU) stages through the host in frame_tiles
+
+    # One HIP graph per frame (trace with the calibrated strategy, then shade): replaying it is one launch call instead of
+    # five.  On one GPU the device is the bound and this changes nothing; with the frame tiled over N GPUs the host is
+    # (DESIGN.md section 6).  Creating a graph traces one frame eagerly first, which is also where the BVH gets calibrated.
+    use_graphs = not args.no_graphs and os.environ.get('RTMI_BENCH_GRAPHS', '1') != '0'
+    if use_graphs:
+        try:
+            for i, it in enumerate(work):
+                if not tiled:
+                    it['graph'] = [capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'].data_ptr(), it['rgba'].data_ptr())]
+                else:
+                    it['graph'] = [capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'].data_ptr(), send[b][i].data_ptr(),
+                                                   capi.FRAME_TILED_PACKED, rank, tiling, slots0) for b in range(2)]
+        except capi.RtError as e:
+            print('frame graphs unavailable (%s): issuing frames eagerly' % e, file=sys.stderr)
+            use_graphs = False
+    graphs_on = [use_graphs]                      # the measurement passes after the timed region issue eagerly
 
     def step():
         if not tiled:
             for it in work:
-                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
-                capi.shade_blinn_phong_frame_d(it['ctx'], it['scene'], it['cam'], it['contacts'].data_ptr(), it['rgba'].data_ptr())
+                if graphs_on[0]:
+                    it['graph'][0].launch()
+                else:
+                    it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
+                    capi.shade_blinn_phong_frame_d(it['ctx'], it['scene'], it['cam'], it['contacts'].data_ptr(), it['rgba'].data_ptr())
             return
         b = step_no[0] & 1
         step_no[0] += 1
         for i, it in enumerate(work):
             if gather_done[b] is not None:
                 it['tstream'].wait_event(gather_done[b])            # send[b] is free again
-            it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
-            # shade straight into this frame's planes of the send buffer (ranks own slots <= slots0)
-            capi.shade_blinn_phong_tiled_packed_d(it['ctx'], it['scene'], it['cam'], rank, tiling, it['contacts'].data_ptr(),
-                                                  send[b][i].data_ptr(), slots0)
+            if graphs_on[0]:
+                it['graph'][b].launch()
+            else:
+                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
+                # shade straight into this frame's planes of the send buffer (ranks own slots <= slots0)
+                capi.shade_blinn_phong_tiled_packed_d(it['ctx'], it['scene'], it['cam'], rank, tiling, it['contacts'].data_ptr(),
+                                                      send[b][i].data_ptr(), slots0)
             gstream.wait_stream(it['tstream'])
         with torch.cuda.stream(gstream):
             # the one collective of a step: issued behind all five frames, runs on the communicator's stream
-            _, w = frame_tiles.gather_to_root(send[b], world, rank, out=gathered, async_op=True)
+            if native_gather:
+                w = dist.gather(send[b], gather_out, dst=0, async_op=True)
+            else:
+                _, w = frame_tiles.gather_to_root(send[b], world, rank, out=gathered, async_op=True)
             w.wait()                                                 # orders the gather stream behind the gather
-            ev = torch.cuda.Event()
-            ev.record(gstream)
-            gather_done[b] = ev
+            gather_events[b].record(gstream)
+            gather_done[b] = gather_events[b]
         if rank == 0:
             for i, it in enumerate(work):
-                capi.untile_rgba_packed_d(gctx, it['cam'], tiling, gathered[0, i].data_ptr(), slots0, it['frame'].data_ptr(),
-                                          rank_stride_floats=len(SCENES) * 3 * slots0)
+                capi.untile_rgba_packed_d(gctx, it['cam'], tiling, gathered_ptrs[i], slots0, frame_ptrs[i], rank_stride_floats=rank_stride)
 
     def fence():
         if dist is not None:
@@ -226,8 +258,6 @@ def main():
         if args.warmup == 0:
             step(); fence()
         check_frames('after the warm-up')
-    for c in ctxs:
-        c.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -236,6 +266,13 @@ def main():
     elapsed = time.perf_counter() - t0
     if args.check_frames and tiled:
         check_frames('after the timed steps')     # the frames of the last, fully overlapped step
+    # HIP-event span of a traversal launch while the five streams overlap: a short eager pass (a graph has no events in it)
+    graphs_on[0] = False
+    for c in ctxs:
+        c.set_profiling(True)
+    for _ in range(min(args.steps, 10)):
+        step()
+    fence()
     kt = dict(launches=0, lane_phase_ms=0.0, wave_phase_ms=0.0)
     for c in ctxs:
         k1 = c.trace_kernel_times()

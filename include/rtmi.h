@@ -222,6 +222,21 @@ int  rt_shade_blinn_phong_tiled_packed(rt_ctx* ctx, const rt_scene* scene, const
 int  rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgb_planes_gathered,
                            uint32_t slots_per_rank, uint64_t rank_stride_floats, void* d_rgba_frame);
 
+/* ---- frame graphs: the launch sequence of one steady-state frame (trace with the strategy the BVH is calibrated to, then
+ *      shading) captured into a HIP graph; replaying it is one launch call instead of five (an easy frame's kernels run for
+ *      60-100 us, issuing them eagerly costs 30-40 us of host time).  The camera, the buffers and the tiling are baked in:
+ *      create a new graph when one of them changes, and after every construct().  layout:
+ *        RT_FRAME_UNTILED       d_contacts = resX*resY contacts, d_out = resX*resY float4 (rt_shade_blinn_phong_frame)
+ *        RT_FRAME_TILED         compact contacts, d_out = compact float4 (rt_shade_blinn_phong_tiled)
+ *        RT_FRAME_TILED_PACKED  compact contacts, d_out = three float planes of slots_per_rank (.._tiled_packed)
+ *      create() traces one frame eagerly first (calibration, camera preparation, buffer sizing) and synchronises.        */
+enum { RT_FRAME_UNTILED = 0, RT_FRAME_TILED = 1, RT_FRAME_TILED_PACKED = 2 };
+typedef struct rt_frame_graph rt_frame_graph;
+int  rt_frame_graph_create(rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks,
+                           int layout, void* d_contacts, void* d_out, uint32_t slots_per_rank, rt_frame_graph** out);
+int  rt_frame_graph_launch(rt_frame_graph* g);     /* on the context's stream, asynchronous */
+void rt_frame_graph_destroy(rt_frame_graph* g);
+
 /* ---- parallel primitives used by the builders ------------------------------------------- */
 /* BitonicSort::sort (Include/Algorithms/Sorting.h:77, BitonicSort.cpp:118-189): uint2 pairs, key = .x,
  * same comparator network => same permutation of equal keys.  n_pow2 must be a power of two.     */

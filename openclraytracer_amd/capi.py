@@ -38,7 +38,7 @@ SYMBOLS = [
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
-    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
+    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
     'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
@@ -104,6 +104,9 @@ def load_library() -> C.CDLL:
     L.rt_shade_blinn_phong_tiled.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.rt_untile_rgba.argtypes = [vp, vp, u32, vp, u32, vp]
     L.rt_shade_blinn_phong_frame.argtypes = [vp, vp, vp, vp, vp]
+    L.rt_frame_graph_create.argtypes = [vp, vp, vp, u32, u32, i32, vp, vp, u32, pvp]
+    L.rt_frame_graph_launch.argtypes = [vp]
+    L.rt_frame_graph_destroy.argtypes = [vp]; L.rt_frame_graph_destroy.restype = None
     L.rt_shade_blinn_phong_tiled_packed.argtypes = [vp, vp, vp, u32, u32, vp, vp, u32]
     L.rt_untile_rgba_packed.argtypes = [vp, vp, u32, vp, u32, u64, vp]
     L.rt_sort_pairs_bitonic.argtypes = [vp, vp, u32]
@@ -463,6 +466,32 @@ def tiles_owned_pixels(cam: np.ndarray, rank: int, nranks: int) -> int:
 def shade_blinn_phong_tiled_d(ctx, scene, cam, rank, nranks, d_contacts, d_rgba):
     ctx.check(ctx.lib.rt_shade_blinn_phong_tiled(ctx.h, scene.h, _p(cam), rank, nranks, C.c_void_p(d_contacts),
                                                  C.c_void_p(d_rgba)))
+
+
+FRAME_UNTILED, FRAME_TILED, FRAME_TILED_PACKED = 0, 1, 2
+
+
+class FrameGraph:
+    """rt_frame_graph: trace + shade of one steady-state frame as a HIP graph (one launch call per replay)."""
+
+    def __init__(self, bvh, scene, cam, d_contacts: int, d_out: int, layout: int = FRAME_UNTILED, rank: int = 0, nranks: int = 1,
+                 slots_per_rank: int = 0):
+        self.ctx = bvh.ctx
+        self.cam = np.array(cam, copy=True)              # the C side reads it only during create()
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.rt_frame_graph_create(bvh.h, scene.h, _p(self.cam), rank, nranks, layout, C.c_void_p(d_contacts),
+                                                          C.c_void_p(d_out), slots_per_rank, C.byref(h)))
+        self.h = h
+        self._launch = self.ctx.lib.rt_frame_graph_launch
+
+    def launch(self):
+        if self._launch(self.h):
+            self.ctx.check(1)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rt_frame_graph_destroy(self.h)
+            self.h = None
 
 
 def shade_blinn_phong_frame_d(ctx, scene, cam, d_primary_contacts, d_rgba):

@@ -822,6 +822,98 @@ int rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, co
 }
 
 // ---------------------------------------------------------------------------------------
+// frame graphs: the steady-state launch sequence of one frame (control-block memset, first-phase kernel, wave-per-ray
+// kernel, shading) captured once into a HIP graph and replayed with one call.  The kernels of an easy frame run for
+// 60-100 us while issuing them takes 30-40 us of host time, and with the frame tiled over N GPUs the host becomes the
+// bound.
+// ---------------------------------------------------------------------------------------
+struct rt_frame_graph {
+    rt_ctx* ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks, int layout,
+                       void* d_contacts, void* d_out, uint32_t slots_per_rank)
+{
+    rt_ctx* ctx = b->ctx;
+    const bool tiled = layout != RT_FRAME_UNTILED;
+    if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts)) return RT_ERROR;
+    if (!tiled)
+        launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts, cam->resX * cam->resY, (float4*)d_out, true, 0, 1);
+    else
+        launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts, rt_tiles_owned_pixels(cam, rank, nranks), (float4*)d_out,
+                     true, rank, nranks, layout == RT_FRAME_TILED_PACKED ? slots_per_rank : 0u);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks, int layout,
+                          void* d_contacts, void* d_out, uint32_t slots_per_rank, rt_frame_graph** out)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!out) return RT_FAIL(ctx, "out is null");
+    *out = nullptr;
+    if (!scene || !d_contacts || !d_out) return RT_FAIL(ctx, "null argument");
+    if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (layout != RT_FRAME_UNTILED && layout != RT_FRAME_TILED && layout != RT_FRAME_TILED_PACKED) return RT_FAIL(ctx, "unknown frame layout");
+    if (layout == RT_FRAME_UNTILED) { rank = 0; nranks = 1; }
+    if (rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (layout == RT_FRAME_TILED_PACKED && slots_per_rank < rt_tiles_owned_pixels(cam, rank, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
+    if (ctx->profiling) return RT_FAIL(ctx, "frame graphs cannot be captured while per-launch profiling is on");
+    RT_ENTER(ctx);
+    if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
+    // one eager frame first: it calibrates the strategy for this (resolution, tiling), prepares the camera and sizes every
+    // buffer, none of which may happen during a capture
+    if (frame_issue(b, scene, cam, rank, nranks, layout, d_contacts, d_out, slots_per_rank)) return RT_ERROR;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (check_trace_error(ctx)) return RT_ERROR;
+    rt_frame_graph* g = new (std::nothrow) rt_frame_graph();
+    if (!g) return RT_FAIL(ctx, "out of host memory");
+    g->ctx = ctx;
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { delete g; return RT_FAIL(ctx, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    const int rc = frame_issue(b, scene, cam, rank, nranks, layout, d_contacts, d_out, slots_per_rank);
+    e = hipStreamEndCapture(ctx->stream, &g->graph);
+    if (rc != RT_SUCCESS || e != hipSuccess || !g->graph) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        (void)hipGetLastError();
+        return rc != RT_SUCCESS ? RT_ERROR : RT_FAIL(ctx, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g->graph);
+        delete g;
+        return RT_FAIL(ctx, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    *out = g;
+    return RT_SUCCESS;
+}
+
+int rt_frame_graph_launch(rt_frame_graph* g)
+{
+    if (!g) return RT_FAIL(nullptr, "frame graph is null");
+    rt_ctx* ctx = g->ctx;
+    RT_ENTER(ctx);
+    RT_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
+    ctx->trace_launched = true;                 // the next synchronising call looks at the kernels' error word
+    return RT_SUCCESS;
+}
+
+void rt_frame_graph_destroy(rt_frame_graph* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
+// ---------------------------------------------------------------------------------------
 // primitives
 // ---------------------------------------------------------------------------------------
 int rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2)

@@ -512,3 +512,50 @@ def test_rotated_cameras_inside_outside_and_on_planes(name, knobs, monkeypatch):
         gb.close(); sc.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('name', ['gardenlight', 'tenryuu'])
+def test_frame_graphs_replay_the_eager_frame(gpu_ctx, name):
+    """rt_frame_graph: trace + shade of a frame captured into a HIP graph.  Replays write the same contacts and colours,
+    bit for bit, as the eager calls, for the untiled frame, the tiled 16-byte layout and the tiled packed planes."""
+    from openclraytracer_amd import capi
+    osc, _ = oracle_bvh(name)
+    sc, gb = gpu_bvh(gpu_ctx, name)
+    res = (333, 200)
+    cam = as_capi_camera(osc.demo_camera(*res))
+    npx = res[0] * res[1]
+    want_c = gb.generate_contacts_primary(cam)
+    want_rgba = capi.shade_blinn_phong(gpu_ctx, sc, cam, want_c)
+    # untiled
+    dc, dr = gpu_ctx.alloc(npx * 32), gpu_ctx.alloc(npx * 16)
+    g = capi.FrameGraph(gb, sc, cam, dc, dr)
+    for _ in range(3):
+        gpu_ctx.fill_u32(dc, 0xDEADBEEF, npx * 8); gpu_ctx.fill_u32(dr, 0xDEADBEEF, npx * 4)
+        g.launch()
+        assert gpu_ctx.download(dc, npx, capi.CONTACT).tobytes() == want_c.tobytes()
+        assert gpu_ctx.download(dr, npx * 4, np.float32).tobytes() == want_rgba.tobytes()
+    g.close(); gpu_ctx.free(dc); gpu_ctx.free(dr)
+    # tiled: rank 1 of RT_TILING(3, 1), 16-byte and packed layouts
+    til = capi.tiling(3, 1)
+    slots0 = capi.tiles_owned_pixels(cam, 0, til)
+    slots = capi.tiles_owned_pixels(cam, 1, til)
+    dc, dr, dp = gpu_ctx.alloc(slots * 32), gpu_ctx.alloc(slots * 16), gpu_ctx.alloc(slots0 * 12)
+    gb.generate_contacts_primary_tiled_d(cam, 1, til, dc)
+    capi.shade_blinn_phong_tiled_d(gpu_ctx, sc, cam, 1, til, dc, dr)
+    capi.shade_blinn_phong_tiled_packed_d(gpu_ctx, sc, cam, 1, til, dc, dp, slots0)
+    want_tc = gpu_ctx.download(dc, slots, capi.CONTACT).tobytes()
+    want_tr = gpu_ctx.download(dr, slots * 4, np.float32).tobytes()
+    want_tp = gpu_ctx.download(dp, slots0 * 3, np.float32).reshape(3, slots0)[:, :slots].tobytes()
+    g1 = capi.FrameGraph(gb, sc, cam, dc, dr, capi.FRAME_TILED, 1, til)
+    g2 = capi.FrameGraph(gb, sc, cam, dc, dp, capi.FRAME_TILED_PACKED, 1, til, slots0)
+    for _ in range(2):
+        gpu_ctx.fill_u32(dc, 0xDEADBEEF, slots * 8); gpu_ctx.fill_u32(dr, 0xDEADBEEF, slots * 4)
+        g1.launch()
+        assert gpu_ctx.download(dc, slots, capi.CONTACT).tobytes() == want_tc
+        assert gpu_ctx.download(dr, slots * 4, np.float32).tobytes() == want_tr
+        gpu_ctx.fill_u32(dc, 0xDEADBEEF, slots * 8); gpu_ctx.fill_u32(dp, 0xDEADBEEF, slots0 * 3)
+        g2.launch()
+        assert gpu_ctx.download(dc, slots, capi.CONTACT).tobytes() == want_tc
+        assert gpu_ctx.download(dp, slots0 * 3, np.float32).reshape(3, slots0)[:, :slots].tobytes() == want_tp
+    g1.close(); g2.close()
+    gpu_ctx.free(dc); gpu_ctx.free(dr); gpu_ctx.free(dp)
