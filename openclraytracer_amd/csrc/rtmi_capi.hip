@@ -392,21 +392,28 @@ int rt_bvh_initialize_frame(rt_bvh* b)
     if (n != b->n) {                                  // grow-only in the reference (CLBuffer::resize); exact here
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         free_build_buffers(b);
-        b->n = n; b->N = N;
-        RT_HIP(ctx, hipMalloc((void**)&b->d_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node)));
-        RT_HIP(ctx, hipMalloc((void**)&b->d_pairs, (size_t)N * sizeof(uint2)));
-        RT_HIP(ctx, hipMalloc((void**)&b->d_counters, (size_t)n * sizeof(uint32_t)));
-        RT_HIP(ctx, hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode) * (ctx->no_search_tree ? 1u : 2u)));
-        RT_HIP(ctx, hipMalloc((void**)&b->d_depth, 256));
-        RT_HIP(ctx, hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t)));
-        RT_HIP(ctx, hipMalloc((void**)&b->d_tree_select, 256));
-        if (!ctx->no_packet4) RT_HIP(ctx, hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * (ctx->no_search_tree ? 1u : 2u)));
-        if (!ctx->no_search_tree) {                   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
-            RT_HIP(ctx, hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node)));
-            RT_HIP(ctx, hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2)));
-            RT_HIP(ctx, hipMalloc((void**)&b->s_counters, (size_t)n * sizeof(uint32_t) + 256));
-            RT_HIP(ctx, hipMalloc((void**)&b->s_pos, (size_t)n * sizeof(uint32_t)));
+        b->n = 0; b->N = 0;                           // stays 0 unless every allocation below succeeds
+        const size_t trees = ctx->no_search_tree ? 1u : 2u;
+        hipError_t e = hipMalloc((void**)&b->d_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_pairs, (size_t)N * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_counters, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode) * trees);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_depth, 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_tree_select, 256);
+        if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * trees);
+        if (e == hipSuccess && !ctx->no_search_tree) {   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
+            e = hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
+            if (e == hipSuccess) e = hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc((void**)&b->s_counters, (size_t)n * sizeof(uint32_t) + 256);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->s_pos, (size_t)n * sizeof(uint32_t));
         }
+        if (e != hipSuccess) {
+            free_build_buffers(b);
+            (void)hipGetLastError();
+            return RT_FAIL(ctx, std::string("initializeFrame: device allocation failed: ") + hipGetErrorString(e));
+        }
+        b->n = n; b->N = N;
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
