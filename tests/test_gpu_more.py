@@ -559,3 +559,30 @@ def test_frame_graphs_replay_the_eager_frame(gpu_ctx, name):
         assert gpu_ctx.download(dp, slots0 * 3, np.float32).reshape(3, slots0)[:, :slots].tobytes() == want_tp
     g1.close(); g2.close()
     gpu_ctx.free(dc); gpu_ctx.free(dr); gpu_ctx.free(dp)
+
+
+def test_frame_graph_error_behaviour(gpu_ctx):
+    """frame graphs refuse what cannot be captured or makes no sense, with a message, and leave the context usable"""
+    from openclraytracer_amd import capi
+    osc, _ = oracle_bvh('cube')
+    sc, gb = gpu_bvh(gpu_ctx, 'cube')
+    cam = as_capi_camera(osc.demo_camera(64, 48))
+    dc, dr = gpu_ctx.alloc(64 * 48 * 32), gpu_ctx.alloc(64 * 48 * 16)
+    with pytest.raises(capi.RtError, match='unknown frame layout'):
+        capi.FrameGraph(gb, sc, cam, dc, dr, layout=7)
+    with pytest.raises(capi.RtError, match='rank/nranks invalid'):
+        capi.FrameGraph(gb, sc, cam, dc, dr, layout=capi.FRAME_TILED, rank=3, nranks=2)
+    with pytest.raises(capi.RtError, match='slots_per_rank too small'):
+        capi.FrameGraph(gb, sc, cam, dc, dr, layout=capi.FRAME_TILED_PACKED, rank=0, nranks=1, slots_per_rank=16)
+    with pytest.raises(capi.RtError, match='null argument'):
+        capi.FrameGraph(gb, sc, cam, 0, dr)
+    gpu_ctx.set_profiling(True)
+    with pytest.raises(capi.RtError, match='profiling'):
+        capi.FrameGraph(gb, sc, cam, dc, dr)
+    gpu_ctx.set_profiling(False)
+    g = capi.FrameGraph(gb, sc, cam, dc, dr)                      # and now it works
+    g.launch()
+    want = gb.generate_contacts_primary(cam)
+    assert gpu_ctx.download(dc, 64 * 48, capi.CONTACT).tobytes() == want.tobytes()
+    g.close(); g.close()                                          # closing twice is harmless
+    gpu_ctx.free(dc); gpu_ctx.free(dr)
