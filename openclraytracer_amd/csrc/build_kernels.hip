@@ -246,6 +246,7 @@ __device__ __forceinline__ void refit_merge(float4 alo, float4 ahi, float4 blo, 
     rhi.x = RMAX(t.x, shi.x); rhi.y = RMAX(t.y, shi.y); rhi.z = RMAX(t.z, shi.z); rhi.w = RMAX(t.w, shi.w);
 }
 
+#define REFIT_RUN 4
 // One walker per pair of sibling leaves climbs towards the root and carries the box it has just computed in registers.
 //   * a node whose other child is a LEAF is merged on the spot: a leaf's box is final, no hand-shake is needed -- this is
 //     every step along a chain of duplicate Morton codes (node i = leaf + node i+1), the deep part of the reference tree;
@@ -268,6 +269,39 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
     for (;;) {
         *reinterpret_cast<float4*>(nodes[current].boundsMin) = lo;
         *reinterpret_cast<float4*>(nodes[current].boundsMax) = hi;
+        // Along a chain of duplicate Morton codes node i is (leaf, node i + 1): the nodes above `current` are current - 1,
+        // current - 2, ...  Four levels are taken per round trip: their records and their leaves' boxes are fetched together,
+        // the chain shape is checked, and the four merges run in registers in the same order as one by one.
+        if (current >= n + REFIT_RUN) {
+            uint4 rec[REFIT_RUN];
+#pragma unroll
+            for (int k = 0; k < REFIT_RUN; k++) rec[k] = *reinterpret_cast<const uint4*>(nodes[current - 1u - (uint32_t)k].data);
+            bool chain = nodes[current].data[0] == current - 1u;
+#pragma unroll
+            for (int k = 0; k < REFIT_RUN; k++)
+                chain = chain && rec[k].y < n && rec[k].z == current - (uint32_t)k &&          // (leaf, the node below)
+                        (k + 1 == REFIT_RUN || rec[k].x == current - 2u - (uint32_t)k);          // its parent is the next one up
+            if (chain) {
+                float4 llo[REFIT_RUN], lhi[REFIT_RUN];
+#pragma unroll
+                for (int k = 0; k < REFIT_RUN; k++) {
+                    llo[k] = *reinterpret_cast<const float4*>(nodes[rec[k].y].boundsMin);
+                    lhi[k] = *reinterpret_cast<const float4*>(nodes[rec[k].y].boundsMax);
+                }
+#pragma unroll
+                for (int k = 0; k < REFIT_RUN; k++) {
+                    float4 rlo, rhi;
+                    refit_merge(llo[k], lhi[k], lo, hi, rlo, rhi);                   // child A = the leaf, child B = the chain below
+                    lo = rlo; hi = rhi;
+                    if (k + 1 < REFIT_RUN) {
+                        *reinterpret_cast<float4*>(nodes[current - 1u - (uint32_t)k].boundsMin) = lo;
+                        *reinterpret_cast<float4*>(nodes[current - 1u - (uint32_t)k].boundsMax) = hi;
+                    }
+                }
+                current -= REFIT_RUN;
+                continue;                                                            // the loop head stores the last one
+            }
+        }
         const uint32_t parent = nodes[current].data[0];
         if (parent == UINT_MAX) break;
         ca = nodes[parent].data[1]; cb = nodes[parent].data[2];
