@@ -246,7 +246,7 @@ __device__ __forceinline__ void refit_merge(float4 alo, float4 ahi, float4 blo, 
     rhi.x = RMAX(t.x, shi.x); rhi.y = RMAX(t.y, shi.y); rhi.z = RMAX(t.z, shi.z); rhi.w = RMAX(t.w, shi.w);
 }
 
-#define REFIT_RUN 4
+#define REFIT_RUN 8
 // One walker per pair of sibling leaves climbs towards the root and carries the box it has just computed in registers.
 //   * a node whose other child is a LEAF is merged on the spot: a leaf's box is final, no hand-shake is needed -- this is
 //     every step along a chain of duplicate Morton codes (node i = leaf + node i+1), the deep part of the reference tree;
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
         *reinterpret_cast<float4*>(nodes[current].boundsMin) = lo;
         *reinterpret_cast<float4*>(nodes[current].boundsMax) = hi;
         // Along a chain of duplicate Morton codes node i is (leaf, node i + 1): the nodes above `current` are current - 1,
-        // current - 2, ...  Four levels are taken per round trip: their records and their leaves' boxes are fetched together,
-        // the chain shape is checked, and the four merges run in registers in the same order as one by one.
+        // current - 2, ...  Eight levels are taken per round trip: their records and their leaves' boxes are fetched together,
+        // the chain shape is checked, and the eight merges run in registers in the same order as one by one.
         if (current >= n + REFIT_RUN) {
             uint4 rec[REFIT_RUN];
 #pragma unroll
