@@ -255,7 +255,7 @@ __device__ __forceinline__ void refit_merge(float4 alo, float4 ahi, float4 blo, 
 //     behind an agent-scope release, the second reads it after an agent-scope acquire (per-CU L1 and per-XCD L2 are not
 //     coherent, MI355X_MICROARCH "inter-workgroup visibility").
 // Same merges in the same operand order as one walker per leaf with a counter at every node, hence the same bytes.
-__global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n)
+__global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
 {
     const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
@@ -266,6 +266,10 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
     float4 lo, hi;
     refit_merge(*reinterpret_cast<const float4*>(nodes[ca].boundsMin), *reinterpret_cast<const float4*>(nodes[ca].boundsMax),
                 *reinterpret_cast<const float4*>(nodes[cb].boundsMin), *reinterpret_cast<const float4*>(nodes[cb].boundsMax), lo, hi);
+    // The walker also carries the height of its sub-tree (a leaf has height 0): the root's height is the tree depth the
+    // traversal stacks are sized from, and no separate pass has to climb from every leaf to the root for it.  At a node
+    // with two inner children the first arriver leaves its height in the upper bits of the arrival counter.
+    uint32_t height = 1;
     for (;;) {
         *reinterpret_cast<float4*>(nodes[current].boundsMin) = lo;
         *reinterpret_cast<float4*>(nodes[current].boundsMax) = hi;
@@ -299,23 +303,27 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
                     }
                 }
                 current -= REFIT_RUN;
+                height += REFIT_RUN;
                 continue;                                                            // the loop head stores the last one
             }
         }
         const uint32_t parent = nodes[current].data[0];
-        if (parent == UINT_MAX) break;
+        if (parent == UINT_MAX) { *depth_out = height; break; }            // the root: only one walker gets here
         ca = nodes[parent].data[1]; cb = nodes[parent].data[2];
         const bool i_am_a = ca == current;
         const uint32_t sibling = i_am_a ? cb : ca;
+        uint32_t sibling_height = 0;
         if (sibling >= n) {
             // inner sibling: whoever comes second merges
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t old = atomicAdd(&counters[parent - n], 1u);
-            if (old == 0) break;                           // first arriver leaves; its box is in memory
+            const uint32_t old = atomicAdd(&counters[parent - n], 1u + (height << 2));     // two bits of arrivals, 30 of height
+            if (old == 0) break;                           // first arriver leaves; its box is in memory, its height in the counter
+            sibling_height = old >> 2;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        height = (height > sibling_height ? height : sibling_height) + 1u;
         const float4 slo = *reinterpret_cast<const float4*>(nodes[sibling].boundsMin);
         const float4 shi = *reinterpret_cast<const float4*>(nodes[sibling].boundsMax);
         float4 rlo, rhi;
@@ -326,9 +334,9 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
     }
 }
 
-void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n)
+void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
 {
-    hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n);
+    hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -351,22 +359,6 @@ __global__ __launch_bounds__(256) void k_relayout(const rt_bvh_node* nodes, Trav
     trav[i] = t;
 }
 
-__global__ __launch_bounds__(256) void k_tree_depth(const rt_bvh_node* nodes, uint32_t n, uint32_t* depth_out)
-{
-    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t d = 0;
-    if (leaf < n) {
-        uint32_t cur = nodes[leaf].data[0];
-        while (cur != UINT_MAX && d < 2 * n) { d++; cur = nodes[cur].data[0]; }
-    }
-    // wave max, then one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_down((int)d, off, 64);
-        d = d > o ? d : o;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(depth_out, d);
-}
-
 // leaf -> position in the sorted pair array.  The radix tree is built over that array, so this is
 // the leaf's rank in the reference's A-first depth-first order (the tie rule of BVH.h:392).
 __global__ __launch_bounds__(256) void k_leaf_positions(const uint2* pairs, uint32_t* pos, uint32_t n)
@@ -376,12 +368,10 @@ __global__ __launch_bounds__(256) void k_leaf_positions(const uint2* pairs, uint
 }
 
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t* depth_out, uint32_t id_offset)
+                     uint32_t n, uint32_t id_offset)
 {
     hipLaunchKernelGGL(k_relayout, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, trav, n, id_offset);
     hipLaunchKernelGGL(k_leaf_positions, dim3((n + 255) / 256), dim3(256), 0, s, pairs, pos, n);
-    (void)hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_tree_depth, dim3((n + 255) / 256), dim3(256), 0, s, nodes, n, depth_out);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -436,8 +436,8 @@ int rt_bvh_construct(rt_bvh* b)
     launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
     launch_bitonic_sort(s, b->d_pairs, b->N);                     // 2. :195
     launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n);           // 3. :204
-    launch_refit(s, b->d_nodes, b->d_counters, b->n);             // 4. :217
-    launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n, b->d_depth);  // traversal records, DFS ranks, depth
+    launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
+    launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n);  // traversal records, DFS ranks
     RT_HIP(ctx, hipGetLastError());
     uint32_t depth = 0;
     RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
@@ -454,9 +454,9 @@ int rt_bvh_construct(rt_bvh* b)
         launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
         launch_bitonic_sort(s, s_pairs, N);
         launch_radix_tree(s, s_nodes, s_pairs, n);
-        launch_refit(s, s_nodes, s_counters, n);
         uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
-        launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, s_depth, n - 1);
+        launch_refit(s, s_nodes, s_counters, n, s_depth);
+        launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s));
     }
