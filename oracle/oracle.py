@@ -1,7 +1,7 @@
 """oracle.py -- TEST INFRASTRUCTURE ONLY: ctypes front-end of oracle/_build/librt_oracle.so.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
-See rt_oracle.h for the parity status ("parity unpinned" for the arithmetic).
+See rt_oracle.h for the parity status (pinned on the reference's own OpenCL C kernels, tests/golden/reference_cl.json).
 """
 from __future__ import annotations
 
@@ -81,6 +81,9 @@ def lib():
         L.orc_morton_buffer_items.argtypes = [u32]
         L.orc_bitonic_sort.argtypes = [vp, u32]
         L.orc_build_bvh.argtypes = [vp, i32, vp, vp]
+        L.orc_morton_leaves.argtypes = [vp, vp, vp]
+        L.orc_radix_tree.argtypes = [vp, vp, u32, i32]
+        L.orc_refit.argtypes = [vp, u32, i32]
         L.orc_check_hierarchy.argtypes = [vp, u32, vp]
         L.orc_trace_primary.argtypes = [vp, vp, u32, vp, vp, vp, i32]
         L.orc_trace_primary_range.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, i32]
@@ -203,6 +206,32 @@ class BVH:
         lib().orc_trace_rays(_p(rays), len(rays), _p(self.nodes), self.n, _p(self.scene.arr), _p(out),
                              C.byref(st), nthreads or ncpu())
         return out, st
+
+
+def set_device_arith(on: bool) -> None:
+    """dot / cross as ROCm's OpenCL C library defines them (fused), i.e. the arithmetic of the reference's DEVICE branch on
+    this GPU, instead of the host branch's.  Only tests that compare with the reference's own kernels switch it on."""
+    lib().orc_set_device_arith(1 if on else 0)
+
+
+def build_stages(scene: Scene, mode: int = 0) -> dict:
+    """The products of every stage of BVHManager::initializeFrame + construct (BVHManager.cpp:122-228), so that each can be
+    compared with what the reference's own kernel makes of the same input (tests/test_gpu_reference_cl.py):
+    leaves / pairs after calculateMortonCodes, sorted pairs, nodes after buildRadixTree, nodes after computeBoundingBoxes."""
+    L = lib()
+    n = scene.n_tris
+    N = int(L.orc_morton_buffer_items(n))
+    nodes = np.zeros(2 * n - 1, dtype=NODE)
+    pairs = np.full(N, 0xFFFFFFFF, dtype=np.uint32).repeat(2).view(PAIR).copy()
+    L.orc_morton_leaves(_p(scene.arr), _p(nodes), _p(pairs))
+    out = dict(n=n, N=N, leaves=nodes.copy(), pairs=pairs.copy())
+    L.orc_bitonic_sort(_p(pairs), N)
+    out['sorted'] = pairs.copy()
+    L.orc_radix_tree(_p(nodes), _p(pairs), n, mode)
+    out['radix'] = nodes.copy()
+    L.orc_refit(_p(nodes), n, mode)
+    out['nodes'] = nodes
+    return out
 
 
 def brute_primary(scene: Scene, cam: np.ndarray, nthreads: int = 0) -> np.ndarray:

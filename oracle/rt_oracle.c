@@ -1,9 +1,9 @@
 /*
  * rt_oracle.c -- CPU restatement of the reference's BVH ray-intersection path.
- * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  "parity unpinned" for the
- * arithmetic: the reference headers cannot be built in this image (Boost
- * absent) and the reference holds no golden vectors; each function cites the
- * reference lines it restates.  Paths are relative to
+ * TEST INFRASTRUCTURE ONLY (see rt_oracle.h for the parity status: pinned on the
+ * reference's own OpenCL C kernels run on an MI355X, tests/golden/reference_cl.json;
+ * the headers' host branch cannot be built in this image, Boost absent).  Each
+ * function cites the reference lines it restates.  Paths are relative to
  * /root/reference/OpenCLRayTracer/ ; "CLData/" = Include/CLData/.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (x86-64 SSE2 => plain IEEE
@@ -155,14 +155,31 @@ int orc_scene_triangle(const void* scene_, uint32_t globalTri, orc_f4 v[3], uint
 static orc_f4 v_sub(orc_f4 a, orc_f4 b) { orc_f4 r = { a.x - b.x, a.y - b.y, a.z - b.z, 0.0f }; return r; }
 static orc_f4 v_add(orc_f4 a, orc_f4 b) { orc_f4 r = { a.x + b.x, a.y + b.y, a.z + b.z, 0.0f }; return r; }
 static orc_f4 v_scale(orc_f4 a, float s) { orc_f4 r = { a.x * s, a.y * s, a.z * s, 0.0f }; return r; }
+/* Which definitions of dot() / cross() the restatement computes with.
+ *   0 (default): the headers' HOST branch, CLPortability.h:266-278 -- separate multiplies and adds.
+ *   1: the headers' DEVICE branch, where dot and cross are the OpenCL C built-ins (CLPortability.h:41-45 leaves them to
+ *      the compiler's library).  ROCm 7.2's library (amdgcn/bitcode/opencl.bc, functions _Z3dotDv3_fS_ and _Z5crossDv3_fS_)
+ *      defines them with fused multiply-adds, restated below; with this switch on, the oracle reproduces the t, hit mask and
+ *      materialIndex of the reference's own generateContacts2 kernel running on the MI355X bit for bit
+ *      (tests/test_gpu_reference_cl.py).  Test infrastructure only; the product restates the host branch. */
+int orc_device_arith = 0;
+void orc_set_device_arith(int on) { orc_device_arith = on; }
 /* CLPortability.h:266-273 */
 static orc_f4 v_cross(orc_f4 a, orc_f4 b)
 {
+    if (orc_device_arith) {
+        orc_f4 d = { fmaf(a.y, b.z, b.y * -a.z), fmaf(a.z, b.x, b.z * -a.x), fmaf(a.x, b.y, b.x * -a.y), 0.0f };
+        return d;
+    }
     orc_f4 r = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0f };
     return r;
 }
 /* CLPortability.h:275-278 */
-static float v_dot(orc_f4 a, orc_f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static float v_dot(orc_f4 a, orc_f4 b)
+{
+    if (orc_device_arith) return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 /* cpu_normalize, CLPortability.h:151-159: l = 1/sqrt(|v|^2), then three multiplies */
 static orc_f4 v_normalize(orc_f4 v)
 {

@@ -5,16 +5,24 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library, and there only as the checker / the reported CPU baseline.
  *
- * PARITY STATUS: "parity unpinned" for the arithmetic.  The reference's
- * dual-target headers (OpenCLRayTracer/Include/CLData/...) need Boost
- * (<boost/utility/binary.hpp>, CLPortability.h:161) and back-slash include
- * paths; Boost is absent from this image, so the reference arithmetic is
- * unbuildable here without writing stand-in headers, and the reference ships
- * no golden vectors or runnable tests for this path.  Every function below is
- * therefore a line-by-line restatement citing the reference file:line it
- * follows.  The only piece pinned by real reference code is the OBJ/MTL
- * parser (vendored tiny_obj_loader.h, which has no Boost dependency): see
- * oracle/ref_tinyobj_dump.cpp and oracle/scene_pack.py.
+ * PARITY STATUS: pinned on the reference's own DEVICE code, run on an MI355X (round 2).
+ *   - The HOST branch of the reference's dual-target headers (OpenCLRayTracer/Include/CLData/..., #ifdef _WIN32) needs Boost
+ *     (<boost/utility/binary.hpp>, CLPortability.h:161); Boost is absent from this image and stand-in headers are not
+ *     allowed, so that branch is unbuildable here.  The reference ships no golden vectors or runnable tests.
+ *   - The DEVICE branch needs neither: `make -C oracle ref_cl` compiles the reference's four .cl files for gfx950 with ROCm
+ *     clang where they lie (oracle/_ref/cl_*.co; -fms-extensions for their back-slash includes is the only extra switch), and
+ *     oracle/ref_cl.py launches those kernels through the HIP module API.  tests/golden/reference_cl.json holds what they
+ *     produced (generator: tests/golden/make_golden_reference_cl.py); tests/test_cpu_reference_pins.py checks this
+ *     restatement against it anywhere, tests/test_gpu_reference_cl.py re-runs the kernels on the GPU box.
+ *   - Bit for bit on all five bundled models: calculateMortonCodes (leaf nodes + Morton pairs), the B8/B4/B2 bitonic network,
+ *     buildRadixTree (guard as written = LITERAL_ZERO stage; FIXED differs in exactly node n-2 and its children's parent
+ *     links), group_prefixSum, and pixelIndex / materialIndex / t of generateContacts2 on the FIXED and the LITERAL_ZERO
+ *     tree -- the last with orc_set_device_arith(1): the device branch's dot() / cross() are OpenCL built-ins, which ROCm's
+ *     library fuses, and the restatement's default is the host branch's separate multiplies and adds (t then differs by
+ *     <= 1.1e-5 relative, the hit mask on one edge-on pixel of Cube).  Normals: fast_normalize on the device, 3e-7.
+ *   - NOT pinned: computeBoundingBoxes (the reference kernel races on the MI355X: 37-12 172 boxes too small, differently
+ *     per run; FIXED = its merges once both children are final), the host-only shading (Shading.h), scene packing beyond
+ *     the vendored OBJ parser (oracle/ref_tinyobj_dump.cpp).
  *
  * All structs are byte-identical to the reference PODs (sizes asserted in
  * rt_oracle.c).  cl_float3 is a 16-byte type on the host (CL/cl_platform.h),
@@ -59,6 +67,9 @@ typedef struct {
 enum { ORC_MODE_FIXED = 0, ORC_MODE_LITERAL_ZERO = 1 };
 
 size_t   orc_sizeof(const char* name);
+/* 0 (default): dot / cross of the headers' host branch; 1: ROCm's OpenCL C built-ins, as the reference's kernels compute
+ * them on the MI355X (see rt_oracle.c).  Global, set before tracing. */
+void     orc_set_device_arith(int on);
 
 /* ---- camera (OpenCLRayTracerDemo.cpp:202-217, CLStructs.h:60-74, Transform.h:397-413) */
 void     orc_demo_camera(const void* scene, uint32_t resX, uint32_t resY, orc_camera* out);

@@ -111,10 +111,19 @@ static int axis_overlaps(float alo, float ahi, float blo, float bhi)
 /* sign() of OpenCL C (6.12.4): 1 / -1 / +-0 / 0 for NaN */
 static float cl_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : (x == 0.0f ? x : 0.0f)); }
 
-static float dot3(orc_f4 a, orc_f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+extern int orc_device_arith;     /* rt_oracle.c: 1 = dot / cross as ROCm's OpenCL C built-ins (fused), the device branch */
+static float dot3(orc_f4 a, orc_f4 b)
+{
+    if (orc_device_arith) return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 static orc_f4 sub3(orc_f4 a, orc_f4 b) { orc_f4 r = { a.x - b.x, a.y - b.y, a.z - b.z, 0.0f }; return r; }
 static orc_f4 cross3(orc_f4 a, orc_f4 b)
 {
+    if (orc_device_arith) {
+        orc_f4 d = { fmaf(a.y, b.z, b.y * -a.z), fmaf(a.z, b.x, b.z * -a.x), fmaf(a.x, b.y, b.x * -a.y), 0.0f };
+        return d;
+    }
     orc_f4 r = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0f };
     return r;
 }

@@ -4,8 +4,12 @@
  *
  * TEST INFRASTRUCTURE ONLY (same rules as rt_oracle.h): tests/, smoke() and bench.py's cpu_baseline leg.
  *
- * PARITY STATUS: "parity unpinned" (see rt_oracle.h: the reference headers need Boost, the reference has no
- * golden vectors).  Every function cites the reference lines it follows.  Where the reference is undefined
+ * PARITY STATUS: pinned on the reference's own kernels run on an MI355X for the stages that stay in range on a consistent
+ * grid (see rt_oracle.h; tests/golden/reference_cl.json): prepareDataKernel (per-triangle cell counts),
+ * countLeavesAndFillCellKernel (leaf resolutions with the DEVICE's pow: equal to the pow_third defined below on every cell of
+ * all five bundled models) and generateContacts2Kernel (pixelIndex / materialIndex / t bit for bit with
+ * orc_set_device_arith(1)).  The remaining build kernels index out of range as written (below) and are not run.
+ * Every function cites the reference lines it follows.  Where the reference is undefined
  * or broken the FIXED reading of SURVEY.md section 8(c) is used and said in place:
  *   - all n triangles are counted / emitted (the kernels skip the last one, TwoLevelGridKernels.cl:48-49,63-64);
  *   - cell ranges are extracted over the whole sorted array (the kernel only works in work-group 0, :81,93),
