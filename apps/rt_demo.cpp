@@ -1,7 +1,7 @@
 // rt_demo -- headless counterpart of the reference's GLUT demo (src/Demos/OpenCLRayTracerDemo/OpenCLRayTracerDemo.cpp):
 // the same five switches (-winH -winW -accStruct -headersPath -scene, :66-73,513-552), the same main() sequence
 // (:130-266: load scene, upload, default camera, manager initialize / initializeFrame / construct) and the same
-// RTFrame() sequence (:271-326) with the host shading loop replaced by the device shading call, then a PPM/raw
+// RTFrame() sequence (:271-326) with the host shading loop replaced by the device shading call, then a PPM / PFM (float) / raw
 // dump instead of the GL point-sprite display.  Written against the reference's class names only.
 #include <chrono>
 #include <cstdio>
@@ -39,7 +39,7 @@ int main(int argc, char* argv[])
         else if (k == "--contacts") rawContacts = v;
     }
     if (window_width <= 0 || window_height <= 0 || scenePath.empty() || accStruct.empty()) {
-        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm] [--contacts raw.bin]" << std::endl;
+        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm|img.pfm] [--contacts raw.bin]" << std::endl;
         return 0;
     }
     if (accStruct != "BVH" && accStruct != "GRID") {              // OpenCLRayTracerDemo.cpp:221-224
@@ -97,7 +97,23 @@ int main(int argc, char* argv[])
         FILE* fc = std::fopen(rawContacts.c_str(), "wb");
         if (fc) { std::fwrite(all.data(), sizeof(Contact), pixelCount, fc); std::fclose(fc); }
     }
-    if (!outPath.empty()) {
+    const bool pfm = outPath.size() > 4 && outPath.compare(outPath.size() - 4, 4, ".pfm") == 0;
+    if (!outPath.empty() && pfm) {
+        // Portable Float Map: the shaded float RGB as it is (the reference hands the float4 colours to a GL VBO,
+        // OpenCLRayTracerDemo.cpp:319); "PF", width height, a negative scale = little endian, rows bottom to top
+        FILE* fo = std::fopen(outPath.c_str(), "wb");
+        if (!fo) { std::perror("fopen"); return 1; }
+        std::fprintf(fo, "PF\n%d %d\n-1.0\n", window_width, window_height);
+        std::vector<float> row((size_t)window_width * 3);
+        for (int y = window_height - 1; y >= 0; y--) {
+            for (int x = 0; x < window_width; x++) {
+                const CL_FLOAT4& c = colors[(size_t)y * window_width + x];
+                row[3 * x] = c.x; row[3 * x + 1] = c.y; row[3 * x + 2] = c.z;
+            }
+            std::fwrite(row.data(), sizeof(float), row.size(), fo);
+        }
+        std::fclose(fo);
+    } else if (!outPath.empty()) {
         FILE* fo = std::fopen(outPath.c_str(), "wb");
         if (!fo) { std::perror("fopen"); return 1; }
         std::fprintf(fo, "P6\n%d %d\n255\n", window_width, window_height);

@@ -150,7 +150,7 @@ def main():
         build_ms[name] = (time.perf_counter() - t0) * 1e3 / 2
         cam = demo_camera(buf, *RES)
         slots = capi.tiles_owned_pixels(cam, rank, tiling) if tiled else npx
-        item = dict(name=name, ctx=sctx, tstream=tstreams[si], scene=scene, bvh=bvh, cam=cam, slots=slots,
+        item = dict(name=name, bytes=buf, ctx=sctx, tstream=tstreams[si], scene=scene, bvh=bvh, cam=cam, slots=slots,
                     contacts=torch.empty(slots * 32, dtype=torch.uint8, device=dev),
                     rgba=torch.empty((slots, 4), dtype=torch.float32, device=dev))
         if tiled:
@@ -243,14 +243,23 @@ def main():
     def check_frames(when):
         # rank 0 traces and shades every frame untiled and compares it with the one the ranks assembled
         if rank == 0:
+            # on a context of its own: the untiled frame needs larger deferred-ray lists than the tiles, and growing them on a
+            # frame's context would invalidate that frame's graphs (rt_frame_graph_launch then reports them stale)
+            cctx = capi.Context(local_rank)
             for it in work:
+                cscene = capi.DeviceScene(cctx, it['bytes'])
+                cbvh = capi.DeviceBVH(cctx, cscene).build()
                 full_c = torch.empty(npx * 32, dtype=torch.uint8, device=dev)
                 full_rgba = torch.empty((npx, 4), dtype=torch.float32, device=dev)
-                it['bvh'].generate_contacts_primary_d(it['cam'], full_c.data_ptr())
-                capi.shade_blinn_phong_d(it['ctx'], it['scene'], it['cam'], full_c.data_ptr(), npx, full_rgba.data_ptr())
+                cbvh.generate_contacts_primary_d(it['cam'], full_c.data_ptr())
+                capi.shade_blinn_phong_d(cctx, cscene, it['cam'], full_c.data_ptr(), npx, full_rgba.data_ptr())
+                cctx.synchronize()
                 torch.cuda.synchronize(dev)
-                if not torch.equal(full_rgba, it['frame']):
+                same = torch.equal(full_rgba, it['frame'])
+                cbvh.close(); cscene.close()
+                if not same:
                     raise SystemExit('frame check failed for %s (%s): the gathered frame differs from the untiled one' % (it['name'], when))
+            cctx.close()
             print('frame check ok (%s): %d gathered frames equal the untiled ones' % (when, len(work)), file=sys.stderr)
         fence()
 

@@ -66,8 +66,12 @@ typedef struct rt_scene rt_scene;   /* device side of CLRayTracer::Scene (Includ
 typedef struct rt_bvh   rt_bvh;     /* device side of AccelerationStructures::BVHManager (BVHManager.h:59-126) */
 
 enum { RT_SUCCESS = 0, RT_ERROR = 1 };
-/* parity modes, SURVEY.md 8(c): FIXED builds all n-1 inner nodes; LITERAL_ZERO is not implemented
- * on the device (rt_bvh_create rejects it) because it encodes undefined behaviour.               */
+/* parity modes, SURVEY.md 8(c).  FIXED (default) builds all n-1 inner nodes and refits with the atomic's return value.
+ * LITERAL_ZERO is the compatibility mode: the radix-tree guard as written (idx < leafCount-2, BVHKernels.cl:58: inner node
+ * n-2 is never built), zero-initialised buffers, one refit walker per work item of the reference's 64-wide launch (the ones
+ * beyond the last leaf clamped to it, BVHKernels.cl:67), parent links outside the node array end a walk -- the visible
+ * artefact of the shipped reference (the spine above the lost node keeps its inverted init boxes and is never entered),
+ * made deterministic.  Node bytes and contacts equal the oracle's LITERAL_ZERO mode; no search tree in this mode.      */
 enum { RT_MODE_FIXED = 0, RT_MODE_LITERAL_ZERO = 1 };
 
 /* ---- context: replaces CLExecutionContext creation (CLExecutionContext.cpp:270-300) ------ */
@@ -166,6 +170,10 @@ int  rt_tlg_generate_contacts_rays(rt_tlg* tlg, const void* d_rays, uint32_t ray
 int  rt_tlg_generate_contacts_primary_tiled(rt_tlg* tlg, const rt_camera* cam, uint32_t rank, uint32_t nranks,
                                             void* d_contacts_compact);      /* frame tiles as for the BVH (below) */
 int  rt_tlg_info_get(const rt_tlg* tlg, rt_tlg_info* out);
+/* construct() calls that ran without the reference's three mid-build read-backs (TwoLevelGridManager.cpp:237,345,393): a REBUILD
+ * is enqueued on the array sizes of the previous build with the counts kept on the device, and one read-back at the end
+ * confirms that the sizes still fit (else the sequence with read-backs runs).  Same products either way.               */
+uint32_t rt_tlg_rebuilds_without_readback(const rt_tlg* tlg);
 /* parity read-back of one build product into host memory (`bytes` must be its exact size, see rt_tlg_info) */
 int  rt_tlg_read(const rt_tlg* tlg, int what, void* h_dst, uint64_t bytes);
 /* pow(x, oneThird) as this library defines it for the grid resolutions (TwoLevelGrid.h:190-198,
@@ -225,7 +233,11 @@ int  rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, c
 /* ---- frame graphs: the launch sequence of one steady-state frame (trace with the strategy the BVH is calibrated to, then
  *      shading) captured into a HIP graph; replaying it is one launch call instead of five (an easy frame's kernels run for
  *      60-100 us, issuing them eagerly costs 30-40 us of host time).  The camera, the buffers and the tiling are baked in:
- *      create a new graph when one of them changes, and after every construct().  layout:
+ *      create a new graph when one of them changes, and after every construct().  A graph also holds the addresses of the
+ *      context's deferred-ray buffers and of the BVH's records: rt_frame_graph_launch returns RT_ERROR ("stale") once a
+ *      later, larger trace on the same context has reallocated those buffers or the BVH has been rebuilt.  Tracing another
+ *      camera position eagerly on the same BVH in between is allowed: launch restores this graph's per-camera marks
+ *      (one small kernel) before replaying.  layout:
  *        RT_FRAME_UNTILED       d_contacts = resX*resY contacts, d_out = resX*resY float4 (rt_shade_blinn_phong_frame)
  *        RT_FRAME_TILED         compact contacts, d_out = compact float4 (rt_shade_blinn_phong_tiled)
  *        RT_FRAME_TILED_PACKED  compact contacts, d_out = three float planes of slots_per_rank (.._tiled_packed)

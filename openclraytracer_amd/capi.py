@@ -44,7 +44,7 @@ SYMBOLS = [
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
     'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
-    'rt_tlg_info_get', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays',
+    'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays',
 ]
 
 
@@ -128,6 +128,7 @@ def load_library() -> C.CDLL:
     L.rt_tlg_generate_contacts_rays.argtypes = [vp, vp, u32, vp]
     L.rt_tlg_generate_contacts_primary_tiled.argtypes = [vp, vp, u32, u32, vp]
     L.rt_tlg_info_get.argtypes = [vp, vp]
+    L.rt_tlg_rebuilds_without_readback.argtypes = [vp]; L.rt_tlg_rebuilds_without_readback.restype = u32
     L.rt_tlg_read.argtypes = [vp, i32, vp, u64]
     L.rt_tlg_pow_third.argtypes = [C.c_float]; L.rt_tlg_pow_third.restype = C.c_float
     L.rt_generate_secondary_rays.argtypes = [vp, vp, vp, vp, u32, i32, C.POINTER(C.c_float), C.c_float, vp, C.POINTER(u32)]
@@ -393,6 +394,12 @@ class DeviceTLG:
         a = np.zeros(len(TLG_INFO_FIELDS), dtype=np.uint32)
         self.ctx.check(self.ctx.lib.rt_tlg_info_get(self.h, _p(a)))
         return dict(zip(TLG_INFO_FIELDS, (int(x) for x in a)))
+
+    def set_densities(self, top_density: float, leaf_density: float):
+        self.ctx.check(self.ctx.lib.rt_tlg_set_densities(self.h, top_density, leaf_density))
+
+    def rebuilds_without_readback(self) -> int:
+        return int(self.ctx.lib.rt_tlg_rebuilds_without_readback(self.h))
 
     def read(self, what: int) -> np.ndarray:
         i = self.info()

@@ -129,100 +129,90 @@ void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nod
 }
 
 // ----------------------------------------------------------------------------------------
-// 3. radix tree: determineRange / findSplit / constructNode, BVH.h:138-321 (the NekoEngine
-//    duplicate-key variant, restated literally).  FIXED mode: all n-1 internal nodes
-//    (the reference kernel's guard idx < leafCount-2, BVHKernels.cl:58, loses node n-2).
+// 3. radix tree over the sorted (morton, leaf) array: what determineRange / findSplit / constructNode compute
+//    (BVH.h:138-321, the duplicate-key variant of Karras 2012), expressed through two monotone predicates.
+//
+//    Sorted keys share fewer and fewer leading bits with a fixed key the further away they lie, so both searches of the
+//    reference are searches for the LAST position at which a monotone predicate still holds, and any bisection finds
+//    the same position as the reference's doubling / halving loops:
+//      span of inner node i   : i itself plus the longest stretch, towards the neighbour that shares MORE leading bits with
+//                               key[i], of keys sharing more leading bits with key[i] than the other neighbour does;
+//                               inside a run of equal keys (both neighbours equal) the node covers the rest of the run;
+//                               node 0 covers everything;
+//      split of a span [f, l] : the last position whose key shares more leading bits with key[f] than key[l] does
+//                               (f itself when key[f] == key[l]).
+//    Children: positions [f, split] and [split + 1, l]; a one-element side is the leaf stored at that position.
+//    `built` = number of inner nodes constructed: n - 1 (FIXED), or n - 2 as the reference kernel's guard has it
+//    (idx < leafCount - 2, BVHKernels.cl:58: inner node n - 2 is never built; LITERAL_ZERO).
 // ----------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t r_clz(uint32_t x) { return x ? (uint32_t)__clz((int)x) : 32u; }  // software_clz: clz(0)=32
+__device__ __forceinline__ int shared_top_bits(uint32_t a, uint32_t b) { return a == b ? 32 : __clz((int)(a ^ b)); }
 
-__device__ int find_split(const uint2* list, int first, int last)
+struct KeySpan { uint32_t first, last; };
+
+__device__ KeySpan inner_node_span(const uint2* __restrict__ keys, uint32_t i, uint32_t n)
 {
-    uint32_t firstCode = list[first].x;
-    uint32_t lastCode = list[last].x;
-    if (firstCode == lastCode) return first;
-    int commonPrefix = (int)r_clz(firstCode ^ lastCode);
-    int split = first;
-    int step = last - first;
-    do {
-        step = (step + 1) >> 1;
-        int newSplit = split + step;
-        if (newSplit < last) {
-            uint32_t splitCode = list[newSplit].x;
-            int splitPrefix = (int)r_clz(firstCode ^ splitCode);
-            if (splitPrefix > commonPrefix) split = newSplit;
-        }
-    } while (step > 1);
-    return split;
+    if (i == 0u) return KeySpan{ 0u, n - 1u };
+    const uint32_t mine = keys[i].x, before = keys[i - 1u].x, after = keys[i + 1u].x;
+    if (before == mine && after == mine) {
+        uint32_t e = i + 1u;                                        // the rest of the run of equal keys
+        while (e + 1u < n && keys[e + 1u].x == mine) e++;
+        return KeySpan{ i, e };
+    }
+    const int with_before = shared_top_bits(mine, before), with_after = shared_top_bits(mine, after);
+    const bool backwards = with_before > with_after;
+    const int floor_bits = backwards ? with_after : with_before;     // what the far neighbour shares: the span must beat it
+    const uint32_t room = backwards ? i : n - 1u - i;                // steps that stay inside the array
+    auto belongs = [&](uint32_t steps) {
+        return steps <= room && shared_top_bits(mine, keys[backwards ? i - steps : i + steps].x) > floor_bits;
+    };
+    uint32_t yes = 0u, no = 1u;                                      // belongs(0) holds trivially
+    while (belongs(no)) { yes = no; no <<= 1; }
+    while (no - yes > 1u) {
+        const uint32_t mid = yes + ((no - yes) >> 1);
+        if (belongs(mid)) yes = mid; else no = mid;
+    }
+    return backwards ? KeySpan{ i - yes, i } : KeySpan{ i, i + yes };
 }
 
-__device__ uint2 determine_range(const uint2* list, int index, uint32_t size)
+__device__ uint32_t span_split(const uint2* __restrict__ keys, KeySpan sp)
 {
-    int lso = (int)size - 1;
-    if (index == 0) return make_uint2(0, (uint32_t)lso);
-    int dir, d_min;
-    int initialindex = index;
-    uint32_t minone = list[index - 1].x;
-    uint32_t precis = list[index].x;
-    uint32_t pluone = list[index + 1].x;
-    if (minone == precis && pluone == precis) {
-        while (index > 0 && index < lso) {
-            index += 1;
-            if (index >= lso || list[index].x != list[index + 1].x) break;
-        }
-        return make_uint2((uint32_t)initialindex, (uint32_t)index);
-    } else {
-        uint32_t lx = r_clz(precis ^ minone);
-        uint32_t ly = r_clz(precis ^ pluone);
-        if (lx > ly) { dir = -1; d_min = (int)ly; }
-        else         { dir = 1;  d_min = (int)lx; }
+    const uint32_t head = keys[sp.first].x, tail = keys[sp.last].x;
+    if (head == tail) return sp.first;
+    const int ends_share = shared_top_bits(head, tail);
+    uint32_t yes = sp.first, no = sp.last;                            // the head shares everything with itself, the tail too little
+    while (no - yes > 1u) {
+        const uint32_t mid = yes + ((no - yes) >> 1);
+        if (shared_top_bits(head, keys[mid].x) > ends_share) yes = mid; else no = mid;
     }
-    int l_max = 2;
-    int testindex = index + l_max * dir;
-    while ((testindex <= lso && testindex >= 0) ? (r_clz(precis ^ list[testindex].x) > (uint32_t)d_min) : false) {
-        l_max = l_max << 1;
-        testindex = index + l_max * dir;
-    }
-    int l = 0;
-    for (int div = 2; l_max / div >= 1; div = div << 1) {
-        int t = l_max / div;
-        int newTest = index + (l + t) * dir;
-        if (newTest <= lso && newTest >= 0) {
-            int splitPrefix = (int)r_clz(precis ^ list[newTest].x);
-            if (splitPrefix > d_min) l = l + t;
-        }
-    }
-    int a = index, b = index + l * dir;
-    return make_uint2((uint32_t)(a < b ? a : b), (uint32_t)(a > b ? a : b));
+    return yes;
 }
 
-__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* mc, uint32_t numLeaves)
+__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* __restrict__ keys, uint32_t n, uint32_t built)
 {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= numLeaves - 1) return;
-    uint2 range = determine_range(mc, (int)idx, numLeaves);
-    int split = find_split(mc, (int)range.x, (int)range.y);
-    uint32_t internal = idx + numLeaves;
-    uint32_t first = range.x < range.y ? range.x : range.y;
-    uint32_t last = range.x > range.y ? range.x : range.y;
-    bool aIsLeaf = first == (uint32_t)split;
-    bool bIsLeaf = last == (uint32_t)(split + 1);
-    uint32_t child_A = aIsLeaf ? mc[split].y : (uint32_t)split + numLeaves;
-    uint32_t child_B = bIsLeaf ? mc[split + 1].y : (uint32_t)split + 1 + numLeaves;
-    rt_bvh_node* nd = &nodes[internal];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= built) return;
+    const KeySpan sp = inner_node_span(keys, i, n);
+    const uint32_t split = span_split(keys, sp);
+    const uint32_t self = n + i;
+    // a side of one position is that position's leaf, otherwise the inner node numbered like the side's boundary position
+    const uint32_t child_a = sp.first == split ? keys[split].y : n + split;
+    const uint32_t child_b = sp.last == split + 1u ? keys[split + 1u].y : n + split + 1u;
+    rt_bvh_node* nd = &nodes[self];
     // init box (FLT_MAX, FLT_MIN) -- FLT_MIN is the smallest POSITIVE normal, as written (BVH.h:309-310)
     nd->boundsMin[0] = FLT_MAX; nd->boundsMin[1] = FLT_MAX; nd->boundsMin[2] = FLT_MAX; nd->boundsMin[3] = 0.0f; // INNER_NODE
     nd->boundsMax[0] = FLT_MIN; nd->boundsMax[1] = FLT_MIN; nd->boundsMax[2] = FLT_MIN; nd->boundsMax[3] = 0.0f;
-    if (internal == numLeaves) nd->data[0] = UINT_MAX;
-    nd->data[1] = child_A;
-    nd->data[2] = child_B;
+    if (i == 0u) nd->data[0] = UINT_MAX;                               // the root has no parent (BVH.h:312-313)
+    nd->data[1] = child_a;
+    nd->data[2] = child_b;
     nd->data[3] = 0;
-    nodes[child_A].data[0] = internal;
-    nodes[child_B].data[0] = internal;
+    nodes[child_a].data[0] = self;
+    nodes[child_b].data[0] = self;
 }
 
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n)
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built)
 {
-    hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, pairs, n);
+    if (built == 0u) return;
+    hipLaunchKernelGGL(k_radix_tree, dim3((built + 255) / 256), dim3(256), 0, s, nodes, pairs, n, built);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -337,6 +327,81 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
 {
     hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
+}
+
+// ----------------------------------------------------------------------------------------
+// 4b. LITERAL_ZERO refit (compatibility mode): computeBoundingBoxes as launched by
+//     BVHManager.cpp:214-217 on zero-initialised buffers, made deterministic: one walker per work item of the
+//     64-wide launch (items beyond the last leaf are clamped to it, BVHKernels.cl:67), every arrival counted, every
+//     arrival after the first merges (the reference re-reads the counter: `> 1`), a parent link outside [n, 2n-1) ends the
+//     walk (the children of the never-built node n-2 still hold the 0 the buffer was cleared to; the reference would
+//     index its counters out of range there).  The genuine walkers run in parallel -- at most two arrive per node, the
+//     second merges final children, decided by the atomic's return value -- and the clamped extra walkers, whose order
+//     matters, run afterwards on one thread in work-item order, exactly as the oracle serialises them.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ void literal_merge(rt_bvh_node* nodes, uint32_t cur)
+{
+    const uint32_t a = nodes[cur].data[1], b = nodes[cur].data[2];
+    const float4 alo = *reinterpret_cast<const float4*>(nodes[a].boundsMin), ahi = *reinterpret_cast<const float4*>(nodes[a].boundsMax);
+    const float4 blo = *reinterpret_cast<const float4*>(nodes[b].boundsMin), bhi = *reinterpret_cast<const float4*>(nodes[b].boundsMax);
+    const float4 slo = *reinterpret_cast<const float4*>(nodes[cur].boundsMin), shi = *reinterpret_cast<const float4*>(nodes[cur].boundsMax);
+    float4 t, lo, hi;                                  // merge3 (AABB.h:107-113) on all four lanes: (A, B), then the node's own box
+    t.x = RMIN(alo.x, blo.x); t.y = RMIN(alo.y, blo.y); t.z = RMIN(alo.z, blo.z); t.w = RMIN(alo.w, blo.w);
+    lo.x = RMIN(t.x, slo.x); lo.y = RMIN(t.y, slo.y); lo.z = RMIN(t.z, slo.z); lo.w = RMIN(t.w, slo.w);
+    t.x = RMAX(ahi.x, bhi.x); t.y = RMAX(ahi.y, bhi.y); t.z = RMAX(ahi.z, bhi.z); t.w = RMAX(ahi.w, bhi.w);
+    hi.x = RMAX(t.x, shi.x); hi.y = RMAX(t.y, shi.y); hi.z = RMAX(t.z, shi.z); hi.w = RMAX(t.w, shi.w);
+    *reinterpret_cast<float4*>(nodes[cur].boundsMin) = lo;
+    *reinterpret_cast<float4*>(nodes[cur].boundsMax) = hi;
+}
+
+__global__ __launch_bounds__(256) void k_refit_literal(rt_bvh_node* nodes, uint32_t* counters, uint32_t n)
+{
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    uint32_t current = nodes[leaf].data[0];
+    while (current != UINT_MAX) {
+        if (current < n || current >= 2u * n - 1u) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t old = atomicAdd(&counters[current - n], 1u);
+        if (old == 0u) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        literal_merge(nodes, current);
+        current = nodes[current].data[0];
+    }
+}
+
+__global__ void k_refit_literal_extras(rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t extras, uint32_t* depth_out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (uint32_t e = 0; e < extras; e++) {
+        uint32_t current = nodes[n - 1u].data[0];
+        while (current != UINT_MAX) {
+            if (current < n || current >= 2u * n - 1u) break;
+            const uint32_t c = ++counters[current - n];
+            if (c <= 1u) break;
+            literal_merge(nodes, current);
+            current = nodes[current].data[0];
+        }
+    }
+    *depth_out = 0u;                                   // k_depth_literal takes the maximum
+}
+
+// longest chain of valid parent links above a leaf (the tree is broken on purpose in this mode: walks end at bad links)
+__global__ __launch_bounds__(256) void k_depth_literal(const rt_bvh_node* nodes, uint32_t n, uint32_t* depth_out)
+{
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    uint32_t d = 0, current = nodes[leaf].data[0];
+    while (current != UINT_MAX && current >= n && current < 2u * n - 1u && d < 2u * n) { d++; current = nodes[current].data[0]; }
+    atomicMax(depth_out, d);
+}
+
+void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
+{
+    hipLaunchKernelGGL(k_refit_literal, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n);
+    const uint32_t launched = ((n + 63u) / 64u) * 64u;              // closestMultipleTo(leafCount, warp), BVHManager.cpp:213
+    hipLaunchKernelGGL(k_refit_literal_extras, dim3(1), dim3(64), 0, s, nodes, counters, n, launched - n, depth_out);
+    hipLaunchKernelGGL(k_depth_literal, dim3((n + 255) / 256), dim3(256), 0, s, nodes, n, depth_out);
 }
 
 // ----------------------------------------------------------------------------------------

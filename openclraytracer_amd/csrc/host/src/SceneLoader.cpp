@@ -27,42 +27,45 @@ enum { SCENE_HEADER = 96, LIGHT = 16, SPHERE = 16, MATERIAL = 96, MODEL_HEADER =
 struct ObjMaterial { float v[19]; std::string name; };    // ambient diffuse specular transmittance emission | Ns Ni d illum
 struct ObjShape { std::vector<float> positions; std::vector<uint32_t> indices; std::vector<int> material_ids; };
 
-bool is_digit(char c) { return c >= '0' && c <= '9'; }
+// A number of the reference's OBJ parser (tiny_obj_loader.h v0.9.17 :266-383), scanned in three parts: integer digits
+// (at least one is required, so ".5" is not a number), an optional fraction, an optional exponent (which needs at least one
+// digit, else the whole token is rejected).  Anything else ends the number silently.  It is NOT a correctly rounded strtod,
+// and byte-identical packing needs its roundings: integer digits accumulate as value * 10 + d, fraction digit k adds
+// d * 10^-k, and the decimal exponent E is applied as value * 5^E * 2^E.
+struct NumberCursor {
+    const char* at;
+    const char* end;
+    bool more() const { return at != end; }
+    bool on_digit() const { return more() && *at >= '0' && *at <= '9'; }
+    bool on_sign() const { return more() && (*at == '+' || *at == '-'); }
+    int take_digit() { return *at++ - '0'; }
+};
 
-// the float grammar of the reference's parser: NOT a correctly rounded strtod (digits accumulated with pow(10,-k))
-bool try_parse_double(const char* s, const char* s_end, double* result)
+bool scan_obj_number(const char* begin, const char* end, double* value_out)
 {
-    if (s >= s_end) return false;
-    double mantissa = 0.0;
-    int exponent = 0;
-    char sign = '+', exp_sign = '+';
-    const char* curr = s;
-    int read = 0;
-    bool end_not_reached = false;
-    if (*curr == '+' || *curr == '-') { sign = *curr; curr++; }
-    else if (!is_digit(*curr)) return false;
-    while ((end_not_reached = (curr != s_end)) && is_digit(*curr)) { mantissa *= 10; mantissa += (int)(*curr - '0'); curr++; read++; }
-    if (read == 0) return false;
-    bool assemble = !end_not_reached;
-    if (!assemble) {
-        if (*curr == '.') {
-            curr++; read = 1;
-            while ((end_not_reached = (curr != s_end)) && is_digit(*curr)) { mantissa += (int)(*curr - '0') * std::pow(10.0, -read); read++; curr++; }
-        } else if (*curr == 'e' || *curr == 'E') {
-        } else assemble = true;
+    NumberCursor c{ begin, end };
+    if (!c.more()) return false;
+    bool negative = false;
+    if (c.on_sign()) negative = *c.at++ == '-';
+    else if (!c.on_digit()) return false;
+    if (!c.on_digit()) return false;                       // a sign alone, or a sign followed by '.'
+    double value = 0.0;
+    while (c.on_digit()) { value *= 10; value += c.take_digit(); }
+    if (c.more() && *c.at == '.') {
+        c.at++;
+        for (int place = 1; c.on_digit(); place++) value += c.take_digit() * std::pow(10.0, -place);
     }
-    if (!assemble && !end_not_reached) assemble = true;
-    if (!assemble && (*curr == 'e' || *curr == 'E')) {
-        curr++;
-        if ((end_not_reached = (curr != s_end)) && (*curr == '+' || *curr == '-')) { exp_sign = *curr; curr++; }
-        else if (curr != s_end && is_digit(*curr)) {}
-        else return false;
-        read = 0;
-        while ((end_not_reached = (curr != s_end)) && is_digit(*curr)) { exponent *= 10; exponent += (int)(*curr - '0'); curr++; read++; }
-        exponent *= (exp_sign == '+' ? 1 : -1);
-        if (read == 0) return false;
+    int exp10 = 0;
+    if (c.more() && (*c.at == 'e' || *c.at == 'E')) {
+        c.at++;
+        bool exp_negative = false;
+        if (c.on_sign()) exp_negative = *c.at++ == '-';
+        else if (!c.on_digit()) return false;
+        if (!c.on_digit()) return false;                   // "1e", "1e+": rejected as a whole
+        while (c.on_digit()) { exp10 *= 10; exp10 += c.take_digit(); }
+        if (exp_negative) exp10 = -exp10;
     }
-    *result = (sign == '+' ? 1 : -1) * std::ldexp(mantissa * std::pow(5.0, exponent), exponent);
+    *value_out = (negative ? -1 : 1) * std::ldexp(value * std::pow(5.0, exp10), exp10);
     return true;
 }
 
@@ -71,7 +74,7 @@ float parse_float(const char*& token)
     token += std::strspn(token, " \t");
     const char* end = token + std::strcspn(token, " \t\r");
     double val = 0.0;
-    try_parse_double(token, end, &val);
+    scan_obj_number(token, end, &val);
     token = end;
     return (float)val;
 }

@@ -44,6 +44,7 @@ static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
         RT_HIP(ctx, hipMalloc((void**)&ctx->d_long_list, want * trace_long_record_bytes()));
         RT_HIP(ctx, hipMalloc((void**)&ctx->d_split_list, want * sizeof(uint32_t)));
         ctx->long_cap = (uint32_t)want;
+        ctx->scratch_generation++;                 // frame graphs created before this hold the freed addresses
         // test knob: what recycled device memory looks like
         if (ctx->poison & 1) RT_HIP(ctx, hipMemsetAsync(ctx->d_long_list, 0xCD, want * trace_long_record_bytes(), ctx->stream));
         if (ctx->poison & 2) RT_HIP(ctx, hipMemsetAsync(ctx->d_split_list, 0xCD, want * sizeof(uint32_t), ctx->stream));
@@ -53,6 +54,7 @@ static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
         if (ctx->d_keys) { (void)hipFree(ctx->d_keys); ctx->d_keys = nullptr; ctx->keys_cap = 0; }
         RT_HIP(ctx, hipMalloc((void**)&ctx->d_keys, work_items * sizeof(unsigned long long)));
         ctx->keys_cap = work_items;
+        ctx->scratch_generation++;
         if (ctx->poison & 4) RT_HIP(ctx, hipMemsetAsync(ctx->d_keys, 0xCD, work_items * sizeof(unsigned long long), ctx->stream));
     }
     return RT_SUCCESS;
@@ -65,12 +67,20 @@ static int check_trace_error(rt_ctx* ctx)
     if (!ctx->trace_launched) return RT_SUCCESS;
     ctx->trace_launched = false;
     uint32_t err = 0;
-    RT_HIP(ctx, hipMemcpy(&err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost));
-    if (err == 1) return RT_FAIL(ctx, "trace kernel: deferred-ray list full while a full traversal stack had to hand off work; frame invalid");
-    if (err == 3) return RT_FAIL(ctx, "trace kernel: packet stack overflowed its spill area; frame invalid");
-    if (err == 4) return RT_FAIL(ctx, "trace kernel: a deferred-ray record does not describe a task of this launch; frame invalid");
-    if (err) return RT_FAIL(ctx, "trace kernel: node pool of the wave-per-ray phase overflowed; frame invalid");
-    return RT_SUCCESS;
+    void* word = (char*)ctx->d_trace_ctrl + trace_ctrl_error_offset();
+    RT_HIP(ctx, hipMemcpy(&err, word, 4, hipMemcpyDeviceToHost));
+    if (!err) return RT_SUCCESS;
+    // the word is sticky on the device (kernels OR a bit per failure, launches do not clear it): every invalid frame since the
+    // last check is reported here, once
+    RT_HIP(ctx, hipMemset(word, 0, 4));
+    std::string msg = "trace kernel:";
+    if (err & (1u << 1)) msg += " deferred-ray list full while a full traversal stack had to hand off work;";
+    if (err & (1u << 2)) msg += " node pool of the wave-per-ray phase overflowed;";
+    if (err & (1u << 3)) msg += " packet stack overflowed its spill area;";
+    if (err & (1u << 4)) msg += " a deferred-ray record does not describe a task of this launch;";
+    if (err & (1u << 5)) msg += " no free spill area for a packet stack;";
+    if (err & ~0x3Eu) msg += " unknown failure bits;";
+    return RT_FAIL(ctx, msg + " frame invalid");
 }
 
 extern "C" {
@@ -93,7 +103,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     ctx->device = device_ordinal;
     if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc(&ctx->d_trace_ctrl, trace_ctrl_bytes())) != hipSuccess) {
+        (e = hipMalloc(&ctx->d_trace_ctrl, trace_ctrl_bytes())) != hipSuccess ||
+        (e = hipMemset(ctx->d_trace_ctrl, 0, trace_ctrl_bytes())) != hipSuccess) {      // launches clear the counters only: the error word starts clean here
         RT_FAIL(nullptr, std::string("context creation failed: ") + hipGetErrorString(e));
         free_ctx_buffers(ctx);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -111,6 +122,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_TRACE_DIAG")) ctx->trace_diagnostics = env[0] == '1';
     if (const char* env = std::getenv("RTMI_CALIBRATION_LOG")) ctx->calibration_log = env[0] == '1';
+    if (const char* env = std::getenv("RTMI_RECALIBRATE")) ctx->recalibrate = env[0] == '1';
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
@@ -340,8 +352,7 @@ int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** 
     if (!ctx || !scene || !out) return RT_FAIL(ctx, "null argument");
     *out = nullptr;
     if (scene->ctx != ctx) return RT_FAIL(ctx, "scene belongs to another context");
-    if (parity_mode != RT_MODE_FIXED)
-        return RT_FAIL(ctx, "only RT_MODE_FIXED is implemented on the device (LITERAL_ZERO encodes undefined behaviour)");
+    if (parity_mode != RT_MODE_FIXED && parity_mode != RT_MODE_LITERAL_ZERO) return RT_FAIL(ctx, "unknown parity mode");
     rt_bvh* b = new (std::nothrow) rt_bvh();
     if (!b) return RT_FAIL(ctx, "out of host memory");
     b->ctx = ctx; b->scene = scene; b->mode = parity_mode;
@@ -393,7 +404,9 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         free_build_buffers(b);
         b->n = 0; b->N = 0;                           // stays 0 unless every allocation below succeeds
-        const size_t trees = ctx->no_search_tree ? 1u : 2u;
+        // LITERAL_ZERO: no search tree (its boxes are not nested: the spine above the never-built node keeps the init boxes)
+        const bool want_search = !ctx->no_search_tree && b->mode == RT_MODE_FIXED;
+        const size_t trees = want_search ? 2u : 1u;
         hipError_t e = hipMalloc((void**)&b->d_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_pairs, (size_t)N * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_counters, (size_t)n * sizeof(uint32_t));
@@ -402,7 +415,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_tree_select, 256);
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * trees);
-        if (e == hipSuccess && !ctx->no_search_tree) {   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
+        if (e == hipSuccess && want_search) {   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
             e = hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_counters, (size_t)n * sizeof(uint32_t) + 256);
@@ -414,6 +427,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             return RT_FAIL(ctx, std::string("initializeFrame: device allocation failed: ") + hipGetErrorString(e));
         }
         b->n = n; b->N = N;
+        b->build_generation++;
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -435,8 +449,10 @@ int rt_bvh_construct(rt_bvh* b)
     const DeviceScene& sc = b->scene->d;
     launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
     launch_bitonic_sort(s, b->d_pairs, b->N);                     // 2. :195
-    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n);           // 3. :204
-    launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
+    const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
+    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
+    if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
+    else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
     launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n);  // traversal records, DFS ranks
     RT_HIP(ctx, hipGetLastError());
     uint32_t depth = 0;
@@ -444,7 +460,8 @@ int rt_bvh_construct(rt_bvh* b)
     // search tree for primary rays: same leaves, better order
     uint32_t search_depth = 0;
     b->have_search_tree = false;
-    if (!ctx->no_search_tree) {
+    const bool want_search = !ctx->no_search_tree && !literal;
+    if (want_search) {
         const uint32_t n = b->n, N = b->N;
         rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
         RT_HIP(ctx, hipMemsetAsync(s_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
@@ -453,23 +470,25 @@ int rt_bvh_construct(rt_bvh* b)
         RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
         launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
         launch_bitonic_sort(s, s_pairs, N);
-        launch_radix_tree(s, s_nodes, s_pairs, n);
+        launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u);
         uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
         launch_refit(s, s_nodes, s_counters, n, s_depth);
         launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s));
     }
-    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (ctx->no_search_tree ? 1u : 2u));
+    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (want_search ? 2u : 1u));
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
     b->max_depth = depth;
     b->search_depth = search_depth;
     // (a degenerate model -- thousands of coincident box centres -- makes this tree as deep as the reference's: no gain then,
     // but the four-wide records may only be used on the search tree, so it is used whenever it exists)
-    b->have_search_tree = !ctx->no_search_tree && search_depth != 0;
+    b->have_search_tree = want_search && search_depth != 0;
     {   // packet kernel: (node, lane mask) stack entries beyond the LDS part live in a per-wave global area
         // the four-wide packet kernel pushes up to three entries per two levels
-        const uint32_t deepest = b->d_quad ? 2u * depth + 16u : depth + 8u;
+        // (the packet kernels walk the search tree by default, whose depth is independent of the reference tree's)
+        const uint32_t deeper = depth > search_depth ? depth : search_depth;
+        const uint32_t deepest = b->d_quad ? 2u * deeper + 16u : deeper + 8u;
         uint32_t need = deepest > trace_packet_stack_entries() ? deepest - trace_packet_stack_entries() : 0u;
         if (need != b->packet_spill_entries) {
             if (b->d_packet_spill) { (void)hipFree(b->d_packet_spill); b->d_packet_spill = nullptr; }
@@ -487,7 +506,12 @@ int rt_bvh_construct(rt_bvh* b)
     b->frame_initialised = false;
     b->built = true;
     b->marked_valid = false;
-    b->tuned = false;
+    b->build_generation++;
+    // Dynamic scenes rebuild every frame (OpenCLRayTracerDemo.cpp:230-234).  The calibrated strategy is a property of how the
+    // model fills the frame, not of one build: it is kept while the triangle count stays (the key holds resolution and tiling),
+    // and every strategy produces the same contacts anyway.  RTMI_RECALIBRATE=1 restores a calibration per construct().
+    if (b->tuned_n != b->n || ctx->recalibrate) b->tuned = false;
+    b->tuned_n = b->n;
     return RT_SUCCESS;
 }
 
@@ -570,6 +594,8 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             if (hipMemcpyAsync(&cand_err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
             valid = cand_err == 0;                                       // e.g. a list too small for this strategy: not a candidate
+            if (cand_err && (hipMemsetAsync((char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 0, 4, ctx->stream) != hipSuccess ||
+                             hipStreamSynchronize(ctx->stream) != hipSuccess)) return false;   // the word is sticky: a discarded candidate must not fail the frame
             last_failed = !valid;
             if (ctx->calibration_log)
                 std::fprintf(stderr, "rtmi calibration: n=%u %ux%u %s budget %u: %.4f ms%s\n", b->n, cam->resX, cam->resY,
@@ -836,8 +862,13 @@ int rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, co
 // ---------------------------------------------------------------------------------------
 struct rt_frame_graph {
     rt_ctx* ctx = nullptr;
+    rt_bvh* bvh = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // what the captured launches depend on besides the caller's buffers: addresses of the context's scratch lists and of the
+    // BVH's records (generations), and the per-camera marks in those records (origin)
+    uint64_t scratch_generation = 0, build_generation = 0;
+    float origin[3] = { 0, 0, 0 };
 };
 
 static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks, int layout,
@@ -879,7 +910,9 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     if (check_trace_error(ctx)) return RT_ERROR;
     rt_frame_graph* g = new (std::nothrow) rt_frame_graph();
     if (!g) return RT_FAIL(ctx, "out of host memory");
-    g->ctx = ctx;
+    g->ctx = ctx; g->bvh = b;
+    g->scratch_generation = ctx->scratch_generation; g->build_generation = b->build_generation;
+    g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
     hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) { delete g; return RT_FAIL(ctx, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
     const int rc = frame_issue(b, scene, cam, rank, nranks, layout, d_contacts, d_out, slots_per_rank);
@@ -904,7 +937,24 @@ int rt_frame_graph_launch(rt_frame_graph* g)
 {
     if (!g) return RT_FAIL(nullptr, "frame graph is null");
     rt_ctx* ctx = g->ctx;
+    rt_bvh* b = g->bvh;
+    // the graph holds raw device addresses: refuse to replay it once one of them has been freed
+    if (g->scratch_generation != ctx->scratch_generation)
+        return RT_FAIL(ctx, "frame graph is stale: the context's deferred-ray buffers were reallocated by a larger trace; create a new graph");
+    if (g->build_generation != b->build_generation || !b->built)
+        return RT_FAIL(ctx, "frame graph is stale: the BVH was rebuilt since the graph was created; create a new graph");
     RT_ENTER(ctx);
+    // the captured frame is the steady state, without k_prepare_camera: if another camera position was traced on this BVH in
+    // between (or the marks were never set), restore this graph's marks first -- one small kernel over the records
+    if (!b->marked_valid || std::memcmp(b->marked_origin, g->origin, sizeof g->origin) != 0) {
+        TraceLaunch t{};
+        t.trav = b->d_trav; t.quad = b->d_quad; t.tree_select = b->d_tree_select; t.n_leaves = b->n;
+        t.search_root = b->have_search_tree ? b->n - 1 : 0u;
+        launch_prepare_camera(ctx->stream, t, g->origin);
+        RT_HIP(ctx, hipGetLastError());
+        std::memcpy(b->marked_origin, g->origin, sizeof g->origin);
+        b->marked_valid = true;
+    }
     RT_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
     ctx->trace_launched = true;                 // the next synchronising call looks at the kernels' error word
     return RT_SUCCESS;

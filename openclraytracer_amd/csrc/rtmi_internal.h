@@ -77,6 +77,7 @@ struct rt_ctx {
     unsigned long long* d_keys = nullptr;   // packet kernel: (t, position) keys of split rays, one per work item, grow-only
     uint64_t keys_cap = 0;
     uint32_t* d_split_list = nullptr;       // long_cap entries
+    uint64_t scratch_generation = 0;        // bumped whenever one of the three buffers above is reallocated (frame graphs hold their addresses)
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
     bool profiling = false;       // rt_ctx_set_profiling: HIP events around the two trace kernels
@@ -86,6 +87,7 @@ struct rt_ctx {
     int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
     bool no_search_tree = false;  // knob (env RTMI_SEARCH_TREE=0): primary rays walk the reference tree
     bool trace_diagnostics = false; // knob (env RTMI_TRACE_DIAG=1)
+    bool recalibrate = false;     // knob (env RTMI_RECALIBRATE=1): every construct() forgets the calibrated trace strategy
     bool calibration_log = false; // knob (env RTMI_CALIBRATION_LOG=1): one stderr line per calibration candidate
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
@@ -129,9 +131,11 @@ struct rt_bvh {
     bool marked_valid = false;
     bool tuned = false;                     // deferral budget calibrated for tuned_key
     uint64_t tuned_key = 0;
+    uint32_t tuned_n = 0;                   // triangle count the strategy was calibrated for (kept across rebuilds of the same size)
     uint32_t tuned_budget = 0;              // 0 = packet kernel, else deferral budget of the two-phase kernels
     bool tuned_packet = false;
     bool tuned_quad = false;                // with tuned_packet: the four-wide packet kernel
+    uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)
     bool frame_initialised = false;
     bool built = false;
 };
@@ -152,7 +156,10 @@ struct rt_tlg {
     uint2* d_pairs = nullptr;           // pairs_pow2
     uint2* d_leaf_pairs = nullptr;      // leaf_pairs_pow2
     uint2* d_leaf_ranges = nullptr;     // leaf_cells_count
-    uint32_t* d_written = nullptr;      // 1 word
+    uint32_t* d_written = nullptr;      // 64 words: [0] leaf pairs written; [4..7] counts of a rebuild without round trips (pairs, leaf cells, leaf pairs)
+    uint32_t leaf_ranges_cap = 0;       // entries d_leaf_ranges holds
+    uint32_t pairs_cap = 0, leaf_cap = 0;   // elements d_pairs / d_leaf_pairs hold (kept across initializeFrame: a rebuild starts on them)
+    uint32_t rebuilds_without_readback = 0;   // diagnostics
     bool frame_initialised = false;
     bool built = false;
 };
@@ -185,7 +192,8 @@ extern "C" __attribute__((visibility("hidden"))) int rt_check_camera(rt_ctx* ctx
 // build_kernels.hip
 void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
 void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs);
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n);
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built);   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO)
+void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);   // boxes + tree depth
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t id_offset = 0);
@@ -226,6 +234,7 @@ struct TraceLaunch {
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
+void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);
 size_t trace_ctrl_bytes();
 size_t trace_ctrl_error_offset();
 void trace_ctrl_counter_offsets(size_t out[6]);
@@ -241,14 +250,17 @@ struct TlgLaunch {
     const DeviceScene* scene;
 };
 void launch_tlg_count_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, uint32_t* counters);
-void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs);
-void launch_segment_bounds(hipStream_t s, const uint2* sorted, uint32_t count, uint2* ranges);
+void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs,
+                         uint32_t pairs_cap);
+// count_dev != null: the real element count is read on the device and `count` is the capacity the grid covers
+void launch_segment_bounds(hipStream_t s, const uint2* sorted, uint32_t count, const uint32_t* count_dev, uint2* ranges, uint32_t ranges_cap);
 void launch_tlg_cell_res(hipStream_t s, const rt_grid_data& g, const uint2* ranges, uint32_t cells, rt_top_cell* top, uint32_t* leaves);
 void launch_tlg_first_leaf(hipStream_t s, rt_top_cell* top, const uint32_t* scan, uint32_t cells);
-void launch_tlg_count_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
-                           const DeviceScene& sc, uint32_t* counters);
-void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
-                          const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* leaf_pairs, uint32_t* written_total);
+void launch_tlg_count_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const uint32_t* count_dev,
+                           const rt_top_cell* top, const DeviceScene& sc, uint32_t* counters);
+void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const uint32_t* count_dev,
+                          const rt_top_cell* top, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* leaf_pairs,
+                          uint32_t leaf_cap, uint32_t* written_total);
 void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks, bool compact,
                               rt_contact* out);
 void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);

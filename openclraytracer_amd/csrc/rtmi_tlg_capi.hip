@@ -4,6 +4,7 @@
 #include "rtmi_internal.h"
 #include "tlg_math.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -33,7 +34,7 @@ static void free_tlg_buffers(rt_tlg* g)
     void** ptrs[] = { (void**)&g->d_counters, (void**)&g->d_scan, (void**)&g->d_scan_scratch, (void**)&g->d_cell_ranges, (void**)&g->d_top,
                       (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written };
     for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    g->counters_cap = 0;
+    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0;
 }
 
 void rt_tlg_destroy(rt_tlg* g)
@@ -92,6 +93,18 @@ static int ensure_counters(rt_tlg* g, uint64_t words)
     return RT_SUCCESS;
 }
 
+// what initializeFrame leaves behind (TwoLevelGridManager.cpp:181-199): counters, scan output, cell ranges and top-level cells zeroed
+static int clear_frame_buffers(rt_tlg* g)
+{
+    rt_ctx* ctx = g->ctx;
+    RT_HIP(ctx, hipMemsetAsync(g->d_counters, 0, g->counters_cap * sizeof(uint32_t), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_scan, 0, g->counters_cap * sizeof(uint32_t), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_cell_ranges, 0, (size_t)g->info.cells * sizeof(uint2), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_top, 0, (size_t)g->info.cells * sizeof(rt_top_cell), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(g->d_written, 0, 256, ctx->stream));
+    return RT_SUCCESS;
+}
+
 int rt_tlg_initialize_frame(rt_tlg* g)
 {
     if (!g) return RT_FAIL(nullptr, "tlg is null");
@@ -112,12 +125,7 @@ int rt_tlg_initialize_frame(rt_tlg* g)
     g->info = rt_tlg_info{};
     g->info.cells = cells;
     if (ensure_counters(g, g->n > cells ? g->n : cells)) return RT_ERROR;
-    // TwoLevelGridManager.cpp:181-199: counters, scan output, cell ranges and top-level cells start zeroed
-    RT_HIP(ctx, hipMemsetAsync(g->d_counters, 0, g->counters_cap * sizeof(uint32_t), ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(g->d_scan, 0, g->counters_cap * sizeof(uint32_t), ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(g->d_cell_ranges, 0, (size_t)cells * sizeof(uint2), ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(g->d_top, 0, (size_t)cells * sizeof(rt_top_cell), ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(g->d_written, 0, 4, ctx->stream));
+    if (clear_frame_buffers(g)) return RT_ERROR;
     g->frame_initialised = true;
     g->built = false;
     return RT_SUCCESS;
@@ -132,12 +140,12 @@ static int read_word(rt_ctx* ctx, const uint32_t* d_src, uint32_t* out)
     return RT_SUCCESS;
 }
 
-int rt_tlg_construct(rt_tlg* g)
+// The reference's sequence with its three 4-byte read-backs: they size the pair arrays, and the sizes of the bitonic
+// networks (powers of two above the counts) are part of the result -- the network's extra levels permute equal keys.
+// Used by the first build and whenever the sizes of the previous build no longer fit.
+static int construct_with_readbacks(rt_tlg* g)
 {
-    if (!g) return RT_FAIL(nullptr, "tlg is null");
     rt_ctx* ctx = g->ctx;
-    if (!g->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
-    RT_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const DeviceScene& sc = g->scene->d;
     const rt_grid_data& G = g->grid;
@@ -151,17 +159,18 @@ int rt_tlg_construct(rt_tlg* g)
     if (pairs == 0) return RT_FAIL(ctx, "no (cell, triangle) pairs: nothing to build");
     if (pairs > 0x3FFFFFFFu) return RT_FAIL(ctx, "too many (cell, triangle) pairs");
     const uint32_t pairs_pow2 = pow2_above(pairs);
-    if (pairs_pow2 != g->info.pairs_pow2 || !g->d_pairs) {
-        if (g->d_pairs) { (void)hipFree(g->d_pairs); g->d_pairs = nullptr; }
+    if (pairs_pow2 != g->pairs_cap || !g->d_pairs) {
+        if (g->d_pairs) { (void)hipFree(g->d_pairs); g->d_pairs = nullptr; g->pairs_cap = 0; }
         RT_HIP(ctx, hipMalloc((void**)&g->d_pairs, (size_t)pairs_pow2 * sizeof(uint2)));
+        g->pairs_cap = pairs_pow2;
     }
     g->info.pairs_count = pairs; g->info.pairs_pow2 = pairs_pow2;
     RT_HIP(ctx, hipMemsetAsync(g->d_pairs, 0xFF, (size_t)pairs_pow2 * sizeof(uint2), s));         // :248-250
     // 2. emit (cell, triangle), sort by cell                                                        (:252-267)
-    launch_tlg_emit_top(s, G, sc, g->d_scan, g->d_counters, g->d_pairs);
+    launch_tlg_emit_top(s, G, sc, g->d_scan, g->d_counters, g->d_pairs, pairs_pow2);
     launch_bitonic_sort(s, g->d_pairs, pairs_pow2);
     // 3. [first, end) of every top-level cell, leaf resolution, leaf-cell count                    (:269-346)
-    launch_segment_bounds(s, g->d_pairs, pairs, g->d_cell_ranges);
+    launch_segment_bounds(s, g->d_pairs, pairs, nullptr, g->d_cell_ranges, cells);
     RT_HIP(ctx, hipMemsetAsync(g->d_counters, 0, g->counters_cap * sizeof(uint32_t), s));
     RT_HIP(ctx, hipMemsetAsync(g->d_scan, 0, g->counters_cap * sizeof(uint32_t), s));
     launch_tlg_cell_res(s, G, g->d_cell_ranges, cells, g->d_top, g->d_counters);
@@ -171,27 +180,103 @@ int rt_tlg_construct(rt_tlg* g)
     launch_tlg_first_leaf(s, g->d_top, g->d_scan, cells);                                           // :347-360
     g->info.leaf_cells_count = leaf_cells;
     // 4. leaf cells overlapped per top-level pair, scan, leaf pair count                            (:362-395)
-    if (ensure_counters(g, pairs)) return RT_ERROR;
-    launch_tlg_count_leaf(s, G, g->d_pairs, pairs, g->d_top, sc, g->d_counters);
+    if (ensure_counters(g, pairs_pow2)) return RT_ERROR;          // (the capacity, so that a later rebuild can scan over it)
+    launch_tlg_count_leaf(s, G, g->d_pairs, pairs, nullptr, g->d_top, sc, g->d_counters);
     launch_scan_inclusive(s, g->d_counters, g->d_scan, pairs, g->d_scan_scratch);
     uint32_t leaf_pairs = 0;
     if (read_word(ctx, g->d_scan + (pairs - 1), &leaf_pairs)) return RT_ERROR;
     if (leaf_pairs > 0x3FFFFFFFu) return RT_FAIL(ctx, "too many (leaf cell, triangle) pairs");
     const uint32_t leaf_pow2 = pow2_above(leaf_pairs);
-    if (g->d_leaf_pairs) { (void)hipFree(g->d_leaf_pairs); g->d_leaf_pairs = nullptr; }
-    if (g->d_leaf_ranges) { (void)hipFree(g->d_leaf_ranges); g->d_leaf_ranges = nullptr; }
-    RT_HIP(ctx, hipMalloc((void**)&g->d_leaf_pairs, (size_t)leaf_pow2 * sizeof(uint2)));
-    RT_HIP(ctx, hipMalloc((void**)&g->d_leaf_ranges, (size_t)(leaf_cells ? leaf_cells : 1) * sizeof(uint2)));
+    if (leaf_pow2 != g->leaf_cap || !g->d_leaf_pairs) {
+        if (g->d_leaf_pairs) { (void)hipFree(g->d_leaf_pairs); g->d_leaf_pairs = nullptr; g->leaf_cap = 0; }
+        RT_HIP(ctx, hipMalloc((void**)&g->d_leaf_pairs, (size_t)leaf_pow2 * sizeof(uint2)));
+        g->leaf_cap = leaf_pow2;
+    }
+    const uint32_t want_ranges = leaf_cells ? leaf_cells : 1u;
+    if (want_ranges > g->leaf_ranges_cap || !g->d_leaf_ranges) {
+        if (g->d_leaf_ranges) { (void)hipFree(g->d_leaf_ranges); g->d_leaf_ranges = nullptr; g->leaf_ranges_cap = 0; }
+        const uint32_t cap = want_ranges + want_ranges / 8u + 64u;   // head room: a rebuild of a slightly changed scene still fits
+        RT_HIP(ctx, hipMalloc((void**)&g->d_leaf_ranges, (size_t)cap * sizeof(uint2)));
+        g->leaf_ranges_cap = cap;
+    }
     g->info.leaf_pairs_count = leaf_pairs; g->info.leaf_pairs_pow2 = leaf_pow2;
     RT_HIP(ctx, hipMemsetAsync(g->d_leaf_pairs, 0xFF, (size_t)leaf_pow2 * sizeof(uint2), s));     // :404-408
-    RT_HIP(ctx, hipMemsetAsync(g->d_leaf_ranges, 0, (size_t)(leaf_cells ? leaf_cells : 1) * sizeof(uint2), s));
+    RT_HIP(ctx, hipMemsetAsync(g->d_leaf_ranges, 0, (size_t)g->leaf_ranges_cap * sizeof(uint2), s));
     // 5. emit (leaf cell, triangle) with the exact triangle / box test, sort, leaf ranges          (:410-466)
-    launch_tlg_emit_leaf(s, G, g->d_pairs, pairs, g->d_top, sc, g->d_scan, g->d_counters, g->d_leaf_pairs, g->d_written);
+    launch_tlg_emit_leaf(s, G, g->d_pairs, pairs, nullptr, g->d_top, sc, g->d_scan, g->d_counters, g->d_leaf_pairs, leaf_pow2, g->d_written);
     launch_bitonic_sort(s, g->d_leaf_pairs, leaf_pow2);
-    launch_segment_bounds(s, g->d_leaf_pairs, leaf_pairs, g->d_leaf_ranges);
+    launch_segment_bounds(s, g->d_leaf_pairs, leaf_pairs, nullptr, g->d_leaf_ranges, leaf_cells);
     uint32_t written = 0;
     if (read_word(ctx, g->d_written, &written)) return RT_ERROR;        // construct() returns with the build finished
     g->info.written_leaf_pairs = written;
+    return RT_SUCCESS;
+}
+
+// A REBUILD (dynamic scenes rebuild per frame, OpenCLRayTracerDemo.cpp:230-234) runs without host round trips: every kernel
+// is enqueued on the array sizes of the previous build, the counts stay on the device (three words behind d_written; the
+// kernels that need a count read it there), and ONE read-back at the end -- which construct() needs anyway, it returns with
+// the build finished -- tells whether the sizes still fit: the same powers of two above the counts (they are part of the
+// result, see above) and a leaf-range array that is large enough.  If so the products are exactly those of the sequence
+// above; if not, that sequence runs.  Writes never pass a capacity either way.
+static int construct_on_previous_sizes(rt_tlg* g, bool* accepted)
+{
+    rt_ctx* ctx = g->ctx;
+    hipStream_t s = ctx->stream;
+    const DeviceScene& sc = g->scene->d;
+    const rt_grid_data& G = g->grid;
+    const uint32_t n = g->n, cells = g->info.cells, P = g->pairs_cap, L = g->leaf_cap;
+    uint32_t* d_cnt = g->d_written + 4;                                   // pairs, leaf cells, leaf pairs
+    *accepted = false;
+    launch_tlg_count_top(s, G, sc, g->d_counters);
+    launch_scan_inclusive(s, g->d_counters, g->d_scan, n, g->d_scan_scratch);
+    RT_HIP(ctx, hipMemcpyAsync(d_cnt + 0, g->d_scan + (n - 1), 4, hipMemcpyDeviceToDevice, s));
+    RT_HIP(ctx, hipMemsetAsync(g->d_pairs, 0xFF, (size_t)P * sizeof(uint2), s));
+    launch_tlg_emit_top(s, G, sc, g->d_scan, g->d_counters, g->d_pairs, P);
+    launch_bitonic_sort(s, g->d_pairs, P);
+    launch_segment_bounds(s, g->d_pairs, P, d_cnt + 0, g->d_cell_ranges, cells);
+    RT_HIP(ctx, hipMemsetAsync(g->d_counters, 0, g->counters_cap * sizeof(uint32_t), s));
+    RT_HIP(ctx, hipMemsetAsync(g->d_scan, 0, g->counters_cap * sizeof(uint32_t), s));
+    launch_tlg_cell_res(s, G, g->d_cell_ranges, cells, g->d_top, g->d_counters);
+    launch_scan_inclusive(s, g->d_counters, g->d_scan, cells, g->d_scan_scratch);
+    RT_HIP(ctx, hipMemcpyAsync(d_cnt + 1, g->d_scan + (cells - 1), 4, hipMemcpyDeviceToDevice, s));
+    launch_tlg_first_leaf(s, g->d_top, g->d_scan, cells);
+    launch_tlg_count_leaf(s, G, g->d_pairs, P, d_cnt + 0, g->d_top, sc, g->d_counters);       // zeros beyond the pairs
+    launch_scan_inclusive(s, g->d_counters, g->d_scan, P, g->d_scan_scratch);                 // over the capacity: same prefix sums, total at the end
+    RT_HIP(ctx, hipMemcpyAsync(d_cnt + 2, g->d_scan + (P - 1), 4, hipMemcpyDeviceToDevice, s));
+    RT_HIP(ctx, hipMemsetAsync(g->d_leaf_pairs, 0xFF, (size_t)L * sizeof(uint2), s));
+    RT_HIP(ctx, hipMemsetAsync(g->d_leaf_ranges, 0, (size_t)g->leaf_ranges_cap * sizeof(uint2), s));
+    launch_tlg_emit_leaf(s, G, g->d_pairs, P, d_cnt + 0, g->d_top, sc, g->d_scan, g->d_counters, g->d_leaf_pairs, L, g->d_written);
+    launch_bitonic_sort(s, g->d_leaf_pairs, L);
+    launch_segment_bounds(s, g->d_leaf_pairs, L, d_cnt + 2, g->d_leaf_ranges, g->leaf_ranges_cap);
+    RT_HIP(ctx, hipGetLastError());
+    uint32_t h[8] = { 0 };
+    RT_HIP(ctx, hipMemcpyAsync(h, g->d_written, sizeof h, hipMemcpyDeviceToHost, s));
+    RT_HIP(ctx, hipStreamSynchronize(s));
+    const uint32_t pairs = h[4], leaf_cells = h[5], leaf_pairs = h[6];
+    if (pairs == 0 || pairs > 0x3FFFFFFFu || leaf_pairs > 0x3FFFFFFFu) return RT_SUCCESS;      // let the full sequence report it
+    if (pow2_above(pairs) != P || pow2_above(leaf_pairs) != L || leaf_cells > g->leaf_ranges_cap) return RT_SUCCESS;
+    g->info.pairs_count = pairs; g->info.pairs_pow2 = P;
+    g->info.leaf_cells_count = leaf_cells;
+    g->info.leaf_pairs_count = leaf_pairs; g->info.leaf_pairs_pow2 = L;
+    g->info.written_leaf_pairs = h[0];
+    *accepted = true;
+    return RT_SUCCESS;
+}
+
+int rt_tlg_construct(rt_tlg* g)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    if (!g->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
+    RT_ENTER(ctx);
+    static const bool allow = [] { const char* e = std::getenv("RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES"); return !(e && e[0] == '0'); }();
+    bool done = false;
+    if (allow && g->d_pairs && g->d_leaf_pairs && g->d_leaf_ranges && g->pairs_cap && g->leaf_cap && g->counters_cap >= g->pairs_cap) {
+        if (construct_on_previous_sizes(g, &done)) return RT_ERROR;
+        if (done) g->rebuilds_without_readback++;
+        else if (clear_frame_buffers(g)) return RT_ERROR;         // the sizes changed: start over from what initializeFrame left
+    }
+    if (!done && construct_with_readbacks(g)) return RT_ERROR;
     g->frame_initialised = false;
     g->built = true;
     return RT_SUCCESS;
@@ -251,6 +336,8 @@ int rt_tlg_info_get(const rt_tlg* g, rt_tlg_info* out)
     *out = g->info;
     return RT_SUCCESS;
 }
+
+uint32_t rt_tlg_rebuilds_without_readback(const rt_tlg* g) { return g ? g->rebuilds_without_readback : 0u; }
 
 int rt_tlg_read(const rt_tlg* g, int what, void* h_dst, uint64_t bytes)
 {

@@ -5,7 +5,7 @@
 //    keys end up in the same order -- that order decides the radix-tree topology, the DFS order
 //    and therefore which of two equal-t hits wins.  The reference runs one launch (+flush+wait)
 //    per 1-3 compare-exchange levels, all through global memory; here every level with
-//    inc < TILE runs inside LDS and only the levels with inc >= TILE touch HBM.
+//    inc < TILE runs inside LDS and the levels with inc >= TILE go through HBM up to eight at a time.
 //  * inclusive uint scan (PrefixSumKernels.cl:28-106 semantics: out[i] = sum_{j<=i} in[j]).
 #include "rtmi_internal.h"
 
@@ -61,18 +61,49 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_lds_merge(uint2* data,
     for (uint32_t t = threadIdx.x; t < tile_elems; t += blockDim.x) data[base + t] = tile[t];
 }
 
-// one compare-exchange level through HBM (ParallelBitonic_B2, SortKernels.cl:269-287)
-__global__ __launch_bounds__(256) void k_bitonic_global(uint2* data, uint32_t half_n, uint32_t inc, uint32_t dir)
+// Up to 8 consecutive compare-exchange levels inc = 2^top .. 2^(top-levels+1), all >= SORT_TILE, in ONE pass through HBM.
+// (The reference fuses two or three levels per launch in registers, ParallelBitonic_B4 / _B8, SortKernels.cl:290-345, selection
+// BitonicSort.cpp:127-153; one level per launch made the networks over the grid's 1-2 M pairs launch bound.)
+// Elements that meet in these levels differ only in index bits [low, top], low = top - levels + 1: a block stages
+// R = 2^levels rows (one per combination of those bits) of C = SORT_TILE / R consecutive elements in LDS -- runs of C * 8
+// bytes (>= 128) in HBM -- and runs the levels there, row against row.  Same comparators, same `reverse` per pair (taken from
+// the global index of the pair's first element), hence the same permutation as one level per launch.
+__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_strided(uint2* data, uint32_t top, uint32_t levels, uint32_t dir)
 {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= half_n) return;
-    uint32_t low = t & (inc - 1);
-    uint32_t i = (t << 1) - low;
-    bool reverse = ((dir & i) == 0);
-    uint2 x0 = data[i], x1 = data[i + inc];
-    order(x0, x1, reverse);
-    data[i] = x0; data[i + inc] = x1;
+    __shared__ uint2 tile[SORT_TILE];
+    const uint32_t low = top + 1u - levels;                 // lowest varying bit; low >= log2(SORT_TILE) >= log2(C)
+    const uint32_t rows = 1u << levels, cols = SORT_TILE >> levels;
+    const uint32_t cols_log = 12u - levels;                 // log2(SORT_TILE) = 12
+    const uint32_t chunks_log = low - cols_log;             // runs of `cols` elements below bit `low`
+    const uint32_t chunk = blockIdx.x & ((1u << chunks_log) - 1u), high = blockIdx.x >> chunks_log;
+    const uint32_t base = (high << (top + 1u)) | (chunk << cols_log);
+    for (uint32_t t = threadIdx.x; t < SORT_TILE; t += SORT_THREADS) {
+        const uint32_t g = t >> cols_log, c = t & (cols - 1u);
+        tile[t] = data[base + (g << low) + c];
+    }
+    __syncthreads();
+    for (int j = (int)levels - 1; j >= 0; j--) {
+        for (uint32_t q = threadIdx.x; q < SORT_TILE / 2u; q += SORT_THREADS) {
+            const uint32_t c = q & (cols - 1u), gp = q >> cols_log;             // gp: the row index without bit j
+            const uint32_t g = ((gp >> j) << (j + 1)) | (gp & ((1u << j) - 1u));
+            const uint32_t a = (g << cols_log) + c, b = a + ((1u << j) << cols_log);
+            const bool reverse = ((dir & (base + (g << low) + c)) == 0u);
+            uint2 x0 = tile[a], x1 = tile[b];
+            order(x0, x1, reverse);
+            tile[a] = x0; tile[b] = x1;
+        }
+        __syncthreads();
+    }
+    for (uint32_t t = threadIdx.x; t < SORT_TILE; t += SORT_THREADS) {
+        const uint32_t g = t >> cols_log, c = t & (cols - 1u);
+        data[base + (g << low) + c] = tile[t];
+    }
+    (void)rows;
 }
+
+#define SORT_FUSED_LEVELS 8u
+
+static uint32_t log2u(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) l++; return l; }
 
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t N)
 {
@@ -81,9 +112,14 @@ void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t N)
     uint32_t blocks = N / tile;
     hipLaunchKernelGGL(k_bitonic_lds_sort, dim3(blocks), dim3(SORT_THREADS), 0, s, pairs, tile);
     for (uint32_t length = tile; length < N; length <<= 1) {
-        for (uint32_t inc = length; inc >= tile; inc >>= 1)
-            hipLaunchKernelGGL(k_bitonic_global, dim3((N / 2 + 255) / 256), dim3(256), 0, s, pairs, N / 2, inc,
-                               length << 1);
+        // levels inc = length .. tile go through HBM, up to eight per pass; the rest of the merge runs in LDS
+        uint32_t top = log2u(length);
+        uint32_t left = top - 12u + 1u;                     // tile == SORT_TILE == 2^12 here (N > tile)
+        while (left) {
+            const uint32_t levels = left < SORT_FUSED_LEVELS ? left : SORT_FUSED_LEVELS;
+            hipLaunchKernelGGL(k_bitonic_strided, dim3(N / SORT_TILE), dim3(SORT_THREADS), 0, s, pairs, top, levels, length << 1);
+            top -= levels; left -= levels;
+        }
         hipLaunchKernelGGL(k_bitonic_lds_merge, dim3(blocks), dim3(SORT_THREADS), 0, s, pairs, tile, length);
     }
 }

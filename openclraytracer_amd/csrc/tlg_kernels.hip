@@ -48,7 +48,7 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_count_top(rt_grid_data g, con
 // writePairsKernel -> writePairs -> writeOverlappingPairs (TwoLevelGrid.h:138-188)
 __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_emit_top(rt_grid_data g, const float4* __restrict__ v0, const float4* __restrict__ v1,
                                                             const float4* __restrict__ v2, uint32_t n, const uint32_t* __restrict__ scan,
-                                                            const uint32_t* __restrict__ counters, uint2* __restrict__ pairs)
+                                                            const uint32_t* __restrict__ counters, uint2* __restrict__ pairs, uint32_t pairs_cap)
 {
     uint32_t i = blockIdx.x * TLG_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_emit_top(rt_grid_data g, cons
     for (uint32_t z = c0[2]; z <= c1[2]; z++)
         for (uint32_t y = c0[1]; y <= c1[1]; y++)
             for (uint32_t x = c0[0]; x <= c1[0]; x++) {
-                if (w < cnt) pairs[first + w] = make_uint2(z * g.resX * g.resY + y * g.resX + x, i);   // getCellIndex :55-59
+                // (pairs_cap: a rebuild that runs on the previous build's array sizes never writes past them; its sizes are checked afterwards)
+                if (w < cnt && first + w < pairs_cap) pairs[first + w] = make_uint2(z * g.resX * g.resY + y * g.resX + x, i);   // getCellIndex :55-59
                 w++;
             }
 }
@@ -75,18 +76,22 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_emit_top(rt_grid_data g, cons
 // extractCellRangesKernel / extractLeafCellsKernel (TwoLevelGridKernels.cl:71-116,176-221): [first, end) of every key
 // in the sorted array.  One thread per element over the whole array (the reference's LDS indexing only works in
 // work-group 0), the last range closes at `count`, UINT_MAX holes never become a cell.
-__global__ __launch_bounds__(TLG_BLOCK) void k_segment_bounds(const uint2* __restrict__ sorted, uint32_t count, uint2* __restrict__ ranges)
+// `count_dev` (may be null): the element count lives on the device (a rebuild without host round trips); the grid then covers
+// the array's capacity.  Keys at or beyond `ranges_cap` are never written (a stale capacity is detected by the host afterwards).
+__global__ __launch_bounds__(TLG_BLOCK) void k_segment_bounds(const uint2* __restrict__ sorted, uint32_t count, const uint32_t* __restrict__ count_dev,
+                                                              uint2* __restrict__ ranges, uint32_t ranges_cap)
 {
+    if (count_dev) { const uint32_t c = *count_dev; count = c < count ? c : count; }     // never beyond the array (`count` = its capacity then)
     uint32_t i = blockIdx.x * TLG_BLOCK + threadIdx.x;
     if (i >= count) return;
     const uint32_t me = sorted[i].x;
     if (i + 1 < count) {
         const uint32_t right = sorted[i + 1].x;
         if (right > me) {
-            ranges[me].y = i + 1;
-            if (right != 0xFFFFFFFFu) ranges[right].x = i + 1;
+            if (me < ranges_cap) ranges[me].y = i + 1;
+            if (right != 0xFFFFFFFFu && right < ranges_cap) ranges[right].x = i + 1;
         }
-    } else if (me != 0xFFFFFFFFu) ranges[me].y = count;
+    } else if (me != 0xFFFFFFFFu && me < ranges_cap) ranges[me].y = count;
 }
 
 // countLeavesAndFillCellKernel -> fillTopLevelCell -> calcLeafCellResolution (TwoLevelGrid.h:193-225)
@@ -160,12 +165,17 @@ __device__ __forceinline__ void axis_range(float base, float step, uint32_t res,
 
 // prepareGridDataForLeaves -> countLeafPairs -> countOverlappingLeafCells (TwoLevelGrid.h:262-323)
 __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_count_leaf(rt_grid_data g, const uint2* __restrict__ pairs, uint32_t pairs_count,
+                                                              const uint32_t* __restrict__ count_dev, uint32_t pairs_cap,
                                                               const rt_top_cell* __restrict__ top, const float4* __restrict__ v0,
                                                               const float4* __restrict__ v1, const float4* __restrict__ v2,
                                                               uint32_t* __restrict__ counters)
 {
+    if (count_dev) { const uint32_t c = *count_dev; pairs_count = c < pairs_cap ? c : pairs_cap; }
     uint32_t p = blockIdx.x * TLG_BLOCK + threadIdx.x;
-    if (p >= pairs_count) return;
+    if (p >= pairs_count) {
+        if (count_dev && p < pairs_cap) counters[p] = 0u;      // as prepareGridDataForLeaves does beyond the pairs (TwoLevelGridKernels.cl:154-155): the scan runs over the capacity
+        return;
+    }
     const uint2 pr = pairs[p];
     const rt_top_cell tc = top[pr.x];
     const float4 a = v0[pr.y], b = v1[pr.y], c = v2[pr.y];
@@ -233,8 +243,10 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_emit_leaf(rt_grid_data g, con
                                                              const rt_top_cell* __restrict__ top, const float4* __restrict__ v0,
                                                              const float4* __restrict__ v1, const float4* __restrict__ v2,
                                                              const uint32_t* __restrict__ scan, const uint32_t* __restrict__ counters,
-                                                             uint2* __restrict__ leaf_pairs, uint32_t* __restrict__ written_total)
+                                                             uint2* __restrict__ leaf_pairs, uint32_t* __restrict__ written_total,
+                                                             const uint32_t* __restrict__ count_dev, uint32_t leaf_cap)
 {
+    if (count_dev) { const uint32_t c = *count_dev; pairs_count = c < pairs_count ? c : pairs_count; }   // `pairs_count` = the array's capacity then
     uint32_t p = blockIdx.x * TLG_BLOCK + threadIdx.x;
     if (p >= pairs_count) return;
     const uint32_t cnt = counters[p];
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_emit_leaf(rt_grid_data g, con
                 const f3 c = f3{ L.baseX + (float)x * L.stepX + half.x, L.baseY + (float)y * L.stepY + half.y,
                                  L.baseZ + (float)z * L.stepZ + half.z };
                 if (aabb_triangle_intersect(c, half, A, B, C)) {
-                    if (w < cnt)
+                    if (w < cnt && first + w < leaf_cap)
                         leaf_pairs[first + w] = make_uint2(z * tc.resX * tc.resY + y * tc.resX + x + tc.firstLeafIdx, pr.y);
                     w++;
                 }
@@ -381,7 +393,14 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
         const uint32_t blk = within >> 6, lp = within & 63u;
         const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3), lx = ((blk & 7u) << 3) + (lp & 7u);
         const uint32_t x = tx * RT_TILE + lx, y = ty * RT_TILE + ly;
-        if (x >= a.cam.resX || y >= a.cam.resY) return;
+        if (x >= a.cam.resX || y >= a.cam.resY) {
+            if (a.compact) {         // slot of a border tile outside the frame: defined as "no contact", as in the BVH kernels
+                float4* z = reinterpret_cast<float4*>(a.out + ((ordinal << 12) + ly * RT_TILE + lx));
+                z[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                z[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            return;
+        }
         generate_ray_xy(a.cam, x, y, o, d);
         pixel = y * a.cam.resX + x;
         out_index = a.compact ? (ordinal << 12) + ly * RT_TILE + lx : pixel;
@@ -468,13 +487,15 @@ void launch_tlg_count_top(hipStream_t s, const rt_grid_data& g, const DeviceScen
 {
     hipLaunchKernelGGL(k_tlg_count_top, blocks_for(sc.n_tris), dim3(TLG_BLOCK), 0, s, g, sc.v0, sc.v1, sc.v2, sc.n_tris, counters);
 }
-void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs)
+void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs,
+                         uint32_t pairs_cap)
 {
-    hipLaunchKernelGGL(k_tlg_emit_top, blocks_for(sc.n_tris), dim3(TLG_BLOCK), 0, s, g, sc.v0, sc.v1, sc.v2, sc.n_tris, scan, counters, pairs);
+    hipLaunchKernelGGL(k_tlg_emit_top, blocks_for(sc.n_tris), dim3(TLG_BLOCK), 0, s, g, sc.v0, sc.v1, sc.v2, sc.n_tris, scan, counters, pairs, pairs_cap);
 }
-void launch_segment_bounds(hipStream_t s, const uint2* sorted, uint32_t count, uint2* ranges)
+// count_dev != null: `count` is the capacity the grid covers and the real count is read on the device
+void launch_segment_bounds(hipStream_t s, const uint2* sorted, uint32_t count, const uint32_t* count_dev, uint2* ranges, uint32_t ranges_cap)
 {
-    if (count) hipLaunchKernelGGL(k_segment_bounds, blocks_for(count), dim3(TLG_BLOCK), 0, s, sorted, count, ranges);
+    if (count) hipLaunchKernelGGL(k_segment_bounds, blocks_for(count), dim3(TLG_BLOCK), 0, s, sorted, count, count_dev, ranges, ranges_cap);
 }
 void launch_tlg_cell_res(hipStream_t s, const rt_grid_data& g, const uint2* ranges, uint32_t cells, rt_top_cell* top, uint32_t* leaves)
 {
@@ -484,18 +505,20 @@ void launch_tlg_first_leaf(hipStream_t s, rt_top_cell* top, const uint32_t* scan
 {
     hipLaunchKernelGGL(k_tlg_first_leaf, blocks_for(cells), dim3(TLG_BLOCK), 0, s, top, scan, cells);
 }
-void launch_tlg_count_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
-                           const DeviceScene& sc, uint32_t* counters)
+void launch_tlg_count_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const uint32_t* count_dev,
+                           const rt_top_cell* top, const DeviceScene& sc, uint32_t* counters)
 {
     if (pairs_count)
-        hipLaunchKernelGGL(k_tlg_count_leaf, blocks_for(pairs_count), dim3(TLG_BLOCK), 0, s, g, pairs, pairs_count, top, sc.v0, sc.v1, sc.v2, counters);
+        hipLaunchKernelGGL(k_tlg_count_leaf, blocks_for(pairs_count), dim3(TLG_BLOCK), 0, s, g, pairs, pairs_count, count_dev, pairs_count, top,
+                           sc.v0, sc.v1, sc.v2, counters);
 }
-void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const rt_top_cell* top,
-                          const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* leaf_pairs, uint32_t* written_total)
+void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pairs, uint32_t pairs_count, const uint32_t* count_dev,
+                          const rt_top_cell* top, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* leaf_pairs,
+                          uint32_t leaf_cap, uint32_t* written_total)
 {
     if (pairs_count)
         hipLaunchKernelGGL(k_tlg_emit_leaf, blocks_for(pairs_count), dim3(TLG_BLOCK), 0, s, g, pairs, pairs_count, top, sc.v0, sc.v1, sc.v2,
-                           scan, counters, leaf_pairs, written_total);
+                           scan, counters, leaf_pairs, written_total, count_dev, leaf_cap);
 }
 
 static TlgTraceArgs tlg_args(const TlgLaunch& t)

@@ -61,17 +61,22 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 
 uint32_t trace_lds_stack_entries() { return LDS_STACK; }
 
-// control block, zeroed before every launch; every word on its own 128-byte line
+// control block; the counters are zeroed before every launch, every word on its own 128-byte line.  The error word is
+// STICKY: kernels OR bit `code` into it, only the host clears it (check_trace_error), so an invalid frame anywhere in a batch
+// of launches is still seen by the next synchronising call.
 #define WORK_SHARDS 16u
 struct TraceCtrl {
     struct { uint32_t next; uint32_t pad[31]; } lshard[WORK_SHARDS];  // wave-per-ray kernel: next batch of deferred rays per shard
     uint32_t long_count;  uint32_t p1[31];   // deferred rays
     uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
-    uint32_t error;       uint32_t p2[31];   // 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow
     uint32_t spill_taken; uint32_t p4[31];   // packet kernels: overflow areas taken in this launch (diagnostic)
     uint32_t long_steps;  uint32_t long_steps_max; uint32_t long_nodes; uint32_t p5[29];   // wave-per-ray kernel: pool steps, all records / longest record (diagnostic)
+    uint32_t error;       uint32_t p2[31];   // bit 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow, 3: packet stack
+                                             // beyond its spill area, 4: bad deferred record, 5: no free spill area.  NOT zeroed per launch.
 };
 static_assert(sizeof(TraceCtrl) == (WORK_SHARDS + 5) * 128, "TraceCtrl layout");
+static_assert(offsetof(TraceCtrl, error) == (WORK_SHARDS + 4) * 128, "the error word follows everything a launch clears");
+#define TRACE_FAIL(word, code) __hip_atomic_fetch_or((word), 1u << (code), RLX_AGENT)
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
 void trace_ctrl_counter_offsets(size_t out[6]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                         for (uint32_t k = 0; k < sp; k++) rec[LR_STACK + k] = stack[k][lane];
                         active = false;
                     } else if (extra != RT_SENTINEL) {
-                        __hip_atomic_store(error_word, 1u, RLX_AGENT);     // nowhere to put the sub-tree: frame invalid
+                        TRACE_FAIL(error_word, 1);     // nowhere to put the sub-tree: frame invalid
                         active = false;
                     } else {
                         may_defer = false;                                 // list full: finish the ray here
@@ -523,7 +528,7 @@ __device__ __forceinline__ uint32_t* spill_acquire(const TraceArgs& a, uint32_t 
                 w = w + 1u == words ? 0u : w + 1u;
             }
         }
-        if (got == 0xFFFFFFFFu) __hip_atomic_store((gu32*)&a.ctrl->error, 5u, RLX_AGENT);
+        if (got == 0xFFFFFFFFu) TRACE_FAIL((gu32*)&a.ctrl->error, 5);
     }
     slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
     if (slot == 0xFFFFFFFFu) return nullptr;
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
                 } else if (a.packet_spill && sp - PACKET_STACK < a.packet_spill_entries && (spill || (spill = spill_acquire(a, wave_gid, lane, spill_slot)))) {
                     if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = cb; e[1] = (uint32_t)mB; e[2] = (uint32_t)(mB >> 32); }
                 } else {
-                    if (lane == 0) __hip_atomic_store((gu32*)&a.ctrl->error, 3u, RLX_AGENT);     // frame invalid
+                    if (lane == 0) TRACE_FAIL((gu32*)&a.ctrl->error, 3);     // frame invalid
                 }
                 sp++;
                 node = ca; in = aV; cur = recA;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
                     rec[LR_WORK] = w; rec[LR_CUR] = 0u; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
                     rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF; rec[LR_PARTIAL] = 0u;
                 } else {
-                    __hip_atomic_store((gu32*)&a.ctrl->error, 1u, RLX_AGENT);          // nowhere to put the ray: frame invalid
+                    TRACE_FAIL((gu32*)&a.ctrl->error, 1);          // nowhere to put the ray: frame invalid
                 }
             }
             ok = ok && !on_ref;                                                         // their contacts are written there
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
                 } else if (a.packet_spill && sp - PACKET_STACK < a.packet_spill_entries && (spill || (spill = spill_acquire(a, wave_gid, lane, spill_slot)))) {
                     if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
                 } else {
-                    if (lane == 0) __hip_atomic_store((gu32*)&a.ctrl->error, 3u, RLX_AGENT);     // frame invalid
+                    if (lane == 0) TRACE_FAIL((gu32*)&a.ctrl->error, 3);     // frame invalid
                 }
                 sp++;
             }
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
                 const bool bad = work >= a.total_work || rec[LR_SP] > LDS_STACK || bad_id(rec[LR_CUR]) || bad_id(rec[LR_EXTRA]) ||
                                  (rec[LR_PENDING] != NO_LEAF && rec[LR_PENDING] >= n_leaves) ||
                                  (rec[LR_BEST_LEAF] != NO_LEAF && rec[LR_BEST_LEAF] >= n_leaves);
-                if (bad) { __hip_atomic_store(error_word, 4u, RLX_AGENT); live = false; }
+                if (bad) { TRACE_FAIL(error_word, 4); live = false; }
             }
             RayState r;
             bool sx, sy, sz;
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             uint32_t nai = (uint32_t)__popcll(mai), nbi = (uint32_t)__popcll(mbi);
             uint32_t nal = (uint32_t)__popcll(mal), nbl = (uint32_t)__popcll(mbl);
             if (n_inner + nai + nbi > POOL_INNER || n_leaf + nal + nbl > POOL_LEAF) {
-                if (lane == 0) __hip_atomic_store(error_word, 2u, RLX_AGENT);   // frame invalid, reported by the host
+                if (lane == 0) TRACE_FAIL(error_word, 2);   // frame invalid, reported by the host
                 n_inner = 0; n_leaf = 0;
                 break;
             }
@@ -1078,7 +1083,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 {
     if (a.total_work == 0) return;
     // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
-    (void)hipMemsetAsync(t.ctrl, 0, sizeof(TraceCtrl), s);
+    (void)hipMemsetAsync(t.ctrl, 0, offsetof(TraceCtrl, error), s);      // the error word is sticky (host-cleared)
     // First-phase kernels: one wave per 64-ray block and the hardware dispatcher as the work queue.  (A persistent grid --
     // resident waves pulling blocks from sharded counters, idle lanes refilled -- measured 25-50 % slower on every bundled
     // scene: Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms)
@@ -1157,14 +1162,21 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.total_work = rt_owned_tiles(total_tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.rays = nullptr;
     a.out = out;
-    if (t.mark_inside && t.n_leaves > 1) {
-        (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
-        const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
-        hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
-                           const_cast<QuadNode*>(t.quad), n_all, n_ref, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11],
-                           const_cast<uint32_t*>(t.tree_select));
+    if (t.mark_inside) {
+        const float origin[3] = { cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11] };
+        launch_prepare_camera(s, t, origin);
     }
     launch<1>(s, t, a);
+}
+
+// the per-camera marks alone (frame graphs replay a steady-state frame, which does not contain this kernel)
+void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3])
+{
+    if (t.n_leaves < 2) return;
+    (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
+    const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
+    hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
+                       const_cast<QuadNode*>(t.quad), n_all, n_ref, origin[0], origin[1], origin[2], const_cast<uint32_t*>(t.tree_select));
 }
 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)

@@ -107,6 +107,30 @@ def test_cpp_scene_loader_equals_oracle_packer(name, tmp_path):
     assert sha(data) == gold('scenes.json')[name]['sha256']
 
 
+def test_cpp_scene_loader_number_grammar(tmp_path):
+    """the number grammar of the reference's OBJ parser (tiny_obj_loader.h:266-383): the C++ loader and the oracle packer
+    must agree byte for byte on tokens a strtod would read differently -- and the parser stage of the oracle is pinned on
+    the reference's own tinyobj (oracle/_ref/tinyobj_dump, test_obj_parser_equals_reference_tinyobj)"""
+    import subprocess
+    import scene_pack
+    odd = ['1e', '-.5', '11e2', '0.1`', '2.5E-1', '+3.', '1.e1', '1e+', '007.250', '-0', '1.0000001', '12345678.9', '1e-3',
+           '3.4028235e38', '1.17549435e-38', '0.30000000000000004', '9.999999e-1', '.', '+', '1e-', '5x', '6.02E+2z']
+    lines = ['v %s %s %s' % (odd[i], odd[(i + 1) % len(odd)], odd[(i + 2) % len(odd)]) for i in range(len(odd))]
+    lines += ['f %d %d %d' % (i + 1, (i + 1) % len(odd) + 1, (i + 2) % len(odd) + 1) for i in range(len(odd))]
+    (tmp_path / 'odd.obj').write_text('\n'.join(lines) + '\n')
+    (tmp_path / 's.txt').write_text('LIGHT 0.0 10.0 -330.0 1000.0\nMESH odd.obj\n')
+    out = str(tmp_path / 's.bin')
+    subprocess.check_call([_host_tools(), 's.txt', out], cwd=str(tmp_path))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        want = scene_pack.load_scene('s.txt')
+    finally:
+        os.chdir(cwd)
+    assert open(out, 'rb').read() == want
+    assert scene_pack.scene_header(want)['totalNumberOfTriangles'] == len(odd)
+
+
 def test_cpp_scene_loader_error_behaviour(tmp_path):
     import subprocess
     r = subprocess.run([_host_tools(), str(tmp_path / 'missing.txt'), str(tmp_path / 'o.bin')], capture_output=True, text=True)
@@ -317,3 +341,23 @@ def test_synthetic_scene_loaders_agree(tmp_path):
         os.chdir(cwd)
     assert open(out, 'rb').read() == want
     assert scene_pack.scene_header(want)['totalNumberOfTriangles'] == 69564
+
+
+def test_literal_zero_hit_counts():
+    """LITERAL_ZERO = the reference's guard as written (inner node n-2 never built) AND its 64-wide refit launch, whose work
+    items beyond the last leaf are clamped to it (BVHKernels.cl:67, BVHManager.cpp:213-217): those extra walkers re-merge the
+    ancestors of the last leaf, which repairs part of the spine above the lost node.  SURVEY.md 8(c) quotes 1552 hits for Cube
+    64x48: that is the same tree refitted WITHOUT the clamped work items (one walker per leaf), reproduced here."""
+    import oracle as orc
+    want = {'cube': (2209, 2209, 1552), 'gardenlight': (624, 624, 272), 'man': (1580, 1513, 434), 'clumsydragon': (533, 257, 257)}
+    for name, (fixed, literal, one_walker_per_leaf) in want.items():
+        sc = orc.Scene(packed_scene(name))
+        cam = sc.demo_camera(64, 48)
+        hits = lambda b: int((b.trace_primary(cam)[0]['normal_t'][:, 3] > 0).sum())
+        assert hits(orc.BVH(sc, 0)) == fixed
+        b = orc.BVH(sc, 1)
+        assert hits(b) == literal
+        nodes = orc.build_stages(sc, 1)['radix'].copy()
+        orc.lib().orc_refit(orc._p(nodes), sc.n_tris, 0)          # n walkers, no clamped extras
+        b.nodes = nodes
+        assert hits(b) == one_walker_per_leaf

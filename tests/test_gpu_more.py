@@ -174,6 +174,13 @@ def test_sort_and_scan_primitives(gpu_ctx):
         pairs['key'] = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
         pairs['value'] = rng.permutation(n).astype(np.uint32)
         assert gpu_ctx.sort_pairs_bitonic(pairs).tobytes() == orc.bitonic_sort(pairs.view(orc.PAIR)).tobytes()
+    # up to nine levels through HBM per merge (eight fused in one pass + one): few distinct keys stress the tie order
+    for n in [1 << 20, 1 << 21]:
+        pairs = np.zeros(n, dtype=capi.PAIR)
+        pairs['key'] = rng.integers(0, 64, size=n, dtype=np.uint32)
+        pairs['key'][rng.integers(0, n, size=n // 7)] = 0xFFFFFFFF             # padding-like entries anywhere
+        pairs['value'] = np.arange(n, dtype=np.uint32)
+        assert gpu_ctx.sort_pairs_bitonic(pairs).tobytes() == orc.bitonic_sort(pairs.view(orc.PAIR)).tobytes()
     for n in [1, 63, 2049, 5000000]:
         a = rng.integers(0, 100, size=n, dtype=np.uint32)
         assert np.array_equal(gpu_ctx.scan_inclusive(a), np.cumsum(a, dtype=np.uint64).astype(np.uint32))
@@ -190,8 +197,8 @@ def test_error_behaviour(gpu_ctx):
     with pytest.raises(capi.RtError, match='totalNumberOfTriangles'):
         capi.DeviceScene(gpu_ctx, bytes(bad))
     sc = capi.DeviceScene(gpu_ctx, packed)
-    with pytest.raises(capi.RtError, match='LITERAL_ZERO'):
-        capi.DeviceBVH(gpu_ctx, sc, mode=1)
+    with pytest.raises(capi.RtError, match='unknown parity mode'):
+        capi.DeviceBVH(gpu_ctx, sc, mode=2)
     b = capi.DeviceBVH(gpu_ctx, sc)
     with pytest.raises(capi.RtError, match='initializeFrame must precede construct'):
         b.construct()
@@ -234,11 +241,24 @@ def test_cpp_host_mirror_end_to_end(gpu_ctx, tmp_path):
     want, _ = ob.trace_primary(osc.demo_camera(160, 120))
     assert open(raw, 'rb').read() == want.tobytes()
     assert open(ppm, 'rb').read().startswith(b'P6\n160 120\n255\n')
+    # float frame (PFM, rows bottom to top): the shaded RGB itself, within 1e-5 relative of the oracle's host shading
+    import oracle as orc
+    pfm = str(tmp_path / 'o.pfm')
+    r = subprocess.run([demo, '-winH', '120', '-winW', '160', '-accStruct', 'BVH', '-headersPath', 'unused', '-scene',
+                        os.path.join('assets', 'scenes', 'gardenlight.txt'), '--out', pfm], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    blob = open(pfm, 'rb').read()
+    head = b'PF\n160 120\n-1.0\n'
+    assert blob.startswith(head) and len(blob) == len(head) + 160 * 120 * 12
+    rgb = np.frombuffer(blob, dtype='<f4', offset=len(head)).reshape(120, 160, 3)[::-1]
+    cam = osc.demo_camera(160, 120)
+    want_rgba = orc.shade_frame(osc, cam, want).reshape(120, 160, 4)
+    err = np.abs(rgb - want_rgba[:, :, :3]) / np.maximum(np.abs(want_rgba[:, :, :3]), 1e-30)
+    assert float(np.where(rgb == want_rgba[:, :, :3], 0.0, err).max()) <= 1e-5
     r = subprocess.run([demo, '-winH', '8', '-winW', '8', '-accStruct', 'OCTREE', '-headersPath', 'x', '-scene', 'x'],
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 1 and 'Unsupported acceleration structure' in r.stdout
     # -accStruct GRID: TwoLevelGridManager behind the same abstract interface (OpenCLRayTracerDemo.cpp:221-224)
-    import oracle as orc
     r = subprocess.run([demo, '-winH', '120', '-winW', '160', '-accStruct', 'GRID', '-headersPath', 'unused', '-scene',
                         os.path.join('assets', 'scenes', 'gardenlight.txt'), '--frames', '2', '--contacts', raw],
                        cwd=ROOT, capture_output=True, text=True, timeout=300)
@@ -586,3 +606,98 @@ def test_frame_graph_error_behaviour(gpu_ctx):
     assert gpu_ctx.download(dc, 64 * 48, capi.CONTACT).tobytes() == want.tobytes()
     g.close(); g.close()                                          # closing twice is harmless
     gpu_ctx.free(dc); gpu_ctx.free(dr)
+
+
+# ---- round 2: LITERAL_ZERO on the device, frame-graph validity, sticky error word ------------------------------------------
+
+@pytest.mark.parametrize('name', ['cube', 'gardenlight', 'tenryuu', 'man', 'clumsydragon'])
+def test_literal_zero_mode_on_the_device(gpu_ctx, name):
+    """SURVEY.md 8(c) LITERAL_ZERO: the reference's guard as written; node bytes, sorted pairs and contacts equal the oracle's
+    LITERAL_ZERO mode (whose radix-tree stage equals the reference kernel's own output, tests/test_gpu_reference_cl.py)."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    osc = orc.Scene(packed_scene(name))
+    ob = orc.BVH(osc, 1)
+    sc = capi.DeviceScene(gpu_ctx, packed_scene(name))
+    gb = capi.DeviceBVH(gpu_ctx, sc, mode=1).build()
+    try:
+        assert gb.read_morton_pairs().tobytes() == ob.pairs.tobytes()
+        nodes = gb.read_nodes()
+        diff = np.nonzero((nodes.view(np.uint8).reshape(-1, 48) != ob.nodes.view(np.uint8).reshape(-1, 48)).any(axis=1))[0]
+        assert diff.size == 0, 'first differing node %d: %s vs %s' % (diff[0], nodes[diff[0]], ob.nodes[diff[0]])
+        assert gb.search_tree()['depth'] == 0
+        for res in ((64, 48), (320, 240)):
+            cam = osc.demo_camera(*res)
+            want, st = ob.trace_primary(cam)
+            got = gb.generate_contacts_primary(as_capi_camera(cam))
+            assert got.tobytes() == want.tobytes()
+            if name == 'cube' and res == (64, 48):
+                assert st.hits == 1552                         # SURVEY.md 8(c): 1552 of the FIXED mode's 2209 hits
+        rays = orc.generate_rays(osc.demo_camera(96, 64))
+        want, _ = ob.trace_rays(rays)
+        assert gb.generate_contacts_rays(rays.view(capi.RAY)).tobytes() == want.tobytes()
+    finally:
+        gb.close(); sc.close()
+
+
+def test_frame_graph_goes_stale_instead_of_replaying_freed_buffers(gpu_ctx):
+    """a graph holds the addresses of the context's deferred-ray lists; a later, larger trace on the same
+    context reallocates them.  Launching the graph must then fail loudly, and a fresh graph must work."""
+    from openclraytracer_amd import capi
+    import oracle as orc
+    from conftest import packed_scene
+    ctx = capi.Context(0)                          # own context: its scratch starts small
+    try:
+        osc = orc.Scene(packed_scene('tenryuu'))
+        ob = orc.BVH(osc, 0)
+        sc = capi.DeviceScene(ctx, packed_scene('tenryuu'))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        cam = osc.demo_camera(320, 240)
+        ccam = as_capi_camera(cam)
+        slots = capi.tiles_owned_pixels(ccam, 1, 4)
+        d_c, d_o = ctx.alloc(slots * 32), ctx.alloc(slots * 16)
+        g = capi.FrameGraph(gb, sc, ccam, d_c, d_o, capi.FRAME_TILED, 1, 4, slots)
+        g.launch(); ctx.synchronize()
+        big = osc.demo_camera(1920, 1080)
+        gb.generate_contacts_primary(as_capi_camera(big))        # untiled full-HD frame on the same context: larger lists
+        with pytest.raises(capi.RtError, match='stale'):
+            g.launch()
+        g.close()
+        g2 = capi.FrameGraph(gb, sc, ccam, d_c, d_o, capi.FRAME_TILED, 1, 4, slots)
+        g2.launch(); ctx.synchronize()
+        want, _ = ob.trace_primary(cam)
+        got = ctx.download(d_c, slots, capi.CONTACT)
+        live = got['normalAndDistance'][:, 3] > 0
+        assert live.any() and set(got['pixelIndex'][live]) <= set(np.nonzero(want['normal_t'][:, 3] > 0)[0])
+        # a rebuild makes it stale as well
+        gb.build()
+        with pytest.raises(capi.RtError, match='stale'):
+            g2.launch()
+        g2.close(); ctx.free(d_c); ctx.free(d_o); gb.close(); sc.close()
+    finally:
+        ctx.close()
+
+
+def test_frame_graph_survives_another_camera_on_the_same_bvh(gpu_ctx):
+    """the per-camera marks live in the shared BVH records; an eager trace with another camera position
+    rewrites them.  Replaying the graph must restore its own marks and give its own camera's contacts."""
+    from openclraytracer_amd import capi
+    import oracle as orc
+    from conftest import packed_scene
+    osc = orc.Scene(packed_scene('gardenlight'))
+    ob = orc.BVH(osc, 0)
+    sc = capi.DeviceScene(gpu_ctx, packed_scene('gardenlight'))
+    gb = capi.DeviceBVH(gpu_ctx, sc).build()
+    cam_a = osc.demo_camera(320, 240)
+    cam_b = cam_a.copy()
+    cam_b['m'][0][3] += 0.37; cam_b['m'][0][7] -= 1.25; cam_b['m'][0][11] += 4.0       # inside the model's box
+    n = 320 * 240
+    d_c, d_o = gpu_ctx.alloc(n * 32), gpu_ctx.alloc(n * 16)
+    g = capi.FrameGraph(gb, sc, as_capi_camera(cam_a), d_c, d_o)
+    want_b, _ = ob.trace_primary(cam_b)
+    assert gb.generate_contacts_primary(as_capi_camera(cam_b)).tobytes() == want_b.tobytes()
+    g.launch(); gpu_ctx.synchronize()
+    want_a, _ = ob.trace_primary(cam_a)
+    assert gpu_ctx.download(d_c, n, capi.CONTACT).tobytes() == want_a.tobytes()
+    g.close(); gpu_ctx.free(d_c); gpu_ctx.free(d_o); gb.close(); sc.close()

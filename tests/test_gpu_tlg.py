@@ -160,3 +160,42 @@ def test_error_behaviour(gpu_ctx):
             gpu_ctx.check(gpu_ctx.lib.rt_tlg_read(g.h, g.TOP_CELLS, out.ctypes.data, 3))
     finally:
         g.close(); sc.close()
+
+
+@pytest.mark.parametrize('name', ['gardenlight', 'tenryuu', 'clumsydragon'])
+def test_rebuild_runs_without_mid_build_readbacks_and_gives_the_same_products(gpu_ctx, name):
+    """dynamic scenes rebuild per frame (OpenCLRayTracerDemo.cpp:230-234): the second construct() runs on the first one's array
+    sizes with the counts kept on the device (no host round trip until the end) and must leave exactly the same products;
+    when the sizes no longer fit (other densities) the sequence with read-backs takes over."""
+    from openclraytracer_amd import capi
+    import oracle as orc
+    osc = orc.Scene(packed_scene(name))
+    sc = capi.DeviceScene(gpu_ctx, packed_scene(name))
+    gg = capi.DeviceTLG(gpu_ctx, sc).build()
+    T = type(gg)
+
+    def check(og):
+        info = gg.info()
+        for k in info:
+            assert info[k] == og.info[k], k
+        for what, want in ((T.TOP_PAIRS, og.top_pairs), (T.CELL_RANGES, og.cell_ranges), (T.TOP_CELLS, og.top_cells),
+                           (T.LEAF_PAIRS, og.leaf_pairs), (T.LEAF_RANGES, og.leaf_ranges)):
+            assert gg.read(what).tobytes() == want.tobytes(), what
+        cam = osc.demo_camera(160, 120)
+        assert gg.generate_contacts_primary(as_capi_camera(cam)).tobytes() == og.trace_primary(cam)[0].tobytes()
+
+    og = orc.TLG(osc)
+    check(og)
+    assert gg.rebuilds_without_readback() == 0
+    for k in range(2):
+        gg.build()
+        assert gg.rebuilds_without_readback() == k + 1
+        check(og)
+    gg.set_densities(3.1, 1.3)                       # other pair counts: the previous sizes do not fit
+    gg.build()
+    check(orc.TLG(osc, 3.1, 1.3))
+    before = gg.rebuilds_without_readback()
+    gg.build()
+    assert gg.rebuilds_without_readback() == before + 1
+    check(orc.TLG(osc, 3.1, 1.3))
+    gg.close(); sc.close()
