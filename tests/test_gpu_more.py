@@ -632,8 +632,9 @@ def test_literal_zero_mode_on_the_device(gpu_ctx, name):
             want, st = ob.trace_primary(cam)
             got = gb.generate_contacts_primary(as_capi_camera(cam))
             assert got.tobytes() == want.tobytes()
-            if name == 'cube' and res == (64, 48):
-                assert st.hits == 1552                         # 1552 of the FIXED mode's 2209 hits
+            if res == (64, 48) and name != 'tenryuu':
+                # hit counts of this mode (tests/test_cpu_oracle_and_host.py::test_literal_zero_hit_counts explains SURVEY's 1552)
+                assert st.hits == {'cube': 2209, 'gardenlight': 624, 'man': 1513, 'clumsydragon': 257}[name]
         rays = orc.generate_rays(osc.demo_camera(96, 64))
         want, _ = ob.trace_rays(rays)
         assert gb.generate_contacts_rays(rays.view(capi.RAY)).tobytes() == want.tobytes()
