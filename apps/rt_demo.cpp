@@ -12,6 +12,7 @@
 #include <vector>
 
 #include <Algorithms/BVHManager.h>
+#include <Algorithms/MultiGPUFrame.h>
 #include <Algorithms/TwoLevelGridManager.h>
 #include <CLData/CLStructs.h>
 #include <Scene/Scene.h>
@@ -26,7 +27,8 @@ using namespace CLRayTracer::AccelerationStructures;
 int main(int argc, char* argv[])
 {
     int window_width = 0, window_height = 0, frames = 1;
-    std::string scenePath, accStruct, headersPath, outPath, rawContacts;
+    std::string scenePath, accStruct, headersPath, outPath, rawContacts, devices;
+    int gpus = 1;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
         if (k == "-winH") window_height = std::atoi(v.c_str());
@@ -37,14 +39,72 @@ int main(int argc, char* argv[])
         else if (k == "--frames") frames = std::atoi(v.c_str());
         else if (k == "--out") outPath = v;
         else if (k == "--contacts") rawContacts = v;
+        else if (k == "--gpus") gpus = std::atoi(v.c_str());          // frame tiled over N GPUs, one gather (BVH only)
+        else if (k == "--devices") devices = v;                        // e.g. 0,0,0: which HIP device each rank uses (default rank r -> device r)
     }
     if (window_width <= 0 || window_height <= 0 || scenePath.empty() || accStruct.empty()) {
-        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm|img.pfm] [--contacts raw.bin]" << std::endl;
+        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm|img.pfm] [--contacts raw.bin] [--gpus n [--devices d0,d1,..]]" << std::endl;
         return 0;
     }
     if (accStruct != "BVH" && accStruct != "GRID") {              // OpenCLRayTracerDemo.cpp:221-224
         std::cout << "Unsupported acceleration structure: " << accStruct << " (BVH or GRID)" << std::endl; return 1; }
     Errata err;
+    if (gpus > 1 || !devices.empty()) {
+        // ---- the frame tiled over several GPUs (new): one context, scene replica and BVH per rank ----
+        if (accStruct != "BVH") { std::cout << "--gpus supports -accStruct BVH" << std::endl; return 1; }
+        std::vector<int> dev;
+        for (size_t p = 0; p < devices.size();) { size_t q = devices.find(',', p); if (q == std::string::npos) q = devices.size(); dev.push_back(std::atoi(devices.substr(p, q - p).c_str())); p = q + 1; }
+        if (dev.empty()) for (int r = 0; r < gpus; r++) dev.push_back(r);
+        const size_t n = dev.size();
+        std::vector<std::unique_ptr<CLExecutionContext>> ctxs(n);
+        std::vector<std::unique_ptr<Scene>> scenes(n);
+        std::vector<std::unique_ptr<BVHManager>> managers(n);
+        std::vector<const CLExecutionContext*> pc; std::vector<const Scene*> ps; std::vector<BVHManager*> pm;
+        for (size_t r = 0; r < n; r++) {
+            try { ctxs[r].reset(new CLExecutionContext(dev[r])); } catch (const CLInterfaceException& e) { std::cout << e; return 1; }
+            scenes[r].reset(new Scene());
+            CHECKED_CALL(scenes[r]->load(scenePath.c_str(), err));
+            CHECKED_CALL(scenes[r]->loadToGPU(*ctxs[r], err));
+            managers[r].reset(new BVHManager(*ctxs[r], *scenes[r]));
+            CHECKED_CALL(managers[r]->initialize(err));
+            CHECKED_CALL(managers[r]->initializeFrame(err));
+            CHECKED_CALL(managers[r]->construct(err));
+            pc.push_back(ctxs[r].get()); ps.push_back(scenes[r].get()); pm.push_back(managers[r].get());
+        }
+        const float* bb = reinterpret_cast<const float*>(scenes[0]->getHostSceneData() + 64);
+        Camera camera;
+        camera.resX = window_width; camera.resY = window_height;
+        camera.FOVDistance = FOVDistFromAngle(90, (float)window_width, (float)window_height);
+        camera.supersampilngFactor = 1;
+        CL_FLOAT3 half, cameraPosition;
+        half.x = (bb[4] - bb[0]) * 0.5f; half.y = (bb[5] - bb[1]) * 0.5f; half.z = (bb[6] - bb[2]) * 0.5f;
+        cameraPosition.x = bb[0] + half.x; cameraPosition.y = bb[1] + half.y; cameraPosition.z = bb[2] - half.z; cameraPosition.w = 0;
+        camera.viewTransform = identityTransform();
+        Quaternion cameraOrientation = zeroRotation();
+        normalizeQuaternion(&cameraOrientation);
+        setOrientationAndPos(&camera.viewTransform, cameraOrientation, cameraPosition);
+        MultiGPUFrame frame(pc, ps, pm);
+        CHECKED_CALL(frame.initialize(camera, n > 1 ? 1u : 0u, err));
+        CHECKED_CALL(frame.render(err));                               // warm-up
+        CHECKED_CALL(frame.finish(err));
+        auto t0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < frames; f++) CHECKED_CALL(frame.render(err));
+        CHECKED_CALL(frame.finish(err));
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
+        std::vector<CL_FLOAT4> colors((size_t)window_width * window_height);
+        CHECKED_CALL(frame.copyFrameToHost(colors.data(), err));
+        size_t hits = 0;
+        for (const CL_FLOAT4& c : colors) hits += c.w > 0;
+        std::cout << "ranks " << n << (frame.usesRCCL() ? " (RCCL gather)" : " (device-copy gather: ranks share a device)") << "  frames " << frames << "  "
+                  << ms << " ms/frame  lit pixels " << hits << std::endl;
+        if (!outPath.empty()) {
+            FILE* fo = std::fopen(outPath.c_str(), "wb");
+            if (!fo) { std::perror("fopen"); return 1; }
+            std::fwrite(colors.data(), sizeof(CL_FLOAT4), colors.size(), fo);      // raw float4 frame
+            std::fclose(fo);
+        }
+        return 0;
+    }
     std::unique_ptr<CLExecutionContext> context;
     try { context.reset(new CLExecutionContext(0)); }
     catch (const CLInterfaceException& e) { std::cout << e; return 1; }

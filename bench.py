@@ -5,28 +5,43 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 One STEP = one frame of EACH of the five bundled TestModels scenes (Cube, Gardenlight, Tenryuu, ManFigure,
-ClumsyDragon; BASELINE.json configs[1]) at 1920x1080, demo default camera: BVH traversal (two HIP kernels) + shading.
-Scene buffers, BVHs and output buffers are resident in HBM before the timed region; BVH build time is reported
-separately.  The five frames of a step are independent and are issued on five HIP streams (one library context per
-scene), so one frame's tail is filled by the next frame's blocks.  With N > 1 every frame is cut into 64x64-pixel tiles dealt round-robin to the ranks (one process per GPU);
-each rank traces and shades its tiles into a compact buffer, ONE gather (RCCL over xGMI) brings them to rank 0, which
-scatters them back to pixel order -- total work per step is fixed, so scaling is "strong".
+ClumsyDragon; BASELINE.json configs[1]) at 1920x1080, demo default camera: BVH traversal + shading.  Scene buffers, BVHs
+and output buffers are resident in HBM before the timed region.  The five frames of a step are independent and are issued
+on five HIP streams (one library context per scene), so one frame's tail is filled by the next frame's blocks.
+
+N > 1 (one process per GPU): every frame is cut into 64x64-pixel tiles dealt over the ranks; each rank traces and shades
+its tiles, ONE gather per frame -- RCCL point-to-point into rank 0, issued by the library itself (rt_multi_frame_*,
+openclraytracer_amd/csrc/rtmi_multi.hip: no Python and no torch in the data path) -- assembles it; total work per step is
+fixed, so scaling is "strong".  torch.distributed (gloo) only carries the barrier, the 128-byte communicator id and the
+max over ranks of the elapsed time.
 
 The line printed by rank 0 also carries
-  roofline      algorithmic bytes of the traversal (56*I + 40*L + 32 per ray; I / L = inner records walked / triangles
-                tested, from the committed counter fixtures tests/golden/search_tree_frames.json for the hierarchy the
-                kernels walk and tests/golden/frames.json for the reference's own traversal order, both computed by the
-                oracle, never taken from the GPU run) divided by the traversal kernels' device time, measured with HIP
-                events on the stream they run on, vs 8 TB/s HBM;
-  cpu_baseline  the CPU oracle (a restatement of the reference's host path) timed on this box's host cores on the same
-                five frames (rank 0, N = 1 only).  A reported baseline, not the target.
+  roofline            HBM: bytes the traversal launch really moves (rocprofv3 FETCH_SIZE / WRITE_SIZE, collected by THIS run in
+                      child processes before the GPU is touched, corrected as MI355X_MICROARCH.md prescribes) over the launch
+                      duration measured live with HIP events, vs 8 TB/s.  The reference algorithm's bytes (SURVEY.md 8(d):
+                      56 I + 40 L + 32 per ray) over the same time are reported beside it: the records are cache resident and one
+                      fetch serves up to 64 rays of a packet, so that figure exceeds the HBM peak and is not a fraction of it.
+  roofline_valu_issue the resource that binds: vector instructions issued (SQ_INSTS_VALU x 2 cycles per wave64 instruction on a
+                      SIMD) over the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 8), per scene and for the
+                      kernel that takes the most time, with the scalar-unit counters beside it.
+  cpu_baseline        the CPU oracle (a restatement of the reference's host path, pinned on the reference's own kernels) timed
+                      on this box's host cores on the same five frames (rank 0, N = 1 only).  A reported baseline, not the target.
+  config5             BASELINE.json configs[4]: the Sponza-class stand-in at 3840x2160, BVH, tiled over the N ranks.
+  per_scene[..].rebuild_plus_trace_ms   the dynamic-scene frame (OpenCLRayTracerDemo.cpp:230-234): initializeFrame + construct +
+                      generateContacts + shade, every frame.
 """
 from __future__ import annotations
 
 import argparse
+import collections
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -38,20 +53,37 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 SCENES = ['cube', 'gardenlight', 'tenryuu', 'man', 'clumsydragon']
 RES = (1920, 1080)
+RES5 = (3840, 2160)         # config 5
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SIMDS = 256 * 4             # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_INST = 2.0  # wave64 vector instruction on a SIMD (MI355X_MICROARCH.md, per-instruction cycle constants)
+ISOLATED_FRAMES = 10        # frames per scene of the isolated (one scene at a time) measurement pass
+PMC_FRAMES = 3              # frames per scene in a counter pass
+PMC_PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']),
+              ('sq', ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_SMEM', 'SQ_INST_CYCLES_SALU', 'SQ_WAIT_INST_ANY',
+                      'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'])]
 
 
-def load_scene_bytes(name):
+def pack_scene_file(scene_txt):
     """Packed scene buffer through the PRODUCT's loader: the C++ Scene::load packing (apps/bin/scene_pack_tool,
     openclraytracer_amd/csrc/host/src/SceneLoader.cpp)."""
-    import subprocess
-    import tempfile
     tool = os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
     if not os.path.exists(tool):
         raise SystemExit('apps/bin/scene_pack_tool is not built: run __graft_entry__.build()')
     with tempfile.NamedTemporaryFile(suffix='.bin') as tmp:
-        subprocess.check_call([tool, os.path.join('assets', 'scenes', name + '.txt'), tmp.name], cwd=ROOT)
+        subprocess.check_call([tool, os.path.relpath(scene_txt, ROOT), tmp.name], cwd=ROOT)
         return open(tmp.name, 'rb').read()
+
+
+def load_scene_bytes(name):
+    return pack_scene_file(os.path.join(ROOT, 'assets', 'scenes', name + '.txt'))
+
+
+def load_atrium_bytes():
+    """config 5's scene: Sponza is not shipped with the reference; seeded procedural stand-in of the same size (assets/synth)"""
+    sys.path.insert(0, os.path.join(ROOT, 'assets', 'synth'))
+    import gen_scenes
+    return pack_scene_file(gen_scenes.ensure()['synth_atrium'])
 
 
 def demo_camera(scene_bytes, resx, resy):
@@ -73,7 +105,104 @@ def demo_camera(scene_bytes, resx, resy):
     return cam
 
 
-ISOLATED_FRAMES = 10         # frames per scene of the isolated (one scene at a time) measurement pass
+# ---------------------------------------------------------------------------------------------------------------------------
+# hardware counters of the traversal launches, collected by this run: bench.py starts itself under rocprofv3 (the program
+# directly behind `--`), once per counter pass, BEFORE this process touches the GPU
+# ---------------------------------------------------------------------------------------------------------------------------
+def pmc_child():
+    """the profiled child: the five scenes, first frame (calibration), then PMC_FRAMES isolated traversal launches per scene
+    whose kernels carry the template tag <1, 2>"""
+    from openclraytracer_amd import capi
+    ctx = capi.Context(0)
+    info = {}
+    for name in SCENES:
+        buf = load_scene_bytes(name)
+        scene = capi.DeviceScene(ctx, buf)
+        bvh = capi.DeviceBVH(ctx, scene).build()
+        cam = demo_camera(buf, *RES)
+        dc = ctx.alloc(RES[0] * RES[1] * 32)
+        bvh.generate_contacts_primary_d(cam, dc)
+        ctx.synchronize()
+        ctx.set_profiling(2)
+        for _ in range(PMC_FRAMES):
+            bvh.generate_contacts_primary_d(cam, dc)
+        ctx.synchronize()
+        ctx.set_profiling(False)
+        info[name] = bvh.trace_strategy()
+        ctx.free(dc); bvh.close(); scene.close()
+    ctx.close()
+    print('PMC_CHILD ' + json.dumps(info), flush=True)
+
+
+def run_pmc_passes(keep_dir=None):
+    """-> dict with per-scene and per-kernel counter sums per traversal launch, or None when rocprofv3 is unavailable"""
+    rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rocprof):
+        return None
+    base = tempfile.mkdtemp(prefix='rtmi_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    rows = []            # (pass, dispatch order, kernel, counter, value)
+    strategies = None
+    try:
+        for tag, counters in PMC_PASSES:
+            out = os.path.join(base, tag)
+            cmd = [rocprof, '--pmc'] + counters + ['--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child']
+            try:
+                r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                print('bench: counter pass %s did not run: %s' % (tag, e), file=sys.stderr)
+                return None
+            line = [l for l in r.stdout.splitlines() if l.startswith('PMC_CHILD ')]
+            if r.returncode != 0 or not line:
+                print('bench: counter pass %s failed (rc %d): %s' % (tag, r.returncode, (r.stderr or r.stdout)[-400:]), file=sys.stderr)
+                return None
+            strategies = json.loads(line[-1][len('PMC_CHILD '):])
+            files = sorted(glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
+            if not files:
+                print('bench: counter pass %s left no counter_collection.csv' % tag, file=sys.stderr)
+                return None
+            for row in csv.DictReader(open(files[-1])):
+                k = row['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+                if k.startswith(('k_trace', 'k_resolve_split')) and k.endswith('<1, 2>'):
+                    rows.append((tag, int(row['Dispatch_Id']), k, row['Counter_Name'], float(row['Counter_Value'])))
+        if keep_dir:
+            os.makedirs(keep_dir, exist_ok=True)
+            with open(os.path.join(keep_dir, 'bench_pmc_rows.csv'), 'w') as f:
+                f.write('pass,dispatch_id,kernel,counter,value\n')
+                for r_ in rows:
+                    f.write('%s,%d,%s,%s,%.3f\n' % r_)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    # dispatches in order: every scene contributes PMC_FRAMES launches = PMC_FRAMES first-phase kernels (+ k_trace_long (+ k_resolve_split))
+    first = ('k_trace<', 'k_trace_packet<', 'k_trace_packet4<')
+    per_scene = {n: collections.defaultdict(float) for n in SCENES}
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
+    kernel_dispatches = collections.defaultdict(int)
+    for tag, _ in PMC_PASSES:
+        disp = sorted({(d, k) for t, d, k, _, _ in rows if t == tag})
+        scene_of, launches = {}, 0
+        for d, k in disp:
+            if k.startswith(first):
+                launches += 1
+            scene_of[d] = SCENES[min((launches - 1) // PMC_FRAMES, len(SCENES) - 1)] if launches else SCENES[0]
+        if launches != PMC_FRAMES * len(SCENES):
+            print('bench: counter pass %s saw %d traversal launches, expected %d' % (tag, launches, PMC_FRAMES * len(SCENES)), file=sys.stderr)
+            return None
+        for t, d, k, c, v in rows:
+            if t == tag:
+                per_scene[scene_of[d]][c] += v / PMC_FRAMES
+                per_kernel[k][c] += v
+        if tag == 'sq':
+            for d, k in disp:
+                kernel_dispatches[k] += 1
+    return dict(per_scene={n: dict(v) for n, v in per_scene.items()}, per_kernel={k: dict(v) for k, v in per_kernel.items()},
+                kernel_dispatches=dict(kernel_dispatches), strategies=strategies)
+
+
+def valu_issue(c):
+    """fraction of the VALU issue peak: wave64 vector instructions x 2 cycles over SIMDs x cycles (GRBM_GUI_ACTIVE sums the 8 XCDs)"""
+    cycles = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+    return (c.get('SQ_INSTS_VALU', 0.0) * VALU_CYCLES_PER_INST / (SIMDS * cycles)) if cycles else None
 
 
 def main():
@@ -82,187 +211,138 @@ def main():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graphs', action='store_true', help='issue every frame eagerly instead of replaying a HIP graph per frame')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic is then null)')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip config 5 and the rebuild-per-frame leg')
+    ap.add_argument('--no-graphs', action='store_true', help='N = 1: issue every frame eagerly instead of replaying a HIP graph per frame')
     ap.add_argument('--check-frames', action='store_true',
-                    help='N > 1: after the warm-up, rank 0 also traces every frame untiled and compares it with the gathered one')
+                    help='tiled: rank 0 also traces every frame untiled and compares it with the assembled one')
+    ap.add_argument('--keep-pmc', default=None, help='directory that receives the raw counter rows of this run')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child()
 
-    import torch
-    from openclraytracer_amd import capi, frame_tiles
-
-    world =int(os.environ.get('WORLD_SIZE', '1'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
-    # RTMI_BENCH_FORCE_TILED=1 (tests): the N > 1 code path -- tiled kernels, RCCL gather issued from the frame streams,
-    # untile -- with a process group of ONE rank, i.e. on real RCCL on a one-GPU box
-    force_tiled = world == 1 and os.environ.get('RTMI_BENCH_FORCE_TILED') == '1'
-    if force_tiled:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29531')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-    tiled = world > 1 or force_tiled
-    # RT_TILING word: with N > 1 rank 0, which gathers the frame, owns `root_extra` more tiles per period of N + root_extra
-    # tiles (default 1: two tiles of three at N = 2), so less of the frame has to cross its links
-    root_extra = int(os.environ.get('RTMI_BENCH_ROOT_EXTRA', '1' if world > 1 else '0'))
-    tiling = capi.tiling(world, root_extra)
+    # tests on a one-GPU box: RTMI_BENCH_FORCE_TILED=1 runs the N > 1 code path with one rank; RTMI_BENCH_GROUP=n runs it with n
+    # ranks inside this process, all on one device (the library then gathers by device copies: RCCL refuses two ranks on a device)
+    group_ranks = int(os.environ.get('RTMI_BENCH_GROUP', '0')) if world == 1 else 0
+    tiled = world > 1 or group_ranks > 0 or os.environ.get('RTMI_BENCH_FORCE_TILED') == '1'
+    nranks = world if world > 1 else max(group_ranks, 1)
+    root_extra = int(os.environ.get('RTMI_BENCH_ROOT_EXTRA', '1' if nranks > 1 else '0'))
+
+    # ---- everything that needs child processes happens before this process touches the GPU ------------------------------
+    scene_bytes = {name: load_scene_bytes(name) for name in SCENES}
+    atrium_bytes = None if args.no_extra_legs else load_atrium_bytes()
+    pmc = None
+    if rank == 0 and not tiled and not args.no_pmc:
+        pmc = run_pmc_passes(args.keep_pmc)
+
+    import torch
+    from openclraytracer_amd import capi
     dist = None
-    if tiled:
+    if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        # RTMI_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo -- a functional rehearsal of the N > 1 path on a
-        # one-GPU box (RCCL refuses two ranks on one device); its timings mean nothing
-        rehearsal = os.environ.get('RTMI_BENCH_REHEARSAL') == '1'
-        if rehearsal:
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group('gloo')
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        dist.init_process_group('gloo')          # control plane only: barrier, the communicator id, max of the elapsed time
+    torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-
-    # One context = one HIP stream per scene: the five frames of a step are independent, so their kernels run side by
-    # side and one frame's tail (a few long rays, a few busy waves) is filled by the next frame's blocks.  torch sees each
-    # stream as an ExternalStream, which orders the RCCL gather of a frame behind that frame's kernels.
-    ctxs = [capi.Context(local_rank) for _ in SCENES]   # raises without a gfx950 device: no fallback
-    ctx = ctxs[0]
-    tstreams = [torch.cuda.ExternalStream(c.get_stream(), device=dev) for c in ctxs]
-
-    frames_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'frames.json')))
-    search_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'search_tree_frames.json')))
-    key = '%dx%d' % RES
-    npx = RES[0] * RES[1]
-    work = []
-    build_ms = {}
-    for si, name in enumerate(SCENES):
-        buf = load_scene_bytes(name)
-        sctx = ctxs[si]
-        scene = capi.DeviceScene(sctx, buf)
-        bvh = capi.DeviceBVH(sctx, scene)
-        t0 = time.perf_counter()
-        bvh.build()
-        bvh.build()
-        build_ms[name] = (time.perf_counter() - t0) * 1e3 / 2
-        cam = demo_camera(buf, *RES)
-        slots = capi.tiles_owned_pixels(cam, rank, tiling) if tiled else npx
-        item = dict(name=name, bytes=buf, ctx=sctx, tstream=tstreams[si], scene=scene, bvh=bvh, cam=cam, slots=slots,
-                    contacts=torch.empty(slots * 32, dtype=torch.uint8, device=dev),
-                    rgba=torch.empty((slots, 4), dtype=torch.float32, device=dev))
-        if tiled:
-            item['slots0'] = capi.tiles_owned_pixels(cam, 0, tiling)      # rank 0 owns the most tiles: gather slot size
-            if rank == 0:
-                item['frame'] = torch.empty((npx, 4), dtype=torch.float32, device=dev)
-        work.append(item)
-
-    if tiled:
-        # The frames of a step travel in ONE gather (fewer, larger collectives: a gather costs ~50 us of host time and the
-        # links into rank 0 are the bound).  12-byte wire format: three float planes per frame and rank,
-        # hit flag in the sign bit of red (rt_shade_blinn_phong_tiled_packed).  The send buffer is double buffered: step k
-        # shades into buffer k & 1 while the gather of step k - 1 may still be reading the other one.
-        slots0 = work[0]['slots0']
-        assert all(it['slots0'] == slots0 for it in work)
-        send = [torch.zeros((len(SCENES), 3, slots0), dtype=torch.float32, device=dev) for _ in range(2)]
-        gathered = torch.empty((world, len(SCENES), 3, slots0), dtype=torch.float32, device=dev) if rank == 0 else None
-        gctx = capi.Context(local_rank)                    # gather + untile stream, ordered behind the five frame streams
-        gstream = torch.cuda.ExternalStream(gctx.get_stream(), device=dev)
-        gather_done = [None, None]                         # event behind the gather that last read send[b]
-        gather_events = [torch.cuda.Event(), torch.cuda.Event()]
-        step_no = [0]
-        # per-step Python work is the bound for N >= 4: everything that can be prepared once is
-        gather_out = list(gathered.unbind(0)) if rank == 0 else None
-        frame_ptrs = [it['frame'].data_ptr() for it in work] if rank == 0 else None
-        gathered_ptrs = [gathered[0, i].data_ptr() for i in range(len(SCENES))] if rank == 0 else None
-        rank_stride = len(SCENES) * 3 * slots0
-        native_gather = dist.get_backend() != 'gloo'      # gloo (rehearsal on one GPU) stages through the host in frame_tiles
-
-    # One HIP graph per frame (trace with the calibrated strategy, then shade): replaying it is one launch call instead of
-    # five.  On one GPU the device is the bound and this changes nothing; with the frame tiled over N GPUs the host is
-    # (DESIGN.md section 6).  Creating a graph traces one frame eagerly first, which is also where the BVH gets calibrated.
-    use_graphs = not args.no_graphs and os.environ.get('RTMI_BENCH_GRAPHS', '1') != '0'
-    if use_graphs:
-        try:
-            for i, it in enumerate(work):
-                if not tiled:
-                    it['graph'] = [capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'].data_ptr(), it['rgba'].data_ptr())]
-                else:
-                    it['graph'] = [capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'].data_ptr(), send[b][i].data_ptr(),
-                                                   capi.FRAME_TILED_PACKED, rank, tiling, slots0) for b in range(2)]
-        except capi.RtError as e:
-            print('frame graphs unavailable (%s): issuing frames eagerly' % e, file=sys.stderr)
-            use_graphs = False
-    graphs_on = [use_graphs]                      # the measurement passes after the timed region issue eagerly
-
-    def step():
-        if not tiled:
-            for it in work:
-                if graphs_on[0]:
-                    it['graph'][0].launch()
-                else:
-                    it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
-                    capi.shade_blinn_phong_frame_d(it['ctx'], it['scene'], it['cam'], it['contacts'].data_ptr(), it['rgba'].data_ptr())
-            return
-        b = step_no[0] & 1
-        step_no[0] += 1
-        for i, it in enumerate(work):
-            if gather_done[b] is not None:
-                it['tstream'].wait_event(gather_done[b])            # send[b] is free again
-            if graphs_on[0]:
-                it['graph'][b].launch()
-            else:
-                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
-                # shade straight into this frame's planes of the send buffer (ranks own slots <= slots0)
-                capi.shade_blinn_phong_tiled_packed_d(it['ctx'], it['scene'], it['cam'], rank, tiling, it['contacts'].data_ptr(),
-                                                      send[b][i].data_ptr(), slots0)
-            gstream.wait_stream(it['tstream'])
-        with torch.cuda.stream(gstream):
-            # the one collective of a step: issued behind all five frames, runs on the communicator's stream
-            if native_gather:
-                w = dist.gather(send[b], gather_out, dst=0, async_op=True)
-            else:
-                _, w = frame_tiles.gather_to_root(send[b], world, rank, out=gathered, async_op=True)
-            w.wait()                                                 # orders the gather stream behind the gather
-            gather_events[b].record(gstream)
-            gather_done[b] = gather_events[b]
-        if rank == 0:
-            for i, it in enumerate(work):
-                capi.untile_rgba_packed_d(gctx, it['cam'], tiling, gathered_ptrs[i], slots0, frame_ptrs[i], rank_stride_floats=rank_stride)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    frames_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'frames.json')))
+    search_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'search_tree_frames.json')))
+    key = '%dx%d' % RES
+    npx = RES[0] * RES[1]
+
+    # One context = one HIP stream per scene (and per rank of an in-process group): the five frames of a step are independent
+    comm_id = None
+    if world > 1:
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
+    main_comm = None
+    work, build_ms = [], {}
+    for name in SCENES:
+        buf = scene_bytes[name]
+        cam = demo_camera(buf, *RES)
+        it = dict(name=name, bytes=buf, cam=cam)
+        ranks_here = range(nranks) if group_ranks else [rank]
+        it['ctxs'] = [capi.Context(local_rank) for _ in ranks_here]        # raises without a gfx950 device: no fallback
+        it['scenes'] = [capi.DeviceScene(c, buf) for c in it['ctxs']]
+        it['bvhs'] = [capi.DeviceBVH(c, s) for c, s in zip(it['ctxs'], it['scenes'])]
+        t0 = time.perf_counter()
+        for b in it['bvhs']:
+            b.build()
+        build_ms[name] = (time.perf_counter() - t0) * 1e3 / len(it['bvhs'])
+        it['ctx'], it['scene'], it['bvh'] = it['ctxs'][0], it['scenes'][0], it['bvhs'][0]
+        if tiled:
+            if group_ranks:
+                it['comms'] = capi.Comm.create_group(it['ctxs'])
+            elif main_comm is None:
+                main_comm = capi.Comm.create(it['ctx'], comm_id, rank, world)      # collective: ncclCommInitRank
+                it['comms'] = [main_comm]
+            else:
+                it['comms'] = [main_comm.share(it['ctx'])]
+            it['frames'] = [capi.MultiFrame(c, b, s, cam, root_extra) for c, b, s in zip(it['comms'], it['bvhs'], it['scenes'])]
+            it['slots'] = it['frames'][0].layout()['own_slots']
+        else:
+            it['slots'] = npx
+            it['contacts'] = it['ctx'].alloc(npx * 32)
+            it['rgba'] = it['ctx'].alloc(npx * 16)
+        work.append(it)
+
+    # N = 1: one HIP graph per frame (trace with the calibrated strategy, then shade): one launch call instead of five.  Creating
+    # a graph traces one frame eagerly first, which is also where the BVH gets calibrated.  (Tiled: the library does the same
+    # inside rt_multi_frame_create, one graph per send buffer.)
+    use_graphs = not tiled and not args.no_graphs and os.environ.get('RTMI_BENCH_GRAPHS', '1') != '0'
+    if use_graphs:
+        for it in work:
+            it['graph'] = capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'], it['rgba'])
+
+    def step():
+        for it in work:
+            if tiled:
+                capi.multi_frame_render(it['frames'])
+            elif use_graphs:
+                it['graph'].launch()
+            else:
+                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'])
+                capi.shade_blinn_phong_frame_d(it['ctx'], it['scene'], it['cam'], it['contacts'], it['rgba'])
+
+    def check_errors():
+        for it in work:
+            if tiled:
+                for f in it['frames']:
+                    f.wait()                       # + the trace kernels' (sticky) error word
+            else:
+                it['ctx'].synchronize()
+
     def check_frames(when):
-        # rank 0 traces and shades every frame untiled and compares it with the one the ranks assembled
+        # rank 0 traces and shades every frame untiled, on a context of its own, and compares with the assembled frame
         if rank == 0:
-            # on a context of its own: the untiled frame needs larger deferred-ray lists than the tiles, and growing them on a
-            # frame's context would invalidate that frame's graphs (rt_frame_graph_launch then reports them stale)
             cctx = capi.Context(local_rank)
             for it in work:
                 cscene = capi.DeviceScene(cctx, it['bytes'])
                 cbvh = capi.DeviceBVH(cctx, cscene).build()
-                full_c = torch.empty(npx * 32, dtype=torch.uint8, device=dev)
-                full_rgba = torch.empty((npx, 4), dtype=torch.float32, device=dev)
-                cbvh.generate_contacts_primary_d(it['cam'], full_c.data_ptr())
-                capi.shade_blinn_phong_d(cctx, cscene, it['cam'], full_c.data_ptr(), npx, full_rgba.data_ptr())
-                cctx.synchronize()
-                torch.cuda.synchronize(dev)
-                same = torch.equal(full_rgba, it['frame'])
+                want = capi.shade_blinn_phong(cctx, cscene, it['cam'], cbvh.generate_contacts_primary(it['cam'])).reshape(-1, 4)
+                it['frames'][0].wait()
+                got = it['frames'][0].download_frame()
                 cbvh.close(); cscene.close()
-                if not same:
-                    raise SystemExit('frame check failed for %s (%s): the gathered frame differs from the untiled one' % (it['name'], when))
+                if got.tobytes() != want.tobytes():
+                    raise SystemExit('frame check failed for %s (%s): the assembled frame differs from the untiled one' % (it['name'], when))
             cctx.close()
-            print('frame check ok (%s): %d gathered frames equal the untiled ones' % (when, len(work)), file=sys.stderr)
+            print('frame check ok (%s): %d assembled frames equal the untiled ones' % (when, len(work)), file=sys.stderr)
         fence()
 
+    for _ in range(args.warmup):
+        step()
+    fence()
     if args.check_frames and tiled:
         if args.warmup == 0:
             step(); fence()
@@ -273,124 +353,171 @@ def main():
     issued = time.perf_counter() - t0            # host time to issue the steps (the floor when the device part shrinks)
     fence()
     elapsed = time.perf_counter() - t0
+    check_errors()                               # an invalid frame anywhere in the timed region fails the run
     if args.check_frames and tiled:
-        check_frames('after the timed steps')     # the frames of the last, fully overlapped step
-    # HIP-event span of a traversal launch while the five streams overlap: a short eager pass (a graph has no events in it)
-    graphs_on[0] = False
-    for c in ctxs:
-        c.set_profiling(True)
-    for _ in range(min(args.steps, 10)):
-        step()
-    fence()
-    kt = dict(launches=0, lane_phase_ms=0.0, wave_phase_ms=0.0)
-    for c in ctxs:
-        k1 = c.trace_kernel_times()
-        for f in kt:
-            kt[f] += k1[f]
-        c.set_profiling(False)
+        check_frames('after the timed steps')     # the frames of the last, fully overlapped steps
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
     rays_per_step = npx * len(SCENES)
     value = rays_per_step * args.steps / elapsed / 1e6
 
-    # ---- per-scene device times (untimed extra pass, HIP events) and the roofline of the traversal kernels
-    # (one scene at a time: what a frame costs when it has the device to itself)
+    # ---- per-scene device times (untimed extra pass, HIP events on the stream the kernels run on; one scene at a time: what a
+    # frame costs when it has the device to itself) -- the launches rocprofv3 lists as <1, 2>
     per_scene = {}
+    tiling = capi.tiling(nranks, root_extra if nranks > 1 else 0)
     for it in work:
         sctx = it['ctx']
+        r0 = 0 if group_ranks else rank
+        dc = sctx.alloc(max(it['slots'], 1) * 32) if tiled else it['contacts']
+        if tiled:
+            trace = lambda it=it, dc=dc: it['bvh'].generate_contacts_primary_tiled_d(it['cam'], r0, tiling, dc)
+        else:
+            trace = lambda it=it, dc=dc: it['bvh'].generate_contacts_primary_d(it['cam'], dc)
         tm = capi.Timer(sctx)
         for _ in range(ISOLATED_FRAMES):       # untimed: the device idled during the fence above and the clocks need a millisecond of work
-            if not tiled:
-                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
-            else:
-                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
-        sctx.set_profiling(2)                  # events + the <1, 2> kernel names: launches that had the device to themselves
+            trace()
+        sctx.set_profiling(2)
         tm.start()
         for _ in range(ISOLATED_FRAMES):
-            if not tiled:
-                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'].data_ptr())
-            else:
-                it['bvh'].generate_contacts_primary_tiled_d(it['cam'], rank, tiling, it['contacts'].data_ptr())
+            trace()
         tm.stop()
         ms = tm.elapsed_ms() / ISOLATED_FRAMES
         k = sctx.trace_kernel_times()
         sctx.set_profiling(False)
-        tm.close()
         fx = frames_fixture[it['name']][key]
         alg = 56 * fx['inner_visits'] + 40 * fx['leaf_tests'] + 32 * fx['rays']
-        # bytes of the records actually walked: primary rays use the search tree (same leaves, fewer inner nodes) when the
-        # BVH has one; counts from tests/golden/search_tree_frames.json (make_golden_search.py)
         st = it['bvh'].search_tree()
         walked = alg
         if st['depth'] and st['used_by_last_camera']:
             sx = search_fixture[it['name']][key]
             walked = 56 * sx['inner_visits'] + 40 * sx['leaf_tests'] + 32 * sx['rays']
-        per_scene[it['name']] = dict(trace_ms=round(ms, 4), first_kernel_ms=round(k['lane_phase_ms'] / ISOLATED_FRAMES, 4),
-                                     wave_per_ray_ms=round(k['wave_phase_ms'] / ISOLATED_FRAMES, 4),
-                                     mrays_per_s=round(it['slots'] / ms / 1e3, 1),
-                                     inner_visits_per_ray=round(fx['inner_visits'] / fx['rays'], 2),
-                                     leaf_tests_per_ray=round(fx['leaf_tests'] / fx['rays'], 2),
-                                     algorithmic_bytes=alg, walked_bytes=walked, search_tree_depth=st['depth'],
-                                     reference_tree_depth=it['bvh'].info()['max_depth'], build_ms=round(build_ms[it['name']], 3),
-                                     strategy=it['bvh'].trace_strategy())
+        ps = dict(trace_ms=round(ms, 4), first_kernel_ms=round(k['lane_phase_ms'] / ISOLATED_FRAMES, 4),
+                  wave_per_ray_ms=round(k['wave_phase_ms'] / ISOLATED_FRAMES, 4), mrays_per_s=round(it['slots'] / ms / 1e3, 1),
+                  inner_visits_per_ray=round(fx['inner_visits'] / fx['rays'], 2), leaf_tests_per_ray=round(fx['leaf_tests'] / fx['rays'], 2),
+                  algorithmic_bytes=alg, walked_bytes=walked, search_tree_depth=st['depth'],
+                  reference_tree_depth=it['bvh'].info()['max_depth'], build_ms=round(build_ms[it['name']], 3),
+                  strategy=it['bvh'].trace_strategy())
+        # the dynamic-scene frame (OpenCLRayTracerDemo.cpp:230-234: the structure is rebuilt per frame when the scene moves):
+        # initializeFrame + construct + generateContacts + shade, every frame, with the calibrated strategy kept across rebuilds
+        if not tiled and not args.no_extra_legs:
+            K = 8
+
+            def dyn(it=it, sctx=sctx):
+                it['bvh'].initialize_frame(); it['bvh'].construct()
+                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'])
+                capi.shade_blinn_phong_frame_d(sctx, it['scene'], it['cam'], it['contacts'], it['rgba'])
+            dyn(); dyn(); sctx.synchronize()
+            tw = time.perf_counter()
+            for _ in range(K):
+                dyn()
+            sctx.synchronize()
+            ps['rebuild_plus_trace_ms'] = round((time.perf_counter() - tw) * 1e3 / K, 4)
+            ps['strategy_after_rebuilds'] = it['bvh'].trace_strategy()
+        tm.close()
+        if tiled:
+            sctx.free(dc)
+        per_scene[it['name']] = ps
+
+    # ---- config 5 (BASELINE.json configs[4]): the Sponza-class stand-in at 3840x2160, BVH, the frame tiled over the ranks --------
+    config5 = None
+    if atrium_bytes is not None:
+        cam5 = demo_camera(atrium_bytes, *RES5)
+        ranks_here = range(nranks) if group_ranks else [rank]
+        c5 = [capi.Context(local_rank) for _ in ranks_here]
+        s5 = [capi.DeviceScene(c, atrium_bytes) for c in c5]
+        tb = time.perf_counter()
+        b5 = [capi.DeviceBVH(c, s).build() for c, s in zip(c5, s5)]
+        build5 = (time.perf_counter() - tb) * 1e3 / len(b5)
+        K5 = 10
+        if tiled:
+            comms5 = capi.Comm.create_group(c5) if group_ranks else [main_comm.share(c5[0])]
+            f5 = [capi.MultiFrame(c, b, s, cam5, root_extra) for c, b, s in zip(comms5, b5, s5)]
+            render5 = lambda: capi.multi_frame_render(f5)
+        else:
+            d5c, d5o = c5[0].alloc(RES5[0] * RES5[1] * 32), c5[0].alloc(RES5[0] * RES5[1] * 16)
+            g5 = capi.FrameGraph(b5[0], s5[0], cam5, d5c, d5o)
+            render5 = g5.launch
+        render5(); render5(); fence()
+        t5 = time.perf_counter()
+        for _ in range(K5):
+            render5()
+        fence()
+        e5 = time.perf_counter() - t5
+        if tiled:
+            for f in f5:
+                f.wait()
+        else:
+            c5[0].synchronize()
+        if dist is not None:
+            t = torch.tensor([e5], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e5 = float(t.item())
+        config5 = dict(workload='Sponza-class stand-in (assets/synth, %d triangles) x 3840x2160 primary rays, BVH trace + shade, frame tiled over %d rank(s), '
+                                'one RCCL gather per frame' % (s5[0].n_tris, nranks), frames=K5, ms_per_frame=round(e5 / K5 * 1e3, 3),
+                       mrays_per_s=round(RES5[0] * RES5[1] * K5 / e5 / 1e6, 1), build_ms=round(build5, 2), reference_tree_depth=b5[0].info()['max_depth'],
+                       search_tree_depth=b5[0].search_tree()['depth'], strategy=b5[0].trace_strategy())
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    launches = max(kt['launches'], 1)
-    trace_ms_concurrent = (kt['lane_phase_ms'] + kt['wave_phase_ms']) / launches   # timed region: launches overlap on five streams
-    alg_total = sum(per_scene[n]['algorithmic_bytes'] for n in SCENES)
-    share = (work[0]['slots'] / float(sum(capi.tiles_owned_pixels(work[0]['cam'], r, tiling) for r in range(world)))) if tiled else 1.0
-    alg_per_launch = alg_total / len(SCENES) * share                                # this rank's share of an average frame
+    # ---- rooflines -------------------------------------------------------------------------------------------------------------
+    share = (work[0]['slots'] / float(sum(capi.tiles_owned_pixels(work[0]['cam'], r, tiling) for r in range(nranks)))) if tiled else 1.0
+    alg_per_launch = sum(per_scene[n]['algorithmic_bytes'] for n in SCENES) / len(SCENES) * share
     walked_per_launch = sum(per_scene[n]['walked_bytes'] for n in SCENES) / len(SCENES) * share
-    # The five frames of a step run side by side on five streams, so in the timed region a launch's HIP-event span contains
-    # the time it shared the device with four others (and queued behind them): it is not a kernel duration any more and
-    # rocprofv3's per-kernel durations of those launches are stretched the same way.  The roofline figure of the kernel is
-    # therefore taken from the isolated pass above -- the same launches on the same frames in the same process, one scene at a
-    # time, ISOLATED_FRAMES each, timed with HIP events on their stream; rocprofv3 lists exactly these launches as <1, 2>.
-    # What the device as a whole moved during the timed region is reported beside it (achieved_all_streams).
     trace_ms_avg = sum(per_scene[n]['first_kernel_ms'] + per_scene[n]['wave_per_ray_ms'] for n in SCENES) / len(SCENES)
-    dev_s = elapsed                                                                 # max over ranks, all streams
-    achieved = walked_per_launch / (trace_ms_avg * 1e-3) / 1e9
-    achieved_ref = alg_per_launch / (trace_ms_avg * 1e-3) / 1e9                     # the reference algorithm's bytes
-    achieved_device = walked_per_launch * launches / dev_s / 1e9                    # all concurrent launches together
+    launch_s = trace_ms_avg * 1e-3
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-    if os.path.exists(tpath) and world == 1:
-        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-    roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+    rv = None
+    if pmc is not None:
+        # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide reads at 64 bytes: doubled
+        # (MI355X_MICROARCH.md, HBM section).  Average over the five scenes, per traversal launch, like the duration.
+        fetch = sum(pmc['per_scene'][n].get('FETCH_SIZE', 0.0) for n in SCENES) / len(SCENES)
+        write = sum(pmc['per_scene'][n].get('WRITE_SIZE', 0.0) for n in SCENES) / len(SCENES)
+        traffic = int((2.0 * fetch + write) * 1024)
+        for n in SCENES:
+            c = pmc['per_scene'][n]
+            per_scene[n]['counters_per_launch'] = {k: round(v, 1) for k, v in c.items()}
+            per_scene[n]['valu_issue_frac'] = round(valu_issue(c), 4) if valu_issue(c) is not None else None
+            per_scene[n]['hbm_bytes_per_launch'] = int((2.0 * c.get('FETCH_SIZE', 0.0) + c.get('WRITE_SIZE', 0.0)) * 1024)
+            per_scene[n]['strategy_in_counter_pass'] = pmc['strategies'][n]
+        # the kernel that takes the most device time in the isolated launches: by GRBM_GUI_ACTIVE summed over its dispatches
+        dom = max(pmc['per_kernel'], key=lambda k: pmc['per_kernel'][k].get('GRBM_GUI_ACTIVE', 0.0))
+        dk = pmc['per_kernel'][dom]
+        nd = max(pmc['kernel_dispatches'].get(dom, 1), 1)
+        rv = dict(bound='valu_issue', kernel=dom, achieved=round(dk.get('SQ_INSTS_VALU', 0.0) * VALU_CYCLES_PER_INST / nd / 1e6, 3),
+                  peak=round(SIMDS * dk.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / nd / 1e6, 3), unit='M SIMD issue cycles per dispatch',
+                  frac=round(valu_issue(dk), 4), dispatches=nd,
+                  formula='SQ_INSTS_VALU x %.0f cycles / (%d SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)' % (VALU_CYCLES_PER_INST, SIMDS),
+                  counters_per_dispatch={k: round(v / nd, 1) for k, v in dk.items()},
+                  salu_per_valu=round(dk.get('SQ_INSTS_SALU', 0.0) / max(dk.get('SQ_INSTS_VALU', 1.0), 1.0), 3),
+                  wait_inst_any_over_wave_cycles=round(dk.get('SQ_WAIT_INST_ANY', 0.0) / max(dk.get('SQ_WAVE_CYCLES', 1.0), 1.0), 4),
+                  all_kernels={k: dict(dispatches=pmc['kernel_dispatches'].get(k, 0), valu_issue_frac=(round(valu_issue(v), 4) if valu_issue(v) else None),
+                                       salu_per_valu=round(v.get('SQ_INSTS_SALU', 0.0) / max(v.get('SQ_INSTS_VALU', 1.0), 1.0), 3))
+                               for k, v in pmc['per_kernel'].items()},
+                  source='rocprofv3 --pmc passes run by this bench invocation (child processes, %d isolated launches per scene)' % PMC_FRAMES)
+    # without the counters: the bytes a launch cannot avoid -- one 32-byte contact per ray -- are the stated lower bound
+    compulsory = 32.0 * npx * share
+    moved = traffic if traffic is not None else compulsory
+    roofline = dict(bound='hbm', achieved=round(moved / launch_s / 1e9, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
+                    frac=round(moved / launch_s / 1e9 / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    achieved_is=('measured HBM bytes per traversal launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 passes of this run) / avg_launch_ms'
+                                 if traffic is not None else 'no counters in this run: the 32-byte contacts a launch must write / avg_launch_ms (lower bound)'),
                     kernel='traversal launch of one frame: k_trace_packet4, k_trace_packet or k_trace, then k_trace_long (+ k_resolve_split) '
-                           'where work was handed over.  Template tags in profiles: <1, 2> = the isolated launches this figure is '
-                           'measured on, <1, 0> = the overlapping launches of the timed region, <1, 1> = first-frame calibration',
+                           'where work was handed over; <1, 2> in profiles = these isolated launches, <1, 0> = the timed region, <1, 1> = calibration',
                     avg_launch_ms=round(trace_ms_avg, 4), isolated_launches=ISOLATED_FRAMES * len(SCENES),
-                    concurrent_streams=len(SCENES),
-                    timed_region_launch_span_ms=round(trace_ms_concurrent, 4),
-                    achieved_all_streams=round(achieved_device, 1),
-                    measured_hbm_gbps=(round(traffic / (trace_ms_avg * 1e-3) / 1e9, 1) if traffic else None),
-                    measured_hbm_frac=(round(traffic / (trace_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None),
-                    binds='instruction issue (VALU / SALU) on cache-resident records, not HBM: frac > 1 and measured_hbm_frac say so',
-                    algorithmic_bytes_per_launch=int(walked_per_launch),
-                    reference_algorithm_bytes_per_launch=int(alg_per_launch),
-                    achieved_reference_algorithm=round(achieved_ref, 1),
-                    note='achieved = bytes of one traversal launch / its HIP-event duration, averaged over the five scenes, measured '
-                         'live in this run on launches that have the device to themselves (avg_launch_ms; rocprofv3 --stats shows the '
-                         'same launches as <1, 2>).  In the timed region the five frames of a step overlap on five streams: a launch\'s '
-                         'event span there (timed_region_launch_span_ms) includes the time it shared the device, and '
-                         'achieved_all_streams = bytes of all traversal launches of the timed region / its duration is the rate of the '
-                         'device as a whole (the walked records are L2-resident for the small scenes, hence above the HBM peak).  '
-                         'Bytes: 56 B per inner record + 40 B per triangle + 32 B contact of the hierarchy actually '
-                         'walked (search tree over the reference leaves); *_reference_algorithm is the same time against the bytes '
-                         'the reference traversal order would touch (SURVEY.md 8(d)); traffic = measured HBM bytes per launch (rocprofv3 FETCH_SIZE / '
-                         'WRITE_SIZE passes, profiles/traffic_latest.json), measured_hbm_* = that traffic over the same launch duration')
+                    reference_algorithm_bytes_per_launch=int(alg_per_launch), walked_bytes_per_launch=int(walked_per_launch),
+                    reference_algorithm_gbps=round(alg_per_launch / launch_s / 1e9, 1), walked_gbps=round(walked_per_launch / launch_s / 1e9, 1),
+                    traffic_over_reference_algorithm=(round(traffic / alg_per_launch, 4) if traffic else None),
+                    binds='not HBM: the records are L2 / scalar-cache resident and a packet fetches a record once for up to 64 rays, so the '
+                          'reference algorithm\'s bytes per second (reference_algorithm_gbps) exceed the HBM peak and are no fraction of it; '
+                          'see roofline_valu_issue')
 
     cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not tiled and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import oracle as orc                     # cpu_baseline leg only: the oracle is the thing timed here
         cores = orc.ncpu()
@@ -398,7 +525,7 @@ def main():
         c_buf = np.zeros(npx, dtype=orc.CONTACT)              # output buffers live outside the timed region, pages touched
         rgba_buf = np.zeros((npx, 4), dtype=np.float32)
         for name in SCENES:
-            osc = orc.Scene(load_scene_bytes(name))
+            osc = orc.Scene(scene_bytes[name])
             ob = orc.BVH(osc, 0)
             cam = osc.demo_camera(*RES)
             t1 = time.perf_counter()
@@ -409,7 +536,7 @@ def main():
         # the same path on ONE thread (SURVEY.md 8(d) asks for both), on a bounded sample: 320x180 frames of the five scenes
         t_one, rays_one = 0.0, 0
         for name in SCENES:
-            osc = orc.Scene(load_scene_bytes(name))
+            osc = orc.Scene(scene_bytes[name])
             ob = orc.BVH(osc, 0)
             cam = osc.demo_camera(320, 180)
             t1 = time.perf_counter()
@@ -430,19 +557,22 @@ def main():
                             single_thread_value=round(rays_one / t_one / 1e6, 4),
                             single_thread_sample='the five scenes at 320x180 (trace + shade), one thread', cpu_model=model)
 
+    par = 'single GPU, the five frames of a step on five HIP streams'
+    if tiled:
+        par = ('64x64 frame tiles dealt over %d ranks (rank 0 owns %d extra per period of %d tiles), one gather of shaded colour per frame to rank 0 '
+               '(12 B per pixel, grouped RCCL send/recv issued by librtmi), the five frames of a step on five HIP streams per rank'
+               % (nranks, root_extra, nranks + root_extra))
+        if group_ranks:
+            par += '; REHEARSAL: all ranks in one process on one device, gather by device copies'
     out = dict(metric='Mrays/s (primary rays, BVH trace + shade, bundled TestModels, 1920x1080)', value=round(value, 1),
                unit='Mrays/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling='strong',
                vs_baseline=None, dtype='f32', data='bundled TestModels OBJ scenes (shipped with the reference), demo default camera',
                config=dict(workload='5 bundled TestModels scenes x 1920x1080 primary rays, BVH traversal + Blinn-Phong shading',
-                           rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES,
-                           parallelism=('single GPU, the five frames of a step on five HIP streams' if world == 1 else
-                                        ('64x64 frame tiles dealt over %d ranks (rank 0 owns %d extra per period of %d tiles), one gather of RGBA '
-                                         '(12 B per pixel on the wire) to rank 0 per step, the five frames of a step on five HIP streams per rank'
-                                         % (world, root_extra, world + root_extra)))),
+                           rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES, parallelism=par),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
-               roofline=roofline, cpu_baseline=cpu_baseline, per_scene=per_scene)
+               roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, config5=config5, per_scene=per_scene)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

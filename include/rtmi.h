@@ -230,6 +230,43 @@ int  rt_shade_blinn_phong_tiled_packed(rt_ctx* ctx, const rt_scene* scene, const
 int  rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, const void* d_rgb_planes_gathered,
                            uint32_t slots_per_rank, uint64_t rank_stride_floats, void* d_rgba_frame);
 
+/* ---- the multi-GPU frame, natively (new functionality: the reference drives one OpenCL device, OpenCLUtils/CLExecutionContext.cpp:193-196;
+ *      SURVEY.md 8(b) `rt_frame_multi`, 8(e)).  One communicator rank per context; every rank holds a replica of the scene and the
+ *      BVH on its own context.  A frame = every rank traces + shades its 64x64 tiles (the calibrated strategy, replayed as a
+ *      frame graph) into three packed float planes, ONE gather -- grouped RCCL point-to-point: ncclRecv from every peer on rank
+ *      0, one ncclSend per peer, N-1 concurrent transfers over the root's xGMI links -- and the untile on rank 0.  Send buffers
+ *      are double buffered: the next frame's tracing overlaps this frame's gather.  No Python, no torch in this path.
+ *        rt_comm_create        one process per GPU: rank 0 makes the 128-byte id (rt_comm_unique_id), the launcher hands it to
+ *                              every rank, all ranks call create (collective: ncclCommInitRank)
+ *        rt_comm_create_group  one process, N contexts (out = array of N): ncclCommInitAll over their devices; contexts that
+ *                              SHARE a device exchange by device copies instead (RCCL refuses two ranks on a device) -- the
+ *                              transport of the one-GPU tests, everything else being the same code
+ *        rt_multi_frame_create collective only in that all ranks must use the same camera and root_extra (RT_TILING: extra tiles
+ *                              per period that rank 0 owns, so that less of the frame crosses its links)
+ *        rt_multi_frame_render frames[0..n): n = 1 with one process per GPU; n = N, in rank order, for a single-process group.
+ *                              Asynchronous.  rt_multi_frame_wait synchronises and reports trace errors.
+ *        rt_multi_frame_pixels rank 0: device pointer of the assembled resX*resY float4 frame (NULL on other ranks)          */
+#define RT_COMM_ID_BYTES 128
+typedef struct rt_comm rt_comm;
+typedef struct rt_multi_frame rt_multi_frame;
+int   rt_comm_unique_id(void* id128);
+int   rt_comm_create(rt_ctx* ctx, const void* id128, int rank, int nranks, rt_comm** out);
+int   rt_comm_create_group(rt_ctx** ctxs, int nranks, rt_comm** out);
+/* another context of the same process and device joins `owner`'s RCCL communicator with a stream of its own (several frames in
+ * flight per rank); every rank must then issue its frames in the same order.  Not for single-process groups.               */
+int   rt_comm_share(const rt_comm* owner, rt_ctx* ctx, rt_comm** out);
+void  rt_comm_destroy(rt_comm* comm);
+int   rt_comm_rank(const rt_comm* comm);
+int   rt_comm_size(const rt_comm* comm);
+int   rt_comm_uses_rccl(const rt_comm* comm);        /* 0: one rank, or a group whose contexts share a device (copies) */
+int   rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t root_extra,
+                            rt_multi_frame** out);
+int   rt_multi_frame_render(rt_multi_frame** frames, int n);
+int   rt_multi_frame_wait(rt_multi_frame* frame);
+void* rt_multi_frame_pixels(const rt_multi_frame* frame);
+int   rt_multi_frame_layout(const rt_multi_frame* frame, uint32_t* tiling, uint32_t* own_slots, uint32_t* root_slots, uint32_t* peer_slots);
+void  rt_multi_frame_destroy(rt_multi_frame* frame);
+
 /* ---- frame graphs: the launch sequence of one steady-state frame (trace with the strategy the BVH is calibrated to, then
  *      shading) captured into a HIP graph; replaying it is one launch call instead of five (an easy frame's kernels run for
  *      60-100 us, issuing them eagerly costs 30-40 us of host time).  The camera, the buffers and the tiling are baked in:

@@ -44,6 +44,8 @@ SYMBOLS = [
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
     'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
+    'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl',
+    'rt_multi_frame_create', 'rt_multi_frame_render', 'rt_multi_frame_wait', 'rt_multi_frame_pixels', 'rt_multi_frame_layout', 'rt_multi_frame_destroy',
     'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays',
 ]
 
@@ -128,6 +130,18 @@ def load_library() -> C.CDLL:
     L.rt_tlg_generate_contacts_rays.argtypes = [vp, vp, u32, vp]
     L.rt_tlg_generate_contacts_primary_tiled.argtypes = [vp, vp, u32, u32, vp]
     L.rt_tlg_info_get.argtypes = [vp, vp]
+    L.rt_comm_unique_id.argtypes = [vp]
+    L.rt_comm_create.argtypes = [vp, vp, i32, i32, pvp]
+    L.rt_comm_create_group.argtypes = [pvp, i32, pvp]
+    L.rt_comm_share.argtypes = [vp, vp, pvp]
+    L.rt_comm_destroy.argtypes = [vp]; L.rt_comm_destroy.restype = None
+    L.rt_comm_rank.argtypes = [vp]; L.rt_comm_size.argtypes = [vp]; L.rt_comm_uses_rccl.argtypes = [vp]
+    L.rt_multi_frame_create.argtypes = [vp, vp, vp, vp, u32, pvp]
+    L.rt_multi_frame_render.argtypes = [pvp, i32]
+    L.rt_multi_frame_wait.argtypes = [vp]
+    L.rt_multi_frame_pixels.argtypes = [vp]; L.rt_multi_frame_pixels.restype = vp
+    L.rt_multi_frame_layout.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.rt_multi_frame_destroy.argtypes = [vp]; L.rt_multi_frame_destroy.restype = None
     L.rt_tlg_rebuilds_without_readback.argtypes = [vp]; L.rt_tlg_rebuilds_without_readback.restype = u32
     L.rt_tlg_read.argtypes = [vp, i32, vp, u64]
     L.rt_tlg_pow_third.argtypes = [C.c_float]; L.rt_tlg_pow_third.restype = C.c_float
@@ -539,3 +553,105 @@ def tile_slot_map(resx: int, resy: int, nranks: int):
     ordinal = np.where(p <= e, q * (e + 1) + p, q)
     slot = ordinal * (T * T) + (y - ty * T) * T + (x - tx * T)
     return rank.astype(np.int64), slot.astype(np.int64)
+
+
+# ---- the native multi-GPU frame (rt_comm_* / rt_multi_frame_*) ------------------------------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """rank 0 of a job with one process per GPU: the id every rank passes to Comm.create (ncclGetUniqueId)"""
+    L = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    if L.rt_comm_unique_id(buf):
+        raise RtError(L.rt_last_error(None).decode())
+    return buf.raw
+
+
+class Comm:
+    """rt_comm: one communicator rank on one context"""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.h = ctx, handle
+
+    @classmethod
+    def create(cls, ctx: Context, comm_id: bytes | None, rank: int, nranks: int) -> 'Comm':
+        h = C.c_void_p()
+        idb = C.create_string_buffer(comm_id, COMM_ID_BYTES) if comm_id is not None else None
+        ctx.check(ctx.lib.rt_comm_create(ctx.h, idb, rank, nranks, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def create_group(cls, ctxs) -> list:
+        """one process, len(ctxs) contexts (RCCL when their devices differ, device copies when they share one)"""
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        out = (C.c_void_p * n)()
+        rc = ctxs[0].lib.rt_comm_create_group(arr, n, out)
+        if rc:
+            raise RtError((ctxs[0].lib.rt_last_error(ctxs[0].h) or ctxs[0].lib.rt_last_error(None) or b'rt_comm_create_group failed').decode())
+        return [cls(ctxs[r], C.c_void_p(out[r])) for r in range(n)]
+
+    def share(self, ctx: Context) -> 'Comm':
+        """another context of this process and device on the same RCCL communicator (several frames in flight per rank)"""
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rt_comm_share(self.h, ctx.h, C.byref(h)))
+        return Comm(ctx, h)
+
+    def rank(self) -> int:
+        return int(self.ctx.lib.rt_comm_rank(self.h))
+
+    def size(self) -> int:
+        return int(self.ctx.lib.rt_comm_size(self.h))
+
+    def uses_rccl(self) -> bool:
+        return bool(self.ctx.lib.rt_comm_uses_rccl(self.h))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rt_comm_destroy(self.h)
+            self.h = None
+
+
+class MultiFrame:
+    """rt_multi_frame: this rank's part of the tiled frame + the gather + (rank 0) the untile"""
+
+    def __init__(self, comm: Comm, bvh, scene, cam: np.ndarray, root_extra: int = 1):
+        self.comm, self.ctx = comm, comm.ctx
+        self.cam = np.array(cam, copy=True)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.rt_multi_frame_create(comm.h, bvh.h, scene.h, _p(self.cam), root_extra, C.byref(h)))
+        self.h = h
+
+    def layout(self) -> dict:
+        v = [C.c_uint32() for _ in range(4)]
+        self.ctx.check(self.ctx.lib.rt_multi_frame_layout(self.h, *[C.byref(x) for x in v]))
+        return dict(tiling=v[0].value, own_slots=v[1].value, root_slots=v[2].value, peer_slots=v[3].value)
+
+    def wait(self):
+        self.ctx.check(self.ctx.lib.rt_multi_frame_wait(self.h))
+
+    def pixels_ptr(self) -> int:
+        return int(self.ctx.lib.rt_multi_frame_pixels(self.h) or 0)
+
+    def download_frame(self) -> np.ndarray:
+        n = int(self.cam['resX'][0]) * int(self.cam['resY'][0])
+        return self.ctx.download(self.pixels_ptr(), n * 4, np.float32).reshape(n, 4)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rt_multi_frame_destroy(self.h)
+            self.h = None
+
+
+def multi_frame_render(frames) -> None:
+    """one frame of the given ranks: [frame] with one process per GPU, all ranks in rank order for a single-process group"""
+    n = len(frames)
+    arr = (C.c_void_p * n)(*[f.h for f in frames])
+    ctx = frames[0].ctx
+    if ctx.lib.rt_multi_frame_render(arr, n):
+        for f in frames:
+            msg = f.ctx.lib.rt_last_error(f.ctx.h)
+            if msg:
+                raise RtError(msg.decode())
+        raise RtError('rt_multi_frame_render failed')

@@ -23,6 +23,7 @@ public:
     /** parity read-back of the hierarchy in the reference's 48-byte BVHNode layout (2n-1 nodes) */
     Common::Result readNodes(void* hostNodes, Common::Errata& err) const;
     unsigned int leavesCount() const { return _bvhLeavesCount; }
+    rt_bvh* deviceHandle() const { return _bvh; }                 // used by MultiGPUFrame of this library
 protected:
     unsigned int _bvhLeavesCount;
     rt_bvh* _bvh;

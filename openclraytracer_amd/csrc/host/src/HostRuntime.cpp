@@ -259,3 +259,74 @@ Result CLRayTracer::AccelerationStructures::generateSecondaryRays(const CLExecut
     outCount = n;
     return Success;
 }
+
+
+// ------------------------------------------------------------------ MultiGPUFrame (new)
+#include <Algorithms/MultiGPUFrame.h>
+namespace CLRayTracer { namespace AccelerationStructures {
+
+MultiGPUFrame::MultiGPUFrame(const std::vector<const CLExecutionContext*>& contexts, const std::vector<const Scene*>& scenes,
+                             const std::vector<BVHManager*>& managers)
+    : _contexts(contexts), _scenes(scenes), _managers(managers), _camera() {}
+
+MultiGPUFrame::~MultiGPUFrame()
+{
+    for (rt_multi_frame* f : _frames) rt_multi_frame_destroy(f);
+    for (rt_comm* c : _comms) rt_comm_destroy(c);
+}
+
+Result MultiGPUFrame::initialize(Camera& cam, unsigned int rootExtra, Errata& err)
+{
+    const size_t n = _contexts.size();
+    if (n == 0 || _scenes.size() != n || _managers.size() != n) { FILL_ERRATA(err, "one context, scene and manager per GPU"); return Error; }
+    for (size_t r = 0; r < n; r++)
+        if (!_contexts[r] || !_scenes[r] || !_managers[r] || !_scenes[r]->deviceHandle() || !_managers[r]->deviceHandle()) {
+            FILL_ERRATA(err, "every rank needs its scene on the GPU and its BVH built"); return Error; }
+    for (rt_multi_frame* f : _frames) rt_multi_frame_destroy(f);
+    _frames.clear();
+    if (_comms.empty()) {
+        std::vector<rt_ctx*> ctxs;
+        for (const CLExecutionContext* c : _contexts) ctxs.push_back(c->handle());
+        _comms.assign(n, nullptr);
+        RTMI_CHECK(*_contexts[0], rt_comm_create_group(ctxs.data(), (int)n, _comms.data()), err);
+    }
+    _camera = cam;
+    _frames.assign(n, nullptr);
+    for (size_t r = 0; r < n; r++)
+        RTMI_CHECK(*_contexts[r], rt_multi_frame_create(_comms[r], _managers[r]->deviceHandle(), _scenes[r]->deviceHandle(),
+                                                        reinterpret_cast<const rt_camera*>(&_camera), rootExtra, &_frames[r]), err);
+    return Success;
+}
+
+Result MultiGPUFrame::render(Errata& err)
+{
+    if (_frames.empty()) { FILL_ERRATA(err, "initialize must precede render"); return Error; }
+    if (rt_multi_frame_render(_frames.data(), (int)_frames.size()) != RT_SUCCESS) {
+        for (const CLExecutionContext* c : _contexts) {
+            const char* m = rt_last_error(c->handle());
+            if (m && *m) { FILL_ERRATA(err, m); return Error; }
+        }
+        FILL_ERRATA(err, "rt_multi_frame_render failed");
+        return Error;
+    }
+    return Success;
+}
+
+Result MultiGPUFrame::finish(Errata& err)
+{
+    for (size_t r = 0; r < _frames.size(); r++) RTMI_CHECK(*_contexts[r], rt_multi_frame_wait(_frames[r]), err);
+    return Success;
+}
+
+Result MultiGPUFrame::copyFrameToHost(void* rgba, Errata& err)
+{
+    if (_frames.empty()) { FILL_ERRATA(err, "initialize must precede copyFrameToHost"); return Error; }
+    if (finish(err) != Success) return Error;
+    RTMI_CHECK(*_contexts[0], rt_buf_download(_contexts[0]->handle(), rgba, rt_multi_frame_pixels(_frames[0]),
+                                              (uint64_t)_camera.resX * _camera.resY * 16u), err);
+    return Success;
+}
+
+bool MultiGPUFrame::usesRCCL() const { return !_comms.empty() && rt_comm_uses_rccl(_comms[0]) != 0; }
+
+}}  // namespace

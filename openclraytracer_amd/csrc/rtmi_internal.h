@@ -276,6 +276,9 @@ void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, co
 void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* gathered,
                                uint32_t slots_per_rank, uint64_t rank_stride, float4* frame);
 
+void launch_untile_rgba_split(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* root_planes, uint32_t root_slots,
+                              const float* peers, uint32_t peer_slots, uint64_t peer_stride, float4* frame);
+
 // tiling helpers shared by host and device (64x64-pixel tiles dealt round-robin)
 #define RT_TILE 64u
 __host__ __device__ inline uint32_t rt_tiles_x(uint32_t resX) { return (resX + RT_TILE - 1) / RT_TILE; }

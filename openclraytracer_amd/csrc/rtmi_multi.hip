@@ -1,0 +1,341 @@
+// rtmi_multi.hip -- the multi-GPU frame behind the C ABI (include/rtmi.h, rt_comm_* / rt_multi_frame_*).
+//
+// New functionality: the reference drives exactly one OpenCL device (CLProgram::compile builds for one device,
+// OpenCLUtils/CLExecutionContext.cpp:193-196).  Rays are independent and the scene + BVH are replicated, so the
+// frame is cut into 64x64-pixel tiles dealt over the ranks (rtmi_internal.h, rt_tile_owner); every rank traces and shades its
+// tiles into three packed float planes (rt_shade_blinn_phong_tiled_packed's 12-byte wire format) and ONE gather brings the
+// planes to rank 0, which scatters them back to pixel order.  The gather is RCCL point-to-point, grouped: ncclRecv from every
+// peer on the root, one ncclSend on each peer -- N-1 concurrent transfers, one per xGMI link of the root (a ring would be bound
+// by a single link).  Nothing of this path runs in Python: one call renders a frame.
+//
+// One communicator rank per context.  Two ways to form a group:
+//   rt_comm_create        one process per GPU (the launcher hands every rank the 128-byte id of rt_comm_unique_id) -- ncclCommInitRank
+//   rt_comm_create_group  one process, N contexts -- ncclCommInitAll over their devices.  When contexts share a device (RCCL refuses
+//                         two ranks on one device) the group exchanges by device-to-device copies instead: the transport of the
+//                         one-GPU tests, everything else -- tiling, double buffering, stream order, untile -- being the same code.
+// RCCL is loaded at run time (dlopen "librccl.so.1"): a process that already holds a copy (torch ships one) keeps using that one.
+#include "rtmi_internal.h"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// ---- the handful of RCCL entry points used, with the types of rccl.h (rccl/rccl.h:40-43,187-260,700-933) ------------------
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;                 // ncclSuccess = 0
+enum { rtNcclFloat32 = 7 };               // ncclFloat32, rccl.h ncclDataType_t
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static const char* load_rccl()
+{
+    if (g_rccl.lib) return nullptr;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return "RCCL (librccl.so.1) cannot be loaded";
+    RcclApi a;
+    a.lib = h;
+#define RT_SYM(field, name) *(void**)(&a.field) = dlsym(h, name); if (!a.field) return "RCCL lacks " name;
+    RT_SYM(GetUniqueId, "ncclGetUniqueId") RT_SYM(CommInitRank, "ncclCommInitRank") RT_SYM(CommInitAll, "ncclCommInitAll")
+    RT_SYM(CommDestroy, "ncclCommDestroy") RT_SYM(Send, "ncclSend") RT_SYM(Recv, "ncclRecv") RT_SYM(GroupStart, "ncclGroupStart")
+    RT_SYM(GroupEnd, "ncclGroupEnd") RT_SYM(GetErrorString, "ncclGetErrorString")
+#undef RT_SYM
+    g_rccl = a;
+    return nullptr;
+}
+
+#define RT_NCCL(ctx, expr)                                                                                       \
+    do {                                                                                                         \
+        ncclResult_t r__ = (expr);                                                                               \
+        if (r__ != 0) return RT_FAIL((ctx), std::string(#expr) + ": " + g_rccl.GetErrorString(r__));            \
+    } while (0)
+
+struct rt_comm {
+    rt_ctx* ctx = nullptr;
+    int rank = 0, nranks = 1;
+    ncclComm_t nccl = nullptr;             // null: the group exchanges by device copies (contexts share a device)
+    hipStream_t stream = nullptr;          // the gather of a frame runs here, behind an event of the context's stream
+    std::vector<rt_comm*> group;           // single-process groups: every rank's communicator, by rank (empty: one process per GPU)
+    bool by_copies = false;
+    bool owns_nccl = true;                 // false: rt_comm_share'd from another communicator of this process
+};
+
+struct rt_multi_frame {
+    rt_comm* comm = nullptr;
+    rt_bvh* bvh = nullptr;
+    const rt_scene* scene = nullptr;
+    rt_camera cam{};
+    uint32_t tiling = 0;                   // RT_TILING word
+    uint32_t own_slots = 0;                // slots of this rank's compact buffers
+    uint32_t root_slots = 0, peer_slots = 0;   // plane strides: rank 0's planes / every peer's planes (the most any peer owns)
+    void* d_contacts = nullptr;            // own_slots contacts
+    float* d_send[2] = { nullptr, nullptr };   // three planes each, double buffered
+    float* d_peers = nullptr;              // root: (nranks - 1) x 3 x peer_slots floats
+    float4* d_frame = nullptr;             // root: the assembled frame
+    rt_frame_graph* graph[2] = { nullptr, nullptr };
+    hipEvent_t traced[2] = { nullptr, nullptr }, gathered[2] = { nullptr, nullptr };
+    bool gathered_valid[2] = { false, false };
+    uint64_t frames = 0;
+};
+
+extern "C" {
+
+int rt_comm_unique_id(void* id128)
+{
+    if (!id128) return RT_FAIL(nullptr, "id buffer is null");
+    if (const char* e = load_rccl()) return RT_FAIL(nullptr, e);
+    ncclUniqueId id;
+    RT_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, id.internal, sizeof id.internal);
+    return RT_SUCCESS;
+}
+
+static int comm_alloc(rt_ctx* ctx, int rank, int nranks, rt_comm** out)
+{
+    rt_comm* c = new (std::nothrow) rt_comm();
+    if (!c) return RT_FAIL(ctx, "out of host memory");
+    c->ctx = ctx; c->rank = rank; c->nranks = nranks;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return RT_FAIL(ctx, std::string("communicator stream: ") + hipGetErrorString(e)); }
+    *out = c;
+    return RT_SUCCESS;
+}
+
+int rt_comm_create(rt_ctx* ctx, const void* id128, int rank, int nranks, rt_comm** out)
+{
+    if (!ctx || !out) return RT_FAIL(ctx, "null argument");
+    *out = nullptr;
+    if (nranks < 1 || nranks > 0xFFFF || rank < 0 || rank >= nranks) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (nranks > 1 && !id128) return RT_FAIL(ctx, "the communicator id is null");
+    rt_comm* c = nullptr;
+    if (comm_alloc(ctx, rank, nranks, &c)) return RT_ERROR;
+    if (nranks > 1) {
+        if (const char* e = load_rccl()) { rt_comm_destroy(c); return RT_FAIL(ctx, e); }
+        ncclUniqueId id;
+        std::memcpy(id.internal, id128, sizeof id.internal);
+        ncclResult_t r = g_rccl.CommInitRank(&c->nccl, nranks, id, rank);      // collective over all ranks' processes
+        if (r != 0) { std::string m = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); rt_comm_destroy(c); return RT_FAIL(ctx, m); }
+    }
+    *out = c;
+    return RT_SUCCESS;
+}
+
+int rt_comm_create_group(rt_ctx** ctxs, int nranks, rt_comm** out)
+{
+    if (!ctxs || !out || nranks < 1 || nranks > 0xFFFF) return RT_FAIL(nullptr, "invalid argument");
+    for (int r = 0; r < nranks; r++) { out[r] = nullptr; if (!ctxs[r]) return RT_FAIL(nullptr, "a context is null"); }
+    bool shared = false;
+    for (int a = 0; a < nranks; a++) for (int b = a + 1; b < nranks; b++) shared = shared || ctxs[a]->device == ctxs[b]->device;
+    std::vector<rt_comm*> all((size_t)nranks, nullptr);
+    for (int r = 0; r < nranks; r++)
+        if (comm_alloc(ctxs[r], r, nranks, &all[r])) { for (rt_comm* c : all) rt_comm_destroy(c); return RT_ERROR; }
+    if (nranks > 1 && !shared) {
+        if (const char* e = load_rccl()) { for (rt_comm* c : all) rt_comm_destroy(c); return RT_FAIL(ctxs[0], e); }
+        std::vector<int> devs; std::vector<ncclComm_t> comms((size_t)nranks, nullptr);
+        for (int r = 0; r < nranks; r++) devs.push_back(ctxs[r]->device);
+        ncclResult_t rc = g_rccl.CommInitAll(comms.data(), nranks, devs.data());
+        if (rc != 0) { std::string m = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc); for (rt_comm* c : all) rt_comm_destroy(c); return RT_FAIL(ctxs[0], m); }
+        for (int r = 0; r < nranks; r++) all[r]->nccl = comms[r];
+    }
+    for (int r = 0; r < nranks; r++) { all[r]->group = all; all[r]->by_copies = nranks > 1 && shared; out[r] = all[r]; }
+    return RT_SUCCESS;
+}
+
+void rt_comm_destroy(rt_comm* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->nccl && c->owns_nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// Several frames in flight per rank (a renderer with several viewports; bench.py's five scenes): another context of the same
+// process and device joins the owner's RCCL communicator with a stream of its own.  RCCL serialises operations on one
+// communicator, so every rank must issue its frames in the same order.  The owner must outlive the sharer.
+int rt_comm_share(const rt_comm* owner, rt_ctx* ctx, rt_comm** out)
+{
+    if (!owner || !ctx || !out) return RT_FAIL(ctx, "null argument");
+    *out = nullptr;
+    if (!owner->group.empty()) return RT_FAIL(ctx, "communicators of a single-process group are not shared: form another group");
+    if (owner->ctx->device != ctx->device) return RT_FAIL(ctx, "a shared communicator must stay on its device");
+    rt_comm* c = nullptr;
+    if (comm_alloc(ctx, owner->rank, owner->nranks, &c)) return RT_ERROR;
+    c->nccl = owner->nccl; c->owns_nccl = false;
+    *out = c;
+    return RT_SUCCESS;
+}
+
+int rt_comm_rank(const rt_comm* c) { return c ? c->rank : -1; }
+int rt_comm_size(const rt_comm* c) { return c ? c->nranks : 0; }
+int rt_comm_uses_rccl(const rt_comm* c) { return c && c->nccl ? 1 : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+void rt_multi_frame_destroy(rt_multi_frame* f)
+{
+    if (!f) return;
+    rt_ctx* ctx = f->comm->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(f->comm->stream);
+    for (int b = 0; b < 2; b++) {
+        if (f->graph[b]) rt_frame_graph_destroy(f->graph[b]);
+        if (f->traced[b]) (void)hipEventDestroy(f->traced[b]);
+        if (f->gathered[b]) (void)hipEventDestroy(f->gathered[b]);
+        if (f->d_send[b]) (void)hipFree(f->d_send[b]);
+    }
+    if (f->d_contacts) (void)hipFree(f->d_contacts);
+    if (f->d_peers) (void)hipFree(f->d_peers);
+    if (f->d_frame) (void)hipFree(f->d_frame);
+    delete f;
+}
+
+int rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t root_extra, rt_multi_frame** out)
+{
+    if (!comm || !bvh || !scene || !out) return RT_FAIL(comm ? comm->ctx : nullptr, "null argument");
+    rt_ctx* ctx = comm->ctx;
+    *out = nullptr;
+    if (bvh->ctx != ctx || scene->ctx != ctx) return RT_FAIL(ctx, "the BVH and the scene must live on the communicator's context");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (root_extra > 0xFFFFu) return RT_FAIL(ctx, "root_extra too large");
+    RT_ENTER(ctx);
+    rt_multi_frame* f = new (std::nothrow) rt_multi_frame();
+    if (!f) return RT_FAIL(ctx, "out of host memory");
+    f->comm = comm; f->bvh = bvh; f->scene = scene; f->cam = *cam;
+    const uint32_t N = (uint32_t)comm->nranks;
+    f->tiling = RT_TILING(N, N > 1 ? root_extra : 0u);
+    f->own_slots = rt_tiles_owned_pixels(cam, (uint32_t)comm->rank, f->tiling);
+    f->root_slots = rt_tiles_owned_pixels(cam, 0, f->tiling);
+    for (uint32_t r = 1; r < N; r++) { const uint32_t s = rt_tiles_owned_pixels(cam, r, f->tiling); if (s > f->peer_slots) f->peer_slots = s; }
+    const uint32_t plane = comm->rank == 0 ? f->root_slots : f->peer_slots;        // plane stride of this rank's send buffers
+    hipError_t e = hipMalloc(&f->d_contacts, (size_t)(f->own_slots ? f->own_slots : 1u) * sizeof(rt_contact));
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipMalloc((void**)&f->d_send[b], (size_t)(plane ? plane : 1u) * 3u * sizeof(float));
+        if (e == hipSuccess) e = hipMemsetAsync(f->d_send[b], 0, (size_t)(plane ? plane : 1u) * 3u * sizeof(float), ctx->stream);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->traced[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->gathered[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess && comm->rank == 0) {
+        e = hipMalloc((void**)&f->d_frame, (size_t)cam->resX * cam->resY * sizeof(float4));
+        if (e == hipSuccess && N > 1) e = hipMalloc((void**)&f->d_peers, (size_t)(N - 1) * 3u * f->peer_slots * sizeof(float));
+    }
+    if (e != hipSuccess) { rt_multi_frame_destroy(f); (void)hipGetLastError(); return RT_FAIL(ctx, std::string("multi-GPU frame buffers: ") + hipGetErrorString(e)); }
+    // one frame graph per send buffer: trace of this rank's tiles with the calibrated strategy + shading into the planes
+    if (f->own_slots) {
+        for (int b = 0; b < 2; b++)
+            if (rt_frame_graph_create(bvh, scene, cam, (uint32_t)comm->rank, f->tiling, RT_FRAME_TILED_PACKED, f->d_contacts, f->d_send[b], plane,
+                                      &f->graph[b])) { rt_multi_frame_destroy(f); return RT_ERROR; }
+    }
+    *out = f;
+    return RT_SUCCESS;
+}
+
+// One frame of every given rank: n = 1 in a job with one process per GPU, n = the group size in a single-process group (all
+// of its ranks, in rank order).  Asynchronous: the trace runs on each context's stream, the gather and the untile on each
+// communicator's stream; rt_multi_frame_wait waits for both.
+int rt_multi_frame_render(rt_multi_frame** frames, int n)
+{
+    if (!frames || n < 1 || !frames[0]) return RT_FAIL(nullptr, "invalid argument");
+    rt_ctx* ctx0 = frames[0]->comm->ctx;
+    const rt_comm* c0 = frames[0]->comm;
+    if (!c0->group.empty() ? n != c0->nranks : n != 1) return RT_FAIL(ctx0, "a single-process group renders all of its ranks in one call, a multi-process rank alone");
+    for (int i = 0; i < n; i++) {
+        if (!frames[i] || frames[i]->comm->nranks != c0->nranks || frames[i]->frames != frames[0]->frames) return RT_FAIL(ctx0, "frames of different groups or out of step");
+        if (!c0->group.empty() && frames[i]->comm != c0->group[(size_t)i]) return RT_FAIL(ctx0, "frames must be given in rank order");
+    }
+    const int b = (int)(frames[0]->frames & 1u);
+    const uint32_t N = (uint32_t)c0->nranks;
+    // 1. every rank: trace + shade its tiles into send[b] (once the gather that last read send[b] is through)
+    for (int i = 0; i < n; i++) {
+        rt_multi_frame* f = frames[i];
+        rt_ctx* ctx = f->comm->ctx;
+        RT_ENTER(ctx);
+        if (f->gathered_valid[b]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, f->gathered[b], 0));
+        if (f->graph[b] && rt_frame_graph_launch(f->graph[b])) return RT_ERROR;
+        RT_HIP(ctx, hipEventRecord(f->traced[b], ctx->stream));
+        RT_HIP(ctx, hipStreamWaitEvent(f->comm->stream, f->traced[b], 0));
+    }
+    // 2. the one collective: the peers' planes to the root
+    if (N > 1 && c0->nccl) {
+        RT_NCCL(ctx0, g_rccl.GroupStart());
+        for (int i = 0; i < n; i++) {
+            rt_multi_frame* f = frames[i];
+            rt_comm* c = f->comm;
+            const size_t count = (size_t)3u * f->peer_slots;
+            (void)hipSetDevice(c->ctx->device);
+            if (c->rank == 0) {
+                for (uint32_t r = 1; r < N; r++)
+                    RT_NCCL(c->ctx, g_rccl.Recv(f->d_peers + (size_t)(r - 1u) * count, count, rtNcclFloat32, (int)r, c->nccl, c->stream));
+            } else if (count) {
+                RT_NCCL(c->ctx, g_rccl.Send(f->d_send[b], count, rtNcclFloat32, 0, c->nccl, c->stream));
+            }
+        }
+        RT_NCCL(ctx0, g_rccl.GroupEnd());
+    } else if (N > 1) {
+        // contexts that share a device (one-GPU tests): the root's stream copies every peer's planes once that peer has traced
+        rt_multi_frame* root = frames[0];
+        rt_ctx* rctx = root->comm->ctx;
+        RT_ENTER(rctx);
+        const size_t count = (size_t)3u * root->peer_slots;
+        for (int i = 1; i < n; i++) {
+            RT_HIP(rctx, hipStreamWaitEvent(root->comm->stream, frames[i]->traced[b], 0));
+            if (count) RT_HIP(rctx, hipMemcpyAsync(root->d_peers + (size_t)(i - 1) * count, frames[i]->d_send[b], count * sizeof(float), hipMemcpyDeviceToDevice, root->comm->stream));
+        }
+    }
+    // 3. root: planes -> pixel order; everybody: send[b] is free again after this point of the communicator's stream
+    for (int i = 0; i < n; i++) {
+        rt_multi_frame* f = frames[i];
+        rt_comm* c = f->comm;
+        RT_ENTER(c->ctx);
+        if (c->rank == 0) {
+            launch_untile_rgba_split(c->stream, f->cam, f->tiling, f->d_send[b], f->root_slots, f->d_peers, f->peer_slots, (uint64_t)3u * f->peer_slots, f->d_frame);
+            RT_HIP(c->ctx, hipGetLastError());
+        }
+        // (copy transport: a peer's buffer is read by the ROOT's stream, so that is where its event goes)
+        hipStream_t reader = (c->by_copies && c->rank != 0) ? frames[0]->comm->stream : c->stream;
+        RT_HIP(c->ctx, hipEventRecord(f->gathered[b], reader));
+        f->gathered_valid[b] = true;
+        f->frames++;
+    }
+    return RT_SUCCESS;
+}
+
+int rt_multi_frame_wait(rt_multi_frame* f)
+{
+    if (!f) return RT_FAIL(nullptr, "frame is null");
+    rt_ctx* ctx = f->comm->ctx;
+    RT_ENTER(ctx);
+    RT_HIP(ctx, hipStreamSynchronize(f->comm->stream));
+    return rt_ctx_synchronize(ctx);               // + the trace kernels' error word
+}
+
+void* rt_multi_frame_pixels(const rt_multi_frame* f) { return f ? (void*)f->d_frame : nullptr; }
+
+int rt_multi_frame_layout(const rt_multi_frame* f, uint32_t* tiling, uint32_t* own_slots, uint32_t* root_slots, uint32_t* peer_slots)
+{
+    if (!f) return RT_FAIL(nullptr, "frame is null");
+    if (tiling) *tiling = f->tiling;
+    if (own_slots) *own_slots = f->own_slots;
+    if (root_slots) *root_slots = f->root_slots;
+    if (peer_slots) *peer_slots = f->peer_slots;
+    return RT_SUCCESS;
+}
+
+}  // extern "C"

@@ -159,6 +159,35 @@ void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nra
     hipLaunchKernelGGL(k_untile_rgba_packed, dim3((n + 255) / 256), dim3(256), 0, s, cam, nranks, gathered, slots_per_rank, rank_stride, frame);
 }
 
+// the multi-GPU frame driver's variant (rtmi_multi.hip): rank 0's planes are read where its shading kernel left them (its own
+// send buffer, plane stride root_slots: nothing of rank 0 is copied), the peers' from the gather buffer, peer r at
+// peers + (r - 1) * peer_stride with plane stride peer_slots
+__global__ __launch_bounds__(256) void k_untile_rgba_split(rt_camera cam, uint32_t nranks, const float* __restrict__ root_planes, uint32_t root_slots,
+                                                           const float* __restrict__ peers, uint32_t peer_slots, uint64_t peer_stride,
+                                                           float4* __restrict__ frame)
+{
+    uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixel >= cam.resX * cam.resY) return;
+    uint32_t y = pixel / cam.resX, x = pixel - y * cam.resX;
+    uint32_t tx = x / RT_TILE, ty = y / RT_TILE;
+    uint32_t tile = ty * rt_tiles_x(cam.resX) + tx;
+    uint32_t rank, ordinal;
+    rt_tile_owner(tile, nranks, rank, ordinal);
+    uint32_t slot = ordinal * (RT_TILE * RT_TILE) + (y - ty * RT_TILE) * RT_TILE + (x - tx * RT_TILE);
+    const float* g = rank == 0u ? root_planes + slot : peers + (uint64_t)(rank - 1u) * peer_stride + slot;
+    const uint64_t plane = rank == 0u ? root_slots : peer_slots;
+    const uint32_t r = __float_as_uint(g[0]);
+    frame[pixel] = make_float4(__uint_as_float(r & 0x7FFFFFFFu), g[plane], g[2u * plane], (r & 0x80000000u) ? 1.0f : 0.0f);
+}
+
+void launch_untile_rgba_split(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* root_planes, uint32_t root_slots,
+                              const float* peers, uint32_t peer_slots, uint64_t peer_stride, float4* frame)
+{
+    uint32_t n = cam.resX * cam.resY;
+    hipLaunchKernelGGL(k_untile_rgba_split, dim3((n + 255) / 256), dim3(256), 0, s, cam, nranks, root_planes, root_slots, peers, peer_slots,
+                       peer_stride, frame);
+}
+
 void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,
                         uint32_t slots_per_rank, float4* frame)
 {

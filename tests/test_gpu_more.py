@@ -455,42 +455,73 @@ def test_secondary_rays_two_bounces(gpu_ctx, name, res):
     assert len(capi.generate_secondary_rays(gpu_ctx, none, 0, light, 1e-3, cam=ccam)) == 0
 
 
-def test_bench_two_rank_rehearsal_assembles_identical_frames():
-    """bench.py's N > 1 path end to end on this one GPU: two ranks (gloo instead of RCCL, which refuses two ranks on one
-    device) trace and shade their tiles of all five 1080p frames, gather, untile; rank 0 checks every assembled frame
-    against the untiled one (torch.equal on the RGBA buffers) and prints the contract's JSON line."""
+def test_bench_group_rehearsal_assembles_identical_frames():
+    """bench.py's N > 1 path on this one GPU: three ranks inside one process (RTMI_BENCH_GROUP=3; the library gathers by device
+    copies because RCCL refuses several ranks on one device) trace and shade their tiles of all five 1080p frames through
+    rt_multi_frame_*; rank 0 checks every assembled frame against the untiled one and prints the contract's JSON line, with the
+    config-5 leg tiled the same way."""
     import subprocess
     import sys as _sys
-    env = dict(os.environ, RTMI_BENCH_REHEARSAL='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([_sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-                        '--check-frames'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, RTMI_BENCH_GROUP='3')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--check-frames'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert 'frame check ok (after the warm-up): 5 gathered frames equal the untiled ones' in r.stderr
-    assert 'frame check ok (after the timed steps): 5 gathered frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the warm-up): 5 assembled frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the timed steps): 5 assembled frames equal the untiled ones' in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1
     out = json.loads(line[0])
-    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['unit'] == 'Mrays/s' and out['value'] > 0
+    assert out['scaling'] == 'strong' and out['unit'] == 'Mrays/s' and out['value'] > 0
+    assert 'REHEARSAL' in out['config']['parallelism']
     assert out['cpu_baseline'] is None and out['roofline']['traffic'] is None      # rank-0-at-N=1-only fields
+    assert out['config5']['mrays_per_s'] > 0 and 'tiled over 3 rank' in out['config5']['workload']
 
 
-def test_bench_tiled_path_on_rccl_with_one_rank():
-    """The same N > 1 code path on REAL RCCL: a process group of one rank (RTMI_BENCH_FORCE_TILED=1), so the asynchronous
-    gather is issued from the five frame streams (torch ExternalStream over the contexts' HIP streams) on the nccl
-    backend, then untiled and compared with the untiled frames."""
+def test_bench_tiled_path_with_one_rank():
+    """The N > 1 code path of a job with one process per GPU, with a job of ONE rank (RTMI_BENCH_FORCE_TILED=1): communicator,
+    frame graphs per send buffer, gather step, untile, compared with the untiled frames."""
     import subprocess
     import sys as _sys
-    env = dict(os.environ, RTMI_BENCH_FORCE_TILED='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT='29533')
+    env = dict(os.environ, RTMI_BENCH_FORCE_TILED='1')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '7', '--warmup', '2', '--check-frames',
-                        '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        '--no-cpu-baseline', '--no-extra-legs'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert 'frame check ok (after the warm-up): 5 gathered frames equal the untiled ones' in r.stderr
-    assert 'frame check ok (after the timed steps): 5 gathered frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the warm-up): 5 assembled frames equal the untiled ones' in r.stderr
+    assert 'frame check ok (after the timed steps): 5 assembled frames equal the untiled ones' in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1 and json.loads(line[0])['value'] > 0
+
+
+def test_bench_default_line_has_measured_rooflines():
+    """the N = 1 line: the counters are collected by the run itself (rocprofv3 child processes), every fraction is <= 1 and
+    recomputes from the fields beside it"""
+    import subprocess
+    import sys as _sys
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RTMI_BENCH_GROUP', 'RTMI_BENCH_FORCE_TILED'):
+        env.pop(k, None)
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '3'], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    rf, rv = out['roofline'], out['roofline_valu_issue']
+    assert out['n_gpus'] == 1 and out['config']['rays_per_step'] == 5 * 1920 * 1080
+    assert rf['bound'] == 'hbm' and rf['traffic'] is not None and 0 < rf['frac'] <= 1
+    assert abs(rf['achieved'] - rf['traffic'] / (rf['avg_launch_ms'] * 1e-3) / 1e9) <= 0.05 * rf['achieved'] + 0.2
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    assert rv['bound'] == 'valu_issue' and 0 < rv['frac'] <= 1
+    c = rv['counters_per_dispatch']
+    assert abs(rv['frac'] - c['SQ_INSTS_VALU'] * 2 / (1024 * c['GRBM_GUI_ACTIVE'] / 8)) < 2e-3
+    for need in ('SQ_INSTS_SALU', 'SQ_INSTS_SMEM', 'SQ_INST_CYCLES_SALU', 'SQ_WAIT_INST_ANY'):
+        assert need in c
+    assert out['cpu_baseline']['value'] > 0 and out['config5']['mrays_per_s'] > 0
+    for n, ps in out['per_scene'].items():
+        assert ps['rebuild_plus_trace_ms'] > 0 and ps['strategy_after_rebuilds'] == ps['strategy'], n
+        assert 0 < ps['valu_issue_frac'] <= 1
 
 
 @pytest.mark.parametrize('knobs', [dict(), dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='1048576'), dict(RTMI_PACKET='1', RTMI_DEFER_BUDGET='32'),
@@ -702,3 +733,98 @@ def test_frame_graph_survives_another_camera_on_the_same_bvh(gpu_ctx):
     want_a, _ = ob.trace_primary(cam_a)
     assert gpu_ctx.download(d_c, n, capi.CONTACT).tobytes() == want_a.tobytes()
     g.close(); gpu_ctx.free(d_c); gpu_ctx.free(d_o); gb.close(); sc.close()
+
+
+# ---- round 2: the native multi-GPU frame driver (rt_comm_* / rt_multi_frame_*) ----------------------------------------------
+
+@pytest.mark.parametrize('nranks,root_extra', [(1, 0), (2, 1), (3, 0), (4, 1), (6, 2)])
+def test_native_multi_frame_group_on_one_device(nranks, root_extra):
+    """one process, N contexts, all on device 0 (the group then exchanges by device copies: RCCL refuses two ranks on a device):
+    tiling, frame graphs per send buffer, double buffering, stream order and the untile are the code a multi-GPU node runs.
+    The assembled frame must equal the untiled one bit for bit, frame after frame, also when the camera of the group changes."""
+    from openclraytracer_amd import capi
+    import oracle as orc
+    from conftest import packed_scene
+    buf = packed_scene('tenryuu')
+    osc = orc.Scene(buf)
+    ctxs = [capi.Context(0) for _ in range(nranks)]
+    try:
+        scenes = [capi.DeviceScene(c, buf) for c in ctxs]
+        bvhs = [capi.DeviceBVH(c, s).build() for c, s in zip(ctxs, scenes)]
+        comms = capi.Comm.create_group(ctxs)
+        assert [c.rank() for c in comms] == list(range(nranks)) and all(c.size() == nranks for c in comms)
+        assert not comms[0].uses_rccl()
+        for res in ((640, 360), (333, 251)):
+            cam = as_capi_camera(osc.demo_camera(*res))
+            frames = [capi.MultiFrame(comms[r], bvhs[r], scenes[r], cam, root_extra) for r in range(nranks)]
+            lay = frames[0].layout()
+            assert lay['tiling'] == capi.tiling(nranks, root_extra if nranks > 1 else 0)
+            assert sum(f.layout()['own_slots'] for f in frames) >= res[0] * res[1]
+            # reference frame: untiled trace + shade on a context of its own
+            rctx = capi.Context(0)
+            rsc = capi.DeviceScene(rctx, buf)
+            rb = capi.DeviceBVH(rctx, rsc).build()
+            want = capi.shade_blinn_phong(rctx, rsc, cam, rb.generate_contacts_primary(cam))
+            rb.close(); rsc.close(); rctx.close()
+            for k in range(5):                                   # both send buffers, gathers overlapping the next trace
+                capi.multi_frame_render(frames)
+                if k in (0, 3, 4):
+                    for f in frames:
+                        f.wait()
+                    got = frames[0].download_frame()
+                    assert got.tobytes() == want.reshape(-1, 4).tobytes(), 'frame %d' % k
+            assert frames[0].pixels_ptr() != 0 and all(f.pixels_ptr() == 0 for f in frames[1:])
+            for f in frames:
+                f.close()
+        for c in comms:
+            c.close()
+        for b in bvhs:
+            b.close()
+        for s in scenes:
+            s.close()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_native_multi_frame_error_behaviour(gpu_ctx):
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    import oracle as orc
+    osc = orc.Scene(packed_scene('cube'))
+    cam = as_capi_camera(osc.demo_camera(128, 96))
+    sc, gb = gpu_bvh(gpu_ctx, 'cube')
+    with pytest.raises(capi.RtError, match='rank/nranks invalid'):
+        capi.Comm.create(gpu_ctx, None, 2, 2)
+    with pytest.raises(capi.RtError, match='id is null'):
+        capi.Comm.create(gpu_ctx, None, 0, 2)
+    comm = capi.Comm.create(gpu_ctx, None, 0, 1)                 # a job of one rank needs no id and no RCCL
+    other = capi.Context(0)
+    osc2 = capi.DeviceScene(other, packed_scene('cube'))
+    ob2 = capi.DeviceBVH(other, osc2).build()
+    with pytest.raises(capi.RtError, match="communicator's context"):
+        capi.MultiFrame(comm, ob2, osc2, cam)
+    f = capi.MultiFrame(comm, gb, sc, cam)
+    capi.multi_frame_render([f]); f.wait()
+    want = capi.shade_blinn_phong(gpu_ctx, sc, cam, gb.generate_contacts_primary(cam))
+    assert f.download_frame().tobytes() == want.reshape(-1, 4).tobytes()
+    f.close(); comm.close(); ob2.close(); osc2.close(); other.close()
+
+
+def test_cpp_demo_tiles_the_frame_over_several_ranks(gpu_ctx, tmp_path):
+    """apps/rt_demo --gpus: the C++ MultiGPUFrame of the host mirror (three ranks sharing device 0 here) writes the same
+    float4 frame as the single-device path, bit for bit"""
+    import subprocess
+    from openclraytracer_amd import capi
+    osc, _ = oracle_bvh('gardenlight')
+    sc, gb = gpu_bvh(gpu_ctx, 'gardenlight')
+    demo = os.path.join(ROOT, 'apps', 'bin', 'rt_demo')
+    raw = str(tmp_path / 'f.bin')
+    r = subprocess.run([demo, '-winH', '240', '-winW', '320', '-accStruct', 'BVH', '-headersPath', 'unused', '-scene',
+                        os.path.join('assets', 'scenes', 'gardenlight.txt'), '--frames', '3', '--devices', '0,0,0', '--out', raw],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'ranks 3' in r.stdout and 'device-copy gather' in r.stdout
+    cam = as_capi_camera(osc.demo_camera(320, 240))
+    want = capi.shade_blinn_phong(gpu_ctx, sc, cam, gb.generate_contacts_primary(cam))
+    assert open(raw, 'rb').read() == want.reshape(-1, 4).tobytes()
