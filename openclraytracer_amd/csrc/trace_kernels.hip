@@ -701,6 +701,151 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 // binary packet kernel.  Nothing is handed over to the wave-per-ray kernel here (the calibration chooses this kernel
 // only where whole blocks are cheap); everything else is as in k_trace_packet.
 // ------------------------------------------------------------------------------------------------
+// Where a wave step of this kernel spends its cycles (variant 2 below stamps four phases with s_memtime; ManFigure 1080p /
+// atrium 4K, cycles per step): waiting for the record 543 / 210, four box tests + ballots 1 329 / 1 385, leaf tests 532 / 480,
+// stack + choosing the next node 767 / 959 -- about 3 000 cycles per step at ~3 (ManFigure, tail of long blocks) and ~7
+// (atrium) waves per SIMD alike (profiles/r02_packet4_phase_cycles.json).  Tried and NOT kept (round 2): the record as two
+// s_load_dwordx16 in one round trip, the triangle data of leaf slots requested before the box tests, and the first inner
+// slot's record requested speculatively.  Through inline assembly the requests are invisible to the compiler, which spilled
+// the destination SGPRs of loads still in flight (a memory fault on the first frame); as ordinary loads the second record
+// does not fit the SGPR file next to the first (106 SGPRs, 340 lane spills), and even without the speculation the wide loads
+// cost 64 lane spills and 41 more VGPRs: ManFigure 0.667 -> 1.109 ms, atrium 18.3 -> 32.2 ms.  The compiler's lazy dword loads
+// hit the scalar cache after the first one and are the better schedule.
+#ifndef RTMI_P4_VARIANT
+#define RTMI_P4_VARIANT 0
+#endif
+#if RTMI_P4_VARIANT == 2      // experiment: the steady-state kernel with cycle stamps per phase (tools/p4_time.py)
+template <int PRIMARY, int CAL>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
+{
+    __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
+    __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
+    __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
+    uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
+    uint32_t* spill = nullptr;                           // taken on the first overflow of the LDS stack
+    uint32_t spill_slot = 0xFFFFFFFFu;
+
+    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
+    // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
+    if ((wave_gid << 6) < a.total_work) {
+        const uint32_t w = (wave_gid << 6) + lane;
+        RayState r;
+        bool sx = false, sy = false, sz = false;
+        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+        r.work = w; r.out_index = 0; r.pixel = 0;
+        bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
+        if (PRIMARY && a.compact && !ok && w < a.total_work) {
+            uint32_t x, y, slot;
+            work_to_pixel(a, w, x, y, slot);
+            float4* o = reinterpret_cast<float4*>(a.out + slot);
+            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        uint32_t sp = 0;
+        // The four-wide records skip the boxes of a node's inner children, which is sound on the search tree only (the host
+        // launches this kernel only when there is one).  A ray that must walk the reference tree box by box (ray_root: a slab
+        // product could be 0 * inf -- the camera on a box plane and a zero direction component) is handed, whole, to the
+        // wave-per-ray kernel, which walks binary records.
+        const bool on_ref = ok && ray_root<PRIMARY>(a, r, plane_bits) == 0u;
+        const uint64_t m_ref = __ballot(on_ref);
+        if (m_ref != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&a.ctrl->long_count, (uint32_t)__popcll(m_ref), RLX_AGENT);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (on_ref) {
+                const uint32_t idx = base + lane_rank(m_ref);
+                if (idx < a.long_cap) {
+                    uint32_t* rec = a.long_list + (uint64_t)idx * LONG_REC_WORDS;
+                    rec[LR_WORK] = w; rec[LR_CUR] = 0u; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
+                    rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF; rec[LR_PARTIAL] = 0u;
+                } else {
+                    TRACE_FAIL((gu32*)&a.ctrl->error, 1);          // nowhere to put the ray: frame invalid
+                }
+            }
+            ok = ok && !on_ref;                                                         // their contacts are written there
+        }
+        bool in = ok;
+        uint32_t node = a.search_root;
+        bool walking = __ballot(in) != 0ull;
+        unsigned long long tA = 0, tB = 0, tC = 0, tD = 0; uint32_t nsteps = 0;
+        while (walking) {
+            const unsigned long long T0 = __builtin_amdgcn_s_memtime();
+            nsteps++;
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+            const float4* p = reinterpret_cast<const float4*>(a.quad + un);
+            const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
+            const float4 q4 = ld_const4(p + 4), q5 = ld_const4(p + 5), q6 = ld_const4(p + 6), q7 = ld_const4(p + 7);
+            const uint32_t id0 = __float_as_uint(q0.w), id1 = __float_as_uint(q1.w), id2 = __float_as_uint(q2.w), id3 = __float_as_uint(q3.w);
+            const uint32_t marks = __float_as_uint(q4.w);
+            asm volatile("" :: "s"(id0), "s"(id1), "s"(id2), "s"(id3), "s"(marks), "s"(q7.x), "s"(q5.x), "s"(q3.x), "s"(q1.x));
+            const unsigned long long T1 = __builtin_amdgcn_s_memtime();
+            bool v0 = false, v1 = false, v2 = false, v3 = false;
+            if (in) {
+                v0 = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                v1 = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
+                v2 = (id2 != RT_SENTINEL) && child_valid<PRIMARY>(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, sx, sy, sz, (marks & 4u) != 0u);
+                v3 = (id3 != RT_SENTINEL) && child_valid<PRIMARY>(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, sx, sy, sz, (marks & 8u) != 0u);
+            }
+            uint64_t m[4] = { __ballot(v0), __ballot(v1), __ballot(v2), __ballot(v3) };
+            const uint32_t ids[4] = { id0, id1, id2, id3 };
+            asm volatile("" :: "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]));
+            const unsigned long long T2 = __builtin_amdgcn_s_memtime();
+            // leaves are tested on the spot by the lanes that reached them
+            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) { if (v0) leaf_test_uniform(a, id0 & ~RT_LEAF_FLAG, r); } m[0] = 0ull; }
+            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) { if (v1) leaf_test_uniform(a, id1 & ~RT_LEAF_FLAG, r); } m[1] = 0ull; }
+            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) { if (v2) leaf_test_uniform(a, id2 & ~RT_LEAF_FLAG, r); } m[2] = 0ull; }
+            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) { if (v3) leaf_test_uniform(a, id3 & ~RT_LEAF_FLAG, r); } m[3] = 0ull; }
+            asm volatile("" :: "v"(r.best_t), "v"(r.best_leaf));
+            const unsigned long long T3 = __builtin_amdgcn_s_memtime();
+            // the first wanted inner child is walked next, the others wait on the stack with their lanes
+            int first = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (m[k] == 0ull) continue;
+                if (first < 0) { first = k; continue; }
+                if (sp < PACKET_STACK) {
+                    if (lane == 0) { st_node[sp] = ids[k]; st_lo[sp] = (uint32_t)m[k]; st_hi[sp] = (uint32_t)(m[k] >> 32); }
+                } else if (a.packet_spill && sp - PACKET_STACK < a.packet_spill_entries && (spill || (spill = spill_acquire(a, wave_gid, lane, spill_slot)))) {
+                    if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
+                } else {
+                    if (lane == 0) TRACE_FAIL((gu32*)&a.ctrl->error, 3);     // frame invalid
+                }
+                sp++;
+            }
+            if (first >= 0) {
+                node = ids[first];
+                in = ((m[first] >> lane) & 1ull) != 0ull;
+            } else if (sp == 0u) walking = false;
+            else {
+                sp--;
+                uint32_t nn, lo, hi;
+                if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
+                else if (spill) { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                        else { nn = 0u; lo = 0u; hi = 0u; }                  // the push failed (error word set): an entry nobody wants
+                node = nn;
+                in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+            }
+            asm volatile("" :: "v"(node), "v"(in ? 1 : 0));
+            const unsigned long long T4 = __builtin_amdgcn_s_memtime();
+            tA += T1 - T0; tB += T2 - T1; tC += T3 - T2; tD += T4 - T3;
+        }
+        if (lane == 0) {
+            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_steps, (uint32_t)(tA >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_steps_max, (uint32_t)(tB >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_nodes, (uint32_t)(tC >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&a.ctrl->spill_taken, (uint32_t)(tD >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&a.ctrl->split_count, nsteps, RLX_AGENT);
+        }
+        if (ok) store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
+
+    }
+    spill_release(a, lane, spill_slot);
+}
+
+#else
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
 {
@@ -811,6 +956,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
     }
     spill_release(a, lane, spill_slot);
 }
+
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // phase 1: up to LONG_BATCH deferred rays per wave, 64 lanes walk their sub-trees together
