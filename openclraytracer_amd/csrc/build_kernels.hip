@@ -187,13 +187,14 @@ __device__ uint32_t span_split(const uint2* __restrict__ keys, KeySpan sp)
     return yes;
 }
 
-__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* __restrict__ keys, uint32_t n, uint32_t built)
+__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* __restrict__ keys, uint32_t n, uint32_t built, uint2* __restrict__ spans)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= built) return;
     const KeySpan sp = inner_node_span(keys, i, n);
     const uint32_t split = span_split(keys, sp);
     const uint32_t self = n + i;
+    if (spans) spans[i] = make_uint2(sp.first, sp.last);      // for the range-query refit
     // a side of one position is that position's leaf, otherwise the inner node numbered like the side's boundary position
     const uint32_t child_a = sp.first == split ? keys[split].y : n + split;
     const uint32_t child_b = sp.last == split + 1u ? keys[split + 1u].y : n + split + 1u;
@@ -209,10 +210,10 @@ __global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const ui
     nodes[child_b].data[0] = self;
 }
 
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built)
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans)
 {
     if (built == 0u) return;
-    hipLaunchKernelGGL(k_radix_tree, dim3((built + 255) / 256), dim3(256), 0, s, nodes, pairs, n, built);
+    hipLaunchKernelGGL(k_radix_tree, dim3((built + 255) / 256), dim3(256), 0, s, nodes, pairs, n, built, spans);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -327,6 +328,148 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
 {
     hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
+}
+
+// ----------------------------------------------------------------------------------------
+// 4a. refit by RANGE QUERIES (large scenes).  The climb above is serial in the depth of the reference tree, and duplicate
+//     Morton codes make that tree a chain (10 835 levels on the Sponza-class stand-in, 129 512 on a 1 M-triangle height
+//     field).  But every inner node covers a contiguous span [first, last] of the sorted leaves, children split the span in
+//     order (A = [first, split], B = [split + 1, last]), and the reference's merges are
+//         lo = RMIN(RMIN(A, B), FLT_MAX),  hi = RMAX(RMAX(A, B), FLT_MIN),   RMIN(a, b) = a < b ? a : b  (the RIGHT operand wins ties).
+//     On NaN-free boxes "right wins ties" makes RMIN the RIGHTMOST minimum of an ordered sequence -- associative, and
+//     idempotent over overlapping pieces as long as pieces are combined left to right (+0 / -0 included: they compare equal,
+//     the rightmost is kept) -- and the clamps against the init box commute with it.  So a node's box is the rightmost
+//     minimum / maximum over its span of the leaf boxes in sorted order, clamped once: the same bits as the climb, without
+//     the climb.  Query structure: per 64-leaf block, running folds from the block's start (prefix) and to its end (suffix);
+//     a sparse table over whole blocks; a span inside one block is folded directly.  NaN boxes (not associative) are
+//     detected and send the build back to the climb.  The tree depth (what the climb carried as the root's height) is the
+//     largest number of spans covering a leaf position: +1 / -1 marks, the library's scan, a maximum.
+// ----------------------------------------------------------------------------------------
+#define RQ_BLOCK 64u
+struct BoxPair { float4 lo, hi; };
+__device__ __forceinline__ BoxPair rm_fold(const BoxPair& a, const BoxPair& b)       // a before b in leaf order
+{
+    BoxPair r;
+    r.lo.x = RMIN(a.lo.x, b.lo.x); r.lo.y = RMIN(a.lo.y, b.lo.y); r.lo.z = RMIN(a.lo.z, b.lo.z); r.lo.w = 0.0f;
+    r.hi.x = RMAX(a.hi.x, b.hi.x); r.hi.y = RMAX(a.hi.y, b.hi.y); r.hi.z = RMAX(a.hi.z, b.hi.z); r.hi.w = 0.0f;
+    return r;
+}
+
+// one thread per 64-leaf block: leaf boxes in sorted order, the folds from the block's start and to its end, the block's fold
+__global__ __launch_bounds__(64) void k_rq_blocks(const rt_bvh_node* __restrict__ nodes, const uint2* __restrict__ pairs, uint32_t n,
+                                                  float4* __restrict__ slo, float4* __restrict__ shi, float4* __restrict__ plo, float4* __restrict__ phi,
+                                                  float4* __restrict__ qlo, float4* __restrict__ qhi, float4* __restrict__ tlo, float4* __restrict__ thi,
+                                                  uint32_t* __restrict__ nan_flag)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t first = b * RQ_BLOCK;
+    if (first >= n) return;
+    const uint32_t end = first + RQ_BLOCK < n ? first + RQ_BLOCK : n;
+    BoxPair acc{};
+    bool nan = false;
+    for (uint32_t j = first; j < end; j++) {
+        const rt_bvh_node* lf = &nodes[pairs[j].y];
+        BoxPair me;
+        me.lo = make_float4(lf->boundsMin[0], lf->boundsMin[1], lf->boundsMin[2], 0.0f);
+        me.hi = make_float4(lf->boundsMax[0], lf->boundsMax[1], lf->boundsMax[2], 0.0f);
+        nan = nan || me.lo.x != me.lo.x || me.lo.y != me.lo.y || me.lo.z != me.lo.z || me.hi.x != me.hi.x || me.hi.y != me.hi.y || me.hi.z != me.hi.z;
+        slo[j] = me.lo; shi[j] = me.hi;
+        acc = j == first ? me : rm_fold(acc, me);
+        plo[j] = acc.lo; phi[j] = acc.hi;
+    }
+    tlo[b] = acc.lo; thi[b] = acc.hi;
+    for (uint32_t j = end; j-- > first;) {
+        BoxPair me; me.lo = slo[j]; me.hi = shi[j];
+        acc = j + 1 == end ? me : rm_fold(me, acc);
+        qlo[j] = acc.lo; qhi[j] = acc.hi;
+    }
+    if (nan) atomicOr(nan_flag, 1u);
+}
+
+// sparse table over blocks, one level per launch: out[b] = fold(in[b], in[b + half]) for b + 2 half <= blocks
+__global__ __launch_bounds__(256) void k_rq_level(const float4* __restrict__ in_lo, const float4* __restrict__ in_hi, float4* __restrict__ out_lo,
+                                                  float4* __restrict__ out_hi, uint32_t blocks, uint32_t half)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b + 2u * half > blocks) return;
+    BoxPair a, c;
+    a.lo = in_lo[b]; a.hi = in_hi[b]; c.lo = in_lo[b + half]; c.hi = in_hi[b + half];
+    const BoxPair r = rm_fold(a, c);
+    out_lo[b] = r.lo; out_hi[b] = r.hi;
+}
+
+__global__ __launch_bounds__(256) void k_rq_refit(rt_bvh_node* __restrict__ nodes, const uint2* __restrict__ spans, uint32_t n,
+                                                  const float4* __restrict__ slo, const float4* __restrict__ shi, const float4* __restrict__ plo,
+                                                  const float4* __restrict__ phi, const float4* __restrict__ qlo, const float4* __restrict__ qhi,
+                                                  const float4* __restrict__ tlo, const float4* __restrict__ thi, uint32_t blocks, int32_t* __restrict__ marks)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1u) return;
+    const uint2 sp = spans[i];
+    const uint32_t bf = sp.x / RQ_BLOCK, bl = sp.y / RQ_BLOCK;
+    BoxPair acc;
+    if (bf == bl) {
+        acc.lo = slo[sp.x]; acc.hi = shi[sp.x];
+        for (uint32_t j = sp.x + 1u; j <= sp.y; j++) { BoxPair me; me.lo = slo[j]; me.hi = shi[j]; acc = rm_fold(acc, me); }
+    } else {
+        acc.lo = qlo[sp.x]; acc.hi = qhi[sp.x];
+        if (bl > bf + 1u) {
+            const uint32_t cnt = bl - bf - 1u;
+            const uint32_t k = 31u - (uint32_t)__clz((int)cnt);                 // largest power of two <= cnt
+            const float4* Llo = tlo + (size_t)k * blocks; const float4* Lhi = thi + (size_t)k * blocks;
+            BoxPair a, c;
+            a.lo = Llo[bf + 1u]; a.hi = Lhi[bf + 1u];
+            c.lo = Llo[bl - (1u << k)]; c.hi = Lhi[bl - (1u << k)];
+            acc = rm_fold(acc, rm_fold(a, c));
+        }
+        BoxPair tail; tail.lo = plo[sp.y]; tail.hi = phi[sp.y];
+        acc = rm_fold(acc, tail);
+    }
+    // the clamps of merge3 against the node's init box (FLT_MAX, FLT_MIN): value preserving, applied once
+    rt_bvh_node* nd = &nodes[n + i];
+    nd->boundsMin[0] = RMIN(acc.lo.x, FLT_MAX); nd->boundsMin[1] = RMIN(acc.lo.y, FLT_MAX); nd->boundsMin[2] = RMIN(acc.lo.z, FLT_MAX); nd->boundsMin[3] = 0.0f;
+    nd->boundsMax[0] = RMAX(acc.hi.x, FLT_MIN); nd->boundsMax[1] = RMAX(acc.hi.y, FLT_MIN); nd->boundsMax[2] = RMAX(acc.hi.z, FLT_MIN); nd->boundsMax[3] = 0.0f;
+    atomicAdd(&marks[sp.x], 1);
+    atomicAdd(&marks[sp.y + 1u], -1);
+}
+
+__global__ __launch_bounds__(256) void k_rq_depth(const uint32_t* __restrict__ covered, uint32_t n, uint32_t* __restrict__ depth_out)
+{
+    uint32_t m = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) m = covered[j] > m ? covered[j] : m;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_down((int)m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63u) == 0u) atomicMax(depth_out, m);
+}
+
+size_t refit_rq_scratch_bytes(uint32_t n)
+{
+    const size_t blocks = (n + RQ_BLOCK - 1) / RQ_BLOCK;
+    size_t levels = 1; while ((1ull << levels) <= blocks) levels++;
+    return (size_t)n * 6 * sizeof(float4) + blocks * levels * 2 * sizeof(float4) + ((size_t)n + 1) * 2 * sizeof(uint32_t) + scan_scratch_words(n + 1) * sizeof(uint32_t) + 256;
+}
+
+// boxes of all inner nodes + the tree depth; *nan_flag_out (device word, zeroed here) != 0 afterwards: NaN boxes, use launch_refit
+void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
+                     uint32_t* nan_flag_out)
+{
+    const uint32_t blocks = (n + RQ_BLOCK - 1) / RQ_BLOCK;
+    uint32_t levels = 1; while ((1ull << levels) <= blocks) levels++;
+    float4* f = (float4*)scratch;
+    float4 *slo = f, *shi = f + n, *plo = f + 2 * (size_t)n, *phi = f + 3 * (size_t)n, *qlo = f + 4 * (size_t)n, *qhi = f + 5 * (size_t)n;
+    float4* tlo = f + 6 * (size_t)n; float4* thi = tlo + (size_t)blocks * levels;
+    int32_t* marks = (int32_t*)(thi + (size_t)blocks * levels);
+    uint32_t* covered = (uint32_t*)marks + (n + 1);
+    uint32_t* scan_scratch = covered + (n + 1);
+    (void)hipMemsetAsync(marks, 0, ((size_t)n + 1) * sizeof(int32_t), s);
+    (void)hipMemsetAsync(nan_flag_out, 0, sizeof(uint32_t), s);
+    (void)hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_rq_blocks, dim3((blocks + 63) / 64), dim3(64), 0, s, nodes, pairs, n, slo, shi, plo, phi, qlo, qhi, tlo, thi, nan_flag_out);
+    for (uint32_t k = 1; k < levels; k++)
+        hipLaunchKernelGGL(k_rq_level, dim3((blocks + 255) / 256), dim3(256), 0, s, tlo + (size_t)(k - 1) * blocks, thi + (size_t)(k - 1) * blocks,
+                           tlo + (size_t)k * blocks, thi + (size_t)k * blocks, blocks, 1u << (k - 1));
+    hipLaunchKernelGGL(k_rq_refit, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, spans, n, slo, shi, plo, phi, qlo, qhi, tlo, thi, blocks, marks);
+    launch_scan_inclusive(s, (const uint32_t*)marks, covered, n, scan_scratch);         // two's complement: the running sums are the cover counts
+    hipLaunchKernelGGL(k_rq_depth, dim3(256), dim3(256), 0, s, covered, n, depth_out);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -123,6 +123,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_TRACE_DIAG")) ctx->trace_diagnostics = env[0] == '1';
     if (const char* env = std::getenv("RTMI_CALIBRATION_LOG")) ctx->calibration_log = env[0] == '1';
     if (const char* env = std::getenv("RTMI_RECALIBRATE")) ctx->recalibrate = env[0] == '1';
+    if (const char* env = std::getenv("RTMI_REFIT")) ctx->refit_choice = env[0] == 'r' ? 1 : env[0] == 'c' ? 2 : 0;
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
@@ -378,6 +379,9 @@ static void free_build_buffers(rt_bvh* b)
     if (b->s_pairs) (void)hipFree(b->s_pairs);
     if (b->s_counters) (void)hipFree(b->s_counters);
     if (b->s_pos) (void)hipFree(b->s_pos);
+    if (b->d_spans) (void)hipFree(b->d_spans);
+    if (b->d_rq_scratch) (void)hipFree(b->d_rq_scratch);
+    b->d_spans = nullptr; b->d_rq_scratch = nullptr;
     b->s_nodes = nullptr; b->s_pairs = nullptr; b->s_counters = nullptr; b->s_pos = nullptr;
     b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
     b->d_depth = nullptr; b->d_pos = nullptr;
@@ -390,6 +394,17 @@ void rt_bvh_destroy(rt_bvh* b)
     (void)hipStreamSynchronize(b->ctx->stream);
     free_build_buffers(b);
     delete b;
+}
+
+// Large scenes refit by range queries instead of climbing parent links (build_kernels.hip 4a): the climb is serial in the depth of
+// the reference tree, which duplicate Morton codes turn into chains of thousands of levels.  Same node bytes either way; below
+// the threshold the single climbing launch is faster than the dozen small launches of the query structure.
+// env RTMI_REFIT=rq / climb forces one (tests run both on every fixture).
+static bool refit_by_range_queries(const rt_ctx* ctx, uint32_t n, int mode)
+{
+    if (mode != RT_MODE_FIXED || n < 256u) return false;
+    if (ctx->refit_choice) return ctx->refit_choice == 1;
+    return n >= (1u << 17);
 }
 
 int rt_bvh_initialize_frame(rt_bvh* b)
@@ -421,6 +436,10 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_counters, (size_t)n * sizeof(uint32_t) + 256);
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_pos, (size_t)n * sizeof(uint32_t));
         }
+        if (e == hipSuccess && refit_by_range_queries(ctx, n, b->mode)) {
+            e = hipMalloc((void**)&b->d_spans, (size_t)(n - 1) * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc(&b->d_rq_scratch, refit_rq_scratch_bytes(n));
+        }
         if (e != hipSuccess) {
             free_build_buffers(b);
             (void)hipGetLastError();
@@ -450,8 +469,16 @@ int rt_bvh_construct(rt_bvh* b)
     launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
     launch_bitonic_sort(s, b->d_pairs, b->N);                     // 2. :195
     const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
-    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
+    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
     if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
+    else if (b->d_spans) {
+        // 4. by range queries; NaN boxes (not associative) send it back to the climb
+        launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_rq_scratch, b->d_depth, b->d_depth + 1);
+        uint32_t nan_boxes = 0;
+        RT_HIP(ctx, hipMemcpyAsync(&nan_boxes, b->d_depth + 1, 4, hipMemcpyDeviceToHost, s));
+        RT_HIP(ctx, hipStreamSynchronize(s));
+        if (nan_boxes) launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
+    }
     else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
     launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n);  // traversal records, DFS ranks
     RT_HIP(ctx, hipGetLastError());

@@ -87,6 +87,7 @@ struct rt_ctx {
     int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
     bool no_search_tree = false;  // knob (env RTMI_SEARCH_TREE=0): primary rays walk the reference tree
     bool trace_diagnostics = false; // knob (env RTMI_TRACE_DIAG=1)
+    int refit_choice = 0;         // knob (env RTMI_REFIT=rq / climb): 1 range-query refit, 2 climbing refit, 0 by triangle count
     bool recalibrate = false;     // knob (env RTMI_RECALIBRATE=1): every construct() forgets the calibrated trace strategy
     bool calibration_log = false; // knob (env RTMI_CALIBRATION_LOG=1): one stderr line per calibration candidate
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
@@ -123,6 +124,8 @@ struct rt_bvh {
     uint2* s_pairs = nullptr;
     uint32_t* s_counters = nullptr;
     uint32_t* s_pos = nullptr;
+    uint2* d_spans = nullptr;          // range-query refit: [first, last] of every inner node + its scratch (large scenes only)
+    void* d_rq_scratch = nullptr;
     uint32_t* d_packet_spill = nullptr;   // packet kernels: bitmap + stack overflow areas, sized from the tree depth
     uint32_t packet_spill_entries = 0;
     uint32_t packet_spill_slots = 0;      // overflow areas = resident waves the device can hold (multiple of 32)
@@ -192,7 +195,10 @@ extern "C" __attribute__((visibility("hidden"))) int rt_check_camera(rt_ctx* ctx
 // build_kernels.hip
 void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
 void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs);
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built);   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO)
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr);   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO)
+size_t refit_rq_scratch_bytes(uint32_t n);
+void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
+                     uint32_t* nan_flag_out);      // range-query refit (large scenes); *nan_flag_out != 0: NaN boxes, redo with launch_refit
 void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);   // boxes + tree depth
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,

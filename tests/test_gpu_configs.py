@@ -180,6 +180,17 @@ def test_one_million_triangles(gpu_ctx):
     try:
         assert gb.read_morton_pairs().tobytes() == ob.pairs.tobytes()
         assert gb.read_nodes().tobytes() == ob.nodes.tobytes()
+        # the reference tree of this scene is one chain of 129 512 levels: the refit runs by range queries (no climb), so a
+        # rebuild takes a few milliseconds (197 ms in round 1, ~30 of them the serial climb)
+        import time
+        assert gb.info()['max_depth'] > 100000
+        gb.build(); gpu_ctx.synchronize()
+        t0 = time.perf_counter()
+        gb.build(); gpu_ctx.synchronize()
+        rebuild_ms = (time.perf_counter() - t0) * 1e3
+        print('1 M triangles: rebuild %.1f ms' % rebuild_ms)
+        assert rebuild_ms < 100.0
+        assert gb.read_nodes().tobytes() == ob.nodes.tobytes()
         cam = osc.demo_camera(192, 108)
         want, st = ob.trace_primary(cam)
         got = gb.generate_contacts_primary(as_capi_camera(cam))

@@ -828,3 +828,54 @@ def test_cpp_demo_tiles_the_frame_over_several_ranks(gpu_ctx, tmp_path):
     cam = as_capi_camera(osc.demo_camera(320, 240))
     want = capi.shade_blinn_phong(gpu_ctx, sc, cam, gb.generate_contacts_primary(cam))
     assert open(raw, 'rb').read() == want.reshape(-1, 4).tobytes()
+
+
+# ---- round 2: refit by range queries (no serial climb) --------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', ['gardenlight', 'tenryuu', 'man', 'clumsydragon'])
+def test_range_query_refit_gives_the_same_node_bytes(name, monkeypatch):
+    """RTMI_REFIT=rq: every inner box as the rightmost minimum / maximum over the node's span of sorted leaves (prefix / suffix
+    folds per 64-leaf block + a sparse table) instead of climbing parent links: same 48-byte nodes, same depth, same contacts."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    monkeypatch.setenv('RTMI_REFIT', 'rq')
+    osc, ob = oracle_bvh(name)
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        nodes = gb.read_nodes()
+        diff = np.nonzero((nodes.view(np.uint8).reshape(-1, 48) != ob.nodes.view(np.uint8).reshape(-1, 48)).any(axis=1))[0]
+        assert diff.size == 0, 'first differing node %d: %s vs %s' % (diff[0], nodes[diff[0]], ob.nodes[diff[0]])
+        rc, depth = ob.check_hierarchy()
+        assert rc == 0 and gb.info()['max_depth'] == depth
+        cam = osc.demo_camera(320, 240)
+        assert gb.generate_contacts_primary(as_capi_camera(cam)).tobytes() == ob.trace_primary(cam)[0].tobytes()
+        gb.build()                                                  # and again on the kept buffers
+        assert gb.read_nodes().tobytes() == ob.nodes.tobytes()
+        gb.close(); sc.close()
+    finally:
+        ctx.close()
+
+
+def test_range_query_refit_falls_back_on_nan_boxes(monkeypatch):
+    """a NaN vertex makes min / max non-associative: the range-query refit detects it and the climbing refit runs instead"""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    monkeypatch.setenv('RTMI_REFIT', 'rq')
+    buf = bytearray(packed_scene('gardenlight'))
+    h = __import__('scene_pack').scene_header(bytes(buf))
+    # first vertex of the first mesh: SceneHeader 96 + lights 16 each + spheres 16 + materials 96 each, ModelHeader 64, MeshHeader 48
+    off = 96 + 16 * h['numberOfLights'] + 16 * h['numberOfSpheres'] + 96 * h['numberOfMaterials'] + 64 + 48
+    buf[off + 4:off + 8] = np.float32(np.nan).tobytes()
+    osc = orc.Scene(bytes(buf))
+    ob = orc.BVH(osc, 0)
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, bytes(buf))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        assert gb.read_nodes().tobytes() == ob.nodes.tobytes()
+        gb.close(); sc.close()
+    finally:
+        ctx.close()
