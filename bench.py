@@ -170,7 +170,7 @@ def run_pmc_passes(keep_dir=None):
             with open(os.path.join(keep_dir, 'bench_pmc_rows.csv'), 'w') as f:
                 f.write('pass,dispatch_id,kernel,counter,value\n')
                 for r_ in rows:
-                    f.write('%s,%d,%s,%s,%.3f\n' % r_)
+                    f.write('%s,%d,"%s",%s,%.3f\n' % r_)
     finally:
         shutil.rmtree(base, ignore_errors=True)
     # dispatches in order: every scene contributes PMC_FRAMES launches = PMC_FRAMES first-phase kernels (+ k_trace_long (+ k_resolve_split))

@@ -98,6 +98,10 @@ int rt_buf_fill_u32(rt_ctx* ctx, void* d_dst, uint32_t pattern, uint64_t count);
  * Scene::load builds it.  The library keeps the raw bytes on the device (getDeviceSceneData())
  * and derives its own SoA triangle table from them with a HIP kernel.                          */
 int         rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_scene** out);
+/* the same for a buffer whose vertex indices are index_bytes wide: 2 = INDEX_TYPE ushort of the reference (SceneBufferParser.h:160,
+ * packed by Scene.cpp:430, wraps beyond 65 535 unique vertices per mesh), 4 = the 32-bit extension (a mesh then occupies
+ * 48 + 16 nv + 4 ni bytes).  Everything downstream works on the triangle table gathered from it.                          */
+int         rt_scene_upload_indexed(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, int index_bytes, rt_scene** out);
 void        rt_scene_destroy(rt_scene* scene);
 const void* rt_scene_device_ptr(const rt_scene* scene);     /* Scene::getDeviceSceneData */
 uint64_t    rt_scene_bytes(const rt_scene* scene);          /* Scene::getSceneDataSize   */

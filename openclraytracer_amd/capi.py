@@ -34,7 +34,7 @@ assert CAMERA.itemsize == 64 and RAY.itemsize == 48 and CONTACT.itemsize == 32 a
 SYMBOLS = [
     'rt_abi_version', 'rt_ctx_create', 'rt_ctx_destroy', 'rt_last_error', 'rt_ctx_set_stream', 'rt_ctx_get_stream',
     'rt_ctx_synchronize', 'rt_ctx_device_info', 'rt_buf_alloc', 'rt_buf_free', 'rt_buf_upload', 'rt_buf_download',
-    'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
+    'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_upload_indexed', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
@@ -85,6 +85,7 @@ def load_library() -> C.CDLL:
     L.rt_buf_download.argtypes = [vp, vp, vp, u64]
     L.rt_buf_fill_u32.argtypes = [vp, vp, u32, u64]
     L.rt_scene_upload.argtypes = [vp, vp, u64, pvp]
+    L.rt_scene_upload_indexed.argtypes = [vp, vp, u64, i32, pvp]
     L.rt_scene_destroy.argtypes = [vp]; L.rt_scene_destroy.restype = None
     L.rt_scene_device_ptr.argtypes = [vp]; L.rt_scene_device_ptr.restype = vp
     L.rt_scene_bytes.argtypes = [vp]; L.rt_scene_bytes.restype = u64
@@ -274,11 +275,14 @@ class Timer:
 class DeviceScene:
     """rt_scene: Scene::loadToGPU of a packed scene buffer."""
 
-    def __init__(self, ctx: Context, scene_bytes: bytes):
+    def __init__(self, ctx: Context, scene_bytes: bytes, index_bytes: int = 2):
         self.ctx = ctx
         self.host = np.frombuffer(bytes(scene_bytes), dtype=np.uint8)
         h = C.c_void_p()
-        ctx.check(ctx.lib.rt_scene_upload(ctx.h, _p(self.host), self.host.nbytes, C.byref(h)))
+        if index_bytes == 2:
+            ctx.check(ctx.lib.rt_scene_upload(ctx.h, _p(self.host), self.host.nbytes, C.byref(h)))
+        else:       # 4: the 32-bit index extension (meshes with more than 65 535 unique vertices)
+            ctx.check(ctx.lib.rt_scene_upload_indexed(ctx.h, _p(self.host), self.host.nbytes, index_bytes, C.byref(h)))
         self.h = h
         self.n_tris = ctx.lib.rt_scene_triangle_count(h)
 

@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void k_gather_triangles(DeviceScene sc)
     const uint16_t* idx = reinterpret_cast<const uint16_t*>(verts + (uint64_t)me.vertex_count * 16);
     f3 v[3];
     for (int k = 0; k < 3; k++) {
-        uint32_t vi = idx[local * 3 + k];                                     // INDEX_TYPE = ushort
+        // INDEX_TYPE = ushort (SceneBufferParser.h:160); 32-bit indices (extension) are read as two halves: meshes are 2-byte aligned
+        const uint32_t e = local * 3 + k;
+        uint32_t vi = sc.index_bytes == 4u ? ((uint32_t)idx[2 * e] | ((uint32_t)idx[2 * e + 1] << 16)) : (uint32_t)idx[e];
         const unsigned char* p = verts + (uint64_t)vi * 16;                   // VERTEX_SIZE = 16
         v[k].x = load_f32_unaligned(p);
         v[k].y = load_f32_unaligned(p + 4);

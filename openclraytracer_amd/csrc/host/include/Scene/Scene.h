@@ -21,11 +21,16 @@ public:
     const char* getHostSceneData() const { return _hostSceneData; }
     cl_ulong getSceneDataSize() const { return _sceneDataSize; }
     rt_scene* deviceHandle() const { return _deviceScene; }      // used by the managers of this library
+    /** extension: 32 = pack and upload 32-bit vertex indices (the reference's ushort indices, SceneBufferParser.h:160, wrap for a
+     *  mesh with more than 65 535 unique vertices); 16 = the reference format (default).  Call before load().           */
+    void setIndexWidth(int bits) { _indexBytes = bits == 32 ? 4 : 2; }
+    int getIndexWidth() const { return _indexBytes * 8; }
 private:
     char* _hostSceneData;
     cl_ulong _sceneDataSize;
     cl_mem _deviceSceneData;
     rt_scene* _deviceScene;
+    int _indexBytes = 2;
 };
 
 }  // namespace

@@ -83,7 +83,7 @@ Result Scene::load(const char* filename, Errata& err)
 {
     std::vector<char> buf;
     std::string msg;
-    if (!rtmi_host::packSceneFile(filename, buf, msg)) { FILL_ERRATA(err, msg); return Error; }
+    if (!rtmi_host::packSceneFile(filename, buf, msg, _indexBytes)) { FILL_ERRATA(err, msg); return Error; }
     delete[] _hostSceneData;
     _hostSceneData = new char[buf.size()];
     std::memcpy(_hostSceneData, buf.data(), buf.size());
@@ -94,7 +94,7 @@ Result Scene::loadToGPU(const CLExecutionContext& context, Errata& err)
 {
     if (!_hostSceneData) { FILL_ERRATA(err, "Scene::load must precede loadToGPU"); return Error; }
     if (_deviceScene) { rt_scene_destroy(_deviceScene); _deviceScene = nullptr; }
-    RTMI_CHECK(context, rt_scene_upload(context.handle(), _hostSceneData, _sceneDataSize, &_deviceScene), err);
+    RTMI_CHECK(context, rt_scene_upload_indexed(context.handle(), _hostSceneData, _sceneDataSize, _indexBytes, &_deviceScene), err);
     _deviceSceneData = const_cast<void*>(rt_scene_device_ptr(_deviceScene));
     return Success;
 }

@@ -22,7 +22,7 @@
 namespace rtmi_host {
 namespace {
 
-enum { SCENE_HEADER = 96, LIGHT = 16, SPHERE = 16, MATERIAL = 96, MODEL_HEADER = 64, MESH_HEADER = 48, VERTEX = 16, INDEX = 2 };
+enum { SCENE_HEADER = 96, LIGHT = 16, SPHERE = 16, MATERIAL = 96, MODEL_HEADER = 64, MESH_HEADER = 48, VERTEX = 16 };
 
 struct ObjMaterial { float v[19]; std::string name; };    // ambient diffuse specular transmittance emission | Ns Ni d illum
 struct ObjShape { std::vector<float> positions; std::vector<uint32_t> indices; std::vector<int> material_ids; };
@@ -273,8 +273,12 @@ bool file_exists(const std::string& p) { std::ifstream f(p.c_str()); return (boo
 
 }  // namespace
 
-bool packSceneFile(const char* filename, std::vector<char>& out, std::string& err)
+bool packSceneFile(const char* filename, std::vector<char>& out, std::string& err, int indexBytes)
 {
+    // INDEX_TYPE: the reference packs ushort indices (SceneBufferParser.h:160, Scene.cpp:430), which wrap for a mesh with
+    // more than 65 535 unique vertices; 4 = the 32-bit extension (rt_scene_upload_indexed / Scene::setIndexWidth)
+    if (indexBytes != 2 && indexBytes != 4) { err = "index width must be 2 or 4 bytes"; return false; }
+    const uint64_t INDEX = (uint64_t)indexBytes;
     std::map<std::string, std::vector<std::string>> raw;     // std::map => keys in sorted order, as in the reference
     {
         std::ifstream f(filename);
@@ -367,7 +371,10 @@ bool packSceneFile(const char* filename, std::vector<char>& out, std::string& er
                 std::memcpy(&out[moff + MESH_HEADER + vi * VERTEX], p, 12);
             }
             size_t ioff = moff + MESH_HEADER + nv * VERTEX;
-            for (uint64_t ii = 0; ii < ni; ii++) { uint16_t v16 = (uint16_t)s.indices[ii]; std::memcpy(&out[ioff + ii * INDEX], &v16, 2); }   // ushort truncation
+            for (uint64_t ii = 0; ii < ni; ii++) {
+                if (INDEX == 2) { uint16_t v16 = (uint16_t)s.indices[ii]; std::memcpy(&out[ioff + ii * 2], &v16, 2); }   // ushort truncation, as the reference
+                else { uint32_t v32 = (uint32_t)s.indices[ii]; std::memcpy(&out[ioff + ii * 4], &v32, 4); }
+            }
             for (int k = 0; k < 3; k++) { scene_lo[k] = lo[k] < scene_lo[k] ? lo[k] : scene_lo[k]; scene_hi[k] = hi[k] > scene_hi[k] ? hi[k] : scene_hi[k]; }
             moff += msize;
         }

@@ -3,5 +3,6 @@
 #include <string>
 #include <vector>
 namespace rtmi_host {
-bool packSceneFile(const char* filename, std::vector<char>& out, std::string& err);
+// indexBytes = 2: the reference's ushort vertex indices (wrap beyond 65 535 unique vertices per mesh); 4: 32-bit indices (extension)
+bool packSceneFile(const char* filename, std::vector<char>& out, std::string& err, int indexBytes = 2);
 }

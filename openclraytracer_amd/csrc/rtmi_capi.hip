@@ -238,8 +238,15 @@ static uint64_t rd64(const unsigned char* p) { uint64_t v; std::memcpy(&v, p, 8)
 
 int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_scene** out)
 {
+    return rt_scene_upload_indexed(ctx, h_scene_buffer, bytes, 2, out);
+}
+
+int rt_scene_upload_indexed(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, int index_bytes, rt_scene** out)
+{
     if (!ctx || !h_scene_buffer || !out) return RT_FAIL(ctx, "null argument");
     *out = nullptr;
+    if (index_bytes != 2 && index_bytes != 4) return RT_FAIL(ctx, "index width must be 2 or 4 bytes");
+    const uint64_t IB = (uint64_t)index_bytes;
     const unsigned char* s = (const unsigned char*)h_scene_buffer;
     // SceneHeader, SceneBufferParser.h:55-66
     if (bytes < 96) return RT_FAIL(ctx, "scene buffer smaller than a SceneHeader");
@@ -265,12 +272,12 @@ int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_
             if (moff + 48 > off + modelSize) { delete sc; return RT_FAIL(ctx, "mesh header outside its model"); }
             uint64_t meshSize = rd64(s + moff), mt = rd64(s + moff + 8), nv = rd64(s + moff + 16), ni = rd64(s + moff + 24),
                      mat = rd64(s + moff + 32);                                  // MeshHeader, :141-149
-            if (meshSize < 48 + 16 * nv + 2 * ni || moff + meshSize > off + modelSize || mt * 3 > ni) {
+            if (meshSize < 48 + 16 * nv + IB * ni || moff + meshSize > off + modelSize || mt * 3 > ni) {
                 delete sc; return RT_FAIL(ctx, "mesh sizes inconsistent");
             }
             const unsigned char* ib = s + moff + 48 + 16 * nv;
             for (uint64_t i = 0; i < mt * 3; i++) {
-                uint16_t v; std::memcpy(&v, ib + 2 * i, 2);
+                uint32_t v = 0; std::memcpy(&v, ib + IB * i, IB);
                 if (v >= nv) { delete sc; return RT_FAIL(ctx, "vertex index out of range"); }
             }
             MeshEntry e{};
@@ -307,6 +314,7 @@ int rt_scene_upload(rt_ctx* ctx, const void* h_scene_buffer, uint64_t bytes, rt_
     float4* base = (float4*)sc->d_tri;
     d.v0 = base; d.v1 = base + nTris; d.v2 = base + 2 * nTris; d.e1 = base + 3 * nTris; d.e2 = base + 4 * nTris;
     d.nrm = base + 5 * nTris; d.ref = (uint4*)(base + 6 * nTris);
+    d.index_bytes = (uint32_t)index_bytes;
     d.n_lights = (uint32_t)nLights; d.n_spheres = (uint32_t)nSpheres; d.n_materials = (uint32_t)nMaterials;
     std::memcpy(d.bb_lo, s + 64, 12);
     std::memcpy(d.bb_hi, s + 80, 12);

@@ -60,6 +60,7 @@ struct DeviceScene {
     float4* nrm;       // normalize(cross(e1,e2)) (Triangle.h:105), ray independent
     uint4*  ref;       // (triangle in mesh, submesh, model, material)
     // scene header fields needed on the device
+    uint32_t index_bytes;      // width of a vertex index in the packed buffer: 2 (reference) or 4 (rt_scene_upload_indexed)
     uint32_t n_lights, n_spheres, n_materials;
     float bb_lo[3], bb_hi[3];
 };
