@@ -376,7 +376,8 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_counters) (void)hipFree(b->d_counters);
     if (b->d_trav) (void)hipFree(b->d_trav);
     if (b->d_quad) (void)hipFree(b->d_quad);
-    b->d_quad = nullptr;
+    if (b->d_quad_cam) (void)hipFree(b->d_quad_cam);
+    b->d_quad = nullptr; b->d_quad_cam = nullptr;
     if (b->d_depth) (void)hipFree(b->d_depth);
     if (b->d_pos) (void)hipFree(b->d_pos);
     if (b->d_packet_spill) (void)hipFree(b->d_packet_spill);
@@ -438,6 +439,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_tree_select, 256);
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * trees);
+        if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad_cam, (size_t)(n - 1) * sizeof(QuadNode) * trees);
         if (e == hipSuccess && want_search) {   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
             e = hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2));
@@ -557,7 +559,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;
-    t.quad = b->d_quad;
+    t.quad = b->d_quad; t.quad_cam = b->d_quad_cam;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
@@ -983,7 +985,7 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     // between (or the marks were never set), restore this graph's marks first -- one small kernel over the records
     if (!b->marked_valid || std::memcmp(b->marked_origin, g->origin, sizeof g->origin) != 0) {
         TraceLaunch t{};
-        t.trav = b->d_trav; t.quad = b->d_quad; t.tree_select = b->d_tree_select; t.n_leaves = b->n;
+        t.trav = b->d_trav; t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.tree_select = b->d_tree_select; t.n_leaves = b->n;
         t.search_root = b->have_search_tree ? b->n - 1 : 0u;
         launch_prepare_camera(ctx->stream, t, g->origin);
         RT_HIP(ctx, hipGetLastError());

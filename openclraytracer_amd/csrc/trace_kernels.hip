@@ -90,7 +90,8 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
-    const QuadNode* __restrict__ quad;          // four-wide records of the same nodes (k_trace_packet4), may be null
+    const QuadNode* __restrict__ quad;          // four-wide records of the same nodes, may be null: what the kernels read -- for primary
+                                                // rays the camera-relative copy (boxes minus the camera position, inside marks)
     uint32_t search_root;                       // primary rays: root record of the search tree (same leaves), 0 = none
     const uint32_t* __restrict__ tree_select;   // primary rays: bit k = the camera's coordinate k equals a box plane
     const float4* __restrict__ v0;
@@ -157,6 +158,51 @@ __device__ __forceinline__ bool child_valid(float lox, float loy, float loz, flo
     return (flag & (tmin > 0.0f)) | inside;
 }
 
+// The same decision for rays whose slab products cannot be NaN -- every ray the four-wide records are walked with: they live
+// on the search tree only, and ray_root keeps rays with a possible 0 * inf off it (a ray with a NaN direction can pass, but no
+// triangle test of such a ray succeeds whatever it visits).  Without NaN the reference's staged test is value-equivalent to the
+// textbook slab test: per axis the two products a = (lo - o) * inv, b = (hi - o) * inv are ordered by the sign of inv, so the
+// sign-selected near / far planes are min(a, b) / max(a, b); "no near exceeds another axis' far" (AABB.h:133-139) together with
+// near_k <= far_k (lo <= hi, monotone rounding) is max3(near) <= min3(far); tmin is max3(near).  Signed zeros compare equal.
+// This form is pure VALU -- v_min / v_max / v_max3 / v_min3, no compare-into-SGPR + select round trips between the vector
+// and the scalar unit, which is what a wave step of the packet kernel waited for.
+__device__ __forceinline__ bool child_valid_nonan(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayState& r,
+                                                  bool inside_marked)
+{
+    const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
+    const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
+    const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return ((tnear <= tfar) & (tnear > 0.0f)) | inside_marked;
+}
+
+// ... and on the camera-relative records of primary rays (k_prepare_camera): d* = plane - origin, subtracted once per camera
+__device__ __forceinline__ bool child_valid_delta(float dlox, float dloy, float dloz, float dhix, float dhiy, float dhiz, const RayState& r,
+                                                  bool inside_marked)
+{
+    const float ax = dlox * r.inv.x, bx = dhix * r.inv.x;
+    const float ay = dloy * r.inv.y, by = dhiy * r.inv.y;
+    const float az = dloz * r.inv.z, bz = dhiz * r.inv.z;
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return ((tnear <= tfar) & (tnear > 0.0f)) | inside_marked;
+}
+
+// a child of a BINARY record: the pure-VALU form on search-tree records (no NaN possible there, see above), the reference's
+// staged form on reference-tree records (where rays with a possible 0 * inf walk)
+template <int PRIMARY>
+__device__ __forceinline__ bool child_valid_on(bool search_tree_record, float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                               const RayState& r, bool sx, bool sy, bool sz, bool inside_marked)
+{
+    if (search_tree_record) {
+        const bool inside = PRIMARY ? inside_marked
+                                    : ((lox <= r.o.x) & (r.o.x <= hix) & (loy <= r.o.y) & (r.o.y <= hiy) & (loz <= r.o.z) & (r.o.z <= hiz));
+        return child_valid_nonan(lox, loy, loz, hix, hiy, hiz, r, inside);
+    }
+    return child_valid<PRIMARY>(lox, loy, loz, hix, hiy, hiz, r, sx, sy, sz, inside_marked);
+}
+
 // Per camera position: (1) isPointInside (AABB.h:178-184) of the camera position for both children of every inner
 // record of both trees, bits 0 / 1 of pad0; (2) whether the camera lies exactly on a box plane.  Only then can a slab
 // product be 0 * inf = NaN (a ray with a zero direction component), which is the one case the equivalence argument
@@ -170,21 +216,27 @@ __device__ __forceinline__ uint32_t inside_bits(const TravNode& t, float ox, flo
     bool ib = (t.b_lo[0] <= ox) & (ox <= t.b_hi[0]) & (t.b_lo[1] <= oy) & (oy <= t.b_hi[1]) & (t.b_lo[2] <= oz) & (oz <= t.b_hi[2]);
     return (ia ? 1u : 0u) | (ib ? 2u : 0u);
 }
-__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, QuadNode* quad, uint32_t n_records, uint32_t n_reference,
+__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const QuadNode* quad, QuadNode* quad_cam, uint32_t n_records, uint32_t n_reference,
                                                         float ox, float oy, float oz, uint32_t* select)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_records) return;
     const TravNode t = trav[i];
     trav[i].pad0 = inside_bits(t, ox, oy, oz);
-    if (quad) {                                            // the same bit per slot of the four-wide record
-        const QuadNode q = quad[i];
+    if (quad) {
+        // the four-wide record relative to this camera: every primary ray has the camera position as origin, so the slab
+        // test's (plane - origin) is the same subtraction for all of them -- done once here, with the same fp32 operation, and
+        // the kernels multiply by 1 / direction directly.  Plus the "camera inside the box" bit per slot.
+        QuadNode q = quad[i];
         uint32_t bits = 0;
         for (int k = 0; k < 4; k++) {
-            const float4 lo = q.q[2 * k], hi = q.q[2 * k + 1];
+            float4& lo = q.q[2 * k]; float4& hi = q.q[2 * k + 1];
             if ((lo.x <= ox) & (ox <= hi.x) & (lo.y <= oy) & (oy <= hi.y) & (lo.z <= oz) & (oz <= hi.z)) bits |= 1u << k;
+            lo.x = lo.x - ox; lo.y = lo.y - oy; lo.z = lo.z - oz;
+            hi.x = hi.x - ox; hi.y = hi.y - oy; hi.z = hi.z - oz;
         }
-        reinterpret_cast<uint32_t*>(&quad[i].q[4])[3] = bits;
+        q.q[4].w = __uint_as_float(bits);
+        quad_cam[i] = q;
     }
     if (i < n_reference && n_records > n_reference) {       // plane test over the reference records, when there is a search tree
         const float o[3] = { ox, oy, oz };
@@ -361,10 +413,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                     const float4 g0 = p[0], g1 = p[1], g2 = p[2], g3 = p[3], g4 = p[4], g5 = p[5], g6 = p[6], g7 = p[7];
                     const uint32_t i0 = __float_as_uint(g0.w), i1 = __float_as_uint(g1.w), i2 = __float_as_uint(g2.w), i3 = __float_as_uint(g3.w);
                     const uint32_t qm = __float_as_uint(g4.w);
-                    uint32_t c0 = child_valid<PRIMARY>(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, r, sx, sy, sz, (qm & 1u) != 0u) ? i0 : RT_SENTINEL;
-                    uint32_t c1 = child_valid<PRIMARY>(g2.x, g2.y, g2.z, g3.x, g3.y, g3.z, r, sx, sy, sz, (qm & 2u) != 0u) ? i1 : RT_SENTINEL;
-                    uint32_t c2 = child_valid<PRIMARY>(g4.x, g4.y, g4.z, g5.x, g5.y, g5.z, r, sx, sy, sz, (qm & 4u) != 0u) ? i2 : RT_SENTINEL;
-                    uint32_t c3 = child_valid<PRIMARY>(g6.x, g6.y, g6.z, g7.x, g7.y, g7.z, r, sx, sy, sz, (qm & 8u) != 0u) ? i3 : RT_SENTINEL;
+                    // (rays on search-tree records cannot produce NaN slab products, ray_root: the pure-VALU form of the test;
+                    //  primary rays read the camera-relative copy of the records)
+                    auto slot_valid = [&](const float4& lo, const float4& hi, uint32_t bit) {
+                        if (PRIMARY) return child_valid_delta(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, (qm & bit) != 0u);
+                        const bool inside = (lo.x <= r.o.x) & (r.o.x <= hi.x) & (lo.y <= r.o.y) & (r.o.y <= hi.y) & (lo.z <= r.o.z) & (r.o.z <= hi.z);
+                        return child_valid_nonan(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, inside);
+                    };
+                    uint32_t c0 = slot_valid(g0, g1, 1u) ? i0 : RT_SENTINEL;
+                    uint32_t c1 = slot_valid(g2, g3, 2u) ? i1 : RT_SENTINEL;
+                    uint32_t c2 = slot_valid(g4, g5, 4u) ? i2 : RT_SENTINEL;
+                    uint32_t c3 = slot_valid(g6, g7, 8u) ? i3 : RT_SENTINEL;
                     if (pending == NO_LEAF) {                      // park one reached leaf right away (no stack round trip)
                         if (c0 != RT_SENTINEL && (c0 & RT_LEAF_FLAG)) { pending = c0 & ~RT_LEAF_FLAG; c0 = RT_SENTINEL; }
                         else if (c1 != RT_SENTINEL && (c1 & RT_LEAF_FLAG)) { pending = c1 & ~RT_LEAF_FLAG; c1 = RT_SENTINEL; }
@@ -384,8 +443,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     uint32_t ca = __float_as_uint(q0.w), cb = __float_as_uint(q1.w);
                     const uint32_t marks = __float_as_uint(q2.w);
-                    bool aValid = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
-                    bool bValid = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
+                    const bool on_search = a.search_root != 0u && cur >= a.search_root;
+                    bool aValid = child_valid_on<PRIMARY>(on_search, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                    bool bValid = child_valid_on<PRIMARY>(on_search, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
                     if (aValid & bValid) {
                         const bool a_leaf = (ca & RT_LEAF_FLAG) != 0u, b_leaf = (cb & RT_LEAF_FLAG) != 0u;
                         if (pending == NO_LEAF && (a_leaf | b_leaf)) {
@@ -652,8 +712,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
             const uint32_t marks = __float_as_uint(q2.w);
             bool aV = false, bV = false;
             if (in) {
-                aV = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
-                bV = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
+                const bool on_search = a.search_root != 0u && node >= a.search_root;          // wave-uniform
+                aV = child_valid_on<PRIMARY>(on_search, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                bV = child_valid_on<PRIMARY>(on_search, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
             }
             uint64_t mA = __ballot(aV), mB = __ballot(bV);
             if ((ca & RT_LEAF_FLAG) != 0u) { if (mA != 0ull) { if (aV) leaf_test_uniform(a, ca & ~RT_LEAF_FLAG, r); } mA = 0ull; }
@@ -910,10 +971,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
             const uint32_t marks = __float_as_uint(q4.w);
             bool v0 = false, v1 = false, v2 = false, v3 = false;
             if (in) {
-                v0 = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
-                v1 = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
-                v2 = (id2 != RT_SENTINEL) && child_valid<PRIMARY>(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, sx, sy, sz, (marks & 4u) != 0u);
-                v3 = (id3 != RT_SENTINEL) && child_valid<PRIMARY>(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, sx, sy, sz, (marks & 8u) != 0u);
+                v0 = child_valid_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u);
+                v1 = child_valid_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u);
+                v2 = (id2 != RT_SENTINEL) && child_valid_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u);
+                v3 = (id3 != RT_SENTINEL) && child_valid_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u);
             }
             uint64_t m[4] = { __ballot(v0), __ballot(v1), __ballot(v2), __ballot(v3) };
             const uint32_t ids[4] = { id0, id1, id2, id3 };
@@ -1129,8 +1190,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 ca = __float_as_uint(q0.w); cb = __float_as_uint(q1.w);
                 const uint32_t marks = __float_as_uint(q2.w);
-                bool aValid = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
-                bValid = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
+                const bool on_search = a.search_root != 0u && node >= a.search_root;
+                bool aValid = child_valid_on<PRIMARY>(on_search, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
+                bValid = child_valid_on<PRIMARY>(on_search, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
                 aIn = aValid & ((ca & RT_LEAF_FLAG) == 0u); aLf = aValid & ((ca & RT_LEAF_FLAG) != 0u);
                 bIn = bValid & ((cb & RT_LEAF_FLAG) == 0u); bLf = bValid & ((cb & RT_LEAF_FLAG) != 0u);
             }
@@ -1283,7 +1345,7 @@ uint32_t trace_packet_stack_entries() { return PACKET_STACK; }
 
 static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
-    a.trav = t.trav; a.quad = t.search_root ? t.quad : nullptr; a.search_root = t.search_root; a.tree_select = t.tree_select;
+    a.trav = t.trav; a.quad = t.search_root ? t.quad : nullptr; a.search_root = t.search_root; a.tree_select = t.tree_select;   // (launch_trace_primary switches to quad_cam)
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
     a.pos = t.pos;
     a.ctrl = (TraceCtrl*)t.ctrl;
@@ -1309,6 +1371,7 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.total_work = rt_owned_tiles(total_tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.rays = nullptr;
     a.out = out;
+    if (a.quad) a.quad = t.quad_cam;                  // boxes minus the camera position (k_prepare_camera)
     if (t.mark_inside) {
         const float origin[3] = { cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11] };
         launch_prepare_camera(s, t, origin);
@@ -1323,7 +1386,7 @@ void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float orig
     (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
     const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
     hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
-                       const_cast<QuadNode*>(t.quad), n_all, n_ref, origin[0], origin[1], origin[2], const_cast<uint32_t*>(t.tree_select));
+                       t.quad, const_cast<QuadNode*>(t.quad_cam), n_all, n_ref, origin[0], origin[1], origin[2], const_cast<uint32_t*>(t.tree_select));
 }
 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)
