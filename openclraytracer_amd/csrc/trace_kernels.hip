@@ -771,7 +771,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 // the destination SGPRs of loads still in flight (a memory fault on the first frame); as ordinary loads the second record
 // does not fit the SGPR file next to the first (106 SGPRs, 340 lane spills), and even without the speculation the wide loads
 // cost 64 lane spills and 41 more VGPRs: ManFigure 0.667 -> 1.109 ms, atrium 18.3 -> 32.2 ms.  The compiler's lazy dword loads
-// hit the scalar cache after the first one and are the better schedule.
+// hit the scalar cache after the first one and are the better schedule.  Also tried after the box tests had become pure VALU
+// (the record wait was then the longest phase, ~900 of ~2 900 cycles on ManFigure): all four inner slots' records requested
+// before the tests with ONE vector load (lane 8 k + j takes the j-th 16 bytes of slot k's record, four VGPRs) and the chosen
+// record read out of those lanes with 32 v_readlane after the tests -- no gain either (ManFigure 0.56-0.59 -> 0.59 ms, atrium
+// 15.3 -> 15.6 ms): 106 SGPRs again (the pop path then has to materialise whole records), and the wait does not go away.
 #ifndef RTMI_P4_VARIANT
 #define RTMI_P4_VARIANT 0
 #endif
@@ -845,10 +849,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
             const unsigned long long T1 = __builtin_amdgcn_s_memtime();
             bool v0 = false, v1 = false, v2 = false, v3 = false;
             if (in) {
-                v0 = child_valid<PRIMARY>(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, sx, sy, sz, (marks & 1u) != 0u);
-                v1 = child_valid<PRIMARY>(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, sx, sy, sz, (marks & 2u) != 0u);
-                v2 = (id2 != RT_SENTINEL) && child_valid<PRIMARY>(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, sx, sy, sz, (marks & 4u) != 0u);
-                v3 = (id3 != RT_SENTINEL) && child_valid<PRIMARY>(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, sx, sy, sz, (marks & 8u) != 0u);
+                v0 = child_valid_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u);
+                v1 = child_valid_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u);
+                v2 = (id2 != RT_SENTINEL) && child_valid_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u);
+                v3 = (id3 != RT_SENTINEL) && child_valid_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u);
             }
             uint64_t m[4] = { __ballot(v0), __ballot(v1), __ballot(v2), __ballot(v3) };
             const uint32_t ids[4] = { id0, id1, id2, id3 };
