@@ -568,6 +568,35 @@ __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t l
     }
 }
 
+// the same for the lanes of `reached` only, without divergent control flow: every lane computes, the update is a select; the
+// tie on t (the rule of the depth-first rank) is rare and sits behind a wave-uniform test
+__device__ __forceinline__ void leaf_test_masked(const TraceArgs& a, uint32_t leaf, RayState& r, bool reached)
+{
+    float4 v0 = ld_const4(a.v0 + leaf), E1 = ld_const4(a.e1 + leaf), E2 = ld_const4(a.e2 + leaf);
+    f3 vert0 = f3_from4(v0), edge1 = f3_from4(E1), edge2 = f3_from4(E2);
+    f3 pvec = f3_cross(r.d, edge2);
+    float det = f3_dot(edge1, pvec);
+    bool flag = reached & (fabsf(det) >= FLT_EPSILON);
+    float inv_det = 1.0f / det;
+    f3 tvec = f3_sub(r.o, vert0);
+    float u = f3_dot(tvec, pvec) * inv_det;
+    flag = flag & (u < 1.0f);
+    flag = flag & (u >= 0.0f);
+    f3 qvec = f3_cross(tvec, edge1);
+    float v = f3_dot(r.d, qvec) * inv_det;
+    flag = flag & ((u + v) <= 1.0f);
+    flag = flag & (v >= 0.0f);
+    float t = f3_dot(edge2, qvec) * inv_det;
+    flag = flag & (t > 0.0f);
+    const bool better = flag & (t < r.best_t);
+    const bool tie = flag & (t == r.best_t) & (r.best_leaf != NO_LEAF);
+    r.best_t = better ? t : r.best_t;
+    r.best_leaf = better ? leaf : r.best_leaf;
+    if (__ballot(tie) != 0ull) {
+        if (tie && a.pos[leaf] < a.pos[r.best_leaf]) r.best_leaf = leaf;
+    }
+}
+
 // Overflow areas of the packet stacks.  One wave per block means far more waves than areas, so a wave takes an area only
 // when its LDS stack overflows (rare) and gives it back when it ends: a bitmap with one bit per area, as many areas as the
 // device can hold resident waves, so a free bit always exists; the search is bounded all the same and reports error 5.
@@ -973,20 +1002,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
             const float4 q4 = ld_const4(p + 4), q5 = ld_const4(p + 5), q6 = ld_const4(p + 6), q7 = ld_const4(p + 7);
             const uint32_t id0 = __float_as_uint(q0.w), id1 = __float_as_uint(q1.w), id2 = __float_as_uint(q2.w), id3 = __float_as_uint(q3.w);
             const uint32_t marks = __float_as_uint(q4.w);
-            bool v0 = false, v1 = false, v2 = false, v3 = false;
-            if (in) {
-                v0 = child_valid_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u);
-                v1 = child_valid_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u);
-                v2 = (id2 != RT_SENTINEL) && child_valid_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u);
-                v3 = (id3 != RT_SENTINEL) && child_valid_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u);
-            }
+            // all 64 lanes evaluate all four boxes (a vector instruction costs the same for one lane as for 64; a divergent `if (in)`
+            // costs an exec-mask region, i.e. scalar instructions and a branch): lanes that do not take part are masked afterwards
+            const bool v0 = in & child_valid_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u);
+            const bool v1 = in & child_valid_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u);
+            const bool v2 = in & (id2 != RT_SENTINEL) & child_valid_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u);
+            const bool v3 = in & (id3 != RT_SENTINEL) & child_valid_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u);
             uint64_t m[4] = { __ballot(v0), __ballot(v1), __ballot(v2), __ballot(v3) };
             const uint32_t ids[4] = { id0, id1, id2, id3 };
             // leaves are tested on the spot by the lanes that reached them
-            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) { if (v0) leaf_test_uniform(a, id0 & ~RT_LEAF_FLAG, r); } m[0] = 0ull; }
-            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) { if (v1) leaf_test_uniform(a, id1 & ~RT_LEAF_FLAG, r); } m[1] = 0ull; }
-            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) { if (v2) leaf_test_uniform(a, id2 & ~RT_LEAF_FLAG, r); } m[2] = 0ull; }
-            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) { if (v3) leaf_test_uniform(a, id3 & ~RT_LEAF_FLAG, r); } m[3] = 0ull; }
+            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) leaf_test_masked(a, id0 & ~RT_LEAF_FLAG, r, v0); m[0] = 0ull; }
+            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) leaf_test_masked(a, id1 & ~RT_LEAF_FLAG, r, v1); m[1] = 0ull; }
+            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) leaf_test_masked(a, id2 & ~RT_LEAF_FLAG, r, v2); m[2] = 0ull; }
+            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) leaf_test_masked(a, id3 & ~RT_LEAF_FLAG, r, v3); m[3] = 0ull; }
             // the first wanted inner child is walked next, the others wait on the stack with their lanes
             int first = -1;
 #pragma unroll
