@@ -657,3 +657,24 @@ void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, u
 {
     hipLaunchKernelGGL(k_relayout_quad, dim3((n_records + 255) / 256), dim3(256), 0, s, trav, quad, n_records);
 }
+
+// ----------------------------------------------------------------------------------------
+// 8. packed triangle records of the packet kernels (rtmi_internal.h, TriRec): bit copies of the SoA table + the leaf's rank
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_triangles(DeviceScene sc, const uint32_t* __restrict__ pos, TriRec* __restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sc.n_tris) return;
+    const float4 v0 = sc.v0[t], e1 = sc.e1[t], e2 = sc.e2[t];
+    TriRec r;
+    r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z;
+    r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
+    r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
+    r.pos = pos[t]; r.material = __float_as_uint(v0.w); r.pad = 0u;
+    out[t] = r;
+}
+
+void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out)
+{
+    if (sc.n_tris) hipLaunchKernelGGL(k_pack_triangles, dim3((sc.n_tris + 255) / 256), dim3(256), 0, s, sc, pos, out);
+}

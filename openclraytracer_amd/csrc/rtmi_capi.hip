@@ -380,6 +380,8 @@ static void free_build_buffers(rt_bvh* b)
     b->d_quad = nullptr; b->d_quad_cam = nullptr;
     if (b->d_depth) (void)hipFree(b->d_depth);
     if (b->d_pos) (void)hipFree(b->d_pos);
+    if (b->d_trirec) (void)hipFree(b->d_trirec);
+    b->d_trirec = nullptr;
     if (b->d_packet_spill) (void)hipFree(b->d_packet_spill);
     b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
     if (b->d_tree_select) (void)hipFree(b->d_tree_select);
@@ -437,6 +439,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode) * trees);
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_depth, 256);
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_trirec, (size_t)n * sizeof(TriRec));
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_tree_select, 256);
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * trees);
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad_cam, (size_t)(n - 1) * sizeof(QuadNode) * trees);
@@ -491,6 +494,7 @@ int rt_bvh_construct(rt_bvh* b)
     }
     else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
     launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n);  // traversal records, DFS ranks
+    launch_pack_triangles(s, sc, b->d_pos, b->d_trirec);
     RT_HIP(ctx, hipGetLastError());
     uint32_t depth = 0;
     RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
@@ -555,7 +559,7 @@ int rt_bvh_construct(rt_bvh* b)
 static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 {
     TraceLaunch t{};
-    t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.n_leaves = b->n;
+    t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.trirec = b->d_trirec; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;

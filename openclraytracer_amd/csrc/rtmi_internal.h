@@ -30,6 +30,12 @@ static_assert(sizeof(TravNode) == 64, "TravNode must be 64 bytes");
 struct __attribute__((aligned(16))) QuadNode { float4 q[8]; };
 static_assert(sizeof(QuadNode) == 128, "QuadNode must be 128 bytes");
 
+// One 48-byte record per triangle for the packet kernels, which fetch a leaf's data through the scalar path: everything the
+// triangle test needs behind ONE address (vertex 0, both edges) plus the leaf's depth-first rank (the tie rule) -- instead of three
+// arrays (three address computations, six scalar loads) and a vector load of the rank in the tie case.
+struct __attribute__((aligned(16))) TriRec { float v0[3]; float e1[3]; float e2[3]; uint32_t pos; uint32_t material; uint32_t pad; };
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
 #define RT_LEAF_FLAG 0x80000000u
 #define RT_SENTINEL 0xFFFFFFFFu   // stack sentinel, BVH.h:352
 #define RT_LONG_LIST_MAX (1u << 20)     // at most this many deferred-ray records (128 MiB)
@@ -119,6 +125,7 @@ struct rt_bvh {
     QuadNode* d_quad_cam = nullptr;    // the same records relative to the current camera position (boxes minus origin, inside marks): k_prepare_camera
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
+    TriRec* d_trirec = nullptr;        // packed triangle records of the packet kernels (filled per build: they hold the rank)
     bool have_search_tree = false;     // d_trav holds 2(n-1) records: reference tree, then the search tree (primary rays)
     uint32_t* d_tree_select = nullptr; // 1 word, bit k: the camera's coordinate k equals a box plane (k_prepare_camera)
     uint32_t search_depth = 0;
@@ -206,6 +213,7 @@ void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t id_offset = 0);
 void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records);
+void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out);
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
@@ -220,6 +228,7 @@ struct TraceLaunch {
     const uint32_t* tree_select;  // per camera: bit k set = the camera's coordinate k equals a box plane
     const DeviceScene* scene;
     const uint32_t* pos;          // leaf -> position in the sorted pair array (DFS rank, tie rule)
+    const TriRec* trirec;         // packed triangle records (packet kernels)
     uint32_t n_leaves;
     void* ctrl;                   // TraceCtrl, zeroed by the launcher
     uint32_t* long_list;          // records of rays deferred to the wave-per-ray phase

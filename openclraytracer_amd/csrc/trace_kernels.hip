@@ -98,6 +98,7 @@ struct TraceArgs {
     const float4* __restrict__ e1;
     const float4* __restrict__ e2;
     const float4* __restrict__ nrm;
+    const TriRec* __restrict__ trirec;     // packed triangle records (packet kernels): vertex 0, edges, rank behind one address
     const uint32_t* __restrict__ pos;      // leaf -> position in the sorted (morton, leaf) array
     TraceCtrl* ctrl;
     uint32_t* long_list;                   // long_cap records
@@ -128,6 +129,7 @@ struct RayState {
     f3 o, d, inv;
     float best_t;
     uint32_t best_leaf;
+    uint32_t best_pos;       // packet kernels: depth-first rank of best_leaf (the tie rule without a load)
     uint32_t work;           // work item (ray) index
     uint32_t out_index;      // where the contact is stored
     uint32_t pixel;          // Contact.pixelIndex
@@ -309,7 +311,7 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayStat
     r.work = w;
     r.inv = f3{ 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };   // INV_DIR_*, AABB.h:115-117
     sx = 0.0f > r.inv.x; sy = 0.0f > r.inv.y; sz = 0.0f > r.inv.z;
-    r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+    r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;      // rank 0 = nothing ranks before it: no tie update without a hit
     return true;
 }
 
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
 
     RayState r;
     r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 };
-    r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.work = 0; r.out_index = 0; r.pixel = 0;
+    r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u; r.work = 0; r.out_index = 0; r.pixel = 0;
     bool sx = false, sy = false, sz = false;
     uint32_t cur = RT_SENTINEL;       // node to visit: inner record index, RT_LEAF_FLAG|leaf, or sentinel
     uint32_t pending = NO_LEAF;       // parked leaf
@@ -572,8 +574,11 @@ __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t l
 // tie on t (the rule of the depth-first rank) is rare and sits behind a wave-uniform test
 __device__ __forceinline__ void leaf_test_masked(const TraceArgs& a, uint32_t leaf, RayState& r, bool reached)
 {
-    float4 v0 = ld_const4(a.v0 + leaf), E1 = ld_const4(a.e1 + leaf), E2 = ld_const4(a.e2 + leaf);
-    f3 vert0 = f3_from4(v0), edge1 = f3_from4(E1), edge2 = f3_from4(E2);
+    // the packed record through the scalar path: one address, twelve dwords
+    const float4* p = reinterpret_cast<const float4*>(a.trirec + leaf);
+    const float4 w0 = ld_const4(p), w1 = ld_const4(p + 1), w2 = ld_const4(p + 2);
+    const f3 vert0 = f3{ w0.x, w0.y, w0.z }, edge1 = f3{ w0.w, w1.x, w1.y }, edge2 = f3{ w1.z, w1.w, w2.x };
+    const uint32_t pos = __float_as_uint(w2.y);
     f3 pvec = f3_cross(r.d, edge2);
     float det = f3_dot(edge1, pvec);
     bool flag = reached & (fabsf(det) >= FLT_EPSILON);
@@ -588,13 +593,11 @@ __device__ __forceinline__ void leaf_test_masked(const TraceArgs& a, uint32_t le
     flag = flag & (v >= 0.0f);
     float t = f3_dot(edge2, qvec) * inv_det;
     flag = flag & (t > 0.0f);
-    const bool better = flag & (t < r.best_t);
-    const bool tie = flag & (t == r.best_t) & (r.best_leaf != NO_LEAF);
+    // lexicographic minimum of (t, depth-first rank): the strict `<` of BVH.h:392 in the reference's walk order
+    const bool better = flag & ((t < r.best_t) | ((t == r.best_t) & (pos < r.best_pos)));
     r.best_t = better ? t : r.best_t;
     r.best_leaf = better ? leaf : r.best_leaf;
-    if (__ballot(tie) != 0ull) {
-        if (tie && a.pos[leaf] < a.pos[r.best_leaf]) r.best_leaf = leaf;
-    }
+    r.best_pos = better ? pos : r.best_pos;
 }
 
 // Overflow areas of the packet stacks.  One wave per block means far more waves than areas, so a wave takes an area only
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
         const uint32_t w = (wave_gid << 6) + lane;
         RayState r;
         bool sx = false, sy = false, sz = false;
-        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;
         r.work = w; r.out_index = 0; r.pixel = 0;
         bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
         if (PRIMARY && a.compact && !ok && w < a.total_work) {
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
         const uint32_t w = (wave_gid << 6) + lane;
         RayState r;
         bool sx = false, sy = false, sz = false;
-        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;
         r.work = w; r.out_index = 0; r.pixel = 0;
         bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
         if (PRIMARY && a.compact && !ok && w < a.total_work) {
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
         const uint32_t w = (wave_gid << 6) + lane;
         RayState r;
         bool sx = false, sy = false, sz = false;
-        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF;
+        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;
         r.work = w; r.out_index = 0; r.pixel = 0;
         bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
         if (PRIMARY && a.compact && !ok && w < a.total_work) {
@@ -1379,7 +1382,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
     a.trav = t.trav; a.quad = t.search_root ? t.quad : nullptr; a.search_root = t.search_root; a.tree_select = t.tree_select;   // (launch_trace_primary switches to quad_cam)
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
-    a.pos = t.pos;
+    a.pos = t.pos; a.trirec = t.trirec;
     a.ctrl = (TraceCtrl*)t.ctrl;
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
