@@ -308,8 +308,9 @@ int  rt_ctx_trace_kernel_times(rt_ctx* ctx, uint64_t* launches, double* lane_pha
 /* diagnostic counters of the LAST traversal launch on this context (synchronises); out[k] for k < n:
  * 0 rays handed to the wave-per-ray kernel, 1 rays whose sub-trees were split between kernels, 2 stack overflow areas the
  * packet kernels took, 3 pool steps of the wave-per-ray kernel over all its records, 4 pool steps of its longest record,
- * 5 inner nodes it visited (3 to 5 are counted only with env RTMI_TRACE_DIAG=1: the counting perturbs that kernel's timing) */
-#define RT_TRACE_COUNTERS 6
+ * 5 inner nodes it visited (3 to 5 are counted only with env RTMI_TRACE_DIAG=1: the counting perturbs that kernel's timing),
+ * 6 8x8 blocks whose wave shared sub-trees with other waves (four-wide packet kernel with a step budget), 7 sub-tree tasks shared */
+#define RT_TRACE_COUNTERS 8
 int  rt_ctx_last_trace_counters(rt_ctx* ctx, uint32_t* out, uint32_t n);
 int  rt_timer_create(rt_ctx* ctx, void** timer);
 int  rt_timer_start(rt_ctx* ctx, void* timer);

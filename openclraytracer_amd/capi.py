@@ -190,9 +190,10 @@ class Context:
         self.check(self.lib.rt_ctx_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))
 
     def last_trace_counters(self) -> dict:
-        out = (C.c_uint32 * 6)()
-        self.check(self.lib.rt_ctx_last_trace_counters(self.h, out, 6))
-        return dict(zip(('deferred_rays', 'split_rays', 'spill_areas_taken', 'wave_per_ray_steps', 'wave_per_ray_steps_max', 'wave_per_ray_nodes'), list(out)))
+        out = (C.c_uint32 * 8)()
+        self.check(self.lib.rt_ctx_last_trace_counters(self.h, out, 8))
+        return dict(zip(('deferred_rays', 'split_rays', 'spill_areas_taken', 'wave_per_ray_steps', 'wave_per_ray_steps_max', 'wave_per_ray_nodes',
+                         'shared_blocks', 'shared_tasks'), list(out)))
 
     def trace_kernel_times(self) -> dict:
         n, a, b = C.c_uint64(), C.c_double(), C.c_double()

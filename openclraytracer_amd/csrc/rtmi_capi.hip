@@ -26,6 +26,8 @@ static void free_ctx_buffers(rt_ctx* ctx)
     if (ctx->d_long_list) (void)hipFree(ctx->d_long_list);
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
     if (ctx->d_split_list) (void)hipFree(ctx->d_split_list);
+    if (ctx->d_task_list) (void)hipFree(ctx->d_task_list);
+    ctx->d_task_list = nullptr;
     ctx->d_trace_ctrl = nullptr; ctx->d_long_list = nullptr; ctx->long_cap = 0;
     ctx->d_keys = nullptr; ctx->keys_cap = 0; ctx->d_split_list = nullptr;
 }
@@ -48,6 +50,11 @@ static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
         // test knob: what recycled device memory looks like
         if (ctx->poison & 1) RT_HIP(ctx, hipMemsetAsync(ctx->d_long_list, 0xCD, want * trace_long_record_bytes(), ctx->stream));
         if (ctx->poison & 2) RT_HIP(ctx, hipMemsetAsync(ctx->d_split_list, 0xCD, want * sizeof(uint32_t), ctx->stream));
+    }
+    if (!ctx->d_task_list && ctx->task_cap) {
+        // sub-tree tasks the waves of the four-wide packet kernel share (16 bytes each); a full queue only means less sharing
+        RT_HIP(ctx, hipMalloc((void**)&ctx->d_task_list, trace_task_bytes(ctx->task_cap)));
+        ctx->scratch_generation++;
     }
     if (work_items > ctx->keys_cap) {
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -127,6 +134,9 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
+    ctx->task_cap = 1u << 8;                      // per queue, 256 queues
+    if (const char* env = std::getenv("RTMI_TASK_CAP")) ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10);          // 0: no sharing
+    if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
     return RT_SUCCESS;
 }
@@ -565,6 +575,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;
     t.quad = b->d_quad; t.quad_cam = b->d_quad_cam;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
+    t.task_shards = b->ctx->d_task_list; t.task_cap = b->ctx->task_cap; t.task_helper_blocks = b->ctx->task_helper_blocks;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
     if (b->ctx->profiling) {
@@ -601,7 +612,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
         static const struct { bool packet; uint32_t budget; bool quad; } candidates[] = {
-            { true, 1u << 20, true },
+            { true, 1u << 20, true }, { true, 32u, true }, { true, 64u, true }, { true, 128u, true }, { true, 256u, true }, { true, 512u, true }, { true, 2048u, true },
             { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
             { false, 8u }, { false, 12u }, { false, 16u }, { false, 24u }, { false, 32u }, { false, 48u }, { false, 64u }, { false, 96u }, { false, 128u }, { false, 192u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
         hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -84,6 +84,8 @@ struct rt_ctx {
     unsigned long long* d_keys = nullptr;   // packet kernel: (t, position) keys of split rays, one per work item, grow-only
     uint64_t keys_cap = 0;
     uint32_t* d_split_list = nullptr;       // long_cap entries
+    void* d_task_list = nullptr;            // trace_task_bytes(task_cap): sub-tree tasks shared between the waves of k_trace_packet4
+    uint32_t task_cap = 0, task_helper_blocks = 0;
     uint64_t scratch_generation = 0;        // bumped whenever one of the three buffers above is reallocated (frame graphs hold their addresses)
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
@@ -248,14 +250,18 @@ struct TraceLaunch {
     uint32_t packet_spill_entries;
     uint32_t packet_spill_slots;  // areas behind the bitmap at the start of packet_spill
     int compute_units;
+    void* task_shards;            // k_trace_packet4: queues of sub-tree tasks shared between waves (trace_task_bytes(task_cap)), may be null
+    uint32_t task_cap;            // entries per queue
+    uint32_t task_helper_blocks;  // 0 = default
 };
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);
 size_t trace_ctrl_bytes();
+size_t trace_task_bytes(uint32_t cap_per_shard);
 size_t trace_ctrl_error_offset();
-void trace_ctrl_counter_offsets(size_t out[6]);
+void trace_ctrl_counter_offsets(size_t out[RT_TRACE_COUNTERS]);
 size_t trace_long_record_bytes();
 uint32_t trace_packet_stack_entries();
 uint32_t trace_lds_stack_entries();

@@ -46,6 +46,9 @@
 //  k_prepare_camera, per camera position: "camera inside child box" bits of every record and the camera-on-a-plane bits.
 #include "rtmi_internal.h"
 #include "device_math.h"
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
 
 #define TRACE_BLOCK 256u
 #define TRACE_WAVES (TRACE_BLOCK / 64u)
@@ -71,15 +74,18 @@ struct TraceCtrl {
     uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
     uint32_t spill_taken; uint32_t p4[31];   // packet kernels: overflow areas taken in this launch (diagnostic)
     uint32_t long_steps;  uint32_t long_steps_max; uint32_t long_nodes; uint32_t p5[29];   // wave-per-ray kernel: pool steps, all records / longest record (diagnostic)
+    uint32_t split_tiles; uint32_t shared_tasks; uint32_t p9[30];   // k_trace_packet4 with shared tasks: blocks whose contacts come out of the key buffer (entries of
+                                             // split_list); tasks published (diagnostic, written by the helper waves at the end)
     uint32_t error;       uint32_t p2[31];   // bit 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow, 3: packet stack
                                              // beyond its spill area, 4: bad deferred record, 5: no free spill area.  NOT zeroed per launch.
 };
-static_assert(sizeof(TraceCtrl) == (WORK_SHARDS + 5) * 128, "TraceCtrl layout");
-static_assert(offsetof(TraceCtrl, error) == (WORK_SHARDS + 4) * 128, "the error word follows everything a launch clears");
+static_assert(sizeof(TraceCtrl) == (WORK_SHARDS + 6) * 128, "TraceCtrl layout");
+static_assert(offsetof(TraceCtrl, error) == (WORK_SHARDS + 5) * 128, "the error word follows everything a launch clears");
 #define TRACE_FAIL(word, code) __hip_atomic_fetch_or((word), 1u << (code), RLX_AGENT)
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
-void trace_ctrl_counter_offsets(size_t out[6]) { out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
+void trace_ctrl_counter_offsets(size_t out[RT_TRACE_COUNTERS]) { out[6] = offsetof(TraceCtrl, split_tiles); out[7] = offsetof(TraceCtrl, shared_tasks);
+                                                  out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
                                                   out[3] = offsetof(TraceCtrl, long_steps); out[4] = offsetof(TraceCtrl, long_steps_max); out[5] = offsetof(TraceCtrl, long_nodes); }
 size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
 
@@ -87,6 +93,20 @@ size_t trace_long_record_bytes() { return LONG_REC_WORDS * sizeof(uint32_t); }
 enum { LR_WORK = 0, LR_CUR = 1, LR_SP = 2, LR_BEST_LEAF = 3, LR_BEST_T = 4, LR_EXTRA = 5, LR_PENDING = 6, LR_PARTIAL = 7, LR_STACK = 8 };
 #define KEY_NONE 0xFFFFFFFFFFFFFFFFull
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+// Sub-tree tasks shared between the waves of k_trace_packet4.  An operation on one address costs ~15 ns at the memory side
+// whoever issues it (32 400 waves bumping one counter: 0.5 ms), so the queue is TASK_SHARDS queues, each with its own line:
+// `published` (a publisher's fetch-add hands it a slot; slots at or beyond the capacity do not exist, the entry stays with its
+// publisher), `taken` (a taker's compare-and-swap, only ever up to min(published, capacity)), the `finished` word the helpers
+// leave on, and the shard's counters of finished block waves and tasks.  A publisher spreads its entries over the shards
+// (lane i: shard home + i), a finished block wave looks at one of them, a helper at two per round.
+// Entry = (block's first work item + 1 [0 = not yet written], node, mask low, mask high), written and read as 16 bytes.
+#define TASK_SHARDS 256u
+#define P4_DBG_JOBS 48u
+#define SHARE_MIN_STEPS 32u
+struct TaskShard { uint32_t taken; uint32_t published; uint32_t finished; uint32_t pad0; uint32_t waves_done; uint32_t tasks_done; uint32_t pad[26]; };
+static_assert(sizeof(TaskShard) == 128, "one line per shard");
+size_t trace_task_bytes(uint32_t cap_per_shard) { return TASK_SHARDS * (sizeof(TaskShard) + (size_t)cap_per_shard * 16u); }
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
@@ -116,6 +136,11 @@ struct TraceArgs {
     uint32_t packet_spill_slots;
     uint32_t long_batch;                   // experiment knob: rays per wave in the wave-per-ray kernel (0 = by count)
     uint32_t diagnostics;                  // count the wave-per-ray kernel's pool steps (perturbs its timing)
+    TaskShard* task_shards;                // k_trace_packet4 with shared tasks: TASK_SHARDS queues, then their entries
+    uint32_t task_cap;                     // entries per queue
+#if RTMI_P4_VARIANT == 3
+    unsigned long long* dbg;               // per wave P4_DBG_JOBS x (start, end, steps << 1 | is_task) on the 100 MHz clock
+#endif
     // primary rays
     rt_camera cam;
     uint32_t rank, nranks, tiles_x;
@@ -191,6 +216,20 @@ __device__ __forceinline__ bool child_valid_delta(float dlox, float dloy, float 
     return ((tnear <= tfar) & (tnear > 0.0f)) | inside_marked;
 }
 
+// ... as the mask of the wave's lanes that enter the box.  The two compares write their lane masks straight into scalar
+// registers and the rest is scalar arithmetic on 64-bit masks; as a per-lane bool the compiler turns every `__ballot` of it into
+// a select and a compare of its own (two vector instructions per slot and step).
+__device__ __forceinline__ uint64_t child_mask_delta(float dlox, float dloy, float dloz, float dhix, float dhiy, float dhiz, const RayState& r,
+                                                     bool inside_marked)
+{
+    const float ax = dlox * r.inv.x, bx = dhix * r.inv.x;
+    const float ay = dloy * r.inv.y, by = dhiy * r.inv.y;
+    const float az = dloz * r.inv.z, bz = dhiz * r.inv.z;
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return (__builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tnear > 0.0f)) | (inside_marked ? ~0ull : 0ull);
+}
+
 // a child of a BINARY record: the pure-VALU form on search-tree records (no NaN possible there, see above), the reference's
 // staged form on reference-tree records (where rays with a possible 0 * inf walk)
 template <int PRIMARY>
@@ -233,6 +272,13 @@ __global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const Qu
         uint32_t bits = 0;
         for (int k = 0; k < 4; k++) {
             float4& lo = q.q[2 * k]; float4& hi = q.q[2 * k + 1];
+            const uint32_t id = __float_as_uint(q.q[k].w);
+            if (id == RT_SENTINEL) {
+                // an unused slot: a box no ray enters (near = +-FLT_MAX / direction is never both positive and below far), so
+                // that the kernels need not look at the id before the test
+                lo.x = lo.y = lo.z = FLT_MAX; hi.x = hi.y = hi.z = -FLT_MAX;
+                continue;
+            }
             if ((lo.x <= ox) & (ox <= hi.x) & (lo.y <= oy) & (oy <= hi.y) & (lo.z <= oz) & (oz <= hi.z)) bits |= 1u << k;
             lo.x = lo.x - ox; lo.y = lo.y - oy; lo.z = lo.z - oz;
             hi.x = hi.x - ox; hi.y = hi.y - oy; hi.z = hi.z - oz;
@@ -544,6 +590,25 @@ __device__ __forceinline__ NodeRec ld_record(const TravNode* trav, uint32_t node
 #else
 #define PACKET_STACK 96u
 #endif
+#ifdef RTMI_TEST_PACKET_STACK
+#define PACKET_VSTACK 2u           // test twin: the lane-resident part of the four-wide kernel's stack overflows at once as well
+#else
+#define PACKET_VSTACK 64u          // k_trace_packet4: stack entries held in lanes of vector registers
+#endif
+// Three scalar values -> lane `l` of three vector registers (v_writelane_b32; the builtin is not exposed by this compiler).  The
+// lane select goes through M0 because a VOP3 instruction may read only one SGPR over the constant bus.  Synchronous: nothing is
+// in flight behind it; the s_nop covers the wait state between the write of M0 and its use as lane select.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"          // M0 is a reserved register: the clobber is a note to the reader
+__device__ __forceinline__ void lane_write3(uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t a, uint32_t b, uint32_t c, uint32_t l)
+{
+    // (uniform by construction; said again for the compiler, which cannot always tell and must put them in scalar registers)
+    a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a); b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c); l = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+    asm("s_mov_b32 m0, %6\n\ts_nop 1\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+        : "+v"(v0), "+v"(v1), "+v"(v2) : "s"(a), "s"(b), "s"(c), "s"(l) : "m0");
+}
+#pragma clang diagnostic pop
 #define PACKET_LOW_LANES 4u        // "a handful of lanes"
 #define PACKET_LOW_RUN 24u         // consecutive low-occupancy steps before the block sheds sub-trees
 
@@ -811,140 +876,80 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
 #ifndef RTMI_P4_VARIANT
 #define RTMI_P4_VARIANT 0
 #endif
-#if RTMI_P4_VARIANT == 2      // experiment: the steady-state kernel with cycle stamps per phase (tools/p4_time.py)
-template <int PRIMARY, int CAL>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
-{
-    __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
-    __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
-    __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
-    uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
-    uint32_t* spill = nullptr;                           // taken on the first overflow of the LDS stack
-    uint32_t spill_slot = 0xFFFFFFFFu;
-
-    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
-    // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
-    if ((wave_gid << 6) < a.total_work) {
-        const uint32_t w = (wave_gid << 6) + lane;
-        RayState r;
-        bool sx = false, sy = false, sz = false;
-        r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;
-        r.work = w; r.out_index = 0; r.pixel = 0;
-        bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
-        if (PRIMARY && a.compact && !ok && w < a.total_work) {
-            uint32_t x, y, slot;
-            work_to_pixel(a, w, x, y, slot);
-            float4* o = reinterpret_cast<float4*>(a.out + slot);
-            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-        uint32_t sp = 0;
-        // The four-wide records skip the boxes of a node's inner children, which is sound on the search tree only (the host
-        // launches this kernel only when there is one).  A ray that must walk the reference tree box by box (ray_root: a slab
-        // product could be 0 * inf -- the camera on a box plane and a zero direction component) is handed, whole, to the
-        // wave-per-ray kernel, which walks binary records.
-        const bool on_ref = ok && ray_root<PRIMARY>(a, r, plane_bits) == 0u;
-        const uint64_t m_ref = __ballot(on_ref);
-        if (m_ref != 0ull) {
-            uint32_t base = 0;
-            if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&a.ctrl->long_count, (uint32_t)__popcll(m_ref), RLX_AGENT);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (on_ref) {
-                const uint32_t idx = base + lane_rank(m_ref);
-                if (idx < a.long_cap) {
-                    uint32_t* rec = a.long_list + (uint64_t)idx * LONG_REC_WORDS;
-                    rec[LR_WORK] = w; rec[LR_CUR] = 0u; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
-                    rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF; rec[LR_PARTIAL] = 0u;
-                } else {
-                    TRACE_FAIL((gu32*)&a.ctrl->error, 1);          // nowhere to put the ray: frame invalid
-                }
-            }
-            ok = ok && !on_ref;                                                         // their contacts are written there
-        }
-        bool in = ok;
-        uint32_t node = a.search_root;
-        bool walking = __ballot(in) != 0ull;
-        unsigned long long tA = 0, tB = 0, tC = 0, tD = 0; uint32_t nsteps = 0;
-        while (walking) {
-            const unsigned long long T0 = __builtin_amdgcn_s_memtime();
-            nsteps++;
-            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
-            const float4* p = reinterpret_cast<const float4*>(a.quad + un);
-            const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
-            const float4 q4 = ld_const4(p + 4), q5 = ld_const4(p + 5), q6 = ld_const4(p + 6), q7 = ld_const4(p + 7);
-            const uint32_t id0 = __float_as_uint(q0.w), id1 = __float_as_uint(q1.w), id2 = __float_as_uint(q2.w), id3 = __float_as_uint(q3.w);
-            const uint32_t marks = __float_as_uint(q4.w);
-            asm volatile("" :: "s"(id0), "s"(id1), "s"(id2), "s"(id3), "s"(marks), "s"(q7.x), "s"(q5.x), "s"(q3.x), "s"(q1.x));
-            const unsigned long long T1 = __builtin_amdgcn_s_memtime();
-            bool v0 = false, v1 = false, v2 = false, v3 = false;
-            if (in) {
-                v0 = child_valid_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u);
-                v1 = child_valid_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u);
-                v2 = (id2 != RT_SENTINEL) && child_valid_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u);
-                v3 = (id3 != RT_SENTINEL) && child_valid_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u);
-            }
-            uint64_t m[4] = { __ballot(v0), __ballot(v1), __ballot(v2), __ballot(v3) };
-            const uint32_t ids[4] = { id0, id1, id2, id3 };
-            asm volatile("" :: "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]));
-            const unsigned long long T2 = __builtin_amdgcn_s_memtime();
-            // leaves are tested on the spot by the lanes that reached them
-            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) { if (v0) leaf_test_uniform(a, id0 & ~RT_LEAF_FLAG, r); } m[0] = 0ull; }
-            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) { if (v1) leaf_test_uniform(a, id1 & ~RT_LEAF_FLAG, r); } m[1] = 0ull; }
-            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) { if (v2) leaf_test_uniform(a, id2 & ~RT_LEAF_FLAG, r); } m[2] = 0ull; }
-            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) { if (v3) leaf_test_uniform(a, id3 & ~RT_LEAF_FLAG, r); } m[3] = 0ull; }
-            asm volatile("" :: "v"(r.best_t), "v"(r.best_leaf));
-            const unsigned long long T3 = __builtin_amdgcn_s_memtime();
-            // the first wanted inner child is walked next, the others wait on the stack with their lanes
-            int first = -1;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (m[k] == 0ull) continue;
-                if (first < 0) { first = k; continue; }
-                if (sp < PACKET_STACK) {
-                    if (lane == 0) { st_node[sp] = ids[k]; st_lo[sp] = (uint32_t)m[k]; st_hi[sp] = (uint32_t)(m[k] >> 32); }
-                } else if (a.packet_spill && sp - PACKET_STACK < a.packet_spill_entries && (spill || (spill = spill_acquire(a, wave_gid, lane, spill_slot)))) {
-                    if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
-                } else {
-                    if (lane == 0) TRACE_FAIL((gu32*)&a.ctrl->error, 3);     // frame invalid
-                }
-                sp++;
-            }
-            if (first >= 0) {
-                node = ids[first];
-                in = ((m[first] >> lane) & 1ull) != 0ull;
-            } else if (sp == 0u) walking = false;
-            else {
-                sp--;
-                uint32_t nn, lo, hi;
-                if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
-                else if (spill) { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
-                        else { nn = 0u; lo = 0u; hi = 0u; }                  // the push failed (error word set): an entry nobody wants
-                node = nn;
-                in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
-            }
-            asm volatile("" :: "v"(node), "v"(in ? 1 : 0));
-            const unsigned long long T4 = __builtin_amdgcn_s_memtime();
-            tA += T1 - T0; tB += T2 - T1; tC += T3 - T2; tD += T4 - T3;
-        }
-        if (lane == 0) {
-            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_steps, (uint32_t)(tA >> 6), RLX_AGENT);
-            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_steps_max, (uint32_t)(tB >> 6), RLX_AGENT);
-            __hip_atomic_fetch_add((gu32*)&a.ctrl->long_nodes, (uint32_t)(tC >> 6), RLX_AGENT);
-            __hip_atomic_fetch_add((gu32*)&a.ctrl->spill_taken, (uint32_t)(tD >> 6), RLX_AGENT);
-            __hip_atomic_fetch_add((gu32*)&a.ctrl->split_count, nsteps, RLX_AGENT);
-        }
-        if (ok) store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
-
-    }
-    spill_release(a, lane, spill_slot);
-}
-
+// -DRTMI_P4_VARIANT=2: cycle stamps (s_memtime) around the four phases of a wave step, summed per launch in units of 64 cycles
+// into ctrl->long_steps (record wait), long_steps_max (box tests + ballots), long_nodes (leaf tests), spill_taken (stack / next
+// node), split_count (steps); read with tools/p4_time.py, the stamps and the atomics slow the kernel down (x 3).
+// -DRTMI_P4_VARIANT=3: (start, end, steps) per wave on the 100 MHz clock all XCDs share, written to the key buffer and from
+// there to the file RTMI_P4_WAVES names (tools/p4_timeline.py): no atomics, the launch takes what it takes without them.
+#if RTMI_P4_VARIANT == 2
+#define P4_STAMP(T) const unsigned long long T = __builtin_amdgcn_s_memtime()
+#define P4_KEEP(...) asm volatile("" :: __VA_ARGS__)
+#define P4_PIN(x) asm volatile("" : "+v"(x))          // what follows and uses x stays behind the stamp before it
 #else
-template <int PRIMARY, int CAL>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
+#define P4_STAMP(T)
+#define P4_KEEP(...)
+#define P4_PIN(x)
+#endif
+// SHARE = 1: a wave that has walked `defer_budget` steps and still has sub-trees waiting publishes its whole stack as TASKS
+// (block, node, lane mask) that any wave may take: waves that have finished their own block look at the task queues before
+// they exit, and helper waves at the end of the grid -- no block of their own -- keep taking tasks until nothing is running any
+// more.  A frame's time was the time of its slowest wave (ManFigure: 633 steps against a mean of 51, Tenryuu 1 979 against 23,
+// atrium 12 544 against 473; -DRTMI_P4_VARIANT=3), not the work divided by the machine.
+// The reference walks every sub-tree a ray's boxes admit, whatever was hit before (BVH.h:343-389), so sub-trees are
+// independent: the parts of a shared block meet in the 64-bit atomic minimum on (t bits, depth-first position) that the split
+// rays of the other kernels use, and the helpers write those blocks' contacts once everything has finished.
+//   * progress: block waves never wait (they take a task only if one is there); helpers wait, but they are far fewer than the
+//     machine's wave slots, so every block wave is dispatched whatever the helpers do;
+//   * exit: the first helper wave only watches: finished block waves == all of them and tasks finished == tasks published,
+//     the three sums over the shards read in that order, each complete before the next starts.  The counters only grow, so
+//     equality means that at the end of the second read nothing was running, and only running waves publish.  It then raises
+//     the `finished` word of every shard, which the other helpers read together with the queue word they are polling.  Every
+//     wave reaches its exit;
+//   * visibility: everything another wave reads during the launch (entries, keys, split list, counters) is written with
+//     device-scope atomic stores / read with device-scope atomic loads, and a wave waits for its stores (vmcnt) before it
+//     writes an entry's valid mark or bumps a finishing counter.  No cache-wide invalidate or write-back is involved: fences
+//     at device scope cost every wave on the XCD its L2 contents (measured: a frame 2 000 times slower);
+//   * registers: what the steps of the walk need of the kernel arguments (records, triangles, budget) stays in scalar
+//     registers; everything else is read again from the kernel-argument segment where it is used (rare_args), otherwise the
+//     arguments of the rare paths stay live across the walk and the kernel spills.
+// One 16-byte access at device scope (the sc1 bit the compiler puts on its device-scope atomic loads and stores; it has no
+// 16-byte atomic type).  An aligned 16-byte access is one request to one cache line, so an entry is seen whole or not at all.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_device(uint32_t* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+    u32x4 v = { x, y, z, w };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 load16_device(const uint32_t* p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }   // s_waitcnt vmcnt(0)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+// the kernel's (only) argument, read from the kernel-argument segment at the point of use: the pointer is made opaque so that
+// the loads can neither be merged with earlier ones nor be moved out of the rarely executed block they stand in
+// (SITE makes the statements differ: identical ones in different branches get merged behind a select of their inputs, which is
+// no longer a scalar value as far as the compiler can tell)
+template <int SITE>
+__device__ __forceinline__ const TraceArgs& rare_args()
+{
+    const TraceArgs* p = (const TraceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; kernel arguments, site %1" : "+s"(p) : "n"(SITE));
+    return *p;
+}
+
+#ifndef P4_WANT_WORD
+#define P4_WANT_WORD 0
+#endif
+template <int PRIMARY, int CAL, int SHARE>
+__global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 {
     __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
     __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
@@ -955,105 +960,378 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet4(TraceArgs a)
     uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
     uint32_t* spill = nullptr;                           // taken on the first overflow of the LDS stack
     uint32_t spill_slot = 0xFFFFFFFFu;
+    // The first PACKET_VSTACK entries of the (node, lane mask) stack live in LANES of three vector registers: entry i = lane i.
+    // A push is three v_writelane (scalar value -> lane sp), a pop three v_readlane straight into scalar registers: no LDS
+    // round trip, no single-lane region around the writes, no v_readfirstlane -- and a wave that shares its stack writes it out
+    // with one store per lane.  Deeper entries go to LDS and then to the global overflow areas as before.
+    uint32_t vs_node = 0u, vs_lo = 0u, vs_hi = 0u;
 
-    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
+#if RTMI_P4_VARIANT == 3
+    const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every XCD
+#endif
+    // the arguments the steps of the walk use (see `registers` above)
+    const QuadNode* const quad = a.quad;
+    const uint32_t budget = a.defer_budget;
+    const uint32_t n_block_waves = (a.total_work + 63u) >> 6;
+    const bool helper = wave_gid >= n_block_waves;       // SHARE only: the grid ends with waves that have no block of their own
     // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
-    if ((wave_gid << 6) < a.total_work) {
-        const uint32_t w = (wave_gid << 6) + lane;
+    uint32_t job_w0 = wave_gid << 6, job_node = 0u;
+    unsigned long long job_mask = 0ull;
+    bool is_task = false, have = !helper;
+#if RTMI_P4_VARIANT == 3
+    uint32_t dbg_jobs = 0;
+#endif
+    for (;;) {
+    if (have) {
+#if RTMI_P4_VARIANT == 3
+        const unsigned long long job_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        const uint32_t w = job_w0 + lane;
         RayState r;
-        bool sx = false, sy = false, sz = false;
         r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;
         r.work = w; r.out_index = 0; r.pixel = 0;
-        bool ok = w < a.total_work && load_ray<PRIMARY>(a, w, r, sx, sy, sz);
-        if (PRIMARY && a.compact && !ok && w < a.total_work) {
-            uint32_t x, y, slot;
-            work_to_pixel(a, w, x, y, slot);
-            float4* o = reinterpret_cast<float4*>(a.out + slot);
-            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        bool ok;
+        uint64_t in;                                     // the lanes that walk the current node
+        uint32_t node;
+        bool split = SHARE && is_task;                   // results go to the key buffer
+        {
+            const TraceArgs& A = rare_args<1>();
+            bool sx = false, sy = false, sz = false;
+            ok = w < A.total_work && load_ray<PRIMARY>(A, w, r, sx, sy, sz);
+            if (!SHARE || !is_task) {
+                if (PRIMARY && A.compact && !ok && w < A.total_work) {
+                    uint32_t x, y, slot;
+                    work_to_pixel(A, w, x, y, slot);
+                    float4* o = reinterpret_cast<float4*>(A.out + slot);
+                    o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                // The four-wide records skip the boxes of a node's inner children, which is sound on the search tree only (the
+                // host launches this kernel only when there is one).  A ray that must walk the reference tree box by box
+                // (ray_root: a slab product could be 0 * inf -- the camera on a box plane and a zero direction component) is
+                // handed, whole, to the wave-per-ray kernel, which walks binary records.
+                const uint32_t plane_bits = (PRIMARY && A.search_root != 0u) ? *A.tree_select : 0u;
+                const bool on_ref = ok && ray_root<PRIMARY>(A, r, plane_bits) == 0u;
+                const uint64_t m_ref = __ballot(on_ref);
+                if (m_ref != 0ull) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&A.ctrl->long_count, (uint32_t)__popcll(m_ref), RLX_AGENT);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (on_ref) {
+                        const uint32_t idx = base + lane_rank(m_ref);
+                        if (idx < A.long_cap) {
+                            uint32_t* rec = A.long_list + (uint64_t)idx * LONG_REC_WORDS;
+                            rec[LR_WORK] = w; rec[LR_CUR] = 0u; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
+                            rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF; rec[LR_PARTIAL] = 0u;
+                        } else {
+                            TRACE_FAIL((gu32*)&A.ctrl->error, 1);          // nowhere to put the ray: frame invalid
+                        }
+                    }
+                    ok = ok && !on_ref;                                                         // their contacts are written there
+                }
+                in = __builtin_amdgcn_ballot_w64(ok);
+                node = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.search_root);
+            } else {
+                in = job_mask;
+                node = job_node;
+            }
         }
-        uint32_t sp = 0;
-        // The four-wide records skip the boxes of a node's inner children, which is sound on the search tree only (the host
-        // launches this kernel only when there is one).  A ray that must walk the reference tree box by box (ray_root: a slab
-        // product could be 0 * inf -- the camera on a box plane and a zero direction component) is handed, whole, to the
-        // wave-per-ray kernel, which walks binary records.
-        const bool on_ref = ok && ray_root<PRIMARY>(a, r, plane_bits) == 0u;
-        const uint64_t m_ref = __ballot(on_ref);
-        if (m_ref != 0ull) {
-            uint32_t base = 0;
-            if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&a.ctrl->long_count, (uint32_t)__popcll(m_ref), RLX_AGENT);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (on_ref) {
-                const uint32_t idx = base + lane_rank(m_ref);
-                if (idx < a.long_cap) {
-                    uint32_t* rec = a.long_list + (uint64_t)idx * LONG_REC_WORDS;
-                    rec[LR_WORK] = w; rec[LR_CUR] = 0u; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
-                    rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF; rec[LR_PARTIAL] = 0u;
-                } else {
-                    TRACE_FAIL((gu32*)&a.ctrl->error, 1);          // nowhere to put the ray: frame invalid
+        // steps until the next sharing: the first time after `defer_budget` steps, then after half as many, ... down to
+        // SHARE_MIN_STEPS; a task starts at half.  Only waves that run long come to share eagerly, and towards the end of a
+        // launch only such waves are left -- which is when other waves have nothing to do
+        uint32_t sp = 0, steps = 0, share_after = (SHARE && is_task) ? (budget >> 1 > SHARE_MIN_STEPS ? budget >> 1 : SHARE_MIN_STEPS) : budget;
+        bool walking = in != 0ull;
+#if RTMI_P4_VARIANT == 2
+        unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+#endif
+#if RTMI_P4_VARIANT >= 2
+        uint32_t nsteps = 0;
+#endif
+        while (walking) {
+            P4_STAMP(T0);
+            if (SHARE && ++steps > share_after) {
+                steps = 0;
+                share_after = share_after >> 1 > SHARE_MIN_STEPS ? share_after >> 1 : SHARE_MIN_STEPS;
+                if (sp != 0u && sp <= PACKET_VSTACK) {
+                    // the whole stack becomes tasks: lane i holds entry i and offers it to shard home + i
+                    // (values read through A come back in vector registers: what decides wave-uniform state is made scalar again)
+                    const TraceArgs& A = rare_args<2>();
+                    const uint32_t long_cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.long_cap);
+                    const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.task_cap);
+                    bool can = true;
+                    const bool first_share = !split;
+                    if (!split) {
+                        uint32_t si = 0;
+                        if (lane == 0) si = __hip_atomic_fetch_add((gu32*)&A.ctrl->split_tiles, 1u, RLX_AGENT);
+                        si = (uint32_t)__builtin_amdgcn_readfirstlane((int)si);
+                        if (si < long_cap) {
+                            if (lane == 0) __hip_atomic_store((gu32*)(A.split_list + si), job_w0, RLX_AGENT);
+                            if (w < A.total_work) __hip_atomic_store((gu64*)A.keys + w, KEY_NONE, RLX_AGENT);
+                            split = true;
+                        } else can = false;                           // no slot in the list of shared blocks: this one stays whole
+                    }
+                    if (can) {
+                        const bool mine = lane < sp;
+                        const uint32_t shard = (wave_gid + lane) & (TASK_SHARDS - 1u);
+                        uint32_t slot = 0xFFFFFFFFu;
+                        if (mine) {
+                            slot = __hip_atomic_fetch_add((gu32*)&A.task_shards[shard].published, 1u, RLX_AGENT);
+                            if (slot >= cap) slot = 0xFFFFFFFFu;          // this queue is full: the entry stays here
+                        }
+                        const bool sent = mine && slot != 0xFFFFFFFFu;
+                        uint32_t* e = reinterpret_cast<uint32_t*>(A.task_shards + TASK_SHARDS) + ((uint64_t)shard * cap + (sent ? slot : 0u)) * 4u;
+                        // keys and split-list slot of a block shared for the first time must be there before its first task is
+                        if (first_share) stores_done();
+                        // one 16-byte store per entry (word 0, the block's first work item + 1, marks it written; the taker reads
+                        // the entry with one 16-byte load)
+                        if (sent) store16_device(e, job_w0 + 1u, vs_node, vs_lo, vs_hi);
+                        // entries that found their queue full move down (through the LDS part of the stack, empty here)
+                        const uint64_t mk = __ballot(mine && !sent);
+                        if (mk != 0ull) {
+                            if (mine && !sent) { const uint32_t k = lane_rank(mk); st_node[k] = vs_node; st_lo[k] = vs_lo; st_hi[k] = vs_hi; }
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < (uint32_t)__popcll(mk)) { vs_node = st_node[lane]; vs_lo = st_lo[lane]; vs_hi = st_hi[lane]; }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        sp = (uint32_t)__popcll(mk);
+                    }
                 }
             }
-            ok = ok && !on_ref;                                                         // their contacts are written there
-        }
-        bool in = ok;
-        uint32_t node = a.search_root;
-        bool walking = __ballot(in) != 0ull;
-        while (walking) {
             const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
-            const float4* p = reinterpret_cast<const float4*>(a.quad + un);
+            const float4* p = reinterpret_cast<const float4*>(quad + un);
             const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
             const float4 q4 = ld_const4(p + 4), q5 = ld_const4(p + 5), q6 = ld_const4(p + 6), q7 = ld_const4(p + 7);
             const uint32_t id0 = __float_as_uint(q0.w), id1 = __float_as_uint(q1.w), id2 = __float_as_uint(q2.w), id3 = __float_as_uint(q3.w);
             const uint32_t marks = __float_as_uint(q4.w);
-            // all 64 lanes evaluate all four boxes (a vector instruction costs the same for one lane as for 64; a divergent `if (in)`
+            P4_KEEP("s"(id0), "s"(id1), "s"(id2), "s"(id3), "s"(marks), "s"(q7.x), "s"(q5.x), "s"(q3.x), "s"(q1.x));
+            P4_STAMP(T1);
+            P4_PIN(r.inv.x);
+            // all 64 lanes evaluate all four boxes (a vector instruction costs the same for one lane as for 64; a divergent `if`
             // costs an exec-mask region, i.e. scalar instructions and a branch): lanes that do not take part are masked afterwards
-            const bool v0 = in & child_valid_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u);
-            const bool v1 = in & child_valid_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u);
-            const bool v2 = in & (id2 != RT_SENTINEL) & child_valid_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u);
-            const bool v3 = in & (id3 != RT_SENTINEL) & child_valid_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u);
-            uint64_t m[4] = { __ballot(v0), __ballot(v1), __ballot(v2), __ballot(v3) };
+            // (an unused slot's camera-relative box is empty and unmarked, k_prepare_camera: no test of its id here)
+            uint64_t m[4] = { in & child_mask_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u),
+                              in & child_mask_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u),
+                              in & child_mask_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u),
+                              in & child_mask_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u) };
             const uint32_t ids[4] = { id0, id1, id2, id3 };
+            P4_KEEP("s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]));
+            P4_STAMP(T2);
             // leaves are tested on the spot by the lanes that reached them
-            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) leaf_test_masked(a, id0 & ~RT_LEAF_FLAG, r, v0); m[0] = 0ull; }
-            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) leaf_test_masked(a, id1 & ~RT_LEAF_FLAG, r, v1); m[1] = 0ull; }
-            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) leaf_test_masked(a, id2 & ~RT_LEAF_FLAG, r, v2); m[2] = 0ull; }
-            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) leaf_test_masked(a, id3 & ~RT_LEAF_FLAG, r, v3); m[3] = 0ull; }
+            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) leaf_test_masked(a, id0 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[0])); m[0] = 0ull; }
+            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) leaf_test_masked(a, id1 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[1])); m[1] = 0ull; }
+            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) leaf_test_masked(a, id2 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[2])); m[2] = 0ull; }
+            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) leaf_test_masked(a, id3 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[3])); m[3] = 0ull; }
+            P4_KEEP("v"(r.best_t), "v"(r.best_leaf), "v"(r.best_pos));
+            P4_STAMP(T3);
+#if P4_WANT_WORD
+            // the first wanted inner child is walked next, the others wait on the stack with their lanes (one bit per slot in a
+            // scalar word: the choice and the pushes are then a find-first-bit and three tests of that word)
+            const uint32_t want = (m[0] != 0ull ? 1u : 0u) | (m[1] != 0ull ? 2u : 0u) | (m[2] != 0ull ? 4u : 0u) | (m[3] != 0ull ? 8u : 0u);
+            const uint32_t rest = want & (want - 1u);
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                if ((rest & (1u << k)) == 0u) continue;
+                if (sp < PACKET_VSTACK) {
+                    lane_write3(vs_node, vs_lo, vs_hi, ids[k], (uint32_t)m[k], (uint32_t)(m[k] >> 32), sp);
+                } else {
+                    const uint32_t ls = sp - PACKET_VSTACK;
+                    if (ls < PACKET_STACK) {
+                        if (lane == 0) { st_node[ls] = ids[k]; st_lo[ls] = (uint32_t)m[k]; st_hi[ls] = (uint32_t)(m[k] >> 32); }
+                    } else {
+                        const TraceArgs& A = rare_args<3>();
+                        if (A.packet_spill && ls - PACKET_STACK < A.packet_spill_entries && (spill || (spill = spill_acquire(A, wave_gid, lane, spill_slot)))) {
+                            if (lane == 0) { uint32_t* e = spill + (uint64_t)(ls - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
+                        } else {
+                            if (lane == 0) TRACE_FAIL((gu32*)&A.ctrl->error, 3);     // frame invalid
+                        }
+                    }
+                }
+                sp++;
+            }
+            if (want != 0u) {
+                node = (want & 1u) ? id0 : (want & 2u) ? id1 : (want & 4u) ? id2 : id3;
+                in = (want & 1u) ? m[0] : (want & 2u) ? m[1] : (want & 4u) ? m[2] : m[3];
+#else
             // the first wanted inner child is walked next, the others wait on the stack with their lanes
             int first = -1;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (m[k] == 0ull) continue;
                 if (first < 0) { first = k; continue; }
-                if (sp < PACKET_STACK) {
-                    if (lane == 0) { st_node[sp] = ids[k]; st_lo[sp] = (uint32_t)m[k]; st_hi[sp] = (uint32_t)(m[k] >> 32); }
-                } else if (a.packet_spill && sp - PACKET_STACK < a.packet_spill_entries && (spill || (spill = spill_acquire(a, wave_gid, lane, spill_slot)))) {
-                    if (lane == 0) { uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
+                if (sp < PACKET_VSTACK) {
+                    lane_write3(vs_node, vs_lo, vs_hi, ids[k], (uint32_t)m[k], (uint32_t)(m[k] >> 32), sp);
                 } else {
-                    if (lane == 0) TRACE_FAIL((gu32*)&a.ctrl->error, 3);     // frame invalid
+                    const uint32_t ls = sp - PACKET_VSTACK;
+                    if (ls < PACKET_STACK) {
+                        if (lane == 0) { st_node[ls] = ids[k]; st_lo[ls] = (uint32_t)m[k]; st_hi[ls] = (uint32_t)(m[k] >> 32); }
+                    } else {
+                        const TraceArgs& A = rare_args<7>();
+                        if (A.packet_spill && ls - PACKET_STACK < A.packet_spill_entries && (spill || (spill = spill_acquire(A, wave_gid, lane, spill_slot)))) {
+                            if (lane == 0) { uint32_t* e = spill + (uint64_t)(ls - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
+                        } else {
+                            if (lane == 0) TRACE_FAIL((gu32*)&A.ctrl->error, 3);     // frame invalid
+                        }
+                    }
                 }
                 sp++;
             }
             if (first >= 0) {
                 node = ids[first];
-                in = ((m[first] >> lane) & 1ull) != 0ull;
+                in = m[first];
+#endif
             } else if (sp == 0u) walking = false;
             else {
                 sp--;
                 uint32_t nn, lo, hi;
-                if (sp < PACKET_STACK) { nn = st_node[sp]; lo = st_lo[sp]; hi = st_hi[sp]; }
-                else if (spill) { const uint32_t* e = spill + (uint64_t)(sp - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
-                        else { nn = 0u; lo = 0u; hi = 0u; }                  // the push failed (error word set): an entry nobody wants
+                if (sp < PACKET_VSTACK) {
+                    nn = (uint32_t)__builtin_amdgcn_readlane((int)vs_node, (int)sp);
+                    lo = (uint32_t)__builtin_amdgcn_readlane((int)vs_lo, (int)sp);
+                    hi = (uint32_t)__builtin_amdgcn_readlane((int)vs_hi, (int)sp);
+                } else {
+                    const uint32_t ls = sp - PACKET_VSTACK;
+                    if (ls < PACKET_STACK) { nn = st_node[ls]; lo = st_lo[ls]; hi = st_hi[ls]; }
+                    else if (spill) { const uint32_t* e = spill + (uint64_t)(ls - PACKET_STACK) * 3u; nn = e[0]; lo = e[1]; hi = e[2]; }
+                    else { nn = 0u; lo = 0u; hi = 0u; }                  // the push failed (error word set): an entry nobody wants
+                    nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)nn);
+                    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+                    hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+                }
                 node = nn;
-                in = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+                in = ((unsigned long long)hi << 32) | lo;
+            }
+#if RTMI_P4_VARIANT == 2
+            P4_KEEP("s"(node), "s"(in));
+            P4_STAMP(T4);
+            tA += T1 - T0; tB += T2 - T1; tC += T3 - T2; tD += T4 - T3;
+#endif
+#if RTMI_P4_VARIANT >= 2
+            nsteps++;
+#endif
+        }
+        const TraceArgs& A = rare_args<4>();
+#if RTMI_P4_VARIANT == 2
+        if (lane == 0) {
+            __hip_atomic_fetch_add((gu32*)&A.ctrl->long_steps, (uint32_t)(tA >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&A.ctrl->long_steps_max, (uint32_t)(tB >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&A.ctrl->long_nodes, (uint32_t)(tC >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&A.ctrl->spill_taken, (uint32_t)(tD >> 6), RLX_AGENT);
+            __hip_atomic_fetch_add((gu32*)&A.ctrl->split_count, nsteps, RLX_AGENT);
+        }
+#elif RTMI_P4_VARIANT == 3
+        if (lane == 0 && !SHARE) { A.keys[3u * wave_gid] = wave_t0; A.keys[3u * wave_gid + 1u] = __builtin_amdgcn_s_memrealtime(); A.keys[3u * wave_gid + 2u] = nsteps; }
+        if (lane == 0 && SHARE && A.dbg) {
+            unsigned long long* d = A.dbg + ((uint64_t)wave_gid * P4_DBG_JOBS + (dbg_jobs < P4_DBG_JOBS - 1u ? dbg_jobs : P4_DBG_JOBS - 1u)) * 3u;
+            d[0] = dbg_jobs == 0u ? wave_t0 : job_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = ((unsigned long long)nsteps << 1) | (is_task ? 1u : 0u);
+        }
+        dbg_jobs++;
+#endif
+        if (!split) {
+            if (ok) store_contact(A, r.out_index, r.pixel, r.best_t, r.best_leaf);
+        } else if (r.best_leaf != NO_LEAF) {
+            __hip_atomic_fetch_min((gu64*)A.keys + w, ((unsigned long long)__float_as_uint(r.best_t) << 32) | r.best_pos, RLX_AGENT);
+        }
+        if (SHARE) {
+            // the helpers read keys and the split list after they have seen these counters
+            if (split) stores_done();
+            TaskShard* mine = A.task_shards + (wave_gid & (TASK_SHARDS - 1u));
+            if (lane == 0) __hip_atomic_fetch_add((gu32*)(is_task ? &mine->tasks_done : &mine->waves_done), 1u, RLX_AGENT);
+        }
+    }
+    if (!SHARE) break;
+    // ---------------- the next job: a task, if one is there (helpers wait for one until nothing is running) ----------------
+    const TraceArgs& A = rare_args<5>();
+    TaskShard* const shards = A.task_shards;
+    uint32_t got_shard = 0xFFFFFFFFu, got_slot = 0u;
+    if (helper && wave_gid == n_block_waves) {
+        // the watching wave: lane l reads shards l, l + 64, ...
+        const uint32_t cap = A.task_cap;
+        for (;;) {
+            uint32_t wd = 0, td = 0, pub = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < TASK_SHARDS / 64u; k++) wd += __hip_atomic_load((gu32*)&shards[lane + 64u * k].waves_done, RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wd) :: "memory");
+#pragma unroll
+            for (uint32_t k = 0; k < TASK_SHARDS / 64u; k++) td += __hip_atomic_load((gu32*)&shards[lane + 64u * k].tasks_done, RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(td) :: "memory");
+#pragma unroll
+            for (uint32_t k = 0; k < TASK_SHARDS / 64u; k++) { const uint32_t c = __hip_atomic_load((gu32*)&shards[lane + 64u * k].published, RLX_AGENT); pub += c < cap ? c : cap; }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pub) :: "memory");
+            const uint32_t published = wave_sum(pub);
+            if (wave_sum(wd) == n_block_waves && wave_sum(td) == published) {
+                if (lane == 0) A.ctrl->shared_tasks = published;          // diagnostic
+#pragma unroll
+                for (uint32_t k = 0; k < TASK_SHARDS / 64u; k++) __hip_atomic_store((gu32*)&shards[lane + 64u * k].finished, 1u, RLX_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    } else {
+        for (uint32_t round = 0;; round++) {
+            // a block wave looks at ONE shard (a device-scope load of one address costs ~60 ns at the memory side whoever issues
+            // it: eight shards per wave were 0.25 ms per frame), a helper at two per round, all the shards in turn; helpers read
+            // the shard's `finished` word along with it
+            const uint32_t look = helper ? (wave_gid * 2u + 2u * round + lane) & (TASK_SHARDS - 1u) : (wave_gid * 7u + round) & (TASK_SHARDS - 1u);
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < (helper ? 2u : 1u)) {
+                const u32x4 v = load16_device(&shards[look].taken);
+                const uint32_t cap = A.task_cap;
+                q = make_uint4(v.x, v.y < cap ? v.y : cap, v.z, 0u);
+            }
+            const uint64_t avail = __ballot(q.x < q.y);
+            if (avail != 0ull) {
+                const uint32_t pick = (uint32_t)__builtin_ctzll(avail);
+                uint32_t ok_slot = 0xFFFFFFFFu;
+                if (lane == pick) {
+                    uint32_t expect = q.x;
+                    if (__hip_atomic_compare_exchange_strong((gu32*)&shards[look].taken, &expect, q.x + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        ok_slot = q.x;
+                }
+                ok_slot = (uint32_t)__builtin_amdgcn_readlane((int)ok_slot, (int)pick);
+                if (ok_slot != 0xFFFFFFFFu) { got_shard = (uint32_t)__builtin_amdgcn_readlane((int)look, (int)pick); got_slot = ok_slot; break; }
+                if (!helper && round >= 3u) break;            // lost the race a few times: others are on it
+                // lost the race: do not come back at once with everybody else who lost it
+                __builtin_amdgcn_s_sleep(8);
+                if ((wave_gid + round) & 1u) __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            if (!helper) break;
+            if (__ballot(q.z != 0u) != 0ull) break;           // the watching wave has seen everything finished
+            __builtin_amdgcn_s_sleep(96);
+        }
+    }
+    if (got_shard == 0xFFFFFFFFu) break;
+    {
+        // the publisher reserved the entry before it wrote it: wait for the valid mark (a few instructions away)
+        const uint32_t* e = reinterpret_cast<const uint32_t*>(shards + TASK_SHARDS) + ((uint64_t)got_shard * A.task_cap + got_slot) * 4u;
+        u32x4 t;
+        do { t = load16_device(e); } while (t.x == 0u);
+        job_w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.x) - 1u;
+        job_node = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y);
+        job_mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)t.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)t.z);
+        is_task = true; have = true;
+    }
+    }
+    const TraceArgs& A = SHARE ? rare_args<6>() : a;          // (without sharing only the overflow bitmap is read here)
+    if (SHARE && helper) {
+        // everything has finished: the shared blocks' contacts come out of the key buffer
+        uint32_t n_split = __hip_atomic_load((gu32*)&A.ctrl->split_tiles, RLX_AGENT);
+        if (n_split > A.long_cap) n_split = A.long_cap;
+        const uint32_t n_helpers = gridDim.x * TRACE_WAVES - n_block_waves;
+        const uint32_t plane_bits = (PRIMARY && A.search_root != 0u) ? *A.tree_select : 0u;
+        for (uint32_t i = wave_gid - n_block_waves; i < n_split; i += n_helpers) {
+            const uint32_t w = __hip_atomic_load((gu32*)(A.split_list + i), RLX_AGENT) + lane;
+            RayState r;
+            bool sx, sy, sz;
+            r.out_index = 0; r.pixel = 0;
+            if (w < A.total_work && load_ray<PRIMARY>(A, w, r, sx, sy, sz) && ray_root<PRIMARY>(A, r, plane_bits) != 0u) {
+                const unsigned long long key = __hip_atomic_load((gu64*)A.keys + w, RLX_AGENT);
+                const bool hit = key != KEY_NONE;
+                store_contact(A, r.out_index, r.pixel, hit ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX, hit ? A.pairs[(uint32_t)key].y : NO_LEAF);
             }
         }
-        if (ok) store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
-
     }
-    spill_release(a, lane, spill_slot);
+    spill_release(A, lane, spill_slot);
 }
-
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // phase 1: up to LONG_BATCH deferred rays per wave, 64 lanes walk their sub-trees together
@@ -1340,7 +1618,40 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     a.n_waves = grid1 * TRACE_WAVES;                     // resident waves of the wave-per-ray kernel
     if (PRIMARY && t.packet && t.packet4 && t.quad && t.search_root) {
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
-        hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+        if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
+            // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
+            (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
+            const uint32_t helpers = t.task_helper_blocks ? t.task_helper_blocks : 512u;      // x TRACE_WAVES waves, far fewer than wave slots
+#if RTMI_P4_VARIANT == 3
+            static unsigned long long* dbg = nullptr; static size_t dbg_n = 0;
+            const size_t want = (size_t)(grid + helpers) * TRACE_WAVES * P4_DBG_JOBS * 3u;
+            if (getenv("RTMI_P4_WAVES")) {
+                if (want > dbg_n) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, want * 8u); dbg_n = want; }
+                (void)hipMemsetAsync(dbg, 0, want * 8u, s);
+                a.dbg = dbg;
+            }
+#endif
+            hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL, 1>), dim3(grid + helpers), dim3(TRACE_BLOCK), 0, s, a);
+#if RTMI_P4_VARIANT == 3
+            if (const char* path = getenv("RTMI_P4_WAVES")) {
+                std::vector<unsigned long long> h(want);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h.data(), dbg, want * 8u, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(path, "wb")) { const unsigned long long hdr[3] = { 0xFFFFFFFFull, (unsigned long long)(grid + helpers) * TRACE_WAVES, P4_DBG_JOBS }; fwrite(hdr, 8u, 3, f); fwrite(h.data(), 8u, want, f); fclose(f); }
+            }
+#endif
+        } else {
+            hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL, 0>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+#if RTMI_P4_VARIANT == 3
+            if (const char* path = getenv("RTMI_P4_WAVES")) {
+                const size_t n = (size_t)grid * TRACE_WAVES * 3u;
+                std::vector<unsigned long long> h(n);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h.data(), t.keys, n * 8u, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8u, n, f); fclose(f); }
+            }
+#endif
+        }
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // rays the four-wide records may not be used for (see the kernel) wait on the deferred list: normally none, and the
         // wave-per-ray kernel returns at once
@@ -1390,6 +1701,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u;
     { static int lb = -1; if (lb < 0) { const char* e = getenv("RTMI_LONG_BATCH"); lb = e ? atoi(e) : 0; if (lb < 0 || lb > (int)LONG_BATCH) lb = 0; } a.long_batch = (uint32_t)lb; }
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
+    a.task_shards = (TaskShard*)t.task_shards; a.task_cap = t.task_cap;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
 }
 
