@@ -134,6 +134,15 @@ def pmc_child():
     print('PMC_CHILD ' + json.dumps(info), flush=True)
 
 
+def kernel_tag(name):
+    """(PRIMARY, CAL) of a traversal kernel's name: k_trace<1, 2>, k_trace_packet4<1, 2, 0> (a third argument: sub-tree sharing)"""
+    try:
+        a = name[name.index('<') + 1:name.rindex('>')].split(',')
+        return int(a[0]), int(a[1])
+    except (ValueError, IndexError):
+        return None
+
+
 def run_pmc_passes(keep_dir=None):
     """-> dict with per-scene and per-kernel counter sums per traversal launch, or None when rocprofv3 is unavailable"""
     rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
@@ -163,7 +172,7 @@ def run_pmc_passes(keep_dir=None):
                 return None
             for row in csv.DictReader(open(files[-1])):
                 k = row['Kernel_Name'].split('(')[0].replace('void ', '').strip()
-                if k.startswith(('k_trace', 'k_resolve_split')) and k.endswith('<1, 2>'):
+                if k.startswith(('k_trace', 'k_resolve_split')) and kernel_tag(k) == (1, 2):
                     rows.append((tag, int(row['Dispatch_Id']), k, row['Counter_Name'], float(row['Counter_Value'])))
         if keep_dir:
             os.makedirs(keep_dir, exist_ok=True)

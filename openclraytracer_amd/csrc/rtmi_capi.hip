@@ -392,6 +392,8 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_pos) (void)hipFree(b->d_pos);
     if (b->d_trirec) (void)hipFree(b->d_trirec);
     b->d_trirec = nullptr;
+    if (b->d_tricam) (void)hipFree(b->d_tricam);
+    b->d_tricam = nullptr;
     if (b->d_packet_spill) (void)hipFree(b->d_packet_spill);
     b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
     if (b->d_tree_select) (void)hipFree(b->d_tree_select);
@@ -453,6 +455,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_tree_select, 256);
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * trees);
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad_cam, (size_t)(n - 1) * sizeof(QuadNode) * trees);
+        if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_tricam, (size_t)n * sizeof(TriCam));
         if (e == hipSuccess && want_search) {   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
             e = hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2));
@@ -569,7 +572,7 @@ int rt_bvh_construct(rt_bvh* b)
 static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 {
     TraceLaunch t{};
-    t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.trirec = b->d_trirec; t.n_leaves = b->n;
+    t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.trirec = b->d_trirec; t.tricam = b->d_tricam; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;
@@ -612,7 +615,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
         static const struct { bool packet; uint32_t budget; bool quad; } candidates[] = {
-            { true, 1u << 20, true }, { true, 32u, true }, { true, 64u, true }, { true, 128u, true }, { true, 256u, true }, { true, 512u, true }, { true, 2048u, true },
+            { true, 1u << 20, true }, { true, 64u, true }, { true, 128u, true }, { true, 256u, true },      // four-wide: whole blocks / sub-trees shared after so many steps
             { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
             { false, 8u }, { false, 12u }, { false, 16u }, { false, 24u }, { false, 32u }, { false, 48u }, { false, 64u }, { false, 96u }, { false, 128u }, { false, 192u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1001,6 +1004,7 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     if (!b->marked_valid || std::memcmp(b->marked_origin, g->origin, sizeof g->origin) != 0) {
         TraceLaunch t{};
         t.trav = b->d_trav; t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.tree_select = b->d_tree_select; t.n_leaves = b->n;
+        t.trirec = b->d_trirec; t.tricam = b->d_tricam;
         t.search_root = b->have_search_tree ? b->n - 1 : 0u;
         launch_prepare_camera(ctx->stream, t, g->origin);
         RT_HIP(ctx, hipGetLastError());

@@ -35,6 +35,11 @@ static_assert(sizeof(QuadNode) == 128, "QuadNode must be 128 bytes");
 // arrays (three address computations, six scalar loads) and a vector load of the rank in the tie case.
 struct __attribute__((aligned(16))) TriRec { float v0[3]; float e1[3]; float e2[3]; uint32_t pos; uint32_t material; uint32_t pad; };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+// The triangle test of PRIMARY rays, which share their origin (the camera): what Triangle.h:66-107 computes from the origin and
+// the triangle alone -- tvec = origin - vertex 0, qvec = tvec x edge 1, edge 2 . qvec -- is the same for every ray of a frame
+// and is computed once per camera position (k_prepare_camera), with the same operations in the same order.
+struct __attribute__((aligned(16))) TriCam { float e1[3]; float e2[3]; float tvec[3]; float qvec[3]; float e2_dot_qvec; uint32_t pos; uint32_t pad[2]; };
+static_assert(sizeof(TriCam) == 64, "TriCam must be 64 bytes");
 
 #define RT_LEAF_FLAG 0x80000000u
 #define RT_SENTINEL 0xFFFFFFFFu   // stack sentinel, BVH.h:352
@@ -128,6 +133,7 @@ struct rt_bvh {
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
     TriRec* d_trirec = nullptr;        // packed triangle records of the packet kernels (filled per build: they hold the rank)
+    TriCam* d_tricam = nullptr;        // ... relative to the current camera position (with the four-wide records): k_prepare_camera
     bool have_search_tree = false;     // d_trav holds 2(n-1) records: reference tree, then the search tree (primary rays)
     uint32_t* d_tree_select = nullptr; // 1 word, bit k: the camera's coordinate k equals a box plane (k_prepare_camera)
     uint32_t search_depth = 0;
@@ -231,6 +237,7 @@ struct TraceLaunch {
     const DeviceScene* scene;
     const uint32_t* pos;          // leaf -> position in the sorted pair array (DFS rank, tie rule)
     const TriRec* trirec;         // packed triangle records (packet kernels)
+    const TriCam* tricam;         // primary rays, four-wide packet kernel: the same relative to the camera position (may be null)
     uint32_t n_leaves;
     void* ctrl;                   // TraceCtrl, zeroed by the launcher
     uint32_t* long_list;          // records of rays deferred to the wave-per-ray phase

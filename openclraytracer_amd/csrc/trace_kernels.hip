@@ -119,6 +119,7 @@ struct TraceArgs {
     const float4* __restrict__ e2;
     const float4* __restrict__ nrm;
     const TriRec* __restrict__ trirec;     // packed triangle records (packet kernels): vertex 0, edges, rank behind one address
+    const TriCam* __restrict__ tricam;     // primary rays: the camera-relative triangle records (k_trace_packet4)
     const uint32_t* __restrict__ pos;      // leaf -> position in the sorted (morton, leaf) array
     TraceCtrl* ctrl;
     uint32_t* long_list;                   // long_cap records
@@ -206,28 +207,28 @@ __device__ __forceinline__ bool child_valid_nonan(float lox, float loy, float lo
 
 // ... and on the camera-relative records of primary rays (k_prepare_camera): d* = plane - origin, subtracted once per camera
 __device__ __forceinline__ bool child_valid_delta(float dlox, float dloy, float dloz, float dhix, float dhiy, float dhiz, const RayState& r,
-                                                  bool inside_marked)
+                                                  float threshold)                 // 0, or -inf with the camera inside the box
 {
     const float ax = dlox * r.inv.x, bx = dhix * r.inv.x;
     const float ay = dloy * r.inv.y, by = dhiy * r.inv.y;
     const float az = dloz * r.inv.z, bz = dhiz * r.inv.z;
     const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    return ((tnear <= tfar) & (tnear > 0.0f)) | inside_marked;
+    return (tnear <= tfar) & (tnear > threshold);
 }
 
 // ... as the mask of the wave's lanes that enter the box.  The two compares write their lane masks straight into scalar
 // registers and the rest is scalar arithmetic on 64-bit masks; as a per-lane bool the compiler turns every `__ballot` of it into
 // a select and a compare of its own (two vector instructions per slot and step).
 __device__ __forceinline__ uint64_t child_mask_delta(float dlox, float dloy, float dloz, float dhix, float dhiy, float dhiz, const RayState& r,
-                                                     bool inside_marked)
+                                                     float threshold)
 {
     const float ax = dlox * r.inv.x, bx = dhix * r.inv.x;
     const float ay = dloy * r.inv.y, by = dhiy * r.inv.y;
     const float az = dloz * r.inv.z, bz = dhiz * r.inv.z;
     const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    return (__builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tnear > 0.0f)) | (inside_marked ? ~0ull : 0ull);
+    return __builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tnear > threshold);
 }
 
 // a child of a BINARY record: the pure-VALU form on search-tree records (no NaN possible there, see above), the reference's
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const Qu
         // test's (plane - origin) is the same subtraction for all of them -- done once here, with the same fp32 operation, and
         // the kernels multiply by 1 / direction directly.  Plus the "camera inside the box" bit per slot.
         QuadNode q = quad[i];
-        uint32_t bits = 0;
+        float thr[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         for (int k = 0; k < 4; k++) {
             float4& lo = q.q[2 * k]; float4& hi = q.q[2 * k + 1];
             const uint32_t id = __float_as_uint(q.q[k].w);
@@ -279,11 +280,16 @@ __global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const Qu
                 lo.x = lo.y = lo.z = FLT_MAX; hi.x = hi.y = hi.z = -FLT_MAX;
                 continue;
             }
-            if ((lo.x <= ox) & (ox <= hi.x) & (lo.y <= oy) & (oy <= hi.y) & (lo.z <= oz) & (oz <= hi.z)) bits |= 1u << k;
+            // camera inside the box: the reference takes the child whatever the slab test says (AABB.h: flag | inside).  With the
+            // origin inside, near <= 0 <= far holds per axis in floating point as well (the signs of the products; a 0 * inf is
+            // excluded by ray_root), so "near <= far" is true by itself and the child is taken iff "near > 0" is replaced by
+            // "near > -inf", true for every ray with one finite 1 / direction: the slot's threshold, a value in the record
+            // instead of a mark the kernels would have to test and combine per slot and step
+            if ((lo.x <= ox) & (ox <= hi.x) & (lo.y <= oy) & (oy <= hi.y) & (lo.z <= oz) & (oz <= hi.z)) thr[k] = -__builtin_inff();
             lo.x = lo.x - ox; lo.y = lo.y - oy; lo.z = lo.z - oz;
             hi.x = hi.x - ox; hi.y = hi.y - oy; hi.z = hi.z - oz;
         }
-        q.q[4].w = __uint_as_float(bits);
+        q.q[4].w = thr[0]; q.q[5].w = thr[1]; q.q[6].w = thr[2]; q.q[7].w = thr[3];
         quad_cam[i] = q;
     }
     if (i < n_reference && n_records > n_reference) {       // plane test over the reference records, when there is a search tree
@@ -293,6 +299,26 @@ __global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const Qu
             if ((o[k] == t.a_lo[k]) | (o[k] == t.a_hi[k]) | (o[k] == t.b_lo[k]) | (o[k] == t.b_hi[k]) | (o[k] == FLT_MIN)) bits |= 1u << k;
         if (bits) __hip_atomic_fetch_or(select, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// the camera-relative triangle records (rtmi_internal.h, TriCam): the operations of leaf_test that involve the origin and the
+// triangle only, in its order
+__global__ __launch_bounds__(256) void k_prepare_triangles(const TriRec* __restrict__ rec, TriCam* __restrict__ out, uint32_t n, float ox, float oy, float oz)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const TriRec t = rec[i];
+    const f3 vert0 = f3{ t.v0[0], t.v0[1], t.v0[2] }, edge1 = f3{ t.e1[0], t.e1[1], t.e1[2] }, edge2 = f3{ t.e2[0], t.e2[1], t.e2[2] };
+    const f3 tvec = f3_sub(f3{ ox, oy, oz }, vert0);
+    const f3 qvec = f3_cross(tvec, edge1);
+    TriCam c;
+    c.e1[0] = edge1.x; c.e1[1] = edge1.y; c.e1[2] = edge1.z;
+    c.e2[0] = edge2.x; c.e2[1] = edge2.y; c.e2[2] = edge2.z;
+    c.tvec[0] = tvec.x; c.tvec[1] = tvec.y; c.tvec[2] = tvec.z;
+    c.qvec[0] = qvec.x; c.qvec[1] = qvec.y; c.qvec[2] = qvec.z;
+    c.e2_dot_qvec = f3_dot(edge2, qvec);
+    c.pos = t.pos; c.pad[0] = c.pad[1] = 0u;
+    out[i] = c;
 }
 
 // triangleIntersect, Triangle.h:66-107, against precomputed edges; keeps the lexicographic min of
@@ -460,18 +486,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                     const float4* p = reinterpret_cast<const float4*>(a.quad + cur);
                     const float4 g0 = p[0], g1 = p[1], g2 = p[2], g3 = p[3], g4 = p[4], g5 = p[5], g6 = p[6], g7 = p[7];
                     const uint32_t i0 = __float_as_uint(g0.w), i1 = __float_as_uint(g1.w), i2 = __float_as_uint(g2.w), i3 = __float_as_uint(g3.w);
-                    const uint32_t qm = __float_as_uint(g4.w);
                     // (rays on search-tree records cannot produce NaN slab products, ray_root: the pure-VALU form of the test;
                     //  primary rays read the camera-relative copy of the records)
-                    auto slot_valid = [&](const float4& lo, const float4& hi, uint32_t bit) {
-                        if (PRIMARY) return child_valid_delta(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, (qm & bit) != 0u);
+                    auto slot_valid = [&](const float4& lo, const float4& hi, float threshold) {
+                        if (PRIMARY) return child_valid_delta(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, threshold);
                         const bool inside = (lo.x <= r.o.x) & (r.o.x <= hi.x) & (lo.y <= r.o.y) & (r.o.y <= hi.y) & (lo.z <= r.o.z) & (r.o.z <= hi.z);
                         return child_valid_nonan(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, inside);
                     };
-                    uint32_t c0 = slot_valid(g0, g1, 1u) ? i0 : RT_SENTINEL;
-                    uint32_t c1 = slot_valid(g2, g3, 2u) ? i1 : RT_SENTINEL;
-                    uint32_t c2 = slot_valid(g4, g5, 4u) ? i2 : RT_SENTINEL;
-                    uint32_t c3 = slot_valid(g6, g7, 8u) ? i3 : RT_SENTINEL;
+                    uint32_t c0 = slot_valid(g0, g1, g4.w) ? i0 : RT_SENTINEL;
+                    uint32_t c1 = slot_valid(g2, g3, g5.w) ? i1 : RT_SENTINEL;
+                    uint32_t c2 = slot_valid(g4, g5, g6.w) ? i2 : RT_SENTINEL;
+                    uint32_t c3 = slot_valid(g6, g7, g7.w) ? i3 : RT_SENTINEL;
                     if (pending == NO_LEAF) {                      // park one reached leaf right away (no stack round trip)
                         if (c0 != RT_SENTINEL && (c0 & RT_LEAF_FLAG)) { pending = c0 & ~RT_LEAF_FLAG; c0 = RT_SENTINEL; }
                         else if (c1 != RT_SENTINEL && (c1 & RT_LEAF_FLAG)) { pending = c1 & ~RT_LEAF_FLAG; c1 = RT_SENTINEL; }
@@ -659,6 +684,31 @@ __device__ __forceinline__ void leaf_test_masked(const TraceArgs& a, uint32_t le
     float t = f3_dot(edge2, qvec) * inv_det;
     flag = flag & (t > 0.0f);
     // lexicographic minimum of (t, depth-first rank): the strict `<` of BVH.h:392 in the reference's walk order
+    const bool better = flag & ((t < r.best_t) | ((t == r.best_t) & (pos < r.best_pos)));
+    r.best_t = better ? t : r.best_t;
+    r.best_leaf = better ? leaf : r.best_leaf;
+    r.best_pos = better ? pos : r.best_pos;
+}
+
+// ... of a primary ray, against the camera-relative record: the ray contributes its direction only
+__device__ __forceinline__ void leaf_test_camera(const TriCam* __restrict__ tricam, uint32_t leaf, RayState& r, bool reached)
+{
+    const float4* p = reinterpret_cast<const float4*>(tricam + leaf);
+    const float4 w0 = ld_const4(p), w1 = ld_const4(p + 1), w2 = ld_const4(p + 2), w3 = ld_const4(p + 3);
+    const f3 edge1 = f3{ w0.x, w0.y, w0.z }, edge2 = f3{ w0.w, w1.x, w1.y }, tvec = f3{ w1.z, w1.w, w2.x }, qvec = f3{ w2.y, w2.z, w2.w };
+    const uint32_t pos = __float_as_uint(w3.y);
+    f3 pvec = f3_cross(r.d, edge2);
+    float det = f3_dot(edge1, pvec);
+    bool flag = reached & (fabsf(det) >= FLT_EPSILON);
+    float inv_det = 1.0f / det;
+    float u = f3_dot(tvec, pvec) * inv_det;
+    flag = flag & (u < 1.0f);
+    flag = flag & (u >= 0.0f);
+    float v = f3_dot(r.d, qvec) * inv_det;
+    flag = flag & ((u + v) <= 1.0f);
+    flag = flag & (v >= 0.0f);
+    float t = w3.x * inv_det;
+    flag = flag & (t > 0.0f);
     const bool better = flag & ((t < r.best_t) | ((t == r.best_t) & (pos < r.best_pos)));
     r.best_t = better ? t : r.best_t;
     r.best_leaf = better ? leaf : r.best_leaf;
@@ -945,9 +995,6 @@ __device__ __forceinline__ const TraceArgs& rare_args()
     return *p;
 }
 
-#ifndef P4_WANT_WORD
-#define P4_WANT_WORD 0
-#endif
 template <int PRIMARY, int CAL, int SHARE>
 __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 {
@@ -971,6 +1018,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 #endif
     // the arguments the steps of the walk use (see `registers` above)
     const QuadNode* const quad = a.quad;
+    const TriCam* const tricam = a.tricam;
     const uint32_t budget = a.defer_budget;
     const uint32_t n_block_waves = (a.total_work + 63u) >> 6;
     const bool helper = wave_gid >= n_block_waves;       // SHARE only: the grid ends with waves that have no block of their own
@@ -1102,83 +1150,56 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
             const float4 q0 = ld_const4(p), q1 = ld_const4(p + 1), q2 = ld_const4(p + 2), q3 = ld_const4(p + 3);
             const float4 q4 = ld_const4(p + 4), q5 = ld_const4(p + 5), q6 = ld_const4(p + 6), q7 = ld_const4(p + 7);
             const uint32_t id0 = __float_as_uint(q0.w), id1 = __float_as_uint(q1.w), id2 = __float_as_uint(q2.w), id3 = __float_as_uint(q3.w);
-            const uint32_t marks = __float_as_uint(q4.w);
-            P4_KEEP("s"(id0), "s"(id1), "s"(id2), "s"(id3), "s"(marks), "s"(q7.x), "s"(q5.x), "s"(q3.x), "s"(q1.x));
+            P4_KEEP("s"(id0), "s"(id1), "s"(id2), "s"(id3), "s"(q4.w), "s"(q7.x), "s"(q5.x), "s"(q3.x), "s"(q1.x));
             P4_STAMP(T1);
             P4_PIN(r.inv.x);
             // all 64 lanes evaluate all four boxes (a vector instruction costs the same for one lane as for 64; a divergent `if`
             // costs an exec-mask region, i.e. scalar instructions and a branch): lanes that do not take part are masked afterwards
             // (an unused slot's camera-relative box is empty and unmarked, k_prepare_camera: no test of its id here)
-            uint64_t m[4] = { in & child_mask_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, (marks & 1u) != 0u),
-                              in & child_mask_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, (marks & 2u) != 0u),
-                              in & child_mask_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, (marks & 4u) != 0u),
-                              in & child_mask_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, (marks & 8u) != 0u) };
+            uint64_t m[4] = { in & child_mask_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, q4.w),
+                              in & child_mask_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, q5.w),
+                              in & child_mask_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w),
+                              in & child_mask_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, q7.w) };
             const uint32_t ids[4] = { id0, id1, id2, id3 };
             P4_KEEP("s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]));
             P4_STAMP(T2);
-            // leaves are tested on the spot by the lanes that reached them
-            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull && id0 != RT_SENTINEL) leaf_test_masked(a, id0 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[0])); m[0] = 0ull; }
-            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull && id1 != RT_SENTINEL) leaf_test_masked(a, id1 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[1])); m[1] = 0ull; }
-            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull && id2 != RT_SENTINEL) leaf_test_masked(a, id2 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[2])); m[2] = 0ull; }
-            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull && id3 != RT_SENTINEL) leaf_test_masked(a, id3 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[3])); m[3] = 0ull; }
+            // leaves are tested on the spot by the lanes that reached them (an unused slot counts as a leaf nobody reaches)
+            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull) leaf_test_camera(tricam, id0 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[0])); m[0] = 0ull; }
+            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull) leaf_test_camera(tricam, id1 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[1])); m[1] = 0ull; }
+            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull) leaf_test_camera(tricam, id2 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[2])); m[2] = 0ull; }
+            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull) leaf_test_camera(tricam, id3 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[3])); m[3] = 0ull; }
             P4_KEEP("v"(r.best_t), "v"(r.best_leaf), "v"(r.best_pos));
             P4_STAMP(T3);
-#if P4_WANT_WORD
-            // the first wanted inner child is walked next, the others wait on the stack with their lanes (one bit per slot in a
-            // scalar word: the choice and the pushes are then a find-first-bit and three tests of that word)
-            const uint32_t want = (m[0] != 0ull ? 1u : 0u) | (m[1] != 0ull ? 2u : 0u) | (m[2] != 0ull ? 4u : 0u) | (m[3] != 0ull ? 8u : 0u);
-            const uint32_t rest = want & (want - 1u);
-#pragma unroll
-            for (int k = 1; k < 4; k++) {
-                if ((rest & (1u << k)) == 0u) continue;
-                if (sp < PACKET_VSTACK) {
-                    lane_write3(vs_node, vs_lo, vs_hi, ids[k], (uint32_t)m[k], (uint32_t)(m[k] >> 32), sp);
-                } else {
-                    const uint32_t ls = sp - PACKET_VSTACK;
-                    if (ls < PACKET_STACK) {
-                        if (lane == 0) { st_node[ls] = ids[k]; st_lo[ls] = (uint32_t)m[k]; st_hi[ls] = (uint32_t)(m[k] >> 32); }
-                    } else {
-                        const TraceArgs& A = rare_args<3>();
-                        if (A.packet_spill && ls - PACKET_STACK < A.packet_spill_entries && (spill || (spill = spill_acquire(A, wave_gid, lane, spill_slot)))) {
-                            if (lane == 0) { uint32_t* e = spill + (uint64_t)(ls - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
-                        } else {
-                            if (lane == 0) TRACE_FAIL((gu32*)&A.ctrl->error, 3);     // frame invalid
-                        }
-                    }
-                }
-                sp++;
-            }
-            if (want != 0u) {
-                node = (want & 1u) ? id0 : (want & 2u) ? id1 : (want & 4u) ? id2 : id3;
-                in = (want & 1u) ? m[0] : (want & 2u) ? m[1] : (want & 4u) ? m[2] : m[3];
-#else
-            // the first wanted inner child is walked next, the others wait on the stack with their lanes
-            int first = -1;
+            // the LAST wanted inner child is walked next, the ones before it wait on the stack with their lanes: a slot that is
+            // wanted first sends the one held so far to the stack and is held itself (the order in which sub-trees are walked
+            // does not matter: every reached leaf is tested, the hit is the lexicographic minimum over all of them)
+            uint32_t held_node = 0u; uint64_t held = 0ull;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (m[k] == 0ull) continue;
-                if (first < 0) { first = k; continue; }
-                if (sp < PACKET_VSTACK) {
-                    lane_write3(vs_node, vs_lo, vs_hi, ids[k], (uint32_t)m[k], (uint32_t)(m[k] >> 32), sp);
-                } else {
-                    const uint32_t ls = sp - PACKET_VSTACK;
-                    if (ls < PACKET_STACK) {
-                        if (lane == 0) { st_node[ls] = ids[k]; st_lo[ls] = (uint32_t)m[k]; st_hi[ls] = (uint32_t)(m[k] >> 32); }
+                if (held != 0ull) {
+                    if (sp < PACKET_VSTACK) {
+                        lane_write3(vs_node, vs_lo, vs_hi, held_node, (uint32_t)held, (uint32_t)(held >> 32), sp);
                     } else {
-                        const TraceArgs& A = rare_args<7>();
-                        if (A.packet_spill && ls - PACKET_STACK < A.packet_spill_entries && (spill || (spill = spill_acquire(A, wave_gid, lane, spill_slot)))) {
-                            if (lane == 0) { uint32_t* e = spill + (uint64_t)(ls - PACKET_STACK) * 3u; e[0] = ids[k]; e[1] = (uint32_t)m[k]; e[2] = (uint32_t)(m[k] >> 32); }
+                        const uint32_t ls = sp - PACKET_VSTACK;
+                        if (ls < PACKET_STACK) {
+                            if (lane == 0) { st_node[ls] = held_node; st_lo[ls] = (uint32_t)held; st_hi[ls] = (uint32_t)(held >> 32); }
                         } else {
-                            if (lane == 0) TRACE_FAIL((gu32*)&A.ctrl->error, 3);     // frame invalid
+                            const TraceArgs& A = rare_args<7>();
+                            if (A.packet_spill && ls - PACKET_STACK < A.packet_spill_entries && (spill || (spill = spill_acquire(A, wave_gid, lane, spill_slot)))) {
+                                if (lane == 0) { uint32_t* e = spill + (uint64_t)(ls - PACKET_STACK) * 3u; e[0] = held_node; e[1] = (uint32_t)held; e[2] = (uint32_t)(held >> 32); }
+                            } else {
+                                if (lane == 0) TRACE_FAIL((gu32*)&A.ctrl->error, 3);     // frame invalid
+                            }
                         }
                     }
+                    sp++;
                 }
-                sp++;
+                held_node = ids[k]; held = m[k];
             }
-            if (first >= 0) {
-                node = ids[first];
-                in = m[first];
-#endif
+            if (held != 0ull) {
+                node = held_node;
+                in = held;
             } else if (sp == 0u) walking = false;
             else {
                 sp--;
@@ -1616,7 +1637,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
     a.n_waves = grid1 * TRACE_WAVES;                     // resident waves of the wave-per-ray kernel
-    if (PRIMARY && t.packet && t.packet4 && t.quad && t.search_root) {
+    if (PRIMARY && t.packet && t.packet4 && t.quad && t.tricam && t.search_root) {
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
             // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
@@ -1693,7 +1714,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
 {
     a.trav = t.trav; a.quad = t.search_root ? t.quad : nullptr; a.search_root = t.search_root; a.tree_select = t.tree_select;   // (launch_trace_primary switches to quad_cam)
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
-    a.pos = t.pos; a.trirec = t.trirec;
+    a.pos = t.pos; a.trirec = t.trirec; a.tricam = t.tricam;
     a.ctrl = (TraceCtrl*)t.ctrl;
     a.long_list = t.long_list; a.long_cap = t.long_cap;
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
@@ -1734,6 +1755,9 @@ void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float orig
     const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
     hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
                        t.quad, const_cast<QuadNode*>(t.quad_cam), n_all, n_ref, origin[0], origin[1], origin[2], const_cast<uint32_t*>(t.tree_select));
+    if (t.tricam && t.trirec)
+        hipLaunchKernelGGL(k_prepare_triangles, dim3((t.n_leaves + 255) / 256), dim3(256), 0, s, t.trirec, const_cast<TriCam*>(t.tricam), t.n_leaves,
+                           origin[0], origin[1], origin[2]);
 }
 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)

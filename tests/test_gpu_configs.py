@@ -109,7 +109,9 @@ for _ in range(2):
     got = gb.generate_contacts_primary(as_capi_camera(cam))
     assert got.tobytes() == want.tobytes(), 'contacts differ from the oracle'
     taken.append(ctx.last_trace_counters()['spill_areas_taken'])
-assert taken[0] > 0 and taken[0] == taken[1], taken
+# (when waves share their sub-trees, who walks what -- and so who overflows -- depends on timing)
+shared = os.environ.get('RTMI_PACKET') == '4' and int(os.environ.get('RTMI_DEFER_BUDGET', '0')) < (1 << 20)
+assert taken[0] > 0 and (shared or taken[0] == taken[1]), taken
 # areas are given back: many more frames than the bitmap could serve without releases
 frames = min(60, 3 * 8192 // taken[0] + 1)
 for _ in range(frames):
@@ -119,7 +121,7 @@ print('overflow areas per frame %%d, %%d more frames ok' %% (taken[0], frames))
 """
 
 
-@pytest.mark.parametrize('packet, budget, scene', [('4', '1048576', 'man'), ('1', '1048576', 'man'), ('1', '64', 'tenryuu'),
+@pytest.mark.parametrize('packet, budget, scene', [('4', '1048576', 'man'), ('4', '16', 'man'), ('1', '1048576', 'man'), ('1', '64', 'tenryuu'),
                                                    ('4', '1048576', 'synth_atrium')])
 def test_packet_stack_overflow_areas(packet, budget, scene):
     """Overflow areas of the packet kernels' (node, lane mask) stacks.  With the 96-entry LDS stacks no bundled or synthetic

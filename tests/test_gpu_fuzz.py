@@ -139,16 +139,18 @@ def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
 
 
 @pytest.mark.parametrize('knobs', [dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='1048576'),
+                                   dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='3'),
                                    dict(RTMI_PACKET='1', RTMI_DEFER_BUDGET='16'),
                                    dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='4', RTMI_LONG_BATCH='4'),
                                    dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='4', RTMI_LONG_BATCH='2'),
                                    dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='1048576')],
-                         ids=['packet4', 'packet16', 'lane4-batch4', 'lane4-batch2', 'lane-inf'])
+                         ids=['packet4', 'packet4-shared', 'packet16', 'lane4-batch4', 'lane4-batch2', 'lane-inf'])
 @pytest.mark.parametrize('seed,kind,n', [(21, 'uniform', 700), (22, 'clustered', 1200), (23, 'lattice', 200), (24, 'degenerate', 900),
                                          (25, 'lattice', 24), (26, 'uniform', 3)])
 def test_random_scene_under_every_forced_strategy(tmp_path, monkeypatch, seed, kind, n, knobs):
     """the same kind of soups and cameras (outside, inside, on a box plane, rotated) with the first-phase kernel and the
-    hand-over budget forced: four-wide packet kernel (unsafe rays go to the wave-per-ray kernel), binary packet kernel that
+    hand-over budget forced: four-wide packet kernel (unsafe rays go to the wave-per-ray kernel), the same sharing its sub-trees between
+    waves after three steps, binary packet kernel that
     sheds almost everything as partial rays, lane-per-ray kernel that hands nearly every ray over after four steps (wave-
     per-ray kernel with two and four rays per wave), lane-per-ray kernel alone.  Primary rays and a ray buffer."""
     import oracle as orc

@@ -299,6 +299,59 @@ def test_forced_trace_strategies_and_full_deferred_list(packet, budget, list_max
         ctx.close()
 
 
+@pytest.mark.parametrize('knobs', [dict(RTMI_DEFER_BUDGET='4'), dict(RTMI_DEFER_BUDGET='64'),
+                                   dict(RTMI_DEFER_BUDGET='4', RTMI_TASK_CAP='1'),            # queues of one entry: most entries stay with their publisher
+                                   dict(RTMI_DEFER_BUDGET='4', RTMI_LONG_LIST_MAX='40'),      # list of shared blocks full: later blocks stay whole
+                                   dict(RTMI_DEFER_BUDGET='8', RTMI_TASK_HELPERS='1'),        # one helper block: three takers and the watching wave
+                                   dict(RTMI_DEFER_BUDGET='4', RTMI_TASK_CAP='0')],           # sharing switched off: the plain kernel
+                         ids=['budget4', 'budget64', 'queues-of-one', 'block-list-full', 'one-helper-block', 'no-queues'])
+def test_four_wide_packets_sharing_sub_trees(knobs, monkeypatch):
+    """k_trace_packet4 with a step budget: waves publish their waiting (node, lane mask) entries as tasks, other waves walk them,
+    the parts of a block meet in the (t, position) keys and the helper waves write those blocks' contacts.  Whatever the
+    budget, the queue capacity and the number of helpers, the contacts are the reference's, frame after frame (the queues and
+    keys of the previous frame are stale memory by then)."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    monkeypatch.setenv('RTMI_POISON', '7')
+    monkeypatch.setenv('RTMI_PACKET', '4')
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    ctx = capi.Context(0)
+    try:
+        for name, res in (('tenryuu', (320, 240)), ('man', (200, 150)), ('cube', (64, 48))):
+            osc, ob = oracle_bvh(name)
+            sc = capi.DeviceScene(ctx, packed_scene(name))
+            gb = capi.DeviceBVH(ctx, sc).build()
+            cam = osc.demo_camera(*res)
+            want, _ = ob.trace_primary(cam)
+            for _ in range(3):
+                got = gb.generate_contacts_primary(as_capi_camera(cam))
+                assert got.tobytes() == want.tobytes(), (name, knobs)
+            c = ctx.last_trace_counters()
+            if knobs.get('RTMI_TASK_CAP') == '0':
+                assert c['shared_blocks'] == 0 and c['shared_tasks'] == 0
+            elif name != 'cube' and knobs['RTMI_DEFER_BUDGET'] == '4':
+                assert c['shared_blocks'] > 0 and c['shared_tasks'] > 0, (name, knobs, c)
+                if knobs.get('RTMI_LONG_LIST_MAX'):
+                    assert c['shared_blocks'] >= 40        # the counter runs on, the list holds the first 40
+            # a tiled (compact) frame of two ranks takes the same path: shared blocks' contacts go to their compact slots
+            ccam = as_capi_camera(cam)
+            nranks = capi.tiling(2, 0)
+            rank_of, slot_of = capi.tile_slot_map(res[0], res[1], nranks)
+            for rank in range(2):
+                slots = capi.tiles_owned_pixels(ccam, rank, nranks)
+                dc = ctx.alloc(max(slots, 1) * 32)
+                ctx.fill_u32(dc, 0xDEADBEEF, max(slots, 1) * 8)
+                gb.generate_contacts_primary_tiled_d(ccam, rank, nranks, dc)
+                compact = ctx.download(dc, slots, capi.CONTACT)
+                mine = rank_of == rank
+                assert compact[slot_of[mine]].tobytes() == want.reshape(-1)[mine].tobytes(), (name, knobs, rank)
+                ctx.free(dc)
+            gb.close(); sc.close()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize('batch', ['1', '2', '4'])
 def test_wave_per_ray_kernel_with_one_two_and_four_rays_per_wave(batch, monkeypatch):
     """The wave-per-ray kernel walks 1, 2 or 4 deferred rays per wave (chosen from the number of deferred rays per resident

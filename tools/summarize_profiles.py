@@ -1,5 +1,7 @@
 """Copies the judged summaries of gpurun_out/<round>/ (tools/profile_round.sh) into profiles/."""
 import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as bench_mod
 newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
 R = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = 'gpurun_out/%s' % R
@@ -25,7 +27,7 @@ with open('profiles/%s_bench_pmc_summary.csv' % R, 'w') as f:
 ks = list(csv.DictReader(open('profiles/%s_bench_kernel_stats.csv' % R)))
 nm = lambda r: r['Name'].split('(')[0].replace('void ', '')
 def launch_summary(tag):
-    st = [r for r in ks if nm(r).startswith(('k_trace', 'k_resolve_split')) and nm(r).endswith('<1, %d>' % tag)]
+    st = [r for r in ks if nm(r).startswith(('k_trace', 'k_resolve_split')) and bench_mod.kernel_tag(nm(r)) == (1, tag)]
     nfr = sum(int(r['Calls']) for r in st if nm(r).startswith(('k_trace<', 'k_trace_packet<', 'k_trace_packet4<')))
     return {'frame_launches': nfr, 'avg_frame_launch_ms': sum(float(r['TotalDurationNs']) for r in st) / max(nfr, 1) / 1e6}
 iso, conc = launch_summary(2), launch_summary(0)
