@@ -51,6 +51,16 @@ static int ensure_long_list(rt_ctx* ctx, uint64_t work_items)
         if (ctx->poison & 1) RT_HIP(ctx, hipMemsetAsync(ctx->d_long_list, 0xCD, want * trace_long_record_bytes(), ctx->stream));
         if (ctx->poison & 2) RT_HIP(ctx, hipMemsetAsync(ctx->d_split_list, 0xCD, want * sizeof(uint32_t), ctx->stream));
     }
+    // queue capacity by frame size: ~8 entries per 8x8 block over the 256 queues (a 4K frame of the atrium publishes 2-3 per block)
+    if (ctx->task_cap_auto) {
+        uint64_t want_cap = work_items / 64u * 8u / 256u;
+        want_cap = want_cap < 64 ? 64 : want_cap > 4096 ? 4096 : want_cap;
+        if (want_cap > ctx->task_cap) {
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_task_list) { (void)hipFree(ctx->d_task_list); ctx->d_task_list = nullptr; }
+            ctx->task_cap = (uint32_t)want_cap;
+        }
+    }
     if (!ctx->d_task_list && ctx->task_cap) {
         // sub-tree tasks the waves of the four-wide packet kernel share (16 bytes each); a full queue only means less sharing
         RT_HIP(ctx, hipMalloc((void**)&ctx->d_task_list, trace_task_bytes(ctx->task_cap)));
@@ -134,8 +144,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
-    ctx->task_cap = 1u << 8;                      // per queue, 256 queues
-    if (const char* env = std::getenv("RTMI_TASK_CAP")) ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10);          // 0: no sharing
+    ctx->task_cap = 64; ctx->task_cap_auto = true;     // per queue, 256 queues; grows with the frame (ensure_long_list)
+    if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
     if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
     return RT_SUCCESS;
@@ -615,7 +625,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
         static const struct { bool packet; uint32_t budget; bool quad; } candidates[] = {
-            { true, 1u << 20, true }, { true, 64u, true }, { true, 128u, true }, { true, 256u, true },      // four-wide: whole blocks / sub-trees shared after so many steps
+            { true, 1u << 20, true }, { true, 64u, true }, { true, 128u, true }, { true, 256u, true }, { true, 1024u, true }, { true, 2048u, true },   // four-wide: whole blocks / sub-trees shared after so many steps
             { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
             { false, 8u }, { false, 12u }, { false, 16u }, { false, 24u }, { false, 32u }, { false, 48u }, { false, 64u }, { false, 96u }, { false, 128u }, { false, 192u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -657,11 +667,24 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
                              cand.packet ? (cand.quad ? "packet4" : "packet") : "lane-per-ray", cand.budget, ms, valid ? "" : " (error word set, discarded)");
             return true;
         };
+        // The candidates are timed with the device to themselves.  Sharing sub-trees between waves fills a launch's idle tail --
+        // which other streams' launches fill as well when frames overlap (bench.py's five streams: ManFigure shared after 256
+        // steps is 0.3 % faster alone and costs the five-frame step 8 %) -- and it costs queue traffic that grows as the budget
+        // shrinks.  So a sharing candidate must win clearly: its time counts 8 % longer, plus 3 % per halving of the budget
+        // below 256 steps.
+        auto handicap = [&](int ci) -> float {
+            const auto& cand = candidates[ci];
+            if (!(cand.packet && cand.quad && cand.budget < (1u << 20))) return 1.0f;
+            float h = 1.08f;
+            for (uint32_t bgt = cand.budget; bgt < 256u; bgt <<= 1) h += 0.03f;
+            return h;
+        };
         auto usable = [&](int ci) {
             const auto& cand = candidates[ci];
             if (cand.packet && ctx->no_packet) return false;
             if (!cand.packet && ctx->force_packet) return false;
             if (cand.quad && (!b->d_quad || !b->have_search_tree)) return false;   // four-wide records are sound on the search tree only
+            if (cand.quad && cand.budget < (1u << 20) && !ctx->d_task_list) return false;   // sub-tree sharing needs its queues
             return true;
         };
         // first pass: every candidate twice unless its first run is hopeless (the first launch of a kernel pays for code and
@@ -674,6 +697,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             if (!warm) { float m; bool v; if (!time_candidate(ci, 3, 0.f, m, v)) { broken = true; break; } warm = true; }
             bool valid = false;
             if (!time_candidate(ci, 2, have ? 2.5f * best_ms : 0.f, cand_ms[ci], valid)) { broken = true; break; }
+            cand_ms[ci] *= handicap(ci);
             cand_ok[ci] = valid;
             if (valid && (!have || cand_ms[ci] < best_ms)) { best_ms = cand_ms[ci]; have = true; }
         }
@@ -689,6 +713,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
                 cand_ok[pick] = false;                                   // taken
                 float m = 0.f; bool valid = false;
                 if (!time_candidate(pick, 3, 0.f, m, valid)) { broken = true; break; }
+                m *= handicap(pick);
                 if (valid && (best_ci < 0 || m < final_best)) { final_best = m; best_ci = pick; }
             }
         }
