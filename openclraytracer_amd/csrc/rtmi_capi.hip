@@ -464,7 +464,13 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_trirec, (size_t)n * sizeof(TriRec));
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_tree_select, 256);
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * trees);
-        if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad_cam, (size_t)(n - 1) * sizeof(QuadNode) * trees);
+        if (e == hipSuccess && !ctx->no_packet4) {
+            // the camera-relative copy, and eight more with the near / far planes already in place for one direction octant
+            // each (memory for vector instructions: 6 of the 16 per box test), unless that would be several GB
+            const size_t one = (size_t)(n - 1) * sizeof(QuadNode) * trees;
+            b->quad_cam_variants = (one * 9 <= ((size_t)4 << 30) && !std::getenv("RTMI_NO_OCTANT_RECORDS")) ? 9u : 1u;
+            e = hipMalloc((void**)&b->d_quad_cam, one * b->quad_cam_variants);
+        }
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_tricam, (size_t)n * sizeof(TriCam));
         if (e == hipSuccess && want_search) {   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
             e = hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
@@ -586,7 +592,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;
-    t.quad = b->d_quad; t.quad_cam = b->d_quad_cam;
+    t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.quad_cam_variants = b->quad_cam_variants;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.task_shards = b->ctx->d_task_list; t.task_cap = b->ctx->task_cap; t.task_helper_blocks = b->ctx->task_helper_blocks;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
@@ -670,13 +676,13 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // The candidates are timed with the device to themselves.  Sharing sub-trees between waves fills a launch's idle tail --
         // which other streams' launches fill as well when frames overlap (bench.py's five streams: ManFigure shared after 256
         // steps is 0.3 % faster alone and costs the five-frame step 8 %) -- and it costs queue traffic that grows as the budget
-        // shrinks.  So a sharing candidate must win clearly: its time counts 8 % longer, plus 3 % per halving of the budget
-        // below 256 steps.
+        // shrinks.  So a sharing candidate must win clearly: its time counts 3 % longer, plus 3 % per halving of the budget
+        // below 1 024 steps.
         auto handicap = [&](int ci) -> float {
             const auto& cand = candidates[ci];
             if (!(cand.packet && cand.quad && cand.budget < (1u << 20))) return 1.0f;
-            float h = 1.08f;
-            for (uint32_t bgt = cand.budget; bgt < 256u; bgt <<= 1) h += 0.03f;
+            float h = 1.03f;
+            for (uint32_t bgt = cand.budget; bgt < 1024u; bgt <<= 1) h += 0.03f;
             return h;
         };
         auto usable = [&](int ci) {
@@ -1028,7 +1034,7 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     // between (or the marks were never set), restore this graph's marks first -- one small kernel over the records
     if (!b->marked_valid || std::memcmp(b->marked_origin, g->origin, sizeof g->origin) != 0) {
         TraceLaunch t{};
-        t.trav = b->d_trav; t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.tree_select = b->d_tree_select; t.n_leaves = b->n;
+        t.trav = b->d_trav; t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.quad_cam_variants = b->quad_cam_variants; t.tree_select = b->d_tree_select; t.n_leaves = b->n;
         t.trirec = b->d_trirec; t.tricam = b->d_tricam;
         t.search_root = b->have_search_tree ? b->n - 1 : 0u;
         launch_prepare_camera(ctx->stream, t, g->origin);

@@ -130,7 +130,8 @@ struct rt_bvh {
     uint32_t* d_counters = nullptr;    // n visit counters (BVHManager.cpp:67)
     TravNode* d_trav = nullptr;        // traversal records: reference tree, then the search tree
     QuadNode* d_quad = nullptr;        // four-wide records of the same nodes (packet kernel), null when disabled
-    QuadNode* d_quad_cam = nullptr;    // the same records relative to the current camera position (boxes minus origin, inside marks): k_prepare_camera
+    QuadNode* d_quad_cam = nullptr;    // the same records relative to the current camera position (k_prepare_camera): the general copy, then
+    uint32_t quad_cam_variants = 1;    // (quad_cam_variants - 1 = 8) copies with the near / far planes in place per direction octant
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
     TriRec* d_trirec = nullptr;        // packed triangle records of the packet kernels (filled per build: they hold the rank)
@@ -232,7 +233,8 @@ size_t scan_scratch_words(uint32_t n);
 struct TraceLaunch {
     const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)
     const QuadNode* quad;         // four-wide records (null: the packet kernel walks the binary records)
-    const QuadNode* quad_cam;     // primary rays: the same records with the camera position subtracted from the boxes (+ inside marks)
+    const QuadNode* quad_cam;     // primary rays: the same records with the camera position subtracted from the boxes (+ thresholds)
+    uint32_t quad_cam_variants;   // 1: the general copy only; 9: + one per direction octant (near / far planes in place)
     uint32_t search_root;         // primary rays: root record of the search tree, 0 = none (walk the reference tree)
     const uint32_t* tree_select;  // per camera: bit k set = the camera's coordinate k equals a box plane
     const DeviceScene* scene;

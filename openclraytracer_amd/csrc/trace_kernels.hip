@@ -110,6 +110,7 @@ size_t trace_task_bytes(uint32_t cap_per_shard) { return TASK_SHARDS * (sizeof(T
 
 struct TraceArgs {
     const TravNode* __restrict__ trav;
+    uint32_t quad_octant_records;               // primary rays: records per copy when the per-octant copies exist (copy 1 + octant), else 0
     const QuadNode* __restrict__ quad;          // four-wide records of the same nodes, may be null: what the kernels read -- for primary
                                                 // rays the camera-relative copy (boxes minus the camera position, inside marks)
     uint32_t search_root;                       // primary rays: root record of the search tree (same leaves), 0 = none
@@ -231,6 +232,16 @@ __device__ __forceinline__ uint64_t child_mask_delta(float dlox, float dloy, flo
     return __builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tnear > threshold);
 }
 
+// ... and on a per-octant copy of those records, for a wave whose rays all have the copy's direction octant: the near planes
+// stand where the low corner stood and the far planes where the high corner stood (k_prepare_camera), so the products are the
+// near and far parameters themselves
+__device__ __forceinline__ uint64_t child_mask_octant(float nx, float ny, float nz, float fx, float fy, float fz, const RayState& r, float threshold)
+{
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(nx * r.inv.x, ny * r.inv.y), nz * r.inv.z);
+    const float tfar = __builtin_fminf(__builtin_fminf(fx * r.inv.x, fy * r.inv.y), fz * r.inv.z);
+    return __builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tnear > threshold);
+}
+
 // a child of a BINARY record: the pure-VALU form on search-tree records (no NaN possible there, see above), the reference's
 // staged form on reference-tree records (where rays with a possible 0 * inf walk)
 template <int PRIMARY>
@@ -259,7 +270,7 @@ __device__ __forceinline__ uint32_t inside_bits(const TravNode& t, float ox, flo
     return (ia ? 1u : 0u) | (ib ? 2u : 0u);
 }
 __global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const QuadNode* quad, QuadNode* quad_cam, uint32_t n_records, uint32_t n_reference,
-                                                        float ox, float oy, float oz, uint32_t* select)
+                                                        float ox, float oy, float oz, uint32_t* select, uint32_t variants)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_records) return;
@@ -291,6 +302,22 @@ __global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const Qu
         }
         q.q[4].w = thr[0]; q.q[5].w = thr[1]; q.q[6].w = thr[2]; q.q[7].w = thr[3];
         quad_cam[i] = q;
+        // One copy per direction octant (bit k of the octant: 1 / direction negative on axis k) with each slot's NEAR planes
+        // where the low corner stands and its FAR planes where the high corner stands.  For a ray of that octant the products
+        // (plane - origin) * (1 / direction) are ordered by the sign of 1 / direction on every axis (lo <= hi, monotone
+        // rounding), so min(a, b) / max(a, b) of the general test ARE these products: a wave whose rays share an octant
+        // multiplies and takes max3 / min3, six vector instructions per box less, same values.
+        for (uint32_t o = 1; o < variants; o++) {
+            const uint32_t oct = o - 1u;
+            QuadNode v = q;
+            for (int k = 0; k < 4; k++) {
+                float4& lo = v.q[2 * k]; float4& hi = v.q[2 * k + 1];
+                if (oct & 1u) { const float t = lo.x; lo.x = hi.x; hi.x = t; }
+                if (oct & 2u) { const float t = lo.y; lo.y = hi.y; hi.y = t; }
+                if (oct & 4u) { const float t = lo.z; lo.z = hi.z; hi.z = t; }
+            }
+            quad_cam[(uint64_t)o * n_records + i] = v;
+        }
     }
     if (i < n_reference && n_records > n_reference) {       // plane test over the reference records, when there is a search tree
         const float o[3] = { ox, oy, oz };
@@ -995,7 +1022,7 @@ __device__ __forceinline__ const TraceArgs& rare_args()
     return *p;
 }
 
-template <int PRIMARY, int CAL, int SHARE>
+template <int PRIMARY, int CAL, int SHARE, int OCT>
 __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 {
     __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
@@ -1017,7 +1044,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
     const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every XCD
 #endif
     // the arguments the steps of the walk use (see `registers` above)
-    const QuadNode* const quad = a.quad;
+    const QuadNode* const quad_general = a.quad;
+    const uint32_t octant_records = a.quad_octant_records;
     const TriCam* const tricam = a.tricam;
     const uint32_t budget = a.defer_budget;
     const uint32_t n_block_waves = (a.total_work + 63u) >> 6;
@@ -1039,13 +1067,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
         r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 }; r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;
         r.work = w; r.out_index = 0; r.pixel = 0;
         bool ok;
-        uint64_t in;                                     // the lanes that walk the current node
-        uint32_t node;
+        uint64_t todo;                                   // the job's lanes that have not walked yet
+        uint32_t node0;                                  // where they start
+        uint32_t my_octant;                              // bit k: 1 / direction negative on axis k
         bool split = SHARE && is_task;                   // results go to the key buffer
         {
             const TraceArgs& A = rare_args<1>();
             bool sx = false, sy = false, sz = false;
             ok = w < A.total_work && load_ray<PRIMARY>(A, w, r, sx, sy, sz);
+            my_octant = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
             if (!SHARE || !is_task) {
                 if (PRIMARY && A.compact && !ok && w < A.total_work) {
                     uint32_t x, y, slot;
@@ -1077,24 +1107,37 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
                     }
                     ok = ok && !on_ref;                                                         // their contacts are written there
                 }
-                in = __builtin_amdgcn_ballot_w64(ok);
-                node = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.search_root);
+                todo = __builtin_amdgcn_ballot_w64(ok);
+                node0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.search_root);
             } else {
-                in = job_mask;
-                node = job_node;
+                todo = job_mask;
+                node0 = job_node;
             }
         }
-        // steps until the next sharing: the first time after `defer_budget` steps, then after half as many, ... down to
-        // SHARE_MIN_STEPS; a task starts at half.  Only waves that run long come to share eagerly, and towards the end of a
-        // launch only such waves are left -- which is when other waves have nothing to do
-        uint32_t sp = 0, steps = 0, share_after = (SHARE && is_task) ? (budget >> 1 > SHARE_MIN_STEPS ? budget >> 1 : SHARE_MIN_STEPS) : budget;
-        bool walking = in != 0ull;
 #if RTMI_P4_VARIANT == 2
         unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
 #endif
 #if RTMI_P4_VARIANT >= 2
         uint32_t nsteps = 0;
 #endif
+        // OCT: the lanes walk in groups of one direction octant each, on that octant's copy of the records (near / far planes in
+        // place, child_mask_octant).  All but the blocks on the image's centre lines are one group; a task's lanes come out
+        // of one group and are one again.  Without the copies: one group on the general records.
+        while (todo != 0ull) {
+        uint64_t in = todo;                              // the lanes that walk the current node
+        const QuadNode* quad = quad_general;
+        if (OCT) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)my_octant, (int)__builtin_ctzll(todo));
+            in = todo & __builtin_amdgcn_ballot_w64(my_octant == o);
+            quad = quad_general + (uint64_t)octant_records * (1u + o);
+        }
+        todo &= ~in;
+        uint32_t node = node0;
+        // steps until the next sharing: the first time after `defer_budget` steps, then after half as many, ... down to
+        // SHARE_MIN_STEPS; a task starts at half.  Only waves that run long come to share eagerly, and towards the end of a
+        // launch only such waves are left -- which is when other waves have nothing to do
+        uint32_t sp = 0, steps = 0, share_after = (SHARE && is_task) ? (budget >> 1 > SHARE_MIN_STEPS ? budget >> 1 : SHARE_MIN_STEPS) : budget;
+        bool walking = true;
         while (walking) {
             P4_STAMP(T0);
             if (SHARE && ++steps > share_after) {
@@ -1156,10 +1199,18 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
             // all 64 lanes evaluate all four boxes (a vector instruction costs the same for one lane as for 64; a divergent `if`
             // costs an exec-mask region, i.e. scalar instructions and a branch): lanes that do not take part are masked afterwards
             // (an unused slot's camera-relative box is empty and unmarked, k_prepare_camera: no test of its id here)
-            uint64_t m[4] = { in & child_mask_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, q4.w),
-                              in & child_mask_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, q5.w),
-                              in & child_mask_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w),
-                              in & child_mask_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, q7.w) };
+            uint64_t m[4];
+            if (OCT) {
+                m[0] = in & child_mask_octant(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, q4.w);
+                m[1] = in & child_mask_octant(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, q5.w);
+                m[2] = in & child_mask_octant(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w);
+                m[3] = in & child_mask_octant(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, q7.w);
+            } else {
+                m[0] = in & child_mask_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, q4.w);
+                m[1] = in & child_mask_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, q5.w);
+                m[2] = in & child_mask_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w);
+                m[3] = in & child_mask_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, q7.w);
+            }
             const uint32_t ids[4] = { id0, id1, id2, id3 };
             P4_KEEP("s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]));
             P4_STAMP(T2);
@@ -1229,6 +1280,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
             nsteps++;
 #endif
         }
+        }                                                // next octant group
         const TraceArgs& A = rare_args<4>();
 #if RTMI_P4_VARIANT == 2
         if (lane == 0) {
@@ -1637,7 +1689,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     if (b1 == 0) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, k_trace_long<PRIMARY, CAL>, TRACE_BLOCK, 0); if (b1 < 1) b1 = 1; }
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
     a.n_waves = grid1 * TRACE_WAVES;                     // resident waves of the wave-per-ray kernel
-    if (PRIMARY && t.packet && t.packet4 && t.quad && t.tricam && t.search_root) {
+    if constexpr (PRIMARY == 1) if (t.packet && t.packet4 && t.quad && t.tricam && t.search_root) {   // (primary rays only: no instance for ray buffers)
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
             // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
@@ -1652,7 +1704,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
                 a.dbg = dbg;
             }
 #endif
-            hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL, 1>), dim3(grid + helpers), dim3(TRACE_BLOCK), 0, s, a);
+            if (a.quad_octant_records) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 1>), dim3(grid + helpers), dim3(TRACE_BLOCK), 0, s, a);
+            else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 0>), dim3(grid + helpers), dim3(TRACE_BLOCK), 0, s, a);
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 std::vector<unsigned long long> h(want);
@@ -1662,7 +1715,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
             }
 #endif
         } else {
-            hipLaunchKernelGGL((k_trace_packet4<PRIMARY, CAL, 0>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+            if (a.quad_octant_records) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 1>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+            else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 0>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 const size_t n = (size_t)grid * TRACE_WAVES * 3u;
@@ -1740,6 +1794,7 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.rays = nullptr;
     a.out = out;
     if (a.quad) a.quad = t.quad_cam;                  // boxes minus the camera position (k_prepare_camera)
+    a.quad_octant_records = (a.quad && t.quad_cam_variants == 9u) ? (t.n_leaves - 1u) * (t.search_root ? 2u : 1u) : 0u;
     if (t.mark_inside) {
         const float origin[3] = { cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11] };
         launch_prepare_camera(s, t, origin);
@@ -1754,7 +1809,8 @@ void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float orig
     (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
     const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
     hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
-                       t.quad, const_cast<QuadNode*>(t.quad_cam), n_all, n_ref, origin[0], origin[1], origin[2], const_cast<uint32_t*>(t.tree_select));
+                       t.quad, const_cast<QuadNode*>(t.quad_cam), n_all, n_ref, origin[0], origin[1], origin[2], const_cast<uint32_t*>(t.tree_select),
+                       t.quad_cam_variants ? t.quad_cam_variants : 1u);
     if (t.tricam && t.trirec)
         hipLaunchKernelGGL(k_prepare_triangles, dim3((t.n_leaves + 255) / 256), dim3(256), 0, s, t.trirec, const_cast<TriCam*>(t.tricam), t.n_leaves,
                            origin[0], origin[1], origin[2]);
