@@ -303,8 +303,11 @@ def test_forced_trace_strategies_and_full_deferred_list(packet, budget, list_max
                                    dict(RTMI_DEFER_BUDGET='4', RTMI_TASK_CAP='1'),            # queues of one entry: most entries stay with their publisher
                                    dict(RTMI_DEFER_BUDGET='4', RTMI_LONG_LIST_MAX='40'),      # list of shared blocks full: later blocks stay whole
                                    dict(RTMI_DEFER_BUDGET='8', RTMI_TASK_HELPERS='1'),        # one helper block: three takers and the watching wave
-                                   dict(RTMI_DEFER_BUDGET='4', RTMI_TASK_CAP='0')],           # sharing switched off: the plain kernel
-                         ids=['budget4', 'budget64', 'queues-of-one', 'block-list-full', 'one-helper-block', 'no-queues'])
+                                   dict(RTMI_DEFER_BUDGET='4', RTMI_TASK_CAP='0'),            # sharing switched off: the plain kernel
+                                   dict(RTMI_DEFER_BUDGET='1048576', RTMI_NO_OCTANT_RECORDS='1'),   # the instances that walk the general camera-relative copy
+                                   dict(RTMI_DEFER_BUDGET='16', RTMI_NO_OCTANT_RECORDS='1')],
+                         ids=['budget4', 'budget64', 'queues-of-one', 'block-list-full', 'one-helper-block', 'no-queues',
+                              'general-records', 'general-records-shared'])
 def test_four_wide_packets_sharing_sub_trees(knobs, monkeypatch):
     """k_trace_packet4 with a step budget: waves publish their waiting (node, lane mask) entries as tasks, other waves walk them,
     the parts of a block meet in the (t, position) keys and the helper waves write those blocks' contacts.  Whatever the
@@ -328,7 +331,7 @@ def test_four_wide_packets_sharing_sub_trees(knobs, monkeypatch):
                 got = gb.generate_contacts_primary(as_capi_camera(cam))
                 assert got.tobytes() == want.tobytes(), (name, knobs)
             c = ctx.last_trace_counters()
-            if knobs.get('RTMI_TASK_CAP') == '0':
+            if knobs.get('RTMI_TASK_CAP') == '0' or knobs['RTMI_DEFER_BUDGET'] == '1048576':
                 assert c['shared_blocks'] == 0 and c['shared_tasks'] == 0
             elif name != 'cube' and knobs['RTMI_DEFER_BUDGET'] == '4':
                 assert c['shared_blocks'] > 0 and c['shared_tasks'] > 0, (name, knobs, c)
