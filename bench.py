@@ -241,7 +241,10 @@ def main():
     group_ranks = int(os.environ.get('RTMI_BENCH_GROUP', '0')) if world == 1 else 0
     tiled = world > 1 or group_ranks > 0 or os.environ.get('RTMI_BENCH_FORCE_TILED') == '1'
     nranks = world if world > 1 else max(group_ranks, 1)
-    root_extra = int(os.environ.get('RTMI_BENCH_ROOT_EXTRA', '1' if nranks > 1 else '0'))
+    # rank 0 gathers, so it owns e + 1 of every N + e tiles (RT_TILING): what it traces itself does not cross a link.  One GPU now
+    # shades ~17.5 Grays/s = 210 GB/s of 12-byte colour, more than a link carries, so the peers' shares are what bounds a step of
+    # five small frames: e = 2 up to four ranks, 1 from eight on ("What the links allow")
+    root_extra = int(os.environ.get('RTMI_BENCH_ROOT_EXTRA', '0' if nranks <= 1 else ('2' if nranks < 8 else '1')))
 
     # ---- everything that needs child processes happens before this process touches the GPU ------------------------------
     scene_bytes = {name: load_scene_bytes(name) for name in SCENES}
