@@ -146,6 +146,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
     ctx->task_cap = 64; ctx->task_cap_auto = true;     // per queue, 256 queues; grows with the frame (ensure_long_list)
     if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
+    if (const char* env = std::getenv("RTMI_SHARE_MIN_BUDGET")) ctx->share_min_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
     return RT_SUCCESS;
@@ -631,7 +632,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
         static const struct { bool packet; uint32_t budget; bool quad; } candidates[] = {
-            { true, 1u << 20, true }, { true, 64u, true }, { true, 128u, true }, { true, 256u, true }, { true, 1024u, true }, { true, 2048u, true },   // four-wide: whole blocks / sub-trees shared after so many steps
+            { true, 1u << 20, true }, { true, 128u, true }, { true, 256u, true }, { true, 1024u, true }, { true, 2048u, true },   // four-wide: whole blocks / sub-trees shared after so many steps
             { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
             { false, 8u }, { false, 12u }, { false, 16u }, { false, 24u }, { false, 32u }, { false, 48u }, { false, 64u }, { false, 96u }, { false, 128u }, { false, 192u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -691,6 +692,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             if (!cand.packet && ctx->force_packet) return false;
             if (cand.quad && (!b->d_quad || !b->have_search_tree)) return false;   // four-wide records are sound on the search tree only
             if (cand.quad && cand.budget < (1u << 20) && !ctx->d_task_list) return false;   // sub-tree sharing needs its queues
+            if (cand.quad && cand.budget < ctx->share_min_budget) return false;             // knob RTMI_SHARE_MIN_BUDGET
             return true;
         };
         // first pass: every candidate twice unless its first run is hopeless (the first launch of a kernel pays for code and

@@ -92,6 +92,7 @@ struct rt_ctx {
     void* d_task_list = nullptr;            // trace_task_bytes(task_cap): sub-tree tasks shared between the waves of k_trace_packet4
     uint32_t task_cap = 0, task_helper_blocks = 0;
     bool task_cap_auto = false;
+    uint32_t share_min_budget = 0;          // calibration: sharing candidates with a smaller budget are not tried
     uint64_t scratch_generation = 0;        // bumped whenever one of the three buffers above is reallocated (frame graphs hold their addresses)
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default

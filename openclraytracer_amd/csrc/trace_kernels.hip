@@ -103,7 +103,12 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 // Entry = (block's first work item + 1 [0 = not yet written], node, mask low, mask high), written and read as 16 bytes.
 #define TASK_SHARDS 256u
 #define P4_DBG_JOBS 48u
+#ifndef SHARE_MIN_STEPS
 #define SHARE_MIN_STEPS 32u
+#endif
+#ifndef SHARE_BOTTOM_HALF
+#define SHARE_BOTTOM_HALF 1
+#endif
 struct TaskShard { uint32_t taken; uint32_t published; uint32_t finished; uint32_t pad0; uint32_t waves_done; uint32_t tasks_done; uint32_t pad[26]; };
 static_assert(sizeof(TaskShard) == 128, "one line per shard");
 size_t trace_task_bytes(uint32_t cap_per_shard) { return TASK_SHARDS * (sizeof(TaskShard) + (size_t)cap_per_shard * 16u); }
@@ -1162,7 +1167,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
                         } else can = false;                           // no slot in the list of shared blocks: this one stays whole
                     }
                     if (can) {
-                        const bool mine = lane < sp;
+                        // SHARE_BOTTOM_HALF: only the older half of the entries (the bottom of the stack: sub-trees hanging higher
+                        // up, the big ones) is offered; the younger, small ones are walked here anyway before the next sharing
+                        const bool mine = lane < (SHARE_BOTTOM_HALF == 1 ? (sp + 1u) / 2u : SHARE_BOTTOM_HALF == 0 ? sp : (sp < (uint32_t)SHARE_BOTTOM_HALF - 1u ? sp : (uint32_t)SHARE_BOTTOM_HALF - 1u));
                         const uint32_t shard = (wave_gid + lane) & (TASK_SHARDS - 1u);
                         uint32_t slot = 0xFFFFFFFFu;
                         if (mine) {
@@ -1176,10 +1183,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
                         // one 16-byte store per entry (word 0, the block's first work item + 1, marks it written; the taker reads
                         // the entry with one 16-byte load)
                         if (sent) store16_device(e, job_w0 + 1u, vs_node, vs_lo, vs_hi);
-                        // entries that found their queue full move down (through the LDS part of the stack, empty here)
-                        const uint64_t mk = __ballot(mine && !sent);
+                        // entries that stay (not offered, or their queue was full) move down (through the LDS part of the stack, empty here)
+                        const uint64_t mk = __ballot(lane < sp && !sent);
                         if (mk != 0ull) {
-                            if (mine && !sent) { const uint32_t k = lane_rank(mk); st_node[k] = vs_node; st_lo[k] = vs_lo; st_hi[k] = vs_hi; }
+                            if (lane < sp && !sent) { const uint32_t k = lane_rank(mk); st_node[k] = vs_node; st_lo[k] = vs_lo; st_hi[k] = vs_hi; }
                             __builtin_amdgcn_wave_barrier();
                             if (lane < (uint32_t)__popcll(mk)) { vs_node = st_node[lane]; vs_lo = st_lo[lane]; vs_hi = st_hi[lane]; }
                             __builtin_amdgcn_wave_barrier();
@@ -1694,7 +1701,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
             // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
             (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
-            const uint32_t helpers = t.task_helper_blocks ? t.task_helper_blocks : 512u;      // x TRACE_WAVES waves, far fewer than wave slots
+            const uint32_t helpers = t.task_helper_blocks ? t.task_helper_blocks : 256u;      // x TRACE_WAVES waves = one per SIMD: far fewer than wave slots
 #if RTMI_P4_VARIANT == 3
             static unsigned long long* dbg = nullptr; static size_t dbg_n = 0;
             const size_t want = (size_t)(grid + helpers) * TRACE_WAVES * P4_DBG_JOBS * 3u;
