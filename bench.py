@@ -388,8 +388,13 @@ def main():
         else:
             trace = lambda it=it, dc=dc: it['bvh'].generate_contacts_primary_d(it['cam'], dc)
         tm = capi.Timer(sctx)
-        for _ in range(ISOLATED_FRAMES):       # untimed: the device idled during the fence above and the clocks need a millisecond of work
-            trace()
+        # untimed: the device idled during the fence above and its clocks need milliseconds of work to come back -- ten frames of
+        # the Cube are 0.4 ms, and its timed launches then ran at a fraction of the clock (0.26 ms instead of 0.035)
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.005:
+            for _ in range(ISOLATED_FRAMES):
+                trace()
+            sctx.synchronize()
         sctx.set_profiling(2)
         tm.start()
         for _ in range(ISOLATED_FRAMES):
