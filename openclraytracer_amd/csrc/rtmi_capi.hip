@@ -593,7 +593,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;
-    t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.quad_cam_variants = b->quad_cam_variants;
+    t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.quad_cam_variants = b->quad_cam_variants; t.no_unsafe_rays = b->capture_no_unsafe_rays;
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.task_shards = b->ctx->d_task_list; t.task_cap = b->ctx->task_cap; t.task_helper_blocks = b->ctx->task_helper_blocks;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
@@ -1001,9 +1001,16 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     g->ctx = ctx; g->bvh = b;
     g->scratch_generation = ctx->scratch_generation; g->build_generation = b->build_generation;
     g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
+    // The four-wide packet kernel hands rays to the wave-per-ray kernel only when the camera sits on a box plane (ray_root): the
+    // eager frame above has computed those bits for this camera position, and a graph is for one position -- so a captured frame
+    // of a camera on no plane leaves the (then empty, ~7 us) wave-per-ray launch out.
+    uint32_t plane_bits = 1u;
+    if (b->d_tree_select && b->have_search_tree) RT_HIP(ctx, hipMemcpy(&plane_bits, b->d_tree_select, sizeof plane_bits, hipMemcpyDeviceToHost));
     hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) { delete g; return RT_FAIL(ctx, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    b->capture_no_unsafe_rays = plane_bits == 0u;
     const int rc = frame_issue(b, scene, cam, rank, nranks, layout, d_contacts, d_out, slots_per_rank);
+    b->capture_no_unsafe_rays = false;
     e = hipStreamEndCapture(ctx->stream, &g->graph);
     if (rc != RT_SUCCESS || e != hipSuccess || !g->graph) {
         if (g->graph) (void)hipGraphDestroy(g->graph);

@@ -133,6 +133,7 @@ struct rt_bvh {
     QuadNode* d_quad = nullptr;        // four-wide records of the same nodes (packet kernel), null when disabled
     QuadNode* d_quad_cam = nullptr;    // the same records relative to the current camera position (k_prepare_camera): the general copy, then
     uint32_t quad_cam_variants = 1;    // (quad_cam_variants - 1 = 8) copies with the near / far planes in place per direction octant
+    bool capture_no_unsafe_rays = false;   // set around a frame-graph capture whose camera is known to sit on no box plane
     uint32_t* d_depth = nullptr;       // max depth (1 word)
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
     TriRec* d_trirec = nullptr;        // packed triangle records of the packet kernels (filled per build: they hold the rank)
@@ -236,6 +237,7 @@ struct TraceLaunch {
     const QuadNode* quad;         // four-wide records (null: the packet kernel walks the binary records)
     const QuadNode* quad_cam;     // primary rays: the same records with the camera position subtracted from the boxes (+ thresholds)
     uint32_t quad_cam_variants;   // 1: the general copy only; 9: + one per direction octant (near / far planes in place)
+    bool no_unsafe_rays;          // the caller knows that the camera sits on no box plane: the four-wide kernel hands no ray over
     uint32_t search_root;         // primary rays: root record of the search tree, 0 = none (walk the reference tree)
     const uint32_t* tree_select;  // per camera: bit k set = the camera's coordinate k equals a box plane
     const DeviceScene* scene;

@@ -1736,8 +1736,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         }
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // rays the four-wide records may not be used for (see the kernel) wait on the deferred list: normally none, and the
-        // wave-per-ray kernel returns at once
-        hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
+        // wave-per-ray kernel returns at once (left out where the caller knows that there are none: frame graphs)
+        if (!t.no_unsafe_rays) hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }

@@ -472,6 +472,24 @@ def test_camera_on_a_box_plane_with_every_kernel(name, packet, budget, monkeypat
         assert gb.search_tree()['used_by_last_camera'] == 2
         if packet == '4':
             assert ctx.last_trace_counters()['deferred_rays'] == 120          # exactly the pixel column with direction.x == 0
+            # frame graphs: a captured frame leaves the wave-per-ray launch out only where the camera sits on no box plane --
+            # here it must stay (those 120 rays), for the camera next to the plane it goes; both replay the oracle's contacts,
+            # also alternately on the same BVH (each replay restores its camera's records first)
+            npx = 160 * 120
+            cam2 = osc.demo_camera(160, 120).copy()
+            cam2['m'][0][3] = 0.123
+            want2, _ = ob.trace_primary(cam2)
+            graphs = []
+            for c in (cam, cam2):
+                dc, dr = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+                graphs.append((capi.FrameGraph(gb, sc, as_capi_camera(c), dc, dr), dc, dr))
+            for _ in range(2):
+                for (g, dc, dr), w in zip(graphs, (want, want2)):
+                    ctx.fill_u32(dc, 0xDEADBEEF, npx * 8)
+                    g.launch()
+                    assert ctx.download(dc, npx, capi.CONTACT).tobytes() == w.tobytes()
+            for g, dc, dr in graphs:
+                g.close(); ctx.free(dc); ctx.free(dr)
         gb.close(); sc.close()
     finally:
         ctx.close()
