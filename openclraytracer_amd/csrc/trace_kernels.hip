@@ -1684,8 +1684,13 @@ template <int PRIMARY, int CAL>
 static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 {
     if (a.total_work == 0) return;
-    // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16)
-    (void)hipMemsetAsync(t.ctrl, 0, offsetof(TraceCtrl, error), s);      // the error word is sticky (host-cleared)
+    // re-initialise every shared word before every launch (cdna_hip_programming.md, Guideline 16) -- unless the launch reads
+    // none: the four-wide kernel without sharing touches the control block only to hand over unsafe rays (there are none, the
+    // caller says), for its sticky error word and for a diagnostic count of overflow areas (which then runs on over such frames)
+    const bool four_wide = PRIMARY == 1 && t.packet && t.packet4 && t.quad && t.tricam && t.search_root;
+    const bool shares = four_wide && t.task_shards && t.task_cap && a.defer_budget < (1u << 20);
+    if (!(four_wide && !shares && t.no_unsafe_rays))
+        (void)hipMemsetAsync(t.ctrl, 0, offsetof(TraceCtrl, error), s);      // the error word is sticky (host-cleared)
     // First-phase kernels: one wave per 64-ray block and the hardware dispatcher as the work queue.  (A persistent grid --
     // resident waves pulling blocks from sharded counters, idle lanes refilled -- measured 25-50 % slower on every bundled
     // scene: Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms)
