@@ -146,6 +146,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';
     ctx->task_cap = 64; ctx->task_cap_auto = true;     // per queue, 256 queues; grows with the frame (ensure_long_list)
     if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
+    if (const char* env = std::getenv("RTMI_FUSED_FRAMES")) ctx->no_fused_frames = env[0] == '0';
     if (const char* env = std::getenv("RTMI_SHARE_MIN_BUDGET")) ctx->share_min_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
@@ -624,7 +625,8 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 // moderately long rays: no deferral), and every budget produces the same contacts.  The first frame of a
 // (BVH, resolution, tiling) combination therefore runs once per candidate, timed with HIP events on the stream,
 // and later frames use the fastest.  RTMI_DEFER_BUDGET fixes the budget and switches the calibration off.
-static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out)
+struct FusedShade { void* rgba; uint32_t plane_stride; bool done; };
+static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out, FusedShade* fused = nullptr)
 {
     rt_ctx* ctx = b->ctx;
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
@@ -737,6 +739,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     TraceLaunch t = make_launch(b, cam);
     if (ctx->defer_budget == 0 && b->tuned) { t.defer_budget = b->tuned_budget; t.packet = b->tuned_packet; t.packet4 = b->tuned_quad; }
     if (ctx->defer_budget != 0 && ctx->force_packet) { t.packet = true; t.packet4 = ctx->force_packet4 && b->d_quad; }
+    if (fused) { t.fused_rgba = fused->rgba; t.fused_plane_stride = fused->plane_stride; t.fused_done = &fused->done; }
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
@@ -964,7 +967,12 @@ static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, u
 {
     rt_ctx* ctx = b->ctx;
     const bool tiled = layout != RT_FRAME_UNTILED;
-    if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts)) return RT_ERROR;
+    // a captured frame whose camera sits on no box plane lets the four-wide kernel shade what it stores (trace_kernels.hip, fused
+    // frame); whether it did is its launcher's answer -- any other strategy leaves the colours to k_shade
+    FusedShade fused{ d_out, layout == RT_FRAME_TILED_PACKED ? slots_per_rank : 0u, false };
+    if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts,
+                            b->capture_no_unsafe_rays && !ctx->no_fused_frames ? &fused : nullptr)) return RT_ERROR;
+    if (fused.done) { RT_HIP(ctx, hipGetLastError()); return RT_SUCCESS; }
     if (!tiled)
         launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts, cam->resX * cam->resY, (float4*)d_out, true, 0, 1);
     else

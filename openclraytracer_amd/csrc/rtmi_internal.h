@@ -93,6 +93,7 @@ struct rt_ctx {
     uint32_t task_cap = 0, task_helper_blocks = 0;
     bool task_cap_auto = false;
     uint32_t share_min_budget = 0;          // calibration: sharing candidates with a smaller budget are not tried
+    bool no_fused_frames = false;           // knob RTMI_FUSED_FRAMES=0: frame graphs always shade with k_shade
     uint64_t scratch_generation = 0;        // bumped whenever one of the three buffers above is reallocated (frame graphs hold their addresses)
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
@@ -238,6 +239,12 @@ struct TraceLaunch {
     const QuadNode* quad_cam;     // primary rays: the same records with the camera position subtracted from the boxes (+ thresholds)
     uint32_t quad_cam_variants;   // 1: the general copy only; 9: + one per direction octant (near / far planes in place)
     bool no_unsafe_rays;          // the caller knows that the camera sits on no box plane: the four-wide kernel hands no ray over
+    // Fused frame (frame graphs): the four-wide kernel shades every contact as it stores it (shade_math.h) -- asked for by
+    // fused_rgba != null, honoured (*fused_done = true) only by that kernel and only with no_unsafe_rays, since contacts that
+    // other kernels write would stay unshaded.  plane stride != 0: three float planes instead of float4 (shade_kernels.hip)
+    void* fused_rgba;
+    uint32_t fused_plane_stride;
+    bool* fused_done;
     uint32_t search_root;         // primary rays: root record of the search tree, 0 = none (walk the reference tree)
     const uint32_t* tree_select;  // per camera: bit k set = the camera's coordinate k equals a box plane
     const DeviceScene* scene;

@@ -46,6 +46,7 @@
 //  k_prepare_camera, per camera position: "camera inside child box" bits of every record and the camera-on-a-plane bits.
 #include "rtmi_internal.h"
 #include "device_math.h"
+#include "shade_math.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -145,6 +146,10 @@ struct TraceArgs {
     uint32_t diagnostics;                  // count the wave-per-ray kernel's pool steps (perturbs its timing)
     TaskShard* task_shards;                // k_trace_packet4 with shared tasks: TASK_SHARDS queues, then their entries
     uint32_t task_cap;                     // entries per queue
+    // fused frame: shade a contact where it is stored (k_trace_packet4 only; null = contacts only)
+    float4* fused_rgba;
+    uint32_t fused_plane_stride;
+    ShadeScene fused_scene;
 #if RTMI_P4_VARIANT == 3
     unsigned long long* dbg;               // per wave P4_DBG_JOBS x (start, end, steps << 1 | is_task) on the 100 MHz clock
 #endif
@@ -457,6 +462,30 @@ __device__ __forceinline__ void store_contact(const TraceArgs& a, uint32_t out_i
     float4* o = reinterpret_cast<float4*>(a.out + out_index);
     o[0] = *reinterpret_cast<float4*>(&head);
     o[1] = nt;
+}
+
+// ... and, in a fused frame, its colour: what k_shade computes from the contact just written, at the index k_shade writes it to
+// (shade_kernels.hip: the frame's own pixel / compact slot; misses are zeros; the packed planes carry the hit in red's sign bit)
+__device__ __forceinline__ void store_colour(const TraceArgs& a, uint32_t out_index, uint32_t pixel, float t, uint32_t leaf)
+{
+    float4 col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool hit = leaf != NO_LEAF && t > 0.0f;
+    if (hit) {
+        rt_contact c;
+        const float4 n = a.nrm[leaf];
+        c.pixelIndex = pixel; c.materialIndex = __float_as_uint(a.v0[leaf].w); c.pad[0] = 0; c.pad[1] = 0;
+        c.normalAndDistance[0] = n.x; c.normalAndDistance[1] = n.y; c.normalAndDistance[2] = n.z; c.normalAndDistance[3] = t;
+        col = shade_one(a.fused_scene, a.cam, c);
+    }
+    if (a.fused_plane_stride) {
+        float* planes = reinterpret_cast<float*>(a.fused_rgba);
+        if (hit) col.x = __uint_as_float(__float_as_uint(col.x) | 0x80000000u);
+        planes[out_index] = col.x;
+        planes[(size_t)a.fused_plane_stride + out_index] = col.y;
+        planes[2u * (size_t)a.fused_plane_stride + out_index] = col.z;
+    } else {
+        a.fused_rgba[out_index] = col;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1027,7 +1056,7 @@ __device__ __forceinline__ const TraceArgs& rare_args()
     return *p;
 }
 
-template <int PRIMARY, int CAL, int SHARE, int OCT>
+template <int PRIMARY, int CAL, int SHARE, int OCT, int FUSE>
 __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 {
     __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
@@ -1088,6 +1117,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
                     float4* o = reinterpret_cast<float4*>(A.out + slot);
                     o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (FUSE) store_colour(A, slot, 0u, 0.0f, NO_LEAF);
                 }
                 // The four-wide records skip the boxes of a node's inner children, which is sound on the search tree only (the
                 // host launches this kernel only when there is one).  A ray that must walk the reference tree box by box
@@ -1306,7 +1336,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
         dbg_jobs++;
 #endif
         if (!split) {
-            if (ok) store_contact(A, r.out_index, r.pixel, r.best_t, r.best_leaf);
+            if (ok) {
+                store_contact(A, r.out_index, r.pixel, r.best_t, r.best_leaf);
+                if (FUSE) store_colour(A, r.out_index, r.pixel, r.best_t, r.best_leaf);
+            }
         } else if (r.best_leaf != NO_LEAF) {
             __hip_atomic_fetch_min((gu64*)A.keys + w, ((unsigned long long)__float_as_uint(r.best_t) << 32) | r.best_pos, RLX_AGENT);
         }
@@ -1406,7 +1439,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
             if (w < A.total_work && load_ray<PRIMARY>(A, w, r, sx, sy, sz) && ray_root<PRIMARY>(A, r, plane_bits) != 0u) {
                 const unsigned long long key = __hip_atomic_load((gu64*)A.keys + w, RLX_AGENT);
                 const bool hit = key != KEY_NONE;
-                store_contact(A, r.out_index, r.pixel, hit ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX, hit ? A.pairs[(uint32_t)key].y : NO_LEAF);
+                const float t = hit ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
+                const uint32_t leaf = hit ? A.pairs[(uint32_t)key].y : NO_LEAF;
+                store_contact(A, r.out_index, r.pixel, t, leaf);
+                if (FUSE) store_colour(A, r.out_index, r.pixel, t, leaf);
             }
         }
     }
@@ -1702,6 +1738,14 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
     a.n_waves = grid1 * TRACE_WAVES;                     // resident waves of the wave-per-ray kernel
     if constexpr (PRIMARY == 1) if (t.packet && t.packet4 && t.quad && t.tricam && t.search_root) {   // (primary rays only: no instance for ray buffers)
+        if (t.fused_rgba && t.no_unsafe_rays) {
+            // every contact of this frame is stored by the kernel below: it shades them as well (one launch and one pass over
+            // the contacts less per frame)
+            a.fused_rgba = (float4*)t.fused_rgba; a.fused_plane_stride = t.fused_plane_stride;
+            a.fused_scene.scene = t.scene->bytes; a.fused_scene.n_lights = t.scene->n_lights; a.fused_scene.n_spheres = t.scene->n_spheres;
+            a.fused_scene.n_materials = t.scene->n_materials;
+            if (t.fused_done) *t.fused_done = true;
+        }
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
             // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
@@ -1716,8 +1760,9 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
                 a.dbg = dbg;
             }
 #endif
-            if (a.quad_octant_records) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 1>), dim3(grid + helpers), dim3(TRACE_BLOCK), 0, s, a);
-            else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 0>), dim3(grid + helpers), dim3(TRACE_BLOCK), 0, s, a);
+            const dim3 g(grid + helpers), blk(TRACE_BLOCK);
+            if (a.quad_octant_records) { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 1, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 1, 0>), g, blk, 0, s, a); }
+            else { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 0, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 0, 0>), g, blk, 0, s, a); }
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 std::vector<unsigned long long> h(want);
@@ -1727,8 +1772,9 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
             }
 #endif
         } else {
-            if (a.quad_octant_records) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 1>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
-            else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 0>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+            const dim3 g(grid), blk(TRACE_BLOCK);
+            if (a.quad_octant_records) { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 1, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 1, 0>), g, blk, 0, s, a); }
+            else { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 0, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 0, 0>), g, blk, 0, s, a); }
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 const size_t n = (size_t)grid * TRACE_WAVES * 3u;
