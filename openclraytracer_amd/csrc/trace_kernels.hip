@@ -51,7 +51,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef TRACE_BLOCK
 #define TRACE_BLOCK 256u
+#endif
 #define TRACE_WAVES (TRACE_BLOCK / 64u)
 #define LDS_STACK 24u            // stack entries per lane in k_trace (observed need at 1080p: <= 18)
 #define NO_LEAF 0xFFFFFFFEu
