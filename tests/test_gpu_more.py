@@ -355,6 +355,40 @@ def test_four_wide_packets_sharing_sub_trees(knobs, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize('name,res', [('tenryuu', (640, 360)), ('man', (320, 240))])
+def test_rebuilt_bvh_keeps_its_strategy_and_contacts(gpu_ctx, name, res):
+    """Dynamic scenes rebuild per frame (OpenCLRayTracerDemo.cpp:230-234): initializeFrame + construct + generateContacts.  The
+    strategy calibrated on the first frame is a property of how the model fills the frame and is kept across rebuilds of the
+    same size (one calibration, not one per frame); the contacts are the oracle's after every rebuild; a frame graph made
+    before a rebuild refuses to replay."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    osc, ob = oracle_bvh(name)
+    sc = capi.DeviceScene(gpu_ctx, packed_scene(name))            # a BVH of its own: the shared one must not be rebuilt under other tests
+    gb = capi.DeviceBVH(gpu_ctx, sc).build()
+    cam = osc.demo_camera(*res)
+    want, _ = ob.trace_primary(cam)
+    ccam = as_capi_camera(cam)
+    assert gb.generate_contacts_primary(ccam).tobytes() == want.tobytes()
+    first = gb.trace_strategy()
+    assert first['budget'] != 0                                  # calibrated
+    for _ in range(3):
+        gb.build()                                               # initializeFrame + construct
+        assert gb.generate_contacts_primary(ccam).tobytes() == want.tobytes()
+        assert gb.trace_strategy() == first
+    npx = res[0] * res[1]
+    dc, dr = gpu_ctx.alloc(npx * 32), gpu_ctx.alloc(npx * 16)
+    g = capi.FrameGraph(gb, sc, ccam, dc, dr)
+    g.launch()
+    assert gpu_ctx.download(dc, npx, capi.CONTACT).tobytes() == want.tobytes()
+    gb.build()
+    with pytest.raises(RuntimeError, match='stale'):
+        g.launch()
+    g.close(); gpu_ctx.free(dc); gpu_ctx.free(dr)
+    assert gb.generate_contacts_primary(ccam).tobytes() == want.tobytes()
+    gb.close(); sc.close()
+
+
 @pytest.mark.parametrize('batch', ['1', '2', '4'])
 def test_wave_per_ray_kernel_with_one_two_and_four_rays_per_wave(batch, monkeypatch):
     """The wave-per-ray kernel walks 1, 2 or 4 deferred rays per wave (chosen from the number of deferred rays per resident
