@@ -1108,7 +1108,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
         uint32_t my_octant;                              // bit k: 1 / direction negative on axis k
         bool split = SHARE && is_task;                   // results go to the key buffer
         {
-            const TraceArgs& A = rare_args<1>();
+            // (without sharing a wave has this one job: what it reads of the arguments here is dead before the walk begins, and
+            //  scalar loads of the by-value copy are back long before the flat loads of rare_args)
+            const TraceArgs& A = SHARE ? rare_args<1>() : a;
             bool sx = false, sy = false, sz = false;
             ok = w < A.total_work && load_ray<PRIMARY>(A, w, r, sx, sy, sz);
             my_octant = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
@@ -1320,7 +1322,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 #endif
         }
         }                                                // next octant group
-        const TraceArgs& A = rare_args<4>();
+        const TraceArgs& A = SHARE ? rare_args<4>() : a;
 #if RTMI_P4_VARIANT == 2
         if (lane == 0) {
             __hip_atomic_fetch_add((gu32*)&A.ctrl->long_steps, (uint32_t)(tA >> 6), RLX_AGENT);
