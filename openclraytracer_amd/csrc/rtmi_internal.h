@@ -185,6 +185,10 @@ struct rt_tlg {
     uint32_t leaf_ranges_cap = 0;       // entries d_leaf_ranges holds
     uint32_t pairs_cap = 0, leaf_cap = 0;   // elements d_pairs / d_leaf_pairs hold (kept across initializeFrame: a rebuild starts on them)
     uint32_t rebuilds_without_readback = 0;   // diagnostics
+    TriCam* d_tricam = nullptr;         // n camera-relative triangle records of the primary-ray trace (rtmi_internal.h, TriCam)
+    float tricam_origin[3] = { 0, 0, 0 };
+    bool tricam_valid = false;
+    uint32_t tricam_n = 0;              // records d_tricam holds
     bool frame_initialised = false;
     bool built = false;
 };
@@ -292,6 +296,8 @@ struct TlgLaunch {
     const uint2* leaf_ranges;
     const uint2* leaf_pairs;
     const DeviceScene* scene;
+    const TriCam* tricam;      // primary rays: the triangle records relative to the camera position (null: the scene's table)
+    bool prepare_tricam;       // ... which this launch (re)computes first: the camera moved, or the scene was rebuilt
 };
 void launch_tlg_count_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, uint32_t* counters);
 void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs,

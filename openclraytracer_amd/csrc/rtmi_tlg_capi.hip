@@ -32,9 +32,9 @@ int rt_tlg_create(rt_ctx* ctx, const rt_scene* scene, rt_tlg** out)
 static void free_tlg_buffers(rt_tlg* g)
 {
     void** ptrs[] = { (void**)&g->d_counters, (void**)&g->d_scan, (void**)&g->d_scan_scratch, (void**)&g->d_cell_ranges, (void**)&g->d_top,
-                      (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written };
+                      (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written, (void**)&g->d_tricam };
     for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0;
+    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false;
 }
 
 void rt_tlg_destroy(rt_tlg* g)
@@ -279,6 +279,7 @@ int rt_tlg_construct(rt_tlg* g)
     if (!done && construct_with_readbacks(g)) return RT_ERROR;
     g->frame_initialised = false;
     g->built = true;
+    g->tricam_valid = false;                      // the scene's triangles may have moved
     return RT_SUCCESS;
 }
 
@@ -289,6 +290,28 @@ static TlgLaunch make_tlg_launch(const rt_tlg* g)
     return t;
 }
 
+// Primary rays share their origin: what the triangle test computes from the origin and the triangle alone is computed once per
+// camera position (TriCam, rtmi_internal.h), as for the BVH's packet kernel.  The table follows the camera and the scene
+// (construct() invalidates it); without it (allocation failed, knob RTMI_TLG_TRICAM=0) the kernel reads the scene's table.
+static void use_camera_triangles(rt_tlg* g, const rt_camera* cam, TlgLaunch& t)
+{
+    static const bool off = [] { const char* e = std::getenv("RTMI_TLG_TRICAM"); return e && e[0] == '0'; }();
+    if (off || g->n == 0) return;
+    if (g->d_tricam && g->tricam_n != g->n) {           // another scene size since: a table of that size
+        (void)hipStreamSynchronize(g->ctx->stream);
+        (void)hipFree(g->d_tricam); g->d_tricam = nullptr; g->tricam_valid = false;
+    }
+    if (!g->d_tricam) {
+        if (hipMalloc((void**)&g->d_tricam, (size_t)g->n * sizeof(TriCam)) != hipSuccess) { (void)hipGetLastError(); g->d_tricam = nullptr; return; }
+        g->tricam_n = g->n; g->tricam_valid = false;
+    }
+    const float o[3] = { cam->viewTransform[3], cam->viewTransform[7], cam->viewTransform[11] };
+    t.tricam = g->d_tricam;
+    t.prepare_tricam = !g->tricam_valid || std::memcmp(o, g->tricam_origin, sizeof o) != 0;
+    std::memcpy(g->tricam_origin, o, sizeof o);
+    g->tricam_valid = true;
+}
+
 int rt_tlg_generate_contacts_primary(rt_tlg* g, const rt_camera* cam, void* d_contacts)
 {
     if (!g) return RT_FAIL(nullptr, "tlg is null");
@@ -297,7 +320,9 @@ int rt_tlg_generate_contacts_primary(rt_tlg* g, const rt_camera* cam, void* d_co
     if (!d_contacts) return RT_FAIL(ctx, "contacts buffer is null");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     RT_ENTER(ctx);
-    launch_tlg_trace_primary(ctx->stream, make_tlg_launch(g), *cam, 0, 1, false, (rt_contact*)d_contacts);
+    TlgLaunch t = make_tlg_launch(g);
+    use_camera_triangles(g, cam, t);
+    launch_tlg_trace_primary(ctx->stream, t, *cam, 0, 1, false, (rt_contact*)d_contacts);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }
@@ -311,7 +336,9 @@ int rt_tlg_generate_contacts_primary_tiled(rt_tlg* g, const rt_camera* cam, uint
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return RT_FAIL(ctx, "rank/nranks invalid");
     RT_ENTER(ctx);
-    launch_tlg_trace_primary(ctx->stream, make_tlg_launch(g), *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
+    TlgLaunch t = make_tlg_launch(g);
+    use_camera_triangles(g, cam, t);
+    launch_tlg_trace_primary(ctx->stream, t, *cam, rank, nranks, true, (rt_contact*)d_contacts_compact);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }

@@ -293,6 +293,7 @@ struct TlgTraceArgs {
     const float4* __restrict__ e1;
     const float4* __restrict__ e2;
     const float4* __restrict__ nrm;
+    const TriCam* __restrict__ tricam;      // primary rays: camera-relative triangle records (null: v0 / e1 / e2)
     uint32_t total_work;
     rt_camera cam;
     uint32_t rank, nranks, tiles_x, compact;
@@ -440,19 +441,31 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
                     uint32_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
                     if (*slot == tri) continue;                               // tested in an earlier cell: a miss, again
                     *slot = tri;
-                    // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions)
-                    const f3 vert0 = f3_from4(a.v0[tri]), edge1 = f3_from4(a.e1[tri]), edge2 = f3_from4(a.e2[tri]);
+                    // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
+                    // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
+                    f3 edge1, edge2, tvec, qvec;
+                    float e2q;
+                    if (PRIMARY && a.tricam) {
+                        const float4* p = reinterpret_cast<const float4*>(a.tricam + tri);
+                        const float4 w0 = p[0], w1 = p[1], w2 = p[2];
+                        edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
+                        e2q = p[3].x;
+                    } else {
+                        const f3 vert0 = f3_from4(a.v0[tri]);
+                        edge1 = f3_from4(a.e1[tri]); edge2 = f3_from4(a.e2[tri]);
+                        tvec = f3_sub(o, vert0);
+                        qvec = f3_cross(tvec, edge1);
+                        e2q = f3_dot(edge2, qvec);
+                    }
                     const f3 pvec = f3_cross(d, edge2);
                     const float det = f3_dot(edge1, pvec);
                     bool flag = fabsf(det) >= FLT_EPSILON;
                     const float inv_det = 1.0f / det;
-                    const f3 tvec = f3_sub(o, vert0);
                     const float u = f3_dot(tvec, pvec) * inv_det;
                     flag = flag & (u < 1.0f) & (u >= 0.0f);
-                    const f3 qvec = f3_cross(tvec, edge1);
                     const float v = f3_dot(d, qvec) * inv_det;
                     flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
-                    const float t = f3_dot(edge2, qvec) * inv_det;        // "* flag" folded into the test
+                    const float t = e2q * inv_det;                         // "* flag" folded into the test
                     if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
                 }
                 if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
@@ -521,6 +534,26 @@ void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pai
                            scan, counters, leaf_pairs, written_total, count_dev, leaf_cap);
 }
 
+// the camera-relative triangle records (TriCam) from the scene's table: the operations of the test above that involve the origin
+// and the triangle only, in its order
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_prepare_triangles(const float4* __restrict__ v0, const float4* __restrict__ e1, const float4* __restrict__ e2,
+                                                                     TriCam* __restrict__ out, uint32_t n, float ox, float oy, float oz)
+{
+    const uint32_t i = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const f3 vert0 = f3_from4(v0[i]), edge1 = f3_from4(e1[i]), edge2 = f3_from4(e2[i]);
+    const f3 tvec = f3_sub(f3{ ox, oy, oz }, vert0);
+    const f3 qvec = f3_cross(tvec, edge1);
+    TriCam c;
+    c.e1[0] = edge1.x; c.e1[1] = edge1.y; c.e1[2] = edge1.z;
+    c.e2[0] = edge2.x; c.e2[1] = edge2.y; c.e2[2] = edge2.z;
+    c.tvec[0] = tvec.x; c.tvec[1] = tvec.y; c.tvec[2] = tvec.z;
+    c.qvec[0] = qvec.x; c.qvec[1] = qvec.y; c.qvec[2] = qvec.z;
+    c.e2_dot_qvec = f3_dot(edge2, qvec);
+    c.pos = 0u; c.pad[0] = c.pad[1] = 0u;
+    out[i] = c;
+}
+
 static TlgTraceArgs tlg_args(const TlgLaunch& t)
 {
     TlgTraceArgs a{};
@@ -538,6 +571,10 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
     const uint32_t tiles = rt_tiles_x(cam.resX) * rt_tiles_y(cam.resY);
     a.total_work = rt_owned_tiles(tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.out = out;
+    a.tricam = t.tricam;
+    if (t.tricam && t.prepare_tricam && t.scene->n_tris)
+        hipLaunchKernelGGL(k_tlg_prepare_triangles, blocks_for(t.scene->n_tris), dim3(TLG_BLOCK), 0, s, t.scene->v0, t.scene->e1, t.scene->e2,
+                           const_cast<TriCam*>(t.tricam), t.scene->n_tris, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11]);
     if (a.total_work) hipLaunchKernelGGL(k_tlg_trace<1>, blocks_for(a.total_work), dim3(TLG_BLOCK), 0, s, a);
 }
 
