@@ -38,12 +38,17 @@
 //     and stays in registers, both children's records are requested before the box tests; (node, lane mask) pairs wait
 //     on an LDS stack; sub-trees only a handful of lanes still want, or everything left once a budget is spent, go to
 //     the deferred list as per-ray partial records whose results meet in a 64-bit atomicMin on (t, position).
-//  k_trace_packet4, the same on the four-wide records of the search tree (two levels per step, nothing handed over).
+//  k_trace_packet4, the kernel most frames run on: the same walk on the four-wide records of the search tree (two levels per
+//     step), on per-camera copies of those records and of the triangles (k_prepare_camera, k_prepare_triangles): box tests
+//     of 10 vector instructions whose results are lane masks in scalar registers, the stack in lanes of vector registers,
+//     optionally (SHARE) the waiting sub-trees of long walks published as tasks for other waves, optionally (FUSE, frame
+//     graphs) the colour written next to the contact.  Described where it stands, below.
 //  k_trace_long, one, two or four deferred records per WAVE: the 64 lanes walk the rays' sub-trees together out of an LDS
 //     node pool (64 nodes per step, children appended with ballot/prefix-popcount compaction, spare lanes running ahead
 //     along duplicate-code chains, leaves collected in a second pool and tested 64 at a time); hits meet in a 64-bit
 //     (t, position) key per ray through an LDS atomic min.
-//  k_prepare_camera, per camera position: "camera inside child box" bits of every record and the camera-on-a-plane bits.
+//  k_prepare_camera / k_prepare_triangles, per camera position: "camera inside child box" bits of the binary records, the
+//     camera-relative copies of the four-wide records (one per direction octant) and of the triangles, the camera-on-a-plane bits.
 #include "rtmi_internal.h"
 #include "device_math.h"
 #include "shade_math.h"
