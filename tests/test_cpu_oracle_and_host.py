@@ -361,3 +361,15 @@ def test_literal_zero_hit_counts():
         orc.lib().orc_refit(orc._p(nodes), sc.n_tris, 0)          # n walkers, no clamped extras
         b.nodes = nodes
         assert hits(b) == one_walker_per_leaf
+
+
+def test_bench_reads_the_tag_of_a_traversal_kernel_name():
+    """rocprofv3 names the traversal kernels by their template arguments; bench.py and tools/summarize_profiles.py tell the
+    steady-state launches (second argument 0), the calibration (1) and the isolated measurement pass (2) apart by them, whatever
+    further arguments a kernel has"""
+    import bench
+    assert bench.kernel_tag('k_trace<1, 2>') == (1, 2)
+    assert bench.kernel_tag('k_trace_packet4<1, 0, 1, 1, 0>') == (1, 0)
+    assert bench.kernel_tag('k_trace_long<0, 1>') == (0, 1)
+    assert bench.kernel_tag('k_shade') is None
+
