@@ -6,6 +6,7 @@
 //  BVHManager.cpp:156-228) and adds the re-layout into 64-byte traversal records.
 // Integer work must be bit-exact with the reference; float work uses device_math.h.
 #include "rtmi_internal.h"
+#include <cstdlib>
 #include "device_math.h"
 
 #include <limits.h>
@@ -617,7 +618,7 @@ void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32
 //    inner children's own boxes is allowed for the same reason the search tree is (any nested hierarchy over the leaves
 //    reaches the same leaves); one wave step then descends two levels.
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t n_records)
+__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t n_records, uint32_t greedy)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_records) return;
@@ -625,19 +626,41 @@ __global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restric
     float lo[4][3], hi[4][3];
     uint32_t id[4];
     int n = 0;
-    for (int c = 0; c < 2; c++) {
-        const uint32_t cid = c ? t.child_b : t.child_a;
-        const float* clo = c ? t.b_lo : t.a_lo;
-        const float* chi = c ? t.b_hi : t.a_hi;
-        if (cid & RT_LEAF_FLAG) {
-            for (int k = 0; k < 3; k++) { lo[n][k] = clo[k]; hi[n][k] = chi[k]; }
-            id[n++] = cid;
-        } else {
-            const TravNode u = trav[cid];
-            for (int k = 0; k < 3; k++) { lo[n][k] = u.a_lo[k]; hi[n][k] = u.a_hi[k]; }
-            id[n++] = u.child_a;
-            for (int k = 0; k < 3; k++) { lo[n][k] = u.b_lo[k]; hi[n][k] = u.b_hi[k]; }
-            id[n++] = u.child_b;
+    if (greedy) {
+        // The slots are any cut of the node's sub-tree with at most four nodes (every leaf below the node is below exactly one
+        // slot, which is all the walk needs).  Instead of always replacing both children by theirs, the slot with the largest
+        // surface area is opened, twice: the boxes a ray is most likely to enter are the ones resolved further, so fewer steps
+        // end in a big box whose children all miss (the usual collapse of a binary hierarchy into a four-wide one).
+        for (int k = 0; k < 3; k++) { lo[0][k] = t.a_lo[k]; hi[0][k] = t.a_hi[k]; lo[1][k] = t.b_lo[k]; hi[1][k] = t.b_hi[k]; }
+        id[0] = t.child_a; id[1] = t.child_b; n = 2;
+        for (int round = 0; round < 2; round++) {
+            int best = -1; float best_area = -1.0f;
+            for (int c = 0; c < n; c++) {
+                if (id[c] & RT_LEAF_FLAG) continue;
+                const float dx = hi[c][0] - lo[c][0], dy = hi[c][1] - lo[c][1], dz = hi[c][2] - lo[c][2];
+                const float area = dx * dy + dy * dz + dz * dx;
+                if (!(area <= best_area)) { best = c; best_area = area; }       // (a NaN area is opened like any other)
+            }
+            if (best < 0) break;
+            const TravNode u = trav[id[best]];
+            for (int k = 0; k < 3; k++) { lo[best][k] = u.a_lo[k]; hi[best][k] = u.a_hi[k]; lo[n][k] = u.b_lo[k]; hi[n][k] = u.b_hi[k]; }
+            id[best] = u.child_a; id[n] = u.child_b; n++;
+        }
+    } else {
+        for (int c = 0; c < 2; c++) {
+            const uint32_t cid = c ? t.child_b : t.child_a;
+            const float* clo = c ? t.b_lo : t.a_lo;
+            const float* chi = c ? t.b_hi : t.a_hi;
+            if (cid & RT_LEAF_FLAG) {
+                for (int k = 0; k < 3; k++) { lo[n][k] = clo[k]; hi[n][k] = chi[k]; }
+                id[n++] = cid;
+            } else {
+                const TravNode u = trav[cid];
+                for (int k = 0; k < 3; k++) { lo[n][k] = u.a_lo[k]; hi[n][k] = u.a_hi[k]; }
+                id[n++] = u.child_a;
+                for (int k = 0; k < 3; k++) { lo[n][k] = u.b_lo[k]; hi[n][k] = u.b_hi[k]; }
+                id[n++] = u.child_b;
+            }
         }
     }
     for (; n < 4; n++) { for (int k = 0; k < 3; k++) { lo[n][k] = FLT_MAX; hi[n][k] = -FLT_MAX; } id[n] = RT_SENTINEL; }
@@ -655,7 +678,8 @@ __global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restric
 
 void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records)
 {
-    hipLaunchKernelGGL(k_relayout_quad, dim3((n_records + 255) / 256), dim3(256), 0, s, trav, quad, n_records);
+    static const uint32_t greedy = [] { const char* e = getenv("RTMI_QUAD_BY_AREA"); return (e && e[0] == '0') ? 0u : 1u; }();
+    hipLaunchKernelGGL(k_relayout_quad, dim3((n_records + 255) / 256), dim3(256), 0, s, trav, quad, n_records, greedy);
 }
 
 // ----------------------------------------------------------------------------------------
