@@ -29,6 +29,11 @@ The line printed by rank 0 also carries
   config5             BASELINE.json configs[4]: the Sponza-class stand-in at 3840x2160, BVH, tiled over the N ranks.
   per_scene[..].rebuild_plus_trace_ms   the dynamic-scene frame (OpenCLRayTracerDemo.cpp:230-234): initializeFrame + construct +
                       generateContacts + shade, every frame.
+  moving_camera       the Demo's RTFrame loop (OpenCLRayTracerDemo.cpp:271-326: the camera is updated before every frame, :275-276):
+                      every frame a new camera position and orientation, the per-camera preparation (k_prepare_camera) inside
+                      the timed region; graph path (rt_frame_graph_set_camera + launch) and eager path, per scene and per step of
+                      five frames, next to the same poses rendered with a camera that stands still.
+  per_scene[..].first_frame_ms          the first generateContacts(Camera&) on a fresh BVH: strategy calibration included.
 """
 from __future__ import annotations
 
@@ -105,18 +110,45 @@ def demo_camera(scene_bytes, resx, resy):
     return cam
 
 
+def moving_cameras(scene_bytes, resx, resy, count):
+    """`count` camera poses around the Demo's default one: the position moves on a small closed curve (2 % of the model's box),
+    the orientation turns by up to +-3 degrees about y and x -- what a user dragging the mouse / holding a key does to the camera
+    between frames (OpenCLRayTracerDemo.cpp:378-460).  Pose 0 is the default camera itself (for ClumsyDragon: on a box plane)."""
+    from openclraytracer_amd import capi
+    base = demo_camera(scene_bytes, resx, resy)
+    f = np.frombuffer(scene_bytes, dtype='<f4', count=8, offset=64)
+    size = (f[4:7] - f[0:3]).astype(np.float64)
+    cams = np.zeros(count, dtype=capi.CAMERA)
+    for k in range(count):
+        cams[k] = base[0]
+        if k == 0:
+            continue
+        t = 2.0 * np.pi * k / count
+        a, b = np.radians(3.0) * np.sin(t), np.radians(3.0) * np.sin(2.0 * t + 0.5)
+        ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+        rot = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]]) @ np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
+        m = cams[k]['viewTransform']
+        for r in range(3):
+            m[4 * r:4 * r + 3] = rot[r].astype(np.float32)
+        m[3] += np.float32(0.02 * size[0] * np.sin(t) + 1e-3 * size[0])
+        m[7] += np.float32(0.02 * size[1] * np.sin(3.0 * t))
+        m[11] += np.float32(0.02 * size[2] * (np.cos(t) - 1.0))
+    return cams
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # hardware counters of the traversal launches, collected by this run: bench.py starts itself under rocprofv3 (the program
 # directly behind `--`), once per counter pass, BEFORE this process touches the GPU
 # ---------------------------------------------------------------------------------------------------------------------------
-def pmc_child():
+def pmc_child(packed_dir):
     """the profiled child: the five scenes, first frame (calibration), then PMC_FRAMES isolated traversal launches per scene
-    whose kernels carry the template tag <1, 2>"""
+    whose kernels carry the template tag <1, 2>.  The scenes come packed from the parent (files in packed_dir): this process
+    runs under the profiler with the GPU initialised and starts no process of its own."""
     from openclraytracer_amd import capi
     ctx = capi.Context(0)
     info = {}
     for name in SCENES:
-        buf = load_scene_bytes(name)
+        buf = open(os.path.join(packed_dir, name + '.bin'), 'rb').read()
         scene = capi.DeviceScene(ctx, buf)
         bvh = capi.DeviceBVH(ctx, scene).build()
         cam = demo_camera(buf, *RES)
@@ -143,19 +175,24 @@ def kernel_tag(name):
         return None
 
 
-def run_pmc_passes(keep_dir=None):
+def run_pmc_passes(scene_bytes, keep_dir=None):
     """-> dict with per-scene and per-kernel counter sums per traversal launch, or None when rocprofv3 is unavailable"""
     rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(rocprof):
         return None
     base = tempfile.mkdtemp(prefix='rtmi_pmc_', dir='/tmp')
+    packed = os.path.join(base, 'packed')
+    os.makedirs(packed)
+    for name, buf in scene_bytes.items():
+        with open(os.path.join(packed, name + '.bin'), 'wb') as f:
+            f.write(buf)
     env = dict(os.environ, TMPDIR='/tmp')
     rows = []            # (pass, dispatch order, kernel, counter, value)
     strategies = None
     try:
         for tag, counters in PMC_PASSES:
             out = os.path.join(base, tag)
-            cmd = [rocprof, '--pmc'] + counters + ['--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child']
+            cmd = [rocprof, '--pmc'] + counters + ['--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child', packed]
             try:
                 r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
             except (OSError, subprocess.TimeoutExpired) as e:
@@ -226,10 +263,10 @@ def main():
     ap.add_argument('--check-frames', action='store_true',
                     help='tiled: rank 0 also traces every frame untiled and compares it with the assembled one')
     ap.add_argument('--keep-pmc', default=None, help='directory that receives the raw counter rows of this run')
-    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--pmc-child', default=None, metavar='DIR', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
-        return pmc_child()
+        return pmc_child(args.pmc_child)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -251,7 +288,7 @@ def main():
     atrium_bytes = None if args.no_extra_legs else load_atrium_bytes()
     pmc = None
     if rank == 0 and not tiled and not args.no_pmc:
-        pmc = run_pmc_passes(args.keep_pmc)
+        pmc = run_pmc_passes(scene_bytes, args.keep_pmc)
 
     import torch
     from openclraytracer_amd import capi
@@ -312,6 +349,15 @@ def main():
     # N = 1: one HIP graph per frame (trace with the calibrated strategy, then shade): one launch call instead of five.  Creating
     # a graph traces one frame eagerly first, which is also where the BVH gets calibrated.  (Tiled: the library does the same
     # inside rt_multi_frame_create, one graph per send buffer.)
+    # the first generateContacts(Camera&) on a fresh BVH calibrates the strategy for this (resolution, tiling): what it costs
+    first_frame_ms = {}
+    if not tiled:
+        for it in work:
+            it['ctx'].synchronize()
+            t1 = time.perf_counter()
+            it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'])
+            it['ctx'].synchronize()
+            first_frame_ms[it['name']] = (time.perf_counter() - t1) * 1e3
     use_graphs = not tiled and not args.no_graphs and os.environ.get('RTMI_BENCH_GRAPHS', '1') != '0'
     if use_graphs:
         for it in work:
@@ -416,6 +462,9 @@ def main():
                   algorithmic_bytes=alg, walked_bytes=walked, search_tree_depth=st['depth'],
                   reference_tree_depth=it['bvh'].info()['max_depth'], build_ms=round(build_ms[it['name']], 3),
                   strategy=it['bvh'].trace_strategy())
+        if it['name'] in first_frame_ms:
+            ps['first_frame_ms'] = round(first_frame_ms[it['name']], 3)
+            ps['first_frame_over_steady_frame'] = round(first_frame_ms[it['name']] / max(ms, 1e-6), 1)
         # the dynamic-scene frame (OpenCLRayTracerDemo.cpp:230-234: the structure is rebuilt per frame when the scene moves):
         # initializeFrame + construct + generateContacts + shade, every frame, with the calibrated strategy kept across rebuilds
         if not tiled and not args.no_extra_legs:
@@ -437,6 +486,94 @@ def main():
             sctx.free(dc)
         per_scene[it['name']] = ps
 
+    # ---- the camera that moves (RTFrame, OpenCLRayTracerDemo.cpp:271-326; the camera is updated before every frame, :275-276) --------
+    moving = None
+    if not tiled and use_graphs and not args.no_extra_legs:
+        M, R = 32, 4
+        for it in work:
+            it['poses'] = moving_cameras(it['bytes'], RES[0], RES[1], M)
+        def pose(it, k):
+            return it['poses'][k % M:k % M + 1]
+        per = {}
+        for it in work:
+            sctx, g = it['ctx'], it['graph']
+            for k in range(M):                              # untimed: host-side plane table, clocks
+                g.set_camera(pose(it, k)); g.launch()
+            sctx.synchronize()
+            kinds = collections.Counter()
+            t1 = time.perf_counter()
+            for k in range(M):
+                g.set_camera(pose(it, k)); g.launch(); kinds[g.last_launch()] += 1
+            sctx.synchronize()
+            mv = (time.perf_counter() - t1) * 1e3 / M
+            still = 0.0
+            for k in range(M):                              # the same poses with a camera that stands still: R replays each
+                g.set_camera(pose(it, k)); g.launch(); sctx.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(R):
+                    g.launch()
+                sctx.synchronize()
+                still += (time.perf_counter() - t1) * 1e3 / R
+            still /= M
+            t1 = time.perf_counter()
+            for k in range(M):
+                it['bvh'].generate_contacts_primary_d(pose(it, k), it['contacts'])
+                capi.shade_blinn_phong_frame_d(sctx, it['scene'], pose(it, k), it['contacts'], it['rgba'])
+            sctx.synchronize()
+            eager = (time.perf_counter() - t1) * 1e3 / M
+            t1 = time.perf_counter()
+            for k in range(M):
+                it['bvh'].generate_contacts_primary_d(pose(it, 1), it['contacts'])
+                capi.shade_blinn_phong_frame_d(sctx, it['scene'], pose(it, 1), it['contacts'], it['rgba'])
+            sctx.synchronize()
+            eager_still = (time.perf_counter() - t1) * 1e3 / M
+            per[it['name']] = dict(moving_graph_ms_per_frame=round(mv, 4), same_poses_still_graph_ms_per_frame=round(still, 4),
+                                   moving_over_still=round(mv / max(still, 1e-9), 3), moving_eager_ms_per_frame=round(eager, 4),
+                                   still_eager_ms_per_frame=round(eager_still, 4),
+                                   launches=dict(with_preparation=kinds[1], steady=kinds[0], eager=kinds[2]))
+            g.set_camera(it['cam'])
+        # the step of five frames on five streams, every frame a new pose
+        K = max(64, min(args.steps, 256))
+        for k in range(M):
+            for it in work:
+                it['graph'].set_camera(pose(it, k)); it['graph'].launch()
+        fence()
+        t1 = time.perf_counter()
+        for k in range(K):
+            for it in work:
+                it['graph'].set_camera(pose(it, k)); it['graph'].launch()
+        issued_mv = time.perf_counter() - t1
+        fence()
+        mv_step = (time.perf_counter() - t1) * 1e3 / K
+        still_step = 0.0
+        for k in range(M):
+            for it in work:
+                it['graph'].set_camera(pose(it, k)); it['graph'].launch()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(R):
+                for it in work:
+                    it['graph'].launch()
+            fence()
+            still_step += (time.perf_counter() - t1) * 1e3 / R
+        still_step /= M
+        t1 = time.perf_counter()
+        for k in range(K):
+            for it in work:
+                it['bvh'].generate_contacts_primary_d(pose(it, k), it['contacts'])
+                capi.shade_blinn_phong_frame_d(it['ctx'], it['scene'], pose(it, k), it['contacts'], it['rgba'])
+        fence()
+        eager_step = (time.perf_counter() - t1) * 1e3 / K
+        check_errors()
+        for it in work:
+            it['graph'].set_camera(it['cam'])
+        moving = dict(what='every frame a new camera position and orientation (%d poses around the default camera, pose 0 = the default camera); '
+                           'k_prepare_camera inside the timed region; graph = rt_frame_graph_set_camera + rt_frame_graph_launch, '
+                           'eager = generateContacts(Camera&) + shade' % M,
+                      step_ms=round(mv_step, 4), mrays_per_s=round(rays_per_step / mv_step / 1e3, 1),
+                      same_poses_still_step_ms=round(still_step, 4), moving_over_still_step=round(mv_step / max(still_step, 1e-9), 3),
+                      eager_step_ms=round(eager_step, 4), host_issue_ms_per_step=round(issued_mv / K * 1e3, 4), steps=K, per_scene=per)
+
     # ---- config 5 (BASELINE.json configs[4]): the Sponza-class stand-in at 3840x2160, BVH, the frame tiled over the ranks --------
     config5 = None
     if atrium_bytes is not None:
@@ -454,6 +591,11 @@ def main():
             render5 = lambda: capi.multi_frame_render(f5)
         else:
             d5c, d5o = c5[0].alloc(RES5[0] * RES5[1] * 32), c5[0].alloc(RES5[0] * RES5[1] * 16)
+            c5[0].synchronize()
+            tf = time.perf_counter()
+            b5[0].generate_contacts_primary_d(cam5, d5c)
+            c5[0].synchronize()
+            first5 = (time.perf_counter() - tf) * 1e3
             g5 = capi.FrameGraph(b5[0], s5[0], cam5, d5c, d5o)
             render5 = g5.launch
         render5(); render5(); fence()
@@ -475,6 +617,9 @@ def main():
                                 'one RCCL gather per frame' % (s5[0].n_tris, nranks), frames=K5, ms_per_frame=round(e5 / K5 * 1e3, 3),
                        mrays_per_s=round(RES5[0] * RES5[1] * K5 / e5 / 1e6, 1), build_ms=round(build5, 2), reference_tree_depth=b5[0].info()['max_depth'],
                        search_tree_depth=b5[0].search_tree()['depth'], strategy=b5[0].trace_strategy())
+        if not tiled:
+            config5['first_frame_ms'] = round(first5, 2)
+            config5['first_frame_over_steady_frame'] = round(first5 / max(e5 / K5 * 1e3, 1e-6), 1)
 
     if rank != 0:
         if dist is not None:
@@ -589,7 +734,7 @@ def main():
                            rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES, parallelism=par),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
-               roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, config5=config5, per_scene=per_scene)
+               roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, config5=config5, per_scene=per_scene)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -288,6 +288,18 @@ typedef struct rt_frame_graph rt_frame_graph;
 int  rt_frame_graph_create(rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks,
                            int layout, void* d_contacts, void* d_out, uint32_t slots_per_rank, rt_frame_graph** out);
 int  rt_frame_graph_launch(rt_frame_graph* g);     /* on the context's stream, asynchronous */
+/* A camera that moves (the Demo sets position and orientation before every RTFrame, OpenCLRayTracerDemo.cpp:275-276; key / mouse
+ * handlers :378-460): the captured kernels get the new camera as new ARGUMENTS (hipGraphExecKernelNodeSetParams), nothing is
+ * captured again, and the next launch replays the sequence that begins with the per-camera preparation (k_prepare_camera: the
+ * camera-relative records of the direction octants this camera can produce, the camera-relative triangle records).  Same
+ * resolution, buffers and tiling as at creation (else RT_ERROR).  Whether the new position lies on a box plane is looked up on
+ * the host (sorted planes of the leaf boxes, read back once per build); a position whose rays would need the wave-per-ray
+ * kernel that the captured frame left out is served by the eager sequence until the camera moves on.  Same contacts and
+ * colours, bit for bit, as the eager calls with that camera.                                                              */
+int  rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam);
+/* what the last rt_frame_graph_launch replayed: 0 the steady-state frame, 1 the frame behind the per-camera preparation,
+ * 2 the eager sequence (see above), -1 nothing yet                                                                        */
+int  rt_frame_graph_last_launch(const rt_frame_graph* g);
 void rt_frame_graph_destroy(rt_frame_graph* g);
 
 /* ---- parallel primitives used by the builders ------------------------------------------- */

@@ -38,7 +38,7 @@ SYMBOLS = [
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
-    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
+    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
     'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
@@ -109,6 +109,8 @@ def load_library() -> C.CDLL:
     L.rt_shade_blinn_phong_frame.argtypes = [vp, vp, vp, vp, vp]
     L.rt_frame_graph_create.argtypes = [vp, vp, vp, u32, u32, i32, vp, vp, u32, pvp]
     L.rt_frame_graph_launch.argtypes = [vp]
+    L.rt_frame_graph_set_camera.argtypes = [vp, vp]
+    L.rt_frame_graph_last_launch.argtypes = [vp]
     L.rt_frame_graph_destroy.argtypes = [vp]; L.rt_frame_graph_destroy.restype = None
     L.rt_shade_blinn_phong_tiled_packed.argtypes = [vp, vp, vp, u32, u32, vp, vp, u32]
     L.rt_untile_rgba_packed.argtypes = [vp, vp, u32, vp, u32, u64, vp]
@@ -509,10 +511,20 @@ class FrameGraph:
                                                           C.c_void_p(d_out), slots_per_rank, C.byref(h)))
         self.h = h
         self._launch = self.ctx.lib.rt_frame_graph_launch
+        self._set_camera = self.ctx.lib.rt_frame_graph_set_camera
 
     def launch(self):
         if self._launch(self.h):
             self.ctx.check(1)
+
+    def set_camera(self, cam):
+        """rt_frame_graph_set_camera: the next launch renders this camera (same resolution); nothing is captured again"""
+        if self._set_camera(self.h, _p(cam)):
+            self.ctx.check(1)
+
+    def last_launch(self) -> int:
+        """0 steady-state replay, 1 replay behind the per-camera preparation, 2 eager sequence, -1 nothing launched yet"""
+        return int(self.ctx.lib.rt_frame_graph_last_launch(self.h))
 
     def close(self):
         if self.h:

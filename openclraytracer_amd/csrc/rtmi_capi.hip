@@ -2,6 +2,9 @@
 // Mirrors the call sequence of the reference managers (BVHManager.cpp, Scene.cpp, CLBuffer.cpp)
 // but enqueues hand-written HIP kernels on one HIP stream instead of JIT-compiled OpenCL.
 #include "rtmi_internal.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
 
 #include <cstdlib>
 #include <cstdio>
@@ -587,7 +590,66 @@ int rt_bvh_construct(rt_bvh* b)
     return RT_SUCCESS;
 }
 
-static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
+// Direction octants (bit k: 1 / direction negative on axis k) the rays of a camera can have: every component of the un-normalised
+// direction (generateRay, CLStructs.h:95-106) is monotone in the pixel's x and in its y, so its extremes over the frame stand at the
+// four corner pixels.  A superset is harmless (a copy of the four-wide records that nobody reads is written), a missing octant
+// is not (the kernel raises error bit 7), hence the margin for the rounding of the fp32 evaluation.
+static uint32_t camera_octants(const rt_camera* cam)
+{
+    const double w = (double)cam->resX, h = (double)cam->resY, fov = (double)cam->FOVDistance;
+    const double cx[2] = { -(0.0 - w * 0.5), -((w - 1.0) - w * 0.5) }, cy[2] = { 0.0 - h * 0.5, (h - 1.0) - h * 0.5 };
+    bool neg[3], pos[3];
+    for (int k = 0; k < 3; k++) {
+        const float* m = cam->viewTransform + 4 * k;
+        neg[k] = pos[k] = false;
+        for (int i = 0; i < 4; i++) {
+            const double dx = cx[i & 1], dy = cy[i >> 1];
+            const double v = dx * m[0] + dy * m[1] + fov * m[2] + m[3];
+            const double mag = std::fabs(dx * m[0]) + std::fabs(dy * m[1]) + std::fabs(fov * m[2]) + std::fabs((double)m[3]);
+            if (!(std::fabs(v) <= 1e300) || !(mag <= 1e300)) { neg[k] = pos[k] = true; break; }
+            if (v - 1e-5 * mag <= 0.0) neg[k] = true;
+            if (v + 1e-5 * mag >= 0.0) pos[k] = true;
+        }
+    }
+    uint32_t mask = 0;
+    for (uint32_t o = 0; o < 8u; o++) {
+        bool can = true;
+        for (int k = 0; k < 3; k++) can = can && ((o >> k) & 1u ? neg[k] : pos[k]);
+        if (can) mask |= 1u << o;
+    }
+    return mask;
+}
+
+// what a first-phase kernel reads of the per-camera records (k_prepare_camera writes that and nothing else)
+static uint32_t strategy_parts(const rt_bvh* b, const rt_camera* cam, bool packet, bool quad)
+{
+    uint32_t parts = RT_PREP_MARKS;                    // ray_root's plane bits; the wave-per-ray / binary kernels' inside bits
+    if (!b->d_quad || !b->have_search_tree) return parts;
+    if (packet && quad) {
+        parts |= RT_PREP_TRIANGLES;
+        parts |= b->quad_cam_variants == 9u ? RT_PREP_OCTANTS(camera_octants(cam)) : RT_PREP_GENERAL;
+    } else if (!packet) {
+        parts |= RT_PREP_GENERAL;                      // the lane-per-ray kernel's four-wide step
+    }
+    return parts;
+}
+static uint32_t calibration_parts(const rt_bvh* b, const rt_camera* cam)
+{
+    return strategy_parts(b, cam, true, true) | strategy_parts(b, cam, false, false) | strategy_parts(b, cam, true, false);
+}
+
+// Per-launch options of a primary frame beyond the strategy: a captured / updated frame graph, a fused colour buffer
+struct FusedShade { void* rgba; uint32_t plane_stride; bool done; };
+struct FrameMode {
+    FusedShade* fused = nullptr;
+    GraphNodes* record = nullptr;          // the launches are being captured: note the kernel nodes
+    GraphNodes* update = nullptr;          // nothing is enqueued: set the arguments of captured nodes
+    bool force_prepare = false;            // (re)compute the per-camera records whatever the BVH's marks say (the graph with the preparation in it)
+    uint32_t plane_bits_known = 0;         // 0x80000000 | bits: the host knows the camera-on-a-plane bits
+    uint32_t parts_drop = 0;               // RT_PREP_* this frame's kernels do not read although their strategy normally does
+};
+
+static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32_t parts = 0, const FrameMode* mode = nullptr)
 {
     TraceLaunch t{};
     t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.trirec = b->d_trirec; t.tricam = b->d_tricam; t.n_leaves = b->n;
@@ -599,7 +661,7 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
     t.task_shards = b->ctx->d_task_list; t.task_cap = b->ctx->task_cap; t.task_helper_blocks = b->ctx->task_helper_blocks;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
-    if (b->ctx->profiling) {
+    if (b->ctx->profiling && !(mode && mode->update)) {
         for (int k = 0; k < 3; k++) {
             hipEvent_t e = nullptr;
             if (hipEventCreate(&e) != hipSuccess) e = nullptr;
@@ -608,16 +670,26 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
         }
     }
     t.compute_units = b->ctx->prop.multiProcessorCount;
-    t.mark_inside = false;
+    t.prepare_parts = 0;
+    if (mode) { t.graph_record = mode->record; t.graph_update = mode->update; t.plane_bits_known = mode->plane_bits_known; }
     if (cam) {
         const float o[3] = { cam->viewTransform[3], cam->viewTransform[7], cam->viewTransform[11] };
-        if (!b->marked_valid || std::memcmp(o, b->marked_origin, sizeof o) != 0) {
-            t.mark_inside = true;
+        const bool same = b->marked_valid && std::memcmp(o, b->marked_origin, sizeof o) == 0;
+        if (mode && (mode->update || mode->record)) {
+            // a captured frame: its preparation node (if it has one) writes `parts` and its kernels read them.  The BVH's marks
+            // are untouched here (nothing runs now): rt_frame_graph_launch sets them when it replays the graph with the preparation
+            t.prepare_parts = mode->force_prepare ? parts : 0u;
+            t.octant_mask = (parts >> 2) & 0xFFu;
+        } else {
+            const uint32_t have = same ? b->marked_parts : 0u;
+            t.prepare_parts = parts & ~have;
             std::memcpy(b->marked_origin, o, sizeof o);
+            b->marked_parts = have | parts;
             b->marked_valid = true;
+            t.octant_mask = (b->marked_parts >> 2) & 0xFFu;
         }
     }
-    b->ctx->trace_launched = true;
+    if (!(mode && mode->update)) b->ctx->trace_launched = true;
     return t;
 }
 
@@ -625,12 +697,12 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr)
 // moderately long rays: no deferral), and every budget produces the same contacts.  The first frame of a
 // (BVH, resolution, tiling) combination therefore runs once per candidate, timed with HIP events on the stream,
 // and later frames use the fastest.  RTMI_DEFER_BUDGET fixes the budget and switches the calibration off.
-struct FusedShade { void* rgba; uint32_t plane_stride; bool done; };
-static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out, FusedShade* fused = nullptr)
+static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out, const FrameMode* mode = nullptr)
 {
     rt_ctx* ctx = b->ctx;
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
     if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key)) {
+        if (mode && (mode->record || mode->update)) return RT_FAIL(ctx, "a frame graph needs a calibrated strategy (trace one frame eagerly first)");
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
         static const struct { bool packet; uint32_t budget; bool quad; } candidates[] = {
@@ -649,7 +721,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // one candidate, `reps` launches, fastest of them; false = runtime failure
         auto time_candidate = [&](int ci, int reps, float give_up_ms, float& ms, bool& valid) -> bool {
             const auto& cand = candidates[ci];
-            TraceLaunch t = make_launch(b, cam);
+            TraceLaunch t = make_launch(b, cam, calibration_parts(b, cam));
             t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
             t.tag = 1;
@@ -661,7 +733,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
                 (void)hipEventRecord(e1, ctx->stream);
                 if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&m, e0, e1) != hipSuccess) return false;
                 ms = rep == 0 ? m : (m < ms ? m : ms);
-                t.mark_inside = false;                                   // the camera is prepared once
+                t.prepare_parts = 0;                                     // the camera is prepared once
                 if (rep == 0 && give_up_ms > 0.f && m > give_up_ms) break;
             }
             uint32_t cand_err = 0;
@@ -736,11 +808,14 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         RT_HIP(ctx, hipGetLastError());
         // fall through: trace once more with the strategy just chosen (the last launch above was some other candidate's)
     }
-    TraceLaunch t = make_launch(b, cam);
-    if (ctx->defer_budget == 0 && b->tuned) { t.defer_budget = b->tuned_budget; t.packet = b->tuned_packet; t.packet4 = b->tuned_quad; }
-    if (ctx->defer_budget != 0 && ctx->force_packet) { t.packet = true; t.packet4 = ctx->force_packet4 && b->d_quad; }
-    if (fused) { t.fused_rgba = fused->rgba; t.fused_plane_stride = fused->plane_stride; t.fused_done = &fused->done; }
+    bool packet = false, quad = false; uint32_t budget = ctx->defer_budget;
+    if (ctx->defer_budget == 0 && b->tuned) { budget = b->tuned_budget; packet = b->tuned_packet; quad = b->tuned_quad; }
+    if (ctx->defer_budget != 0 && ctx->force_packet) { packet = true; quad = ctx->force_packet4 && b->d_quad; }
+    TraceLaunch t = make_launch(b, cam, strategy_parts(b, cam, packet, quad) & ~(mode ? mode->parts_drop : 0u), mode);
+    t.defer_budget = budget; t.packet = packet; t.packet4 = quad;
+    if (mode && mode->fused) { t.fused_rgba = mode->fused->rgba; t.fused_plane_stride = mode->fused->plane_stride; t.fused_done = &mode->fused->done; }
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
+    if (mode && mode->update) return mode->update->failed ? RT_FAIL(ctx, "frame graph: a kernel node could not be updated") : RT_SUCCESS;
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }
@@ -954,31 +1029,132 @@ int rt_untile_rgba_packed(rt_ctx* ctx, const rt_camera* cam, uint32_t nranks, co
 struct rt_frame_graph {
     rt_ctx* ctx = nullptr;
     rt_bvh* bvh = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    const rt_scene* scene = nullptr;
+    // the frame: everything frame_issue needs to issue it again (eagerly, or as new arguments of the captured kernels)
+    rt_camera cam{};
+    uint32_t rank = 0, nranks = 1, slots_per_rank = 0;
+    int layout = RT_FRAME_UNTILED;
+    void* d_contacts = nullptr; void* d_out = nullptr;
+    // [0] the steady-state frame; [1] the same behind the per-camera preparation (k_prepare_camera): what a frame costs whose
+    // camera has moved.  Moving the camera re-sets the arguments of the captured kernels, it does not capture again.
+    hipGraph_t graph[2] = { nullptr, nullptr };
+    hipGraphExec_t exec[2] = { nullptr, nullptr };
+    GraphNodes nodes[2];
+    bool dirty[2] = { false, false };        // the camera changed since this exec's arguments were set
     // what the captured launches depend on besides the caller's buffers: addresses of the context's scratch lists and of the
-    // BVH's records (generations), and the per-camera marks in those records (origin)
+    // BVH's records (generations), and the per-camera records of this camera position (origin, parts)
     uint64_t scratch_generation = 0, build_generation = 0;
     float origin[3] = { 0, 0, 0 };
+    uint32_t parts = 0;                      // RT_PREP_* this frame's kernels read
+    bool four_wide = false, octant_records = false;   // strategy: the four-wide packet kernel (on per-octant records: x-plane rays stay)
+    bool no_unsafe = false;                  // captured without the wave-per-ray launch (and, unless switched off, with fused shading)
+    bool eager = false;                      // the current camera cannot be served by the captured sequence: launch issues the frame eagerly
+    uint32_t plane_bits_known = 0;
+    int last_launch = -1;                    // 0 steady state, 1 with the preparation, 2 eager
 };
 
+static void current_strategy(const rt_bvh* b, bool& packet, bool& quad)
+{
+    const rt_ctx* ctx = b->ctx;
+    packet = false; quad = false;
+    if (ctx->defer_budget == 0 && b->tuned) { packet = b->tuned_packet; quad = b->tuned_quad; }
+    if (ctx->defer_budget != 0 && ctx->force_packet) { packet = true; quad = ctx->force_packet4 && b->d_quad; }
+    if (quad && (!b->d_quad || !b->d_tricam || !b->have_search_tree)) quad = false;        // (launch_tagged's own condition)
+}
+
+// "Does this camera coordinate equal a plane of a box" answered on the host: every box of either tree is a union of leaf boxes,
+// clamped against the FLT_MIN the reference starts its maxima from (BVH.h:310), so the planes of all boxes are among the planes of
+// the leaf boxes and FLT_MIN -- a superset of what k_prepare_camera finds on the device, which is the safe side.
+static int ensure_host_planes(rt_bvh* b)
+{
+    rt_ctx* ctx = b->ctx;
+    if (b->h_planes_generation == b->build_generation && !b->h_planes[0].empty()) return RT_SUCCESS;
+    std::vector<rt_bvh_node> leaves(b->n);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(leaves.data(), b->d_nodes, (size_t)b->n * sizeof(rt_bvh_node), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; k++) {
+        std::vector<float>& v = b->h_planes[k];
+        v.clear(); v.reserve(2 * (size_t)b->n + 1);
+        for (uint32_t i = 0; i < b->n; i++) {
+            const float lo = leaves[i].boundsMin[k], hi = leaves[i].boundsMax[k];
+            if (lo == lo) v.push_back(lo);
+            if (hi == hi) v.push_back(hi);
+        }
+        v.push_back(FLT_MIN);
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+    b->h_planes_generation = b->build_generation;
+    return RT_SUCCESS;
+}
+static uint32_t host_plane_bits(const rt_bvh* b, const float origin[3])
+{
+    uint32_t bits = 0;
+    for (int k = 0; k < 3; k++)
+        if (origin[k] == origin[k] && std::binary_search(b->h_planes[k].begin(), b->h_planes[k].end(), origin[k])) bits |= 1u << k;
+    return bits;
+}
+
 static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks, int layout,
-                       void* d_contacts, void* d_out, uint32_t slots_per_rank)
+                       void* d_contacts, void* d_out, uint32_t slots_per_rank, FrameMode* mode = nullptr)
 {
     rt_ctx* ctx = b->ctx;
     const bool tiled = layout != RT_FRAME_UNTILED;
     // a captured frame whose camera sits on no box plane lets the four-wide kernel shade what it stores (trace_kernels.hip, fused
     // frame); whether it did is its launcher's answer -- any other strategy leaves the colours to k_shade
     FusedShade fused{ d_out, layout == RT_FRAME_TILED_PACKED ? slots_per_rank : 0u, false };
-    if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts,
-                            b->capture_no_unsafe_rays && !ctx->no_fused_frames ? &fused : nullptr)) return RT_ERROR;
-    if (fused.done) { RT_HIP(ctx, hipGetLastError()); return RT_SUCCESS; }
+    FrameMode plain;
+    FrameMode* m = mode ? mode : &plain;
+    m->fused = b->capture_no_unsafe_rays && !ctx->no_fused_frames ? &fused : nullptr;
+    const bool update = m->update != nullptr;
+    if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts, m)) return RT_ERROR;
+    if (fused.done) { if (!update) RT_HIP(ctx, hipGetLastError()); return RT_SUCCESS; }
     if (!tiled)
-        launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts, cam->resX * cam->resY, (float4*)d_out, true, 0, 1);
+        launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts, cam->resX * cam->resY, (float4*)d_out, true, 0, 1, 0, m->record, m->update);
     else
         launch_shade(ctx->stream, scene->d, *cam, (const rt_contact*)d_contacts, rt_tiles_owned_pixels(cam, rank, nranks), (float4*)d_out,
-                     true, rank, nranks, layout == RT_FRAME_TILED_PACKED ? slots_per_rank : 0u);
+                     true, rank, nranks, layout == RT_FRAME_TILED_PACKED ? slots_per_rank : 0u, m->record, m->update);
+    if (update) return m->update->failed ? RT_FAIL(ctx, "frame graph: a kernel node could not be updated") : RT_SUCCESS;
     RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+static FrameMode graph_mode(rt_frame_graph* g, int which, bool update)
+{
+    FrameMode m;
+    if (update) m.update = &g->nodes[which]; else m.record = &g->nodes[which];
+    m.force_prepare = which == 1;
+    m.plane_bits_known = g->plane_bits_known;
+    // without the wave-per-ray kernel nothing reads the marks of the binary records, and the plane bits come by value
+    m.parts_drop = (g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u;
+    return m;
+}
+
+static int graph_issue(rt_frame_graph* g, FrameMode* m)
+{
+    rt_bvh* b = g->bvh;
+    b->capture_no_unsafe_rays = g->no_unsafe;
+    const int rc = frame_issue(b, g->scene, &g->cam, g->rank, g->nranks, g->layout, g->d_contacts, g->d_out, g->slots_per_rank, m);
+    b->capture_no_unsafe_rays = false;
+    return rc;
+}
+
+static int capture_frame(rt_frame_graph* g, int which)
+{
+    rt_ctx* ctx = g->ctx;
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) return RT_FAIL(ctx, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+    FrameMode m = graph_mode(g, which, false);
+    const int rc = graph_issue(g, &m);
+    e = hipStreamEndCapture(ctx->stream, &g->graph[which]);
+    if (rc != RT_SUCCESS || e != hipSuccess || !g->graph[which]) {
+        (void)hipGetLastError();
+        return rc != RT_SUCCESS ? RT_ERROR : RT_FAIL(ctx, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    if (g->nodes[which].failed) return RT_FAIL(ctx, "frame graph: the captured kernel nodes could not be identified");
+    e = hipGraphInstantiate(&g->exec[which], g->graph[which], nullptr, nullptr, 0);
+    if (e != hipSuccess) return RT_FAIL(ctx, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    g->nodes[which].exec = g->exec[which];
     return RT_SUCCESS;
 }
 
@@ -1006,35 +1182,69 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     if (check_trace_error(ctx)) return RT_ERROR;
     rt_frame_graph* g = new (std::nothrow) rt_frame_graph();
     if (!g) return RT_FAIL(ctx, "out of host memory");
-    g->ctx = ctx; g->bvh = b;
+    g->ctx = ctx; g->bvh = b; g->scene = scene;
+    g->cam = *cam; g->rank = rank; g->nranks = nranks; g->layout = layout; g->slots_per_rank = slots_per_rank;
+    g->d_contacts = d_contacts; g->d_out = d_out;
     g->scratch_generation = ctx->scratch_generation; g->build_generation = b->build_generation;
     g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
-    // The four-wide packet kernel hands rays to the wave-per-ray kernel only when the camera sits on a box plane (ray_root): the
-    // eager frame above has computed those bits for this camera position, and a graph is for one position -- so a captured frame
-    // of a camera on no plane leaves the (then empty, ~7 us) wave-per-ray launch out.
-    uint32_t plane_bits = 1u;
-    if (b->d_tree_select && b->have_search_tree) RT_HIP(ctx, hipMemcpy(&plane_bits, b->d_tree_select, sizeof plane_bits, hipMemcpyDeviceToHost));
-    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
-    if (e != hipSuccess) { delete g; return RT_FAIL(ctx, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
-    b->capture_no_unsafe_rays = plane_bits == 0u;
-    const int rc = frame_issue(b, scene, cam, rank, nranks, layout, d_contacts, d_out, slots_per_rank);
-    b->capture_no_unsafe_rays = false;
-    e = hipStreamEndCapture(ctx->stream, &g->graph);
-    if (rc != RT_SUCCESS || e != hipSuccess || !g->graph) {
-        if (g->graph) (void)hipGraphDestroy(g->graph);
-        delete g;
-        (void)hipGetLastError();
-        return rc != RT_SUCCESS ? RT_ERROR : RT_FAIL(ctx, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    bool packet = false, quad = false;
+    current_strategy(b, packet, quad);
+    g->four_wide = packet && quad;
+    g->octant_records = g->four_wide && b->quad_cam_variants == 9u;
+    // The four-wide packet kernel hands rays to the wave-per-ray kernel only when the camera sits on a box plane (ray_root; on its
+    // per-octant records: on a y or z plane): the eager frame above has computed those bits for this camera position, so a
+    // captured frame of a camera on no such plane leaves the (then empty, ~7 us) wave-per-ray launch out.  When the camera
+    // moves (rt_frame_graph_set_camera) the bits are looked up on the host.
+    uint32_t plane_bits = 7u;
+    if (b->d_tree_select && b->have_search_tree) {
+        const hipError_t e = hipMemcpy(&plane_bits, b->d_tree_select, sizeof plane_bits, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { delete g; return RT_FAIL(ctx, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     }
-    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGraphDestroy(g->graph);
-        delete g;
-        return RT_FAIL(ctx, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    g->plane_bits_known = 0x80000000u | (plane_bits & 7u);
+    g->no_unsafe = g->four_wide && (plane_bits & (g->octant_records ? 6u : 7u)) == 0u;
+    g->parts = strategy_parts(b, cam, packet, quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
+    for (int which = 0; which < 2; which++) {
+        if (capture_frame(g, which) != RT_SUCCESS) { rt_frame_graph_destroy(g); return RT_ERROR; }
     }
     *out = g;
     return RT_SUCCESS;
 }
+
+// The Demo moves its camera between frames (OpenCLRayTracerDemo.cpp:275-276 sets position and orientation before RTFrame,
+// key / mouse handlers :378-460): the captured kernels get the new camera as new arguments, and the next launch replays the
+// sequence that starts with the per-camera preparation.  Same resolution, buffers and tiling as at creation.
+int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
+{
+    if (!g) return RT_FAIL(nullptr, "frame graph is null");
+    rt_ctx* ctx = g->ctx;
+    rt_bvh* b = g->bvh;
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (cam->resX != g->cam.resX || cam->resY != g->cam.resY) return RT_FAIL(ctx, "frame graph: the resolution is part of the graph; create a new one");
+    if (g->build_generation != b->build_generation || !b->built)
+        return RT_FAIL(ctx, "frame graph is stale: the BVH was rebuilt since the graph was created; create a new graph");
+    if (std::memcmp(cam, &g->cam, sizeof *cam) == 0) return RT_SUCCESS;
+    RT_ENTER(ctx);
+    g->cam = *cam;
+    g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
+    g->dirty[0] = g->dirty[1] = true;
+    g->eager = false;
+    if (g->four_wide) {
+        if (ensure_host_planes(b)) return RT_ERROR;
+        const uint32_t bits = host_plane_bits(b, g->origin);
+        g->plane_bits_known = 0x80000000u | bits;
+        // a frame captured without the wave-per-ray kernel cannot walk rays that must use the reference tree: such a camera
+        // position (measure zero, but "x = 0" happens) gets the eager sequence until the camera leaves the plane
+        if (g->no_unsafe && (bits & (g->octant_records ? 6u : 7u)) != 0u) g->eager = true;
+    } else {
+        g->plane_bits_known = 0;              // the preparation node computes the bits on the device, the kernels read them there
+    }
+    bool packet = false, quad = false;
+    current_strategy(b, packet, quad);
+    g->parts = strategy_parts(b, cam, packet, quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
+    return RT_SUCCESS;
+}
+
+int rt_frame_graph_last_launch(const rt_frame_graph* g) { return g ? g->last_launch : -1; }
 
 int rt_frame_graph_launch(rt_frame_graph* g)
 {
@@ -1047,19 +1257,27 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     if (g->build_generation != b->build_generation || !b->built)
         return RT_FAIL(ctx, "frame graph is stale: the BVH was rebuilt since the graph was created; create a new graph");
     RT_ENTER(ctx);
-    // the captured frame is the steady state, without k_prepare_camera: if another camera position was traced on this BVH in
-    // between (or the marks were never set), restore this graph's marks first -- one small kernel over the records
-    if (!b->marked_valid || std::memcmp(b->marked_origin, g->origin, sizeof g->origin) != 0) {
-        TraceLaunch t{};
-        t.trav = b->d_trav; t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.quad_cam_variants = b->quad_cam_variants; t.tree_select = b->d_tree_select; t.n_leaves = b->n;
-        t.trirec = b->d_trirec; t.tricam = b->d_tricam;
-        t.search_root = b->have_search_tree ? b->n - 1 : 0u;
-        launch_prepare_camera(ctx->stream, t, g->origin);
-        RT_HIP(ctx, hipGetLastError());
+    if (g->eager) {
+        g->last_launch = 2;
+        return frame_issue(b, g->scene, &g->cam, g->rank, g->nranks, g->layout, g->d_contacts, g->d_out, g->slots_per_rank);
+    }
+    // the per-camera records live in the BVH: if they are not this camera's (the camera moved, another position was traced on
+    // this BVH in between, another strategy prepared other parts), replay the sequence that starts with the preparation
+    const bool same = b->marked_valid && std::memcmp(b->marked_origin, g->origin, sizeof g->origin) == 0;
+    const int which = (same && (b->marked_parts & g->parts) == g->parts) ? 0 : 1;
+    if (g->dirty[which]) {
+        FrameMode m = graph_mode(g, which, true);
+        g->nodes[which].failed = false;
+        if (graph_issue(g, &m) != RT_SUCCESS) return RT_ERROR;
+        g->dirty[which] = false;
+    }
+    RT_HIP(ctx, hipGraphLaunch(g->exec[which], ctx->stream));
+    if (which == 1) {
         std::memcpy(b->marked_origin, g->origin, sizeof g->origin);
+        b->marked_parts = same ? (b->marked_parts | g->parts) : g->parts;
         b->marked_valid = true;
     }
-    RT_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
+    g->last_launch = which;
     ctx->trace_launched = true;                 // the next synchronising call looks at the kernels' error word
     return RT_SUCCESS;
 }
@@ -1069,8 +1287,10 @@ void rt_frame_graph_destroy(rt_frame_graph* g)
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
+    for (int k = 0; k < 2; k++) {
+        if (g->exec[k]) (void)hipGraphExecDestroy(g->exec[k]);
+        if (g->graph[k]) (void)hipGraphDestroy(g->graph[k]);
+    }
     delete g;
 }
 

@@ -152,8 +152,13 @@ struct rt_bvh {
     uint32_t packet_spill_entries = 0;
     uint32_t packet_spill_slots = 0;      // overflow areas = resident waves the device can hold (multiple of 32)
     uint32_t max_depth = 0;
-    float marked_origin[3] = { 0, 0, 0 };   // camera position the records' inside bits were computed for
+    float marked_origin[3] = { 0, 0, 0 };   // camera position the per-camera records were computed for
     bool marked_valid = false;
+    uint32_t marked_parts = 0;              // ... and which of them (RT_PREP_* bits): a strategy prepares only what it reads
+    // planes of the leaf boxes per axis, sorted, on the host (+ FLT_MIN, BVH.h:310): "does this camera coordinate equal a box
+    // plane" without asking the device -- read back on first use per build (movable frame graphs, rt_frame_graph_set_camera)
+    std::vector<float> h_planes[3];
+    uint64_t h_planes_generation = 0;
     bool tuned = false;                     // deferral budget calibrated for tuned_key
     uint64_t tuned_key = 0;
     uint32_t tuned_n = 0;                   // triangle count the strategy was calibrated for (kept across rebuilds of the same size)
@@ -237,7 +242,47 @@ void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
 int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch);
 size_t scan_scratch_words(uint32_t n);
 // trace_kernels.hip
+// What k_prepare_camera writes per camera position (a strategy asks for what it reads; the rest is not written):
+#define RT_PREP_MARKS   1u          // "camera inside child box" bits of the binary records of both trees + the camera-on-a-plane bits
+#define RT_PREP_GENERAL 2u          // the camera-relative copy of the four-wide records (general box test)
+#define RT_PREP_OCTANT(o) (4u << (o))   // ... with the near / far planes in place for direction octant o
+#define RT_PREP_OCTANTS(mask) (((mask) & 0xFFu) << 2)
+#define RT_PREP_TRIANGLES 0x400u    // the camera-relative triangle records (k_prepare_triangles)
+// Kernel nodes of a captured frame, by role: a frame graph whose camera moves re-sets their arguments
+// (hipGraphExecKernelNodeSetParams) instead of being captured again.  The launchers record a node while its launch is captured
+// (TraceLaunch::graph_record) and, in update mode (TraceLaunch::graph_update), compute the arguments exactly as for a launch
+// and set them on the recorded node instead of launching.
+enum { RT_NODE_PREP_CAMERA = 0, RT_NODE_TRACE, RT_NODE_LONG, RT_NODE_RESOLVE, RT_NODE_SHADE, RT_NODE_KINDS };
+struct GraphNodes {
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t node[RT_NODE_KINDS] = {};
+    bool failed = false;          // a node was missing, appeared twice, or the runtime refused the new arguments
+};
+template <typename K, typename A>
+inline void rt_launch_node(GraphNodes* record, GraphNodes* update, int kind, K kernel, dim3 grid, dim3 block, hipStream_t s, A& args)
+{
+    if (update) {
+        hipKernelNodeParams p{};
+        void* params[1] = { (void*)&args };
+        p.func = (void*)kernel; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = params; p.extra = nullptr;
+        if (!update->node[kind] || hipGraphExecKernelNodeSetParams(update->exec, update->node[kind], &p) != hipSuccess) update->failed = true;
+        return;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, 0, s, args);
+    if (record) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        const hipGraphNode_t* deps = nullptr; size_t n_deps = 0;
+        if (hipStreamGetCaptureInfo_v2(s, &st, nullptr, nullptr, &deps, &n_deps) != hipSuccess || st != hipStreamCaptureStatusActive || n_deps != 1 ||
+            record->node[kind]) record->failed = true;
+        else record->node[kind] = deps[0];
+    }
+}
 struct TraceLaunch {
+    GraphNodes* graph_record;     // capture in progress: kernel nodes are noted here
+    GraphNodes* graph_update;     // no launches: the arguments a launch would get are set on these nodes
+    uint32_t prepare_parts;       // RT_PREP_* to (re)compute before the trace (0: nothing)
+    uint32_t octant_mask;         // primary rays, four-wide kernel on per-octant records: the octant copies that are valid
+    uint32_t plane_bits_known;    // 0x80000000 | bits: the host knows the camera-on-a-plane bits (else the kernels read tree_select)
     const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)
     const QuadNode* quad;         // four-wide records (null: the packet kernel walks the binary records)
     const QuadNode* quad_cam;     // primary rays: the same records with the camera position subtracted from the boxes (+ thresholds)
@@ -261,7 +306,6 @@ struct TraceLaunch {
     uint32_t long_cap;            // records available
     uint32_t defer_budget;        // 0 = default
     hipEvent_t ev[3];             // optional: recorded before phase 0, between the phases, after phase 1
-    bool mark_inside;             // primary rays: (re)compute the per-node "camera inside box" bits first
     bool diagnostics;             // knob RTMI_TRACE_DIAG=1: the wave-per-ray kernel counts its pool steps
     int tag;                      // kernel-name tag: 0 steady state, 1 first-frame calibration, 2 isolated measurement pass
                                   // (rt_ctx_set_profiling(ctx, 2)); same code, separate names in profiles
@@ -281,7 +325,7 @@ struct TraceLaunch {
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
-void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);
+void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);   // t.prepare_parts
 size_t trace_ctrl_bytes();
 size_t trace_task_bytes(uint32_t cap_per_shard);
 size_t trace_ctrl_error_offset();
@@ -320,7 +364,8 @@ void launch_secondary_emit(hipStream_t s, const rt_camera* cam, const rt_ray* ra
                            const uint32_t* scan, int kind, const float target[3], float eps, rt_ray* out);
 // shade_kernels.hip
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,
-                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks, uint32_t plane_stride = 0);
+                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks, uint32_t plane_stride = 0,
+                  GraphNodes* graph_record = nullptr, GraphNodes* graph_update = nullptr);
 void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float4* gathered,
                         uint32_t slots_per_rank, float4* frame);
 void launch_untile_rgba_packed(hipStream_t s, const rt_camera& cam, uint32_t nranks, const float* gathered,

@@ -73,6 +73,7 @@ struct rt_comm {
     std::vector<rt_comm*> group;           // single-process groups: every rank's communicator, by rank (empty: one process per GPU)
     bool by_copies = false;
     bool owns_nccl = true;                 // false: rt_comm_share'd from another communicator of this process
+    bool broken = false;                   // a gather failed half way: the ranks are out of step, every later render fails at once
 };
 
 struct rt_multi_frame {
@@ -257,6 +258,7 @@ int rt_multi_frame_render(rt_multi_frame** frames, int n)
     const rt_comm* c0 = frames[0]->comm;
     if (!c0->group.empty() ? n != c0->nranks : n != 1) return RT_FAIL(ctx0, "a single-process group renders all of its ranks in one call, a multi-process rank alone");
     for (int i = 0; i < n; i++) {
+        if (frames[i] && frames[i]->comm->broken) return RT_FAIL(ctx0, "this communicator is broken: an earlier gather failed half way");
         if (!frames[i] || frames[i]->comm->nranks != c0->nranks || frames[i]->frames != frames[0]->frames) return RT_FAIL(ctx0, "frames of different groups or out of step");
         if (!c0->group.empty() && frames[i]->comm != c0->group[(size_t)i]) return RT_FAIL(ctx0, "frames must be given in rank order");
     }
@@ -275,19 +277,31 @@ int rt_multi_frame_render(rt_multi_frame** frames, int n)
     // 2. the one collective: the peers' planes to the root
     if (N > 1 && c0->nccl) {
         RT_NCCL(ctx0, g_rccl.GroupStart());
-        for (int i = 0; i < n; i++) {
+        // a failing Send / Recv must not leave the group open on this thread (the next RCCL call would hang or misbehave): close
+        // it, mark the communicators broken -- this rank's frame counters have not advanced, the peers' may have -- and report
+        // the FIRST error
+        ncclResult_t bad = 0; const char* what = nullptr; rt_ctx* bad_ctx = ctx0;
+        for (int i = 0; i < n && !bad; i++) {
             rt_multi_frame* f = frames[i];
             rt_comm* c = f->comm;
             const size_t count = (size_t)3u * f->peer_slots;
             (void)hipSetDevice(c->ctx->device);
             if (c->rank == 0) {
-                for (uint32_t r = 1; r < N; r++)
-                    RT_NCCL(c->ctx, g_rccl.Recv(f->d_peers + (size_t)(r - 1u) * count, count, rtNcclFloat32, (int)r, c->nccl, c->stream));
+                for (uint32_t r = 1; r < N && !bad; r++) {
+                    bad = g_rccl.Recv(f->d_peers + (size_t)(r - 1u) * count, count, rtNcclFloat32, (int)r, c->nccl, c->stream);
+                    if (bad) { what = "ncclRecv"; bad_ctx = c->ctx; }
+                }
             } else if (count) {
-                RT_NCCL(c->ctx, g_rccl.Send(f->d_send[b], count, rtNcclFloat32, 0, c->nccl, c->stream));
+                bad = g_rccl.Send(f->d_send[b], count, rtNcclFloat32, 0, c->nccl, c->stream);
+                if (bad) { what = "ncclSend"; bad_ctx = c->ctx; }
             }
         }
-        RT_NCCL(ctx0, g_rccl.GroupEnd());
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (bad || end) {
+            for (int i = 0; i < n; i++) frames[i]->comm->broken = true;
+            return RT_FAIL(bad_ctx, std::string(bad ? what : "ncclGroupEnd") + ": " + g_rccl.GetErrorString(bad ? bad : end) +
+                                    " (the gather was abandoned; this communicator renders no further frames)");
+        }
     } else if (N > 1) {
         // contexts that share a device (one-GPU tests): the root's stream copies every peer's planes once that peer has traced
         rt_multi_frame* root = frames[0];

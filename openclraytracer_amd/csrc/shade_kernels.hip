@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
 }
 
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,
-                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks, uint32_t plane_stride)
+                  uint32_t count, float4* rgba, bool tiled, uint32_t rank, uint32_t nranks, uint32_t plane_stride,
+                  GraphNodes* graph_record, GraphNodes* graph_update)
 {
     if (!count) return;
     ShadeArgs a{};
@@ -58,8 +59,8 @@ void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, co
     a.cam = cam;
     a.contacts = contacts; a.count = count; a.rgba = rgba;
     a.tiled = tiled ? 1u : 0u; a.rank = rank; a.nranks = nranks; a.tiles_x = rt_tiles_x(cam.resX); a.plane_stride = plane_stride;
-    if (!tiled) (void)hipMemsetAsync(rgba, 0, (size_t)cam.resX * cam.resY * sizeof(float4), s);   // memset(colors,0), :298
-    hipLaunchKernelGGL(k_shade, dim3((count + 255) / 256), dim3(256), 0, s, a);
+    if (!tiled && !graph_update) (void)hipMemsetAsync(rgba, 0, (size_t)cam.resX * cam.resY * sizeof(float4), s);   // memset(colors,0), :298
+    rt_launch_node(graph_record, graph_update, RT_NODE_SHADE, k_shade, dim3((count + 255) / 256), dim3(256), s, a);
 }
 
 // gathered[r * slots_per_rank + ordinal*4096 + ly*64 + lx]  ->  frame[y*resX + x]

@@ -85,7 +85,9 @@ struct TraceCtrl {
     uint32_t split_tiles; uint32_t shared_tasks; uint32_t p9[30];   // k_trace_packet4 with shared tasks: blocks whose contacts come out of the key buffer (entries of
                                              // split_list); tasks published (diagnostic, written by the helper waves at the end)
     uint32_t error;       uint32_t p2[31];   // bit 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow, 3: packet stack
-                                             // beyond its spill area, 4: bad deferred record, 5: no free spill area.  NOT zeroed per launch.
+                                             // beyond its spill area, 4: bad deferred record, 5: no free spill area, 6: a ray was handed over
+                                             // in a frame captured without the wave-per-ray kernel, 7: a ray of a direction octant whose record
+                                             // copy was not prepared.  NOT zeroed per launch.
 };
 static_assert(sizeof(TraceCtrl) == (WORK_SHARDS + 6) * 128, "TraceCtrl layout");
 static_assert(offsetof(TraceCtrl, error) == (WORK_SHARDS + 5) * 128, "the error word follows everything a launch clears");
@@ -128,6 +130,9 @@ struct TraceArgs {
                                                 // rays the camera-relative copy (boxes minus the camera position, inside marks)
     uint32_t search_root;                       // primary rays: root record of the search tree (same leaves), 0 = none
     const uint32_t* __restrict__ tree_select;   // primary rays: bit k = the camera's coordinate k equals a box plane
+    uint32_t plane_bits_known;                  // 0x80000000 | those bits when the host knows them (movable frame graphs): tree_select is not read
+    uint32_t octant_mask;                       // four-wide kernel on per-octant records: bit o = the copy of octant o is valid for this camera
+    uint32_t no_unsafe_rays;                    // the launcher left the wave-per-ray kernel out: a ray handed over would be lost (error bit 6)
     const float4* __restrict__ v0;
     const float4* __restrict__ e1;
     const float4* __restrict__ e2;
@@ -286,72 +291,98 @@ __device__ __forceinline__ uint32_t inside_bits(const TravNode& t, float ox, flo
     bool ib = (t.b_lo[0] <= ox) & (ox <= t.b_hi[0]) & (t.b_lo[1] <= oy) & (oy <= t.b_hi[1]) & (t.b_lo[2] <= oz) & (oz <= t.b_hi[2]);
     return (ia ? 1u : 0u) | (ib ? 2u : 0u);
 }
-__global__ __launch_bounds__(256) void k_prepare_camera(TravNode* trav, const QuadNode* quad, QuadNode* quad_cam, uint32_t n_records, uint32_t n_reference,
-                                                        float ox, float oy, float oz, uint32_t* select, uint32_t variants)
+// One kernel per camera position, three kinds of blocks (one launch, one graph node):
+//   quads     eight lanes per four-wide record of the tree that is walked with them (the search tree), one 16-byte part each: loads
+//             and stores are contiguous 128-byte lines per record, the partner's half of a box comes through a lane exchange;
+//   marks     one thread per binary record of both trees: inside bits, camera-on-a-plane bits;
+//   triangles one thread per triangle: the camera-relative record.
+// `parts` (RT_PREP_*) says what is written: a strategy prepares what it reads -- the four-wide packet kernel the copies of the
+// direction octants its camera can produce (the demo camera: four of eight) and the triangles, the lane-per-ray kernel the
+// general copy, the wave-per-ray and binary packet kernels the marks -- since a moving camera pays this per frame
+// (OpenCLRayTracerDemo.cpp:275-276 updates the camera before every RTFrame).
+struct PrepareArgs {
+    TravNode* trav; uint32_t n_records, n_reference;
+    const QuadNode* quad; QuadNode* quad_cam; uint32_t quad_first, quad_count; unsigned long long copy_stride;   // copy c of record i: quad_cam[c * copy_stride + i]
+    const TriRec* trirec; TriCam* tricam; uint32_t n_tris;
+    float ox, oy, oz;
+    uint32_t* select;
+    uint32_t parts;
+    uint32_t blocks_quads, blocks_marks;       // block ranges: quads, then marks, then triangles
+};
+__device__ __forceinline__ float4 shfl_xor4(const float4& v, int m)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_records) return;
-    const TravNode t = trav[i];
-    trav[i].pad0 = inside_bits(t, ox, oy, oz);
-    if (quad) {
+    return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
+}
+__global__ __launch_bounds__(256) void k_prepare_camera(PrepareArgs a)
+{
+    const float ox = a.ox, oy = a.oy, oz = a.oz;
+    if (blockIdx.x < a.blocks_quads) {
         // the four-wide record relative to this camera: every primary ray has the camera position as origin, so the slab
         // test's (plane - origin) is the same subtraction for all of them -- done once here, with the same fp32 operation, and
-        // the kernels multiply by 1 / direction directly.  Plus the "camera inside the box" bit per slot.
-        QuadNode q = quad[i];
-        float thr[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-        for (int k = 0; k < 4; k++) {
-            float4& lo = q.q[2 * k]; float4& hi = q.q[2 * k + 1];
-            const uint32_t id = __float_as_uint(q.q[k].w);
-            if (id == RT_SENTINEL) {
-                // an unused slot: a box no ray enters (near = +-FLT_MAX / direction is never both positive and below far), so
-                // that the kernels need not look at the id before the test
-                lo.x = lo.y = lo.z = FLT_MAX; hi.x = hi.y = hi.z = -FLT_MAX;
-                continue;
-            }
-            // camera inside the box: the reference takes the child whatever the slab test says (AABB.h: flag | inside).  With the
-            // origin inside, near <= 0 <= far holds per axis in floating point as well (the signs of the products; a 0 * inf is
-            // excluded by ray_root), so "near <= far" is true by itself and the child is taken iff "near > 0" is replaced by
-            // "near > -inf", true for every ray with one finite 1 / direction: the slot's threshold, a value in the record
-            // instead of a mark the kernels would have to test and combine per slot and step
-            if ((lo.x <= ox) & (ox <= hi.x) & (lo.y <= oy) & (oy <= hi.y) & (lo.z <= oz) & (oz <= hi.z)) thr[k] = -__builtin_inff();
-            lo.x = lo.x - ox; lo.y = lo.y - oy; lo.z = lo.z - oz;
-            hi.x = hi.x - ox; hi.y = hi.y - oy; hi.z = hi.z - oz;
-        }
-        q.q[4].w = thr[0]; q.q[5].w = thr[1]; q.q[6].w = thr[2]; q.q[7].w = thr[3];
-        quad_cam[i] = q;
+        // the kernels multiply by 1 / direction directly.  Part j of a record: q[j] = (low corner of slot j / 2, .) for even j,
+        // (high corner, .) for odd j; .w of parts 0-3 are the slots' ids, .w of parts 4-7 their thresholds (below).
+        const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+        const uint32_t lane = threadIdx.x & 63u, j = lane & 7u, base = lane & ~7u;
+        uint32_t rec = gid >> 3;
+        const bool live = rec < a.quad_count;
+        rec = a.quad_first + (live ? rec : 0u);
+        const float4 v = a.quad[rec].q[j];
+        const float4 p = shfl_xor4(v, 1);                                 // the other corner of my slot
+        const float4 lo = (j & 1u) ? p : v, hi = (j & 1u) ? v : p;
+        const uint32_t id = __float_as_uint(__shfl(v.w, (int)(base + (j >> 1)), 64));
+        // an unused slot: a box no ray enters (near = +-FLT_MAX / direction is never both positive and below far), so that the
+        // kernels need not look at the id before the test
+        const bool unused = id == RT_SENTINEL;
+        // camera inside the box: the reference takes the child whatever the slab test says (AABB.h: flag | inside).  With the
+        // origin inside, near <= 0 <= far holds per axis in floating point as well (the signs of the products; a 0 * inf is
+        // excluded by ray_root, or ignored by max3 / min3 on the x axis), so "near <= far" is true by itself and the child is taken
+        // iff "near > 0" is replaced by "near > -inf", true for every ray with one finite 1 / direction: the slot's THRESHOLD,
+        // a value in the record instead of a mark the kernels would have to test and combine per slot and step
+        const bool inside = !unused & (lo.x <= ox) & (ox <= hi.x) & (lo.y <= oy) & (oy <= hi.y) & (lo.z <= oz) & (oz <= hi.z);
+        const float thr_slot = inside ? -__builtin_inff() : 0.0f;          // of slot j / 2 (both of its lanes hold it)
+        const float thr_part = __shfl(thr_slot, (int)(base + 2u * (j & 3u)), 64);   // part 4 + k carries slot k's
+        float4 d;
+        if (unused) { const float e = (j & 1u) ? -FLT_MAX : FLT_MAX; d.x = e; d.y = e; d.z = e; }
+        else { d.x = v.x - ox; d.y = v.y - oy; d.z = v.z - oz; }
+        d.w = j < 4u ? v.w : thr_part;
+        const float4 dp = shfl_xor4(d, 1);
+        if (!live) return;
+        if (a.parts & RT_PREP_GENERAL) a.quad_cam[rec].q[j] = d;
         // One copy per direction octant (bit k of the octant: 1 / direction negative on axis k) with each slot's NEAR planes
         // where the low corner stands and its FAR planes where the high corner stands.  For a ray of that octant the products
         // (plane - origin) * (1 / direction) are ordered by the sign of 1 / direction on every axis (lo <= hi, monotone
         // rounding), so min(a, b) / max(a, b) of the general test ARE these products: a wave whose rays share an octant
         // multiplies and takes max3 / min3, six vector instructions per box less, same values.
-        for (uint32_t o = 1; o < variants; o++) {
-            const uint32_t oct = o - 1u;
-            QuadNode v = q;
-            for (int k = 0; k < 4; k++) {
-                float4& lo = v.q[2 * k]; float4& hi = v.q[2 * k + 1];
-                if (oct & 1u) { const float t = lo.x; lo.x = hi.x; hi.x = t; }
-                if (oct & 2u) { const float t = lo.y; lo.y = hi.y; hi.y = t; }
-                if (oct & 4u) { const float t = lo.z; lo.z = hi.z; hi.z = t; }
-            }
-            quad_cam[(uint64_t)o * n_records + i] = v;
+#pragma unroll
+        for (uint32_t o = 0; o < 8u; o++) {
+            if (!(a.parts & RT_PREP_OCTANT(o))) continue;
+            float4 w = d;
+            if (o & 1u) w.x = dp.x;
+            if (o & 2u) w.y = dp.y;
+            if (o & 4u) w.z = dp.z;
+            a.quad_cam[(unsigned long long)(1u + o) * a.copy_stride + rec].q[j] = w;
         }
+        return;
     }
-    if (i < n_reference && n_records > n_reference) {       // plane test over the reference records, when there is a search tree
-        const float o[3] = { ox, oy, oz };
-        uint32_t bits = 0;
-        for (int k = 0; k < 3; k++)
-            if ((o[k] == t.a_lo[k]) | (o[k] == t.a_hi[k]) | (o[k] == t.b_lo[k]) | (o[k] == t.b_hi[k]) | (o[k] == FLT_MIN)) bits |= 1u << k;
-        if (bits) __hip_atomic_fetch_or(select, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x < a.blocks_quads + a.blocks_marks) {
+        const uint32_t i = (blockIdx.x - a.blocks_quads) * blockDim.x + threadIdx.x;
+        if (i >= a.n_records) return;
+        const TravNode t = a.trav[i];
+        a.trav[i].pad0 = inside_bits(t, ox, oy, oz);
+        if (i < a.n_reference && a.n_records > a.n_reference) {       // plane test over the reference records, when there is a search tree
+            const float o[3] = { ox, oy, oz };
+            uint32_t bits = 0;
+            for (int k = 0; k < 3; k++)
+                if ((o[k] == t.a_lo[k]) | (o[k] == t.a_hi[k]) | (o[k] == t.b_lo[k]) | (o[k] == t.b_hi[k]) | (o[k] == FLT_MIN)) bits |= 1u << k;
+            if (bits) __hip_atomic_fetch_or(a.select, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
     }
-}
-
-// the camera-relative triangle records (rtmi_internal.h, TriCam): the operations of leaf_test that involve the origin and the
-// triangle only, in its order
-__global__ __launch_bounds__(256) void k_prepare_triangles(const TriRec* __restrict__ rec, TriCam* __restrict__ out, uint32_t n, float ox, float oy, float oz)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const TriRec t = rec[i];
+    // the camera-relative triangle records (rtmi_internal.h, TriCam): the operations of leaf_test that involve the origin and the
+    // triangle only, in its order
+    const uint32_t i = (blockIdx.x - a.blocks_quads - a.blocks_marks) * blockDim.x + threadIdx.x;
+    if (i >= a.n_tris) return;
+    const TriRec t = a.trirec[i];
     const f3 vert0 = f3{ t.v0[0], t.v0[1], t.v0[2] }, edge1 = f3{ t.e1[0], t.e1[1], t.e1[2] }, edge2 = f3{ t.e2[0], t.e2[1], t.e2[2] };
     const f3 tvec = f3_sub(f3{ ox, oy, oz }, vert0);
     const f3 qvec = f3_cross(tvec, edge1);
@@ -362,7 +393,7 @@ __global__ __launch_bounds__(256) void k_prepare_triangles(const TriRec* __restr
     c.qvec[0] = qvec.x; c.qvec[1] = qvec.y; c.qvec[2] = qvec.z;
     c.e2_dot_qvec = f3_dot(edge2, qvec);
     c.pos = t.pos; c.pad[0] = c.pad[1] = 0u;
-    out[i] = c;
+    a.tricam[i] = c;
 }
 
 // triangleIntersect, Triangle.h:66-107, against precomputed edges; keeps the lexicographic min of
@@ -429,6 +460,13 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayStat
     sx = 0.0f > r.inv.x; sy = 0.0f > r.inv.y; sz = 0.0f > r.inv.z;
     r.best_t = FLT_MAX; r.best_leaf = NO_LEAF; r.best_pos = 0u;      // rank 0 = nothing ranks before it: no tie update without a hit
     return true;
+}
+
+// the camera-on-a-plane bits of this frame: computed by k_prepare_camera on the device, or handed over by a host that knows them
+__device__ __forceinline__ uint32_t camera_plane_bits(const TraceArgs& a)
+{
+    if (a.search_root == 0u) return 0u;
+    return (a.plane_bits_known & 0x80000000u) ? (a.plane_bits_known & 7u) : *a.tree_select;
 }
 
 // root record a ray starts from: the search tree's, unless there is none or the ray could produce 0 * inf in a slab test
@@ -508,7 +546,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
     const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
     gu32* long_count = (gu32*)&a.ctrl->long_count;
     gu32* error_word = (gu32*)&a.ctrl->error;
-    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
+    const uint32_t plane_bits = PRIMARY ? camera_plane_bits(a) : 0u;
 
     RayState r;
     r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 };
@@ -828,7 +866,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
     uint32_t* spill = nullptr;
     uint32_t spill_slot = 0xFFFFFFFFu;
 
-    const uint32_t plane_bits = (PRIMARY && a.search_root != 0u) ? *a.tree_select : 0u;
+    const uint32_t plane_bits = PRIMARY ? camera_plane_bits(a) : 0u;
     // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
     if ((wave_gid << 6) < a.total_work) {
         const uint32_t w = (wave_gid << 6) + lane;
@@ -1044,7 +1082,13 @@ __device__ __forceinline__ u32x4 load16_device(const uint32_t* p)
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
-__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }   // s_waitcnt vmcnt(0)
+// "My stores and atomics have been performed": every vector-memory operation of this wave issued so far is acknowledged.  What
+// another wave reads during the launch is written with sc1 stores / device-scope atomics (performed at the device-coherent level)
+// and read with sc1 loads, so this wait IS the release, and no acquire-side invalidate is needed: nothing shared is read through
+// a cached (non-sc1) load.  Written as the instruction itself: a workgroup-scope release fence compiles to `s_waitcnt lgkmcnt(0)`
+// only on gfx950 (the vmcnt wait used to come from a neighbouring returning atomic, by luck of the schedule), and an agent-scope
+// fence writes back / invalidates caches for every wave of the CU (measured: a frame 2 000 times slower).
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll
@@ -1132,10 +1176,20 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
                 // host launches this kernel only when there is one).  A ray that must walk the reference tree box by box
                 // (ray_root: a slab product could be 0 * inf -- the camera on a box plane and a zero direction component) is
                 // handed, whole, to the wave-per-ray kernel, which walks binary records.
-                const uint32_t plane_bits = (PRIMARY && A.search_root != 0u) ? *A.tree_select : 0u;
+                // On the per-octant records a 0 * inf on the X axis is harmless ("the first axis"): in the
+                // reference's staged test (AABB.h:126-139) a NaN x product only ever stands on the side of a comparison that makes
+                // it false and is replaced by the y value in the ternary max / min that follow -- exactly what -inf (near) / +inf
+                // (far) would do, which is also what the products of every other box on that axis are; the test is then monotone
+                // under nesting again and the search-tree argument holds.  v_max3 / v_min3 ignore a NaN operand the same way
+                // (child_mask_octant).  A NaN on y or z makes the staged test forget earlier constraints -- the result depends on
+                // the reference's own hierarchy -- so only those rays go to the reference tree.  (The general records' min / max of
+                // the two products would turn NaN into the wrong infinity: without the copies every plane axis counts.)
+                const uint32_t plane_bits = PRIMARY ? (OCT ? camera_plane_bits(A) & ~1u : camera_plane_bits(A)) : 0u;
                 const bool on_ref = ok && ray_root<PRIMARY>(A, r, plane_bits) == 0u;
                 const uint64_t m_ref = __ballot(on_ref);
+                if (OCT && __ballot(ok && ((A.octant_mask >> my_octant) & 1u) == 0u) != 0ull) TRACE_FAIL((gu32*)&A.ctrl->error, 7);   // frame invalid
                 if (m_ref != 0ull) {
+                    if (A.no_unsafe_rays) TRACE_FAIL((gu32*)&A.ctrl->error, 6);       // nobody will walk them: frame invalid
                     uint32_t base = 0;
                     if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&A.ctrl->long_count, (uint32_t)__popcll(m_ref), RLX_AGENT);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1439,7 +1493,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
         uint32_t n_split = __hip_atomic_load((gu32*)&A.ctrl->split_tiles, RLX_AGENT);
         if (n_split > A.long_cap) n_split = A.long_cap;
         const uint32_t n_helpers = gridDim.x * TRACE_WAVES - n_block_waves;
-        const uint32_t plane_bits = (PRIMARY && A.search_root != 0u) ? *A.tree_select : 0u;
+        const uint32_t plane_bits = PRIMARY ? (OCT ? camera_plane_bits(A) & ~1u : camera_plane_bits(A)) : 0u;     // as where the blocks start
         for (uint32_t i = wave_gid - n_block_waves; i < n_split; i += n_helpers) {
             const uint32_t w = __hip_atomic_load((gu32*)(A.split_list + i), RLX_AGENT) + lane;
             RayState r;
@@ -1734,7 +1788,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     // caller says), for its sticky error word and for a diagnostic count of overflow areas (which then runs on over such frames)
     const bool four_wide = PRIMARY == 1 && t.packet && t.packet4 && t.quad && t.tricam && t.search_root;
     const bool shares = four_wide && t.task_shards && t.task_cap && a.defer_budget < (1u << 20);
-    if (!(four_wide && !shares && t.no_unsafe_rays))
+    GraphNodes* const rec = t.graph_record; GraphNodes* const upd = t.graph_update;      // (update mode: arguments are set on captured nodes, nothing is enqueued)
+    if (!(four_wide && !shares && t.no_unsafe_rays) && !upd)
         (void)hipMemsetAsync(t.ctrl, 0, offsetof(TraceCtrl, error), s);      // the error word is sticky (host-cleared)
     // First-phase kernels: one wave per 64-ray block and the hardware dispatcher as the work queue.  (A persistent grid --
     // resident waves pulling blocks from sharded counters, idle lanes refilled -- measured 25-50 % slower on every bundled
@@ -1755,10 +1810,11 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
             a.fused_scene.n_materials = t.scene->n_materials;
             if (t.fused_done) *t.fused_done = true;
         }
+        a.no_unsafe_rays = t.no_unsafe_rays ? 1u : 0u;
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
             // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
-            (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
+            if (!upd) (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
             const uint32_t helpers = t.task_helper_blocks ? t.task_helper_blocks : 256u;      // x TRACE_WAVES waves = one per SIMD: far fewer than wave slots
 #if RTMI_P4_VARIANT == 3
             static unsigned long long* dbg = nullptr; static size_t dbg_n = 0;
@@ -1770,8 +1826,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
             }
 #endif
             const dim3 g(grid + helpers), blk(TRACE_BLOCK);
-            if (a.quad_octant_records) { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 1, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 1, 0>), g, blk, 0, s, a); }
-            else { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 0, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 1, 0, 0>), g, blk, 0, s, a); }
+            if (a.quad_octant_records) { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 1, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 1, 0>, g, blk, s, a); }
+            else { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 0, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 0, 0>, g, blk, s, a); }
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 std::vector<unsigned long long> h(want);
@@ -1782,8 +1838,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
 #endif
         } else {
             const dim3 g(grid), blk(TRACE_BLOCK);
-            if (a.quad_octant_records) { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 1, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 1, 0>), g, blk, 0, s, a); }
-            else { if (a.fused_rgba) hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 0, 1>), g, blk, 0, s, a); else hipLaunchKernelGGL((k_trace_packet4<1, CAL, 0, 0, 0>), g, blk, 0, s, a); }
+            if (a.quad_octant_records) { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 1, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 1, 0>, g, blk, s, a); }
+            else { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 0, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 0, 0>, g, blk, s, a); }
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 const size_t n = (size_t)grid * TRACE_WAVES * 3u;
@@ -1797,27 +1853,27 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // rays the four-wide records may not be used for (see the kernel) wait on the deferred list: normally none, and the
         // wave-per-ray kernel returns at once (left out where the caller knows that there are none: frame graphs)
-        if (!t.no_unsafe_rays) hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
+        if (!t.no_unsafe_rays) rt_launch_node(rec, upd, RT_NODE_LONG, k_trace_long<PRIMARY, CAL>, dim3(grid1), dim3(TRACE_BLOCK), s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
     if (PRIMARY && t.packet) {
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
-        hipLaunchKernelGGL((k_trace_packet<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+        rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet<PRIMARY, CAL>, dim3(grid), dim3(TRACE_BLOCK), s, a);
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // without a budget the packet kernel hands nothing over: the wave-per-ray and resolve kernels would find empty lists
         if (a.defer_budget < (1u << 20)) {
-            hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
-            hipLaunchKernelGGL((k_resolve_split<PRIMARY, CAL>), dim3(64), dim3(256), 0, s, a);
+            rt_launch_node(rec, upd, RT_NODE_LONG, k_trace_long<PRIMARY, CAL>, dim3(grid1), dim3(TRACE_BLOCK), s, a);
+            rt_launch_node(rec, upd, RT_NODE_RESOLVE, k_resolve_split<PRIMARY, CAL>, dim3(64), dim3(256), s, a);
         }
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
     if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
-    hipLaunchKernelGGL((k_trace<PRIMARY, CAL>), dim3(grid), dim3(TRACE_BLOCK), 0, s, a);
+    rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace<PRIMARY, CAL>, dim3(grid), dim3(TRACE_BLOCK), s, a);
     if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
     // wave-per-ray phase: the number of deferred rays lives on the device; a fixed grid pulls from the list
-    hipLaunchKernelGGL((k_trace_long<PRIMARY, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
+    rt_launch_node(rec, upd, RT_NODE_LONG, k_trace_long<PRIMARY, CAL>, dim3(grid1), dim3(TRACE_BLOCK), s, a);
     if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
 }
 
@@ -1862,25 +1918,38 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.out = out;
     if (a.quad) a.quad = t.quad_cam;                  // boxes minus the camera position (k_prepare_camera)
     a.quad_octant_records = (a.quad && t.quad_cam_variants == 9u) ? (t.n_leaves - 1u) * (t.search_root ? 2u : 1u) : 0u;
-    if (t.mark_inside) {
+    a.octant_mask = t.octant_mask; a.plane_bits_known = t.plane_bits_known;
+    if (t.prepare_parts) {
         const float origin[3] = { cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11] };
         launch_prepare_camera(s, t, origin);
     }
     launch<1>(s, t, a);
 }
 
-// the per-camera marks alone (frame graphs replay a steady-state frame, which does not contain this kernel)
+// the per-camera records: t.prepare_parts says which (see k_prepare_camera)
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3])
 {
-    if (t.n_leaves < 2) return;
-    (void)hipMemsetAsync(const_cast<uint32_t*>(t.tree_select), 0, sizeof(uint32_t), s);
+    if (t.n_leaves < 2 || t.prepare_parts == 0u) return;
+    PrepareArgs a{};
     const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
-    hipLaunchKernelGGL(k_prepare_camera, dim3((n_all + 255) / 256), dim3(256), 0, s, const_cast<TravNode*>(t.trav),
-                       t.quad, const_cast<QuadNode*>(t.quad_cam), n_all, n_ref, origin[0], origin[1], origin[2], const_cast<uint32_t*>(t.tree_select),
-                       t.quad_cam_variants ? t.quad_cam_variants : 1u);
-    if (t.tricam && t.trirec)
-        hipLaunchKernelGGL(k_prepare_triangles, dim3((t.n_leaves + 255) / 256), dim3(256), 0, s, t.trirec, const_cast<TriCam*>(t.tricam), t.n_leaves,
-                           origin[0], origin[1], origin[2]);
+    a.trav = const_cast<TravNode*>(t.trav); a.n_records = n_all; a.n_reference = n_ref;
+    a.quad = t.quad; a.quad_cam = const_cast<QuadNode*>(t.quad_cam);
+    // the four-wide records are walked on the search tree only (the reference tree's are never read: see k_trace's four-wide step)
+    a.quad_first = t.search_root ? t.search_root : 0u; a.quad_count = n_all - a.quad_first; a.copy_stride = n_all;
+    a.trirec = t.trirec; a.tricam = const_cast<TriCam*>(t.tricam); a.n_tris = t.n_leaves;
+    a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
+    a.select = const_cast<uint32_t*>(t.tree_select);
+    a.parts = t.prepare_parts;
+    if (!t.quad || !t.quad_cam) a.parts &= ~(RT_PREP_GENERAL | RT_PREP_OCTANTS(0xFFu));
+    if (t.quad_cam_variants != 9u) a.parts &= ~RT_PREP_OCTANTS(0xFFu);
+    if (!t.tricam || !t.trirec) a.parts &= ~RT_PREP_TRIANGLES;
+    a.blocks_quads = (a.parts & (RT_PREP_GENERAL | RT_PREP_OCTANTS(0xFFu))) ? (uint32_t)(((uint64_t)a.quad_count * 8u + 255u) / 256u) : 0u;
+    a.blocks_marks = (a.parts & RT_PREP_MARKS) ? (n_all + 255u) / 256u : 0u;
+    const uint32_t blocks_tris = (a.parts & RT_PREP_TRIANGLES) ? (t.n_leaves + 255u) / 256u : 0u;
+    const uint32_t grid = a.blocks_quads + a.blocks_marks + blocks_tris;
+    if (grid == 0u) return;
+    if ((a.parts & RT_PREP_MARKS) && !t.graph_update) (void)hipMemsetAsync(a.select, 0, sizeof(uint32_t), s);
+    rt_launch_node(t.graph_record, t.graph_update, RT_NODE_PREP_CAMERA, k_prepare_camera, dim3(grid), dim3(256), s, a);
 }
 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)

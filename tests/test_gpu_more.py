@@ -486,8 +486,9 @@ def test_camera_on_a_box_plane_falls_back_to_the_reference_tree(gpu_ctx, name):
 @pytest.mark.parametrize('name', ['man', 'clumsydragon'])
 def test_camera_on_a_box_plane_with_every_kernel(name, packet, budget, monkeypatch):
     """the same camera (x on a plane of leaf boxes, a pixel column with direction.x == 0) under every forced strategy: the
-    four-wide records skip the boxes of inner children, which is sound on the search tree only, so the four-wide packet
-    kernel hands such rays to the wave-per-ray kernel and the lane-per-ray kernel walks them with binary steps."""
+    four-wide records skip the boxes of inner children, which is sound on the search tree only, so the lane-per-ray kernel
+    walks such rays with binary steps on the reference tree (and the four-wide packet kernel hands them to the wave-per-ray
+    kernel when the plane is a y or z plane: test_cameras_on_planes_of_every_axis)."""
     from openclraytracer_amd import capi
     from conftest import packed_scene
     monkeypatch.setenv('RTMI_PACKET', packet)
@@ -505,10 +506,12 @@ def test_camera_on_a_box_plane_with_every_kernel(name, packet, budget, monkeypat
             assert got.tobytes() == want.tobytes()
         assert gb.search_tree()['used_by_last_camera'] == 2
         if packet == '4':
-            assert ctx.last_trace_counters()['deferred_rays'] == 120          # exactly the pixel column with direction.x == 0
-            # frame graphs: a captured frame leaves the wave-per-ray launch out only where the camera sits on no box plane --
-            # here it must stay (those 120 rays), for the camera next to the plane it goes; both replay the oracle's contacts,
-            # also alternately on the same BVH (each replay restores its camera's records first)
+            # round 3: a 0 * inf on the X axis is absorbed by the staged test (tests/test_cpu_plane_rays.py),
+            # so on its per-octant records the four-wide kernel keeps the pixel column with direction.x == 0 (round 2: 120 rays
+            # handed to the wave-per-ray kernel, which walked the reference tree's depth-237 chains for them)
+            assert ctx.last_trace_counters()['deferred_rays'] == 0
+            # frame graphs: a captured frame leaves the wave-per-ray launch out where no ray needs it -- both cameras here; both
+            # replay the oracle's contacts, also alternately on the same BVH (each replay restores its camera's records first)
             npx = 160 * 120
             cam2 = osc.demo_camera(160, 120).copy()
             cam2['m'][0][3] = 0.123
@@ -1050,3 +1053,163 @@ def test_32_bit_vertex_indices(gpu_ctx, tmp_path):
     assert ca.tobytes() == cb.tobytes() and na.tobytes() == nb.tobytes()
     with pytest.raises(capi.RtError, match='index width'):
         capi.DeviceScene(gpu_ctx, s16, 3)
+
+
+# ---- round 3: cameras on planes of every axis, the camera that moves ---------------------------------------------------------
+
+@pytest.mark.parametrize('knobs', [dict(), dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='1048576'), dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='64'),
+                                   dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='1048576', RTMI_NO_OCTANT_RECORDS='1'),
+                                   dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='32')],
+                         ids=['calibrated', 'packet4', 'packet4-share64', 'packet4-general-records', 'lane32'])
+@pytest.mark.parametrize('name', ['man', 'tenryuu'])
+def test_cameras_on_planes_of_every_axis(name, knobs, monkeypatch):
+    """cameras whose x, y or z coordinate equals a plane of leaf boxes AND that have rays with a zero direction component on that
+    axis (tests/plane_rays.py: plane_camera), i.e. rays that multiply 0 by inf in the slab test.  On x the four-wide kernel keeps
+    them on its per-octant records (NaN on the first axis is absorbed); on y and z, and without the per-octant records, they
+    walk the reference tree.  The oracle walks the reference tree with the reference's staged test: contacts equal it bit for bit."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    import plane_rays as pr
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    osc, ob = oracle_bvh(name)
+    rng = np.random.default_rng(11)
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        for axis in (0, 1, 2):
+            for trial in range(2):
+                value = ob.nodes[('lo', 'hi')[trial]][int(rng.integers(0, ob.n)), axis]
+                if value == 0:
+                    value = ob.nodes['hi'][int(rng.integers(0, ob.n)), axis]
+                cam = pr.plane_camera(osc, (96, 64), axis, value)
+                rays = orc_rays(cam)
+                with np.errstate(all='ignore'):
+                    risky = int((~np.isfinite(np.float32(1.0) / rays['direction'][:, axis])).sum())
+                assert risky >= 64
+                want, _ = ob.trace_primary(cam)
+                got = gb.generate_contacts_primary(as_capi_camera(cam))
+                assert got.tobytes() == want.tobytes(), (name, knobs, axis, trial)
+                if knobs.get('RTMI_PACKET') == '4':
+                    handed_over = ctx.last_trace_counters()['deferred_rays']
+                    general = 'RTMI_NO_OCTANT_RECORDS' in knobs
+                    assert handed_over == (0 if (axis == 0 and not general) else risky), (axis, handed_over, risky)
+        gb.close(); sc.close()
+    finally:
+        ctx.close()
+
+
+def orc_rays(cam):
+    import oracle as orc
+    return orc.generate_rays(cam)
+
+
+@pytest.mark.parametrize('knobs', [dict(), dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='128'), dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='24'),
+                                   dict(RTMI_PACKET='1', RTMI_DEFER_BUDGET='256'), dict(RTMI_FUSED_FRAMES='0')],
+                         ids=['calibrated', 'packet4-share128', 'lane24', 'packet256', 'unfused'])
+@pytest.mark.parametrize('name,layout', [('tenryuu', 'untiled'), ('clumsydragon', 'packed'), ('gardenlight', 'tiled')])
+def test_frame_graph_follows_a_moving_camera(name, layout, knobs, monkeypatch):
+    """rt_frame_graph_set_camera (the Demo updates its camera before every RTFrame, OpenCLRayTracerDemo.cpp:275-276): one graph,
+    a camera that translates and turns every frame -- outside and inside the model, on an x plane (stays in the graph), on a y
+    plane with a pixel row of zero direction.y (served by the eager sequence), and back.  Every frame's contacts and colours
+    equal the eager calls with that camera bit for bit (which the other tests pin on the oracle; every third frame is compared
+    with the oracle directly), under every strategy, untiled and tiled; eager traces of other cameras on the same BVH in between
+    do not disturb it."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    import plane_rays as pr
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    osc, ob = oracle_bvh(name)
+    res = (200, 120)
+    npx = res[0] * res[1]
+    rng = np.random.default_rng(3)
+    lo = ob.nodes['lo'][:ob.n, :3].min(0)
+    hi = ob.nodes['hi'][:ob.n, :3].max(0)
+
+    def pose(i):
+        cam = osc.demo_camera(*res).copy()
+        m = cam['m'][0]
+        if i == 4:                                        # x on a plane, a pixel column with direction.x == 0
+            return pr.plane_camera(osc, res, 0, ob.nodes['lo'][17 % ob.n, 0])
+        if i == 7:                                        # y on a plane, a pixel row with direction.y == 0
+            return pr.plane_camera(osc, res, 1, ob.nodes['hi'][23 % ob.n, 1])
+        a, b = rng.uniform(-0.9, 0.9, 2)
+        ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+        rot = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]]) @ np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
+        for r in range(3):
+            for c in range(3):
+                m[r * 4 + c] = np.float32(rot[r, c])
+        p = lo + (hi - lo) * rng.uniform(-0.4, 1.4, 3)
+        m[3], m[7], m[11] = [np.float32(x) for x in p]
+        return cam
+
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        cam0 = as_capi_camera(osc.demo_camera(*res))
+        if layout == 'untiled':
+            rank, til, slots, kind = 0, 1, npx, capi.FRAME_UNTILED
+            d_c, d_o = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+            out_words = npx * 4
+        else:
+            rank, til = 1, capi.tiling(3, 1)
+            slots = capi.tiles_owned_pixels(cam0, rank, til)
+            slots0 = capi.tiles_owned_pixels(cam0, 0, til)
+            kind = capi.FRAME_TILED_PACKED if layout == 'packed' else capi.FRAME_TILED
+            d_c = ctx.alloc(slots * 32)
+            d_o = ctx.alloc(slots0 * 12 if layout == 'packed' else slots * 16)
+            out_words = slots0 * 3 if layout == 'packed' else slots * 4
+        g = capi.FrameGraph(gb, sc, cam0, d_c, d_o, kind, rank, til, slots0 if layout == 'packed' else 0)
+        d_c2 = ctx.alloc(slots * 32)
+        d_o2 = ctx.alloc(out_words * 4)
+        kinds = set()
+        for i in range(10):
+            cam = pose(i)
+            ccam = as_capi_camera(cam)
+            # the eager frame of this camera into buffers of its own
+            if layout == 'untiled':
+                gb.generate_contacts_primary_d(ccam, d_c2)
+                capi.shade_blinn_phong_frame_d(ctx, sc, ccam, d_c2, d_o2)
+            else:
+                gb.generate_contacts_primary_tiled_d(ccam, rank, til, d_c2)
+                if layout == 'packed':
+                    capi.shade_blinn_phong_tiled_packed_d(ctx, sc, ccam, rank, til, d_c2, d_o2, slots0)
+                else:
+                    capi.shade_blinn_phong_tiled_d(ctx, sc, ccam, rank, til, d_c2, d_o2)
+            want_c = ctx.download(d_c2, slots, capi.CONTACT)
+            want_o = ctx.download(d_o2, out_words, np.float32)
+            if i % 3 == 0 and layout == 'untiled':
+                assert want_c.tobytes() == ob.trace_primary(cam)[0].tobytes()
+            if i % 2:                                     # somebody else's camera on the same BVH in between
+                gb.generate_contacts_primary(as_capi_camera(pose(100 + i)))
+            ctx.fill_u32(d_c, 0xDEADBEEF, slots * 8); ctx.fill_u32(d_o, 0xDEADBEEF, out_words)
+            g.set_camera(ccam)
+            g.launch()
+            got_c = ctx.download(d_c, slots, capi.CONTACT)
+            got_o = ctx.download(d_o, out_words, np.float32)
+            kinds.add(g.last_launch())
+            assert got_c.tobytes() == want_c.tobytes(), (name, layout, knobs, i)
+            if layout == 'packed':
+                assert got_o.reshape(3, slots0)[:, :slots].tobytes() == want_o.reshape(3, slots0)[:, :slots].tobytes(), (name, layout, knobs, i)
+            else:
+                assert got_o.tobytes() == want_o.tobytes(), (name, layout, knobs, i)
+            # the camera stands still: the steady-state sequence, same bytes
+            ctx.fill_u32(d_c, 0xDEADBEEF, slots * 8)
+            g.launch()
+            assert ctx.download(d_c, slots, capi.CONTACT).tobytes() == want_c.tobytes()
+            kinds.add(g.last_launch())
+        four_wide = gb.trace_strategy()['kernel'] == 'packet4'
+        assert 1 in kinds and (0 in kinds or 2 in kinds)
+        if four_wide:
+            assert kinds == {0, 1, 2}                    # the y-plane pose could not be served by the captured sequence
+        with pytest.raises(capi.RtError, match='resolution'):
+            g.set_camera(as_capi_camera(osc.demo_camera(64, 48)))
+        g.close()
+        for d in (d_c, d_o, d_c2, d_o2):
+            ctx.free(d)
+        gb.close(); sc.close()
+    finally:
+        ctx.close()
