@@ -15,6 +15,7 @@
 #include <Algorithms/MultiGPUFrame.h>
 #include <Algorithms/TwoLevelGridManager.h>
 #include <CLData/CLStructs.h>
+#include <CLData/Shading.h>
 #include <Scene/Scene.h>
 
 using namespace CLRayTracer;
@@ -29,6 +30,7 @@ int main(int argc, char* argv[])
     int window_width = 0, window_height = 0, frames = 1;
     std::string scenePath, accStruct, headersPath, outPath, rawContacts, devices;
     int gpus = 1;
+    bool referenceFrame = false;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
         if (k == "-winH") window_height = std::atoi(v.c_str());
@@ -40,10 +42,11 @@ int main(int argc, char* argv[])
         else if (k == "--out") outPath = v;
         else if (k == "--contacts") rawContacts = v;
         else if (k == "--gpus") gpus = std::atoi(v.c_str());          // frame tiled over N GPUs, one gather (BVH only)
+        else if (k == "--reference-frame") referenceFrame = std::atoi(v.c_str()) != 0;   // RTFrame as the reference wrote it: contacts to the host, host shading loop
         else if (k == "--devices") devices = v;                        // e.g. 0,0,0: which HIP device each rank uses (default rank r -> device r)
     }
     if (window_width <= 0 || window_height <= 0 || scenePath.empty() || accStruct.empty()) {
-        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm|img.pfm] [--contacts raw.bin] [--gpus n [--devices d0,d1,..]]" << std::endl;
+        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm|img.pfm] [--contacts raw.bin] [--reference-frame 1] [--gpus n [--devices d0,d1,..]]" << std::endl;
         return 0;
     }
     if (accStruct != "BVH" && accStruct != "GRID") {              // OpenCLRayTracerDemo.cpp:221-224
@@ -142,6 +145,25 @@ int main(int argc, char* argv[])
         normalizeQuaternion(&cameraOrientation);
         setOrientationAndPos(&camera.viewTransform, cameraOrientation, cameraPosition);
         CHECKED_CALL(accelerationStruct->generateContacts(camera, err));
+        if (referenceFrame) {
+            // the rest of RTFrame as the reference has it (OpenCLRayTracerDemo.cpp:287-316), statement by statement: every contact the
+            // buffer holds comes to the host (its ALLOCATED size: the buffer only grows, :287), the colours are cleared, and
+            // cpuShadeBlinnPhong runs per contact with a hit
+            int contactsCount = (int)(accelerationStruct->getPrimaryContacts()->getActualSize() / sizeof(struct Contact));
+            std::vector<Contact> contacts((size_t)contactsCount);
+            CHECKED_CALL(accelerationStruct->getPrimaryContacts()->copyToHost(contacts.data(), err));
+            std::memset(colors.data(), 0, pixelCount * sizeof(CL_FLOAT4));
+            CL_FLOAT4 color;
+            for (int i = 0; i < contactsCount; i++) {
+                color.x = 0.0f; color.y = 0.0f; color.z = 0.0f; color.w = 1.0f;
+                struct Contact contact = contacts[i];
+                if (contact.contactDist > 0 && contact.pixelIndex < pixelCount) {
+                    cpuShadeBlinnPhong(&camera, &contact, (char*)scene.getHostSceneData(), color);
+                    colors[contact.pixelIndex] = color;
+                }
+            }
+            continue;
+        }
         unsigned contactsCount = (unsigned)pixelCount;
         CHECKED_CALL(shadeBlinnPhong(*context, scene, camera, *accelerationStruct->getPrimaryContacts(), contactsCount, colorsBuffer, err));
         CHECKED_CALL(colorsBuffer.copyToHost(colors.data(), err));
@@ -149,7 +171,7 @@ int main(int argc, char* argv[])
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
     size_t hits = 0;
     for (const CL_FLOAT4& c : colors) hits += c.w > 0;
-    std::cout << "frames " << frames << "  " << ms << " ms/frame (incl. read-back)  lit pixels " << hits << std::endl;
+    std::cout << "frames " << frames << "  " << ms << (referenceFrame ? " ms/frame (contacts to the host + host shading loop)" : " ms/frame (incl. read-back)") << "  lit pixels " << hits << std::endl;
     if (!rawContacts.empty()) {
         std::vector<Contact> contacts(pixelCount);
         std::vector<char> all(accelerationStruct->getPrimaryContacts()->getActualSize());

@@ -251,6 +251,15 @@ def valu_issue(c):
     return (c.get('SQ_INSTS_VALU', 0.0) * VALU_CYCLES_PER_INST / (SIMDS * cycles)) if cycles else None
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress on stderr (a long run must keep talking: the GPU pool takes seven silent minutes for a hang)"""
+    if os.environ.get('RANK', '0') == '0':
+        print('bench [%6.1f s] %s' % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -288,7 +297,9 @@ def main():
     atrium_bytes = None if args.no_extra_legs else load_atrium_bytes()
     pmc = None
     if rank == 0 and not tiled and not args.no_pmc:
+        note('counter passes (rocprofv3 --pmc, child processes)')
         pmc = run_pmc_passes(scene_bytes, args.keep_pmc)
+    note('scenes, BVHs, first frames')
 
     import torch
     from openclraytracer_amd import capi
@@ -357,7 +368,7 @@ def main():
             t1 = time.perf_counter()
             it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'])
             it['ctx'].synchronize()
-            first_frame_ms[it['name']] = (time.perf_counter() - t1) * 1e3
+            first_frame_ms[it['name']] = ((time.perf_counter() - t1) * 1e3, it['bvh'].calibration_launches())
     use_graphs = not tiled and not args.no_graphs and os.environ.get('RTMI_BENCH_GRAPHS', '1') != '0'
     if use_graphs:
         for it in work:
@@ -398,6 +409,7 @@ def main():
             print('frame check ok (%s): %d assembled frames equal the untiled ones' % (when, len(work)), file=sys.stderr)
         fence()
 
+    note('warm-up and timed steps')
     for _ in range(args.warmup):
         step()
     fence()
@@ -425,6 +437,7 @@ def main():
     # frame costs when it has the device to itself) -- the launches rocprofv3 lists as <1, 2>
     per_scene = {}
     tiling = capi.tiling(nranks, root_extra if nranks > 1 else 0)
+    note('timed region done: %.4f ms per step; isolated pass per scene' % (elapsed / args.steps * 1e3))
     for it in work:
         sctx = it['ctx']
         r0 = 0 if group_ranks else rank
@@ -463,8 +476,9 @@ def main():
                   reference_tree_depth=it['bvh'].info()['max_depth'], build_ms=round(build_ms[it['name']], 3),
                   strategy=it['bvh'].trace_strategy())
         if it['name'] in first_frame_ms:
-            ps['first_frame_ms'] = round(first_frame_ms[it['name']], 3)
-            ps['first_frame_over_steady_frame'] = round(first_frame_ms[it['name']] / max(ms, 1e-6), 1)
+            ps['first_frame_ms'] = round(first_frame_ms[it['name']][0], 3)
+            ps['first_frame_over_steady_frame'] = round(first_frame_ms[it['name']][0] / max(ms, 1e-6), 1)
+            ps['calibration_launches'] = first_frame_ms[it['name']][1]
         # the dynamic-scene frame (OpenCLRayTracerDemo.cpp:230-234: the structure is rebuilt per frame when the scene moves):
         # initializeFrame + construct + generateContacts + shade, every frame, with the calibrated strategy kept across rebuilds
         if not tiled and not args.no_extra_legs:
@@ -490,8 +504,11 @@ def main():
     moving = None
     if not tiled and use_graphs and not args.no_extra_legs:
         M, R = 32, 4
+        note('moving-camera leg')
         for it in work:
             it['poses'] = moving_cameras(it['bytes'], RES[0], RES[1], M)
+            it['graph'].close()                             # the rebuild-per-frame leg above has rebuilt the BVH: a graph of its own
+            it['graph'] = capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'], it['rgba'])
         def pose(it, k):
             return it['poses'][k % M:k % M + 1]
         per = {}
@@ -527,12 +544,14 @@ def main():
                 capi.shade_blinn_phong_frame_d(sctx, it['scene'], pose(it, 1), it['contacts'], it['rgba'])
             sctx.synchronize()
             eager_still = (time.perf_counter() - t1) * 1e3 / M
+            note('  moving camera, %s: %.4f ms per frame moving, %.4f standing still' % (it['name'], mv, still))
             per[it['name']] = dict(moving_graph_ms_per_frame=round(mv, 4), same_poses_still_graph_ms_per_frame=round(still, 4),
                                    moving_over_still=round(mv / max(still, 1e-9), 3), moving_eager_ms_per_frame=round(eager, 4),
                                    still_eager_ms_per_frame=round(eager_still, 4),
                                    launches=dict(with_preparation=kinds[1], steady=kinds[0], eager=kinds[2]))
             g.set_camera(it['cam'])
         # the step of five frames on five streams, every frame a new pose
+        note('  moving camera, five streams')
         K = max(64, min(args.steps, 256))
         for k in range(M):
             for it in work:
@@ -577,6 +596,7 @@ def main():
     # ---- config 5 (BASELINE.json configs[4]): the Sponza-class stand-in at 3840x2160, BVH, the frame tiled over the ranks --------
     config5 = None
     if atrium_bytes is not None:
+        note('config 5 leg')
         cam5 = demo_camera(atrium_bytes, *RES5)
         ranks_here = range(nranks) if group_ranks else [rank]
         c5 = [capi.Context(local_rank) for _ in ranks_here]
@@ -619,6 +639,7 @@ def main():
                        search_tree_depth=b5[0].search_tree()['depth'], strategy=b5[0].trace_strategy())
         if not tiled:
             config5['first_frame_ms'] = round(first5, 2)
+            config5['calibration_launches'] = b5[0].calibration_launches()
             config5['first_frame_over_steady_frame'] = round(first5 / max(e5 / K5 * 1e3, 1e-6), 1)
 
     if rank != 0:
@@ -680,6 +701,7 @@ def main():
 
     cpu_baseline = None
     if world == 1 and not tiled and not args.no_cpu_baseline:
+        note('CPU baseline')
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import oracle as orc                     # cpu_baseline leg only: the oracle is the thing timed here
         cores = orc.ncpu()

@@ -7,7 +7,17 @@
 //  * min/max are the TERNARY macros of CLData/CLPortability.h:147-148, not v_min/v_max:
 //    they differ for NaN and for signed zeros.
 #pragma once
+// Dual target: the device code of librtmi.so (hipcc) and, for cpuShadeBlinnPhong of the host mirror (csrc/host, g++
+// -ffp-contract=off), the same functions as plain inline C++ -- one statement of the arithmetic for both.
+#if defined(__HIP__) || defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define RT_FN __device__ __forceinline__
+#else
+#include <math.h>
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 v = { x, y, z, w }; return v; }
+#define RT_FN static inline
+#endif
 #include <float.h>
 #include <stdint.h>
 
@@ -16,30 +26,41 @@
 
 struct f3 { float x, y, z; };
 
-__device__ __forceinline__ f3 f3_sub(f3 a, f3 b) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
-__device__ __forceinline__ f3 f3_add(f3 a, f3 b) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
-__device__ __forceinline__ f3 f3_scale(f3 a, float s) { return f3{ a.x * s, a.y * s, a.z * s }; }
-// cross / dot, CLPortability.h:266-278
-__device__ __forceinline__ f3 f3_cross(f3 a, f3 b)
+RT_FN f3 f3_sub(f3 a, f3 b) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+RT_FN f3 f3_add(f3 a, f3 b) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+RT_FN f3 f3_scale(f3 a, float s) { return f3{ a.x * s, a.y * s, a.z * s }; }
+// cross / dot, CLPortability.h:266-278 (the HOST branch: separate multiplies and adds -- what the library computes).
+// -DRTMI_DEVICE_ARITH=1 (test twin librtmi_devarith.so only): the DEVICE branch leaves dot() / cross() to the OpenCL C library
+// (CLPortability.h:41-45), and ROCm 7.2's (amdgcn/bitcode/opencl.bc, _Z3dotDv3_fS_ / _Z5crossDv3_fS_) fuses them as below; the
+// oracle restates the same behind orc_set_device_arith (oracle/rt_oracle.c).
+#if defined(RTMI_DEVICE_ARITH) && RTMI_DEVICE_ARITH
+RT_FN f3 f3_cross(f3 a, f3 b)
+{
+    return f3{ __builtin_fmaf(a.y, b.z, b.y * -a.z), __builtin_fmaf(a.z, b.x, b.z * -a.x), __builtin_fmaf(a.x, b.y, b.x * -a.y) };
+}
+RT_FN float f3_dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+#else
+RT_FN f3 f3_cross(f3 a, f3 b)
 {
     return f3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
 }
-__device__ __forceinline__ float f3_dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_FN float f3_dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+#endif
 // cpu_normalize, CLPortability.h:151-159
-__device__ __forceinline__ f3 f3_normalize(f3 v)
+RT_FN f3 f3_normalize(f3 v)
 {
     float l = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
     return f3{ v.x * l, v.y * l, v.z * l };
 }
 // LENGTH3, CLPortability.h:280
-__device__ __forceinline__ float f3_length(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+RT_FN float f3_length(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
 
-__device__ __forceinline__ f3 f3_from4(float4 v) { return f3{ v.x, v.y, v.z }; }
+RT_FN f3 f3_from4(float4 v) { return f3{ v.x, v.y, v.z }; }
 
 // generateRay, CLStructs.h:95-106 with transformVectorByMatrix_const (Transform.h:282-295):
 // the translation column is added to the direction; origin = translation.
 // x = pixelIndex % resX, y = pixelIndex / resX
-__device__ __forceinline__ void generate_ray_xy(const rt_camera& cam, uint32_t x, uint32_t y, f3& origin, f3& dir)
+RT_FN void generate_ray_xy(const rt_camera& cam, uint32_t x, uint32_t y, f3& origin, f3& dir)
 {
     float dx = -((float)x - (float)cam.resX * 0.5f);
     float dy = (float)y - (float)cam.resY * 0.5f;
@@ -52,7 +73,7 @@ __device__ __forceinline__ void generate_ray_xy(const rt_camera& cam, uint32_t x
     dir = f3_normalize(v);
     origin = f3{ m[3], m[7], m[11] };
 }
-__device__ __forceinline__ void generate_ray(const rt_camera& cam, uint32_t pixelIndex, f3& origin, f3& dir)
+RT_FN void generate_ray(const rt_camera& cam, uint32_t pixelIndex, f3& origin, f3& dir)
 {
     generate_ray_xy(cam, pixelIndex % cam.resX, pixelIndex / cam.resX, origin, dir);
 }

@@ -709,33 +709,31 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             { true, 1u << 20, true }, { true, 128u, true }, { true, 256u, true }, { true, 1024u, true }, { true, 2048u, true },   // four-wide: whole blocks / sub-trees shared after so many steps
             { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
             { false, 8u }, { false, 12u }, { false, 16u }, { false, 24u }, { false, 32u }, { false, 48u }, { false, 64u }, { false, 96u }, { false, 128u }, { false, 192u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
+        enum { P4_NONE = 0, P4_128 = 1, P4_256 = 2, P4_1024 = 3, P4_2048 = 4, PK_256 = 6, PK_NONE = 9, LANE_8 = 10, LANE_16 = 12, LANE_128 = 18, LANE_NONE = 24 };
         hipEvent_t e0 = nullptr, e1 = nullptr;
         RT_HIP(ctx, hipEventCreate(&e0));
         RT_HIP(ctx, hipEventCreate(&e1));
         constexpr int N_CAND = (int)(sizeof candidates / sizeof candidates[0]);
-        float cand_ms[N_CAND];
-        bool cand_ok[N_CAND];
+        static_assert(N_CAND == LANE_NONE + 1, "candidate indices");
+        float cand_ms[N_CAND];            // fastest sample so far, handicap applied
+        int cand_n[N_CAND];               // samples taken; -1: produced an invalid frame (or is not usable here)
         bool broken = false;              // a runtime call failed: give up
         bool last_failed = false;         // the most recent launch left an invalid frame behind
-        bool warm = false;
-        // one candidate, `reps` launches, fastest of them; false = runtime failure
-        auto time_candidate = [&](int ci, int reps, float give_up_ms, float& ms, bool& valid) -> bool {
+        uint32_t launches = 0;
+        const uint32_t cal_parts = calibration_parts(b, cam);
+        // one launch of one candidate; false = runtime failure
+        auto run_once = [&](int ci, float& ms, bool& valid) -> bool {
             const auto& cand = candidates[ci];
-            TraceLaunch t = make_launch(b, cam, calibration_parts(b, cam));
+            TraceLaunch t = make_launch(b, cam, cal_parts);              // (the camera is prepared by the first of them)
             t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
             t.tag = 1;
             ms = 0.f;
-            for (int rep = 0; rep < reps; rep++) {
-                float m = 0.f;
-                (void)hipEventRecord(e0, ctx->stream);
-                launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
-                (void)hipEventRecord(e1, ctx->stream);
-                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&m, e0, e1) != hipSuccess) return false;
-                ms = rep == 0 ? m : (m < ms ? m : ms);
-                t.prepare_parts = 0;                                     // the camera is prepared once
-                if (rep == 0 && give_up_ms > 0.f && m > give_up_ms) break;
-            }
+            (void)hipEventRecord(e0, ctx->stream);
+            launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
+            (void)hipEventRecord(e1, ctx->stream);
+            launches++;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
             uint32_t cand_err = 0;
             if (hipMemcpyAsync(&cand_err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
@@ -769,42 +767,72 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             if (cand.quad && cand.budget < ctx->share_min_budget) return false;             // knob RTMI_SHARE_MIN_BUDGET
             return true;
         };
-        // first pass: every candidate twice unless its first run is hopeless (the first launch of a kernel pays for code and
-        // cache warm-up, and one sample of a 0.2 ms frame is too noisy to rank strategies that differ by 10 %); the very
-        // first candidate is launched a few times beforehand, untimed in effect, so that it is not measured on idle clocks
-        float best_ms = 0.f; bool have = false;
-        for (int ci = 0; ci < N_CAND && !broken; ci++) {
-            cand_ok[ci] = false; cand_ms[ci] = 0.f;
-            if (!usable(ci)) continue;
-            if (!warm) { float m; bool v; if (!time_candidate(ci, 3, 0.f, m, v)) { broken = true; break; } warm = true; }
-            bool valid = false;
-            if (!time_candidate(ci, 2, have ? 2.5f * best_ms : 0.f, cand_ms[ci], valid)) { broken = true; break; }
-            cand_ms[ci] *= handicap(ci);
-            cand_ok[ci] = valid;
-            if (valid && (!have || cand_ms[ci] < best_ms)) { best_ms = cand_ms[ci]; have = true; }
+        for (int ci = 0; ci < N_CAND; ci++) { cand_ms[ci] = 0.f; cand_n[ci] = usable(ci) ? 0 : -1; }
+        // one more sample of a candidate: the fastest of its samples counts
+        auto sample = [&](int ci) {
+            if (broken || ci < 0 || ci >= N_CAND || cand_n[ci] < 0) return;
+            float m = 0.f; bool valid = false;
+            if (!run_once(ci, m, valid)) { broken = true; return; }
+            if (!valid) { cand_n[ci] = -1; return; }
+            m *= handicap(ci);
+            cand_ms[ci] = cand_n[ci] == 0 ? m : (m < cand_ms[ci] ? m : cand_ms[ci]);
+            cand_n[ci]++;
+        };
+        auto best_of = [&](int skip) {
+            int best = -1;
+            for (int ci = 0; ci < N_CAND; ci++)
+                if (ci != skip && cand_n[ci] > 0 && (best < 0 || cand_ms[ci] < cand_ms[best])) best = ci;
+            return best;
+        };
+        // The first frame is bounded: about ten full-size launches instead of round 2's ~65 (25 candidates x 2 + warm-up + a
+        // final round; 1.2 s of GPU time over the bench's six BVHs against 0.1-7.5 ms frames).  A coarse pass over few, widely
+        // spaced candidates, one sample each; then the neighbours of the best; then the two fastest once more -- a 0.1 ms frame
+        // cannot rank strategies 10 % apart on one sample, and the first launches run on idle clocks, hence an untimed
+        // warm-up launch.  With four-wide records (search tree present) only the four-wide packet kernel competes: since
+        // round 3 it keeps the x-plane rays that used to make the lane-per-ray kernel win on ClumsyDragon, and round 2's
+        // full calibration picked it on every other BVH.  RTMI_CALIBRATE_ALL=1 restores the exhaustive pass over all 25.
+        static const bool calibrate_all = [] { const char* e = std::getenv("RTMI_CALIBRATE_ALL"); return e && e[0] == '1'; }();
+        {
+            int warm = -1;
+            for (int ci = 0; ci < N_CAND && warm < 0; ci++) if (cand_n[ci] == 0) warm = ci;
+            if (warm >= 0) { float m; bool v = false; if (!run_once(warm, m, v)) broken = true; }
         }
-        // final: the three fastest again, back to back on a warm device, three launches each; the fastest of those wins
-        int best_ci = -1;
-        if (!broken && have) {
-            float final_best = 0.f;
-            for (int round = 0; round < 3 && !broken; round++) {
-                int pick = -1;
-                for (int ci = 0; ci < N_CAND; ci++)
-                    if (cand_ok[ci] && (pick < 0 || cand_ms[ci] < cand_ms[pick])) pick = ci;
-                if (pick < 0) break;
-                cand_ok[pick] = false;                                   // taken
-                float m = 0.f; bool valid = false;
-                if (!time_candidate(pick, 3, 0.f, m, valid)) { broken = true; break; }
-                m *= handicap(pick);
-                if (valid && (best_ci < 0 || m < final_best)) { final_best = m; best_ci = pick; }
+        if (calibrate_all) {
+            for (int ci = 0; ci < N_CAND; ci++) { sample(ci); sample(ci); }
+            for (int round = 0, a = best_of(-1); round < 2 && a >= 0; round++) { const int c = best_of(a); sample(a); sample(c); a = best_of(-1); }
+        } else if (cand_n[P4_NONE] == 0) {
+            sample(P4_NONE); sample(P4_1024); sample(P4_128);
+            const int first = best_of(-1);
+            if (first == P4_128) sample(P4_256);
+            else if (first == P4_1024) { sample(P4_2048); sample(P4_256); }
+            // (whole blocks won: the sharing candidates lost with their handicap, a budget between or beyond them would too)
+            const int a = best_of(-1), c = best_of(a);
+            sample(a); sample(c);
+            sample(best_of(-1));
+        } else {
+            // no four-wide records (LITERAL_ZERO mode, RTMI_SEARCH_TREE=0 / RTMI_PACKET4=0): lane-per-ray budgets and the binary packet kernel
+            sample(LANE_16); sample(LANE_128); sample(LANE_NONE); sample(PK_256); sample(PK_NONE);
+            const int first = best_of(-1);
+            if (first >= LANE_8 && first < LANE_NONE) {
+                // the neighbours of the best lane-per-ray budget, two candidates away on either side (the list is ~sqrt(2) apart)
+                sample(first - 2 >= LANE_8 ? first - 2 : LANE_8);
+                sample(first + 3 < LANE_NONE ? first + 3 : LANE_NONE - 1);
+            } else if (first >= 5 && first < LANE_8) {
+                sample(first == PK_NONE ? 8 : first + 1);
+                if (first > 5) sample(first - 1);
             }
+            const int a = best_of(-1), c = best_of(a);
+            sample(a); sample(c);
         }
-        have = !broken && best_ci >= 0;
+        const int best_ci = broken ? -1 : best_of(-1);
+        const bool have = best_ci >= 0;
         const uint32_t best = have ? candidates[best_ci].budget : 1024u;
         const bool best_packet = have && candidates[best_ci].packet, best_quad = have && candidates[best_ci].quad;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (!have) return RT_FAIL(ctx, "trace calibration: no strategy produced a valid frame");
         b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best_packet; b->tuned_quad = best_quad;
+        b->calibration_launches = launches;
+        (void)last_failed;
         RT_HIP(ctx, hipGetLastError());
         // fall through: trace once more with the strategy just chosen (the last launch above was some other candidate's)
     }
@@ -893,6 +921,8 @@ int rt_bvh_trace_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget)
                                                           : (b->tuned && b->tuned_packet ? (b->tuned_quad ? 2 : 1) : 0);
     return RT_SUCCESS;
 }
+
+uint32_t rt_bvh_calibration_launches(const rt_bvh* b) { return b ? b->calibration_launches : 0u; }
 
 int rt_bvh_search_tree(const rt_bvh* b, uint32_t* depth, int* used_by_last_camera)
 {

@@ -165,6 +165,7 @@ struct rt_bvh {
     uint32_t tuned_budget = 0;              // 0 = packet kernel, else deferral budget of the two-phase kernels
     bool tuned_packet = false;
     bool tuned_quad = false;                // with tuned_packet: the four-wide packet kernel
+    uint32_t calibration_launches = 0;      // full-size launches the last calibration took (diagnostic)
     uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)
     bool frame_initialised = false;
     bool built = false;
@@ -189,6 +190,7 @@ struct rt_tlg {
     uint32_t* d_written = nullptr;      // 64 words: [0] leaf pairs written; [4..7] counts of a rebuild without round trips (pairs, leaf cells, leaf pairs)
     uint32_t leaf_ranges_cap = 0;       // entries d_leaf_ranges holds
     uint32_t pairs_cap = 0, leaf_cap = 0;   // elements d_pairs / d_leaf_pairs hold (kept across initializeFrame: a rebuild starts on them)
+    uint32_t cells_cap = 0;                 // entries d_cell_ranges / d_top hold (the `cells` of the initializeFrame that allocated them)
     uint32_t rebuilds_without_readback = 0;   // diagnostics
     TriCam* d_tricam = nullptr;         // n camera-relative triangle records of the primary-ray trace (rtmi_internal.h, TriCam)
     float tricam_origin[3] = { 0, 0, 0 };

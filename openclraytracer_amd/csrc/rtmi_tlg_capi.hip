@@ -118,8 +118,10 @@ int rt_tlg_initialize_frame(rt_tlg* g)
     if (cells != g->info.cells || !g->d_top) {
         if (g->d_cell_ranges) { (void)hipFree(g->d_cell_ranges); g->d_cell_ranges = nullptr; }
         if (g->d_top) { (void)hipFree(g->d_top); g->d_top = nullptr; }
+        g->cells_cap = 0;
         RT_HIP(ctx, hipMalloc((void**)&g->d_cell_ranges, (size_t)cells * sizeof(uint2)));
         RT_HIP(ctx, hipMalloc((void**)&g->d_top, (size_t)cells * sizeof(rt_top_cell)));
+        g->cells_cap = cells;
     }
     if (!g->d_written) RT_HIP(ctx, hipMalloc((void**)&g->d_written, 256));
     g->info = rt_tlg_info{};
@@ -227,6 +229,17 @@ static int construct_on_previous_sizes(rt_tlg* g, bool* accepted)
     const uint32_t n = g->n, cells = g->info.cells, P = g->pairs_cap, L = g->leaf_cap;
     uint32_t* d_cnt = g->d_written + 4;                                   // pairs, leaf cells, leaf pairs
     *accepted = false;
+    // Every kernel below is enqueued on a CAPACITY, not on a count the host has seen: each of them must belong to the arrays as they
+    // are now.  (Round 2, 09:07: the counters / scan arrays were sized for the pair COUNT of the build with read-backs while this
+    // sequence zeroes counters[count .. P) (k_tlg_count_leaf) and scans over P, the power of two above it -- writes past the end of
+    // d_counters / d_scan that went unnoticed until initializeFrame with other densities moved the allocations, then a GPU memory
+    // fault inside construct().  Fixed by sizing them for P, `ensure_counters(g, pairs_pow2)`; asserted here for every array.)
+    if (!(g->counters_cap >= n && g->counters_cap >= cells && g->counters_cap >= P))
+        return RT_FAIL(ctx, "internal: the counter / scan arrays are smaller than what a rebuild on the previous sizes scans over");
+    if (!(cells && cells <= g->cells_cap && g->d_cell_ranges && g->d_top))
+        return RT_FAIL(ctx, "internal: the cell arrays do not belong to this initializeFrame");
+    if (!(P && L && g->d_pairs && g->d_leaf_pairs && g->d_leaf_ranges && g->leaf_ranges_cap && g->d_written))
+        return RT_FAIL(ctx, "internal: a rebuild on the previous sizes without previous arrays");
     launch_tlg_count_top(s, G, sc, g->d_counters);
     launch_scan_inclusive(s, g->d_counters, g->d_scan, n, g->d_scan_scratch);
     RT_HIP(ctx, hipMemcpyAsync(d_cnt + 0, g->d_scan + (n - 1), 4, hipMemcpyDeviceToDevice, s));

@@ -1,7 +1,12 @@
 // shade_math.h -- cpuShadeBlinnPhong per contact (Include/CLData/Shading.h:74-166, lightEnergyPercentage Primitives/Light.h:55-58),
 // shared by k_shade and by the traversal kernels that shade a contact as they store it (trace_kernels.hip, fused frames).
+// Dual target like device_math.h: the host mirror's cpuShadeBlinnPhong (csrc/host/include/CLData/Shading.h) compiles shade_one with g++.
 #pragma once
+#if defined(__HIP__) || defined(__HIPCC__)
 #include "rtmi_internal.h"
+#else
+#include "../../include/rtmi.h"
+#endif
 #include "device_math.h"
 
 struct ShadeScene {
@@ -9,12 +14,12 @@ struct ShadeScene {
     uint32_t n_lights, n_spheres, n_materials;
 };
 
-__device__ __forceinline__ float light_energy_percentage(float distance, float lightEnergy)
+RT_FN float light_energy_percentage(float distance, float lightEnergy)
 {
     return RMAX((1.0f - distance / lightEnergy), 0.0f);
 }
 
-__device__ __forceinline__ float4 shade_one(const ShadeScene& a, const rt_camera& cam, const rt_contact& c)
+RT_FN float4 shade_one(const ShadeScene& a, const rt_camera& cam, const rt_contact& c)
 {
     // default material, Shading.h:76-96
     f3 ambient = { 0.2f, 0.2f, 0.2f }, diffuse = { 1.0f, 1.0f, 1.0f }, specular = { 1.0f, 0.0f, 0.0f };

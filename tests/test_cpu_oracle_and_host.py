@@ -373,3 +373,30 @@ def test_bench_reads_the_tag_of_a_traversal_kernel_name():
     assert bench.kernel_tag('k_trace_long<0, 1>') == (0, 1)
     assert bench.kernel_tag('k_shade') is None
 
+
+
+def test_host_cpu_shade_blinn_phong_equals_the_oracle():
+    """the host mirror's cpuShadeBlinnPhong(Camera*, Contact*, char*, CL_FLOAT4&) (Include/CLData/Shading.h:74-166; what an unmodified
+    RTFrame calls per contact, OpenCLRayTracerDemo.cpp:298-316) -- csrc/shade_math.h compiled by g++ -- gives the oracle's colours bit
+    for bit on the oracle's contacts (same operations, same libm), on every bundled model.  No GPU involved."""
+    import ctypes as C
+    import oracle as orc
+    lib = C.CDLL(os.path.join(ROOT, 'openclraytracer_amd', 'librtmi_host.so'))
+    fn = getattr(lib, '_Z18cpuShadeBlinnPhongP6CameraP7ContactPcR10CL_FLOAT4_')
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    for name in MODELS:
+        buf = packed_scene(name)
+        osc = orc.Scene(buf)
+        ob = orc.BVH(osc, 0)
+        cam = osc.demo_camera(64, 48)
+        contacts, _ = ob.trace_primary(cam)
+        want = orc.shade_frame(osc, cam, contacts).reshape(-1, 4)
+        scene = np.frombuffer(buf, dtype=np.uint8).copy()
+        out = np.zeros(4, dtype=np.float32)
+        hits = np.nonzero(contacts['normal_t'][:, 3] > 0)[0]
+        assert len(hits) > 100
+        for i in hits:
+            c = contacts[i:i + 1].copy()
+            fn(cam.ctypes.data, c.ctypes.data, scene.ctypes.data, out.ctypes.data)
+            assert out.tobytes() == want[c['pixelIndex'][0]].tobytes(), (name, int(i))

@@ -1213,3 +1213,26 @@ def test_frame_graph_follows_a_moving_camera(name, layout, knobs, monkeypatch):
         gb.close(); sc.close()
     finally:
         ctx.close()
+
+
+def test_cpp_reference_frame_loop(gpu_ctx, tmp_path):
+    """apps/rt_demo --reference-frame 1: RTFrame as the reference wrote it (OpenCLRayTracerDemo.cpp:287-316) -- every contact of the
+    primary buffer to the host, colours cleared, cpuShadeBlinnPhong per contact on the host (the mirror's CLData/Shading.h) -- gives
+    the frame the device-shaded path gives, within 1e-5 relative (device powf), same lit pixels."""
+    import subprocess
+    demo = os.path.join(ROOT, 'apps', 'bin', 'rt_demo')
+    frames = {}
+    for mode in ('0', '1'):
+        pfm = str(tmp_path / ('f%s.pfm' % mode))
+        r = subprocess.run([demo, '-winH', '300', '-winW', '400', '-accStruct', 'BVH', '-headersPath', 'unused', '-scene',
+                            os.path.join('assets', 'scenes', 'tenryuu.txt'), '--reference-frame', mode, '--out', pfm],
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ('host shading loop' in r.stdout) == (mode == '1')
+        blob = open(pfm, 'rb').read()
+        head = b'PF\n400 300\n-1.0\n'
+        frames[mode] = np.frombuffer(blob, dtype='<f4', offset=len(head)).reshape(300, 400, 3)
+    a, b = frames['0'], frames['1']
+    assert ((a != 0).any(axis=2) == (b != 0).any(axis=2)).all() and (b != 0).any()
+    err = np.abs(a - b) / np.maximum(np.abs(a), 1e-30)
+    assert float(np.where(a == b, 0.0, err).max()) <= 1e-5

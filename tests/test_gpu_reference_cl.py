@@ -8,24 +8,47 @@ orc.set_device_arith(True) and must then reproduce t, hit mask and materialIndex
 product (host-branch arithmetic, as the oracle's default) must agree on the hit mask up to exact edge ties and on t within
 2e-5 relative.  The normal goes through fast_normalize (CLPortability.h:412), an approximation: 3e-7 absolute.
 """
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import MODELS, as_capi_camera, gpu_bvh, oracle_bvh, packed_scene
+from conftest import MODELS, ROOT, as_capi_camera, gpu_bvh, oracle_bvh, packed_scene
 
 pytestmark = pytest.mark.gpu
 
 RES = (320, 240)
 
 
-@pytest.fixture(scope='module')
-def ref():
+def _ref_fixture(build):
     import ref_cl
-    if not ref_cl.available('strict'):
-        pytest.skip('oracle/_ref/cl_strict/*.co not built (needs /root/reference: make -C oracle ref_cl)')
-    r = ref_cl.RefCL('strict')
+    if not ref_cl.available(build):
+        # the code objects are built from /root/reference (git-ignored artefacts that travel to the GPU box with the tree): where the
+        # reference is present they must exist -- __graft_entry__.build() makes them -- and a missing one is a failure, not a skip
+        if os.path.isdir('/root/reference/OpenCLRayTracer'):
+            pytest.fail('oracle/_ref/cl_%s/*.co missing although /root/reference is present: run __graft_entry__.build() (make -C oracle ref_cl)' % build)
+        pytest.skip('oracle/_ref/cl_%s/*.co not in this tree (built from /root/reference by make -C oracle ref_cl; they travel with the tree)' % build)
+    r = ref_cl.RefCL(build)
     yield r
     r.close()
+
+
+@pytest.fixture(scope='module')
+def ref():
+    yield from _ref_fixture('strict')
+
+
+@pytest.fixture(scope='module')
+def ref_default():
+    yield from _ref_fixture('default')
+
+
+# distances between the product (host-branch arithmetic) and the reference's kernels as ROCm compiles them, measured on the
+# MI355X per model at 320x240 (tools/ref_cl_distances.py wrote the file): upper bounds, a smaller distance is no failure
+DIST = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_cl_distances.json')))
 
 
 def _rows(a):
@@ -111,11 +134,12 @@ def test_reference_ray_kernel_equals_the_oracle_bit_for_bit(gpu_ctx, ref, name, 
         _, gb = gpu_bvh(gpu_ctx, name)
         prod = gb.generate_contacts_rays(rays.view(capi.RAY))
         ph = prod['normalAndDistance'][:, 3] > 0
-        assert int((ph != hit).sum()) <= 2
+        d = DIST['strict'][name]['generateContacts2']
+        assert int((ph != hit).sum()) <= d['hit_mask_differs']
         both = ph & hit
-        assert (prod['materialIndex'][both] != got['materialIndex'][both]).sum() <= 64     # cube: rays along face edges
+        assert int((prod['materialIndex'][both] != got['materialIndex'][both]).sum()) <= d['material_differs']     # cube: rays along face edges
         tp, tr = prod['normalAndDistance'][both, 3], got['normal_t'][both, 3]
-        assert (np.abs(tp - tr) / tr).max() <= 2e-5
+        assert float((np.abs(tp - tr) / tr).max()) <= d['t_rel_max'] * 1.0001
 
 
 @pytest.mark.parametrize('name', MODELS)
@@ -128,10 +152,77 @@ def test_reference_primary_kernel_agrees_with_the_product(gpu_ctx, ref, name):
     prod = gb.generate_contacts_primary(as_capi_camera(cam))
     assert (got['pixelIndex'] == prod['pixelIndex']).all()
     gh, ph = got['normal_t'][:, 3] > 0, prod['normalAndDistance'][:, 3] > 0
-    assert int((gh != ph).sum()) <= 4
+    d = DIST['strict'][name]['generateContacts']
+    assert int((gh != ph).sum()) <= d['hit_mask_differs']
     both = gh & ph
+    assert int((prod['materialIndex'][both] != got['materialIndex'][both]).sum()) <= d['material_differs']
     tp, tr = prod['normalAndDistance'][both, 3], got['normal_t'][both, 3]
-    assert (np.abs(tp - tr) / tr).max() <= 2e-5
+    assert float((np.abs(tp - tr) / tr).max()) <= d['t_rel_max'] * 1.0001
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_reference_kernels_with_their_own_build_options(gpu_ctx, ref_default, name):
+    """the same two ray kernels built with the reference's OWN options (BVHManager.cpp:86: no -cl-fp32-correctly-rounded-divide-sqrt,
+    contraction allowed) -- `cl_default`: the product's distances to them, asserted like the strict build's"""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, ob = oracle_bvh(name)
+    cam = osc.demo_camera(*RES)
+    rays = orc.generate_rays(cam)
+    _, gb = gpu_bvh(gpu_ctx, name)
+    for kernel, got, prod in (('generateContacts2', ref_default.generate_contacts2(rays, ob.nodes, ob.n, packed_scene(name)),
+                               gb.generate_contacts_rays(rays.view(capi.RAY))),
+                              ('generateContacts', ref_default.generate_contacts(cam, ob.nodes, ob.n, packed_scene(name)),
+                               gb.generate_contacts_primary(as_capi_camera(cam)))):
+        d = DIST['default'][name][kernel]
+        assert (got['pixelIndex'] == prod['pixelIndex']).all()
+        gh, ph = got['normal_t'][:, 3] > 0, prod['normalAndDistance'][:, 3] > 0
+        assert int((gh != ph).sum()) <= d['hit_mask_differs'], kernel
+        both = gh & ph
+        assert int((prod['materialIndex'][both] != got['materialIndex'][both]).sum()) <= d['material_differs'], kernel
+        tp, tr = prod['normalAndDistance'][both, 3], got['normal_t'][both, 3]
+        assert float((np.abs(tp - tr) / tr).max()) <= d['t_rel_max'] * 1.0001, kernel
+
+
+_DEVARITH_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from openclraytracer_amd import capi
+ctx = capi.Context(0)
+buf = open(sys.argv[1], 'rb').read()
+rays = np.load(sys.argv[2]).view(capi.RAY)
+sc = capi.DeviceScene(ctx, buf)
+bvh = capi.DeviceBVH(ctx, sc, mode=int(sys.argv[4])).build()
+np.save(sys.argv[3], bvh.generate_contacts_rays(rays).view(np.uint8))
+bvh.close(); sc.close(); ctx.close()
+"""
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('name', MODELS)
+def test_device_arith_twin_equals_the_reference_ray_kernel_bit_for_bit(ref, name, mode, tmp_path):
+    """librtmi_devarith.so = the library with dot() / cross() of its traversal kernels fused as ROCm's OpenCL C built-ins are
+    (csrc/device_math.h, RTMI_DEVICE_ARITH; csrc/Makefile).  Its ray-buffer entry -- lane-per-ray + wave-per-ray kernels, search
+    tree, four-wide steps and all -- gives the pixelIndex, materialIndex and every bit of t of the reference's own
+    generateContacts2 kernel run on this GPU, on the FIXED tree and on the LITERAL_ZERO tree: the product's machinery is exact,
+    what separates the shipped library from the reference's device branch is those two library functions alone."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, _ = oracle_bvh(name)
+    ob = orc.BVH(osc, mode)
+    rays = orc.generate_rays(osc.demo_camera(*RES))
+    got = ref.generate_contacts2(rays, ob.nodes, ob.n, packed_scene(name))
+    scene_path, rays_path, out_path = str(tmp_path / 's.bin'), str(tmp_path / 'r.npy'), str(tmp_path / 'c.npy')
+    open(scene_path, 'wb').write(packed_scene(name))
+    np.save(rays_path, rays.view(np.uint8))
+    env = dict(os.environ, RTMI_LIBRARY='librtmi_devarith.so')
+    r = subprocess.run([sys.executable, '-c', _DEVARITH_SCRIPT % dict(root=ROOT), scene_path, rays_path, out_path, str(mode)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    prod = np.load(out_path).view(capi.CONTACT).reshape(-1)
+    assert (_key(got) == _key(prod, 'normalAndDistance')).all(), 'pixelIndex / materialIndex / t bits'
+    hit = got['normal_t'][:, 3] > 0
+    assert hit.any() and np.abs(got['normal_t'][hit, :3] - prod['normalAndDistance'][hit, :3]).max() <= 3e-7
 
 
 @pytest.mark.parametrize('name', MODELS)
