@@ -128,9 +128,10 @@ int  rt_bvh_info(const rt_bvh* bvh, uint32_t* leaves, uint32_t* morton_items, ui
  * (budget 0 = not calibrated yet); env RTMI_DEFER_BUDGET=<n> (+ RTMI_PACKET=0/1/4) fixes it.  Speed knobs only: every
  * setting gives the same contacts.                                                                                     */
 int  rt_bvh_trace_strategy(const rt_bvh* bvh, int* packet_kernel, uint32_t* budget);
-/* full-size launches the last calibration took (about ten: a coarse pass over few candidates, the neighbours of the best, the two
+/* full-size launches the last calibration took (about a dozen: a coarse pass over few candidates, the neighbours of the best, the two
  * fastest once more; env RTMI_CALIBRATE_ALL=1: the exhaustive pass over all 25 candidates); 0 = not calibrated                  */
 uint32_t rt_bvh_calibration_launches(const rt_bvh* bvh);
+float    rt_bvh_calibration_gpu_ms(const rt_bvh* bvh);        /* device time of those launches (HIP events on the stream) */
 /* Primary rays (all with the camera position as origin) walk a second hierarchy over the same leaf boxes, ordered by
  * properly normalised Morton codes (depth ~25-50 instead of the reference tree's 94-10 835).  A leaf whose box passes the
  * reference's child test has only ancestors that pass it, in ANY hierarchy of nested boxes over these leaves, so the set of

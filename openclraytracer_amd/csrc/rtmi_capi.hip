@@ -720,6 +720,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         bool broken = false;              // a runtime call failed: give up
         bool last_failed = false;         // the most recent launch left an invalid frame behind
         uint32_t launches = 0;
+        float gpu_ms = 0.f;               // device time of all calibration launches (events on the stream)
         const uint32_t cal_parts = calibration_parts(b, cam);
         // one launch of one candidate; false = runtime failure
         auto run_once = [&](int ci, float& ms, bool& valid) -> bool {
@@ -734,6 +735,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             (void)hipEventRecord(e1, ctx->stream);
             launches++;
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
+            gpu_ms += ms;
             uint32_t cand_err = 0;
             if (hipMemcpyAsync(&cand_err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
@@ -784,27 +786,34 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
                 if (ci != skip && cand_n[ci] > 0 && (best < 0 || cand_ms[ci] < cand_ms[best])) best = ci;
             return best;
         };
-        // The first frame is bounded: about ten full-size launches instead of round 2's ~65 (25 candidates x 2 + warm-up + a
+        // The first frame is bounded: about a dozen full-size launches instead of round 2's ~65 (25 candidates x 2 + warm-up + a
         // final round; 1.2 s of GPU time over the bench's six BVHs against 0.1-7.5 ms frames).  A coarse pass over few, widely
         // spaced candidates, one sample each; then the neighbours of the best; then the two fastest once more -- a 0.1 ms frame
         // cannot rank strategies 10 % apart on one sample, and the first launches run on idle clocks, hence an untimed
-        // warm-up launch.  With four-wide records (search tree present) only the four-wide packet kernel competes: since
-        // round 3 it keeps the x-plane rays that used to make the lane-per-ray kernel win on ClumsyDragon, and round 2's
-        // full calibration picked it on every other BVH.  RTMI_CALIBRATE_ALL=1 restores the exhaustive pass over all 25.
+        // warm-up launch.  With four-wide records the binary packet kernel does not compete (round 2's full calibration never
+        // picked it where the four-wide kernel was available); the lane-per-ray kernel does: ClumsyDragon's centre columns
+        // walk ~80 records per ray against a mean of 3.6, and one wave per such ray (wave-per-ray kernel behind a lane-per-ray
+        // budget of 16 steps) beats eight of them in one packet.  RTMI_CALIBRATE_ALL=1 restores the exhaustive pass over all 25.
         static const bool calibrate_all = [] { const char* e = std::getenv("RTMI_CALIBRATE_ALL"); return e && e[0] == '1'; }();
         {
             int warm = -1;
             for (int ci = 0; ci < N_CAND && warm < 0; ci++) if (cand_n[ci] == 0) warm = ci;
             if (warm >= 0) { float m; bool v = false; if (!run_once(warm, m, v)) broken = true; }
         }
+        auto refine_lane = [&](int first) {
+            // the neighbours of the best lane-per-ray budget, two candidates away on either side (the list is ~sqrt(2) apart)
+            sample(first - 2 >= LANE_8 ? first - 2 : LANE_8);
+            sample(first + 2 < LANE_NONE ? first + 2 : LANE_NONE - 1);
+        };
         if (calibrate_all) {
             for (int ci = 0; ci < N_CAND; ci++) { sample(ci); sample(ci); }
             for (int round = 0, a = best_of(-1); round < 2 && a >= 0; round++) { const int c = best_of(a); sample(a); sample(c); a = best_of(-1); }
         } else if (cand_n[P4_NONE] == 0) {
-            sample(P4_NONE); sample(P4_1024); sample(P4_128);
+            sample(P4_NONE); sample(P4_1024); sample(P4_128); sample(LANE_16); sample(LANE_128);
             const int first = best_of(-1);
             if (first == P4_128) sample(P4_256);
             else if (first == P4_1024) { sample(P4_2048); sample(P4_256); }
+            else if (first >= LANE_8 && first < LANE_NONE) refine_lane(first);
             // (whole blocks won: the sharing candidates lost with their handicap, a budget between or beyond them would too)
             const int a = best_of(-1), c = best_of(a);
             sample(a); sample(c);
@@ -813,11 +822,8 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             // no four-wide records (LITERAL_ZERO mode, RTMI_SEARCH_TREE=0 / RTMI_PACKET4=0): lane-per-ray budgets and the binary packet kernel
             sample(LANE_16); sample(LANE_128); sample(LANE_NONE); sample(PK_256); sample(PK_NONE);
             const int first = best_of(-1);
-            if (first >= LANE_8 && first < LANE_NONE) {
-                // the neighbours of the best lane-per-ray budget, two candidates away on either side (the list is ~sqrt(2) apart)
-                sample(first - 2 >= LANE_8 ? first - 2 : LANE_8);
-                sample(first + 3 < LANE_NONE ? first + 3 : LANE_NONE - 1);
-            } else if (first >= 5 && first < LANE_8) {
+            if (first >= LANE_8 && first < LANE_NONE) refine_lane(first);
+            else if (first >= 5 && first < LANE_8) {
                 sample(first == PK_NONE ? 8 : first + 1);
                 if (first > 5) sample(first - 1);
             }
@@ -831,7 +837,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (!have) return RT_FAIL(ctx, "trace calibration: no strategy produced a valid frame");
         b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best_packet; b->tuned_quad = best_quad;
-        b->calibration_launches = launches;
+        b->calibration_launches = launches; b->calibration_gpu_ms = gpu_ms;
         (void)last_failed;
         RT_HIP(ctx, hipGetLastError());
         // fall through: trace once more with the strategy just chosen (the last launch above was some other candidate's)
@@ -923,6 +929,7 @@ int rt_bvh_trace_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget)
 }
 
 uint32_t rt_bvh_calibration_launches(const rt_bvh* b) { return b ? b->calibration_launches : 0u; }
+float rt_bvh_calibration_gpu_ms(const rt_bvh* b) { return b ? b->calibration_gpu_ms : 0.f; }
 
 int rt_bvh_search_tree(const rt_bvh* b, uint32_t* depth, int* used_by_last_camera)
 {

@@ -166,6 +166,7 @@ struct rt_bvh {
     bool tuned_packet = false;
     bool tuned_quad = false;                // with tuned_packet: the four-wide packet kernel
     uint32_t calibration_launches = 0;      // full-size launches the last calibration took (diagnostic)
+    float calibration_gpu_ms = 0.f;         // ... and their device time
     uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)
     bool frame_initialised = false;
     bool built = false;

@@ -615,9 +615,13 @@ def test_bench_default_line_has_measured_rooflines():
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RTMI_BENCH_GROUP', 'RTMI_BENCH_FORCE_TILED'):
         env.pop(k, None)
-    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '3'], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # (the bench reports its progress on stderr; kept in a file under gpurun_out/ so that a run that stalls shows where)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    err_path = os.path.join(ROOT, 'gpurun_out', 'test_bench_default_line.err')
+    with open(err_path, 'w') as err_file:
+        r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '3'], cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=err_file, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + open(err_path).read()[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
     rf, rv = out['roofline'], out['roofline_valu_issue']
     assert out['n_gpus'] == 1 and out['config']['rays_per_step'] == 5 * 1920 * 1080
@@ -633,6 +637,11 @@ def test_bench_default_line_has_measured_rooflines():
     for n, ps in out['per_scene'].items():
         assert ps['rebuild_plus_trace_ms'] > 0 and ps['strategy_after_rebuilds'] == ps['strategy'], n
         assert 0 < ps['valu_issue_frac'] <= 1
+        assert ps['first_frame_ms'] > 0 and 0 < ps['calibration_launches'] <= 14 and ps['calibration_gpu_ms'] > 0
+    mv = out['moving_camera']
+    assert mv['step_ms'] > 0 and mv['same_poses_still_step_ms'] > 0 and set(mv['per_scene']) == set(out['per_scene'])
+    for n, ps in mv['per_scene'].items():
+        assert ps['launches']['with_preparation'] + ps['launches']['eager'] == 32, n       # every frame paid for its camera
 
 
 @pytest.mark.parametrize('knobs', [dict(), dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='1048576'), dict(RTMI_PACKET='1', RTMI_DEFER_BUDGET='32'),
@@ -1150,6 +1159,7 @@ def test_frame_graph_follows_a_moving_camera(name, layout, knobs, monkeypatch):
         sc = capi.DeviceScene(ctx, packed_scene(name))
         gb = capi.DeviceBVH(ctx, sc).build()
         cam0 = as_capi_camera(osc.demo_camera(*res))
+        gb.generate_contacts_primary(cam0)               # the context's lists at full-frame size before a tiled graph holds their addresses
         if layout == 'untiled':
             rank, til, slots, kind = 0, 1, npx, capi.FRAME_UNTILED
             d_c, d_o = ctx.alloc(npx * 32), ctx.alloc(npx * 16)

@@ -222,7 +222,8 @@ def test_device_arith_twin_equals_the_reference_ray_kernel_bit_for_bit(ref, name
     prod = np.load(out_path).view(capi.CONTACT).reshape(-1)
     assert (_key(got) == _key(prod, 'normalAndDistance')).all(), 'pixelIndex / materialIndex / t bits'
     hit = got['normal_t'][:, 3] > 0
-    assert hit.any() and np.abs(got['normal_t'][hit, :3] - prod['normalAndDistance'][hit, :3]).max() <= 3e-7
+    # (the normal: the twin keeps the library's precomputed one -- host-branch cross, exact normalize -- against fast_normalize of the fused cross)
+    assert hit.any() and np.abs(got['normal_t'][hit, :3] - prod['normalAndDistance'][hit, :3]).max() <= 3e-6
 
 
 @pytest.mark.parametrize('name', MODELS)
