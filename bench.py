@@ -301,19 +301,28 @@ def main():
         pmc = run_pmc_passes(scene_bytes, args.keep_pmc)
     note('scenes, BVHs, first frames')
 
-    import torch
-    from openclraytracer_amd import capi
-    dist = None
+    # Which HIP runtime serves the process: librtmi.so is linked against the system's (/opt/rocm), torch ships a copy of its own
+    # (an older ROCm) that satisfies the same dependency when it is loaded first.  Measured in round 3: under torch's copy a graph
+    # instance whose kernel arguments were re-set (the camera that moves) replays three times slower and the five-stream
+    # moving-camera loop stalls; under the system runtime neither happens.  N = 1 therefore runs without torch (device-wide
+    # fences come from the library).  N > 1 needs torch.distributed (gloo: barrier, communicator id, max of the elapsed time) and
+    # loads torch FIRST, as in round 2, so that the library, RCCL and torch share ONE runtime; that path replays captured frames
+    # only.
+    torch, dist, dev = None, None, None
     if world > 1:
+        import torch
         import torch.distributed as dist
-        dist.init_process_group('gloo')          # control plane only: barrier, the communicator id, max of the elapsed time
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+        dist.init_process_group('gloo')          # control plane only
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    from openclraytracer_amd import capi
 
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if torch is not None:
+            torch.cuda.synchronize(dev)
+        capi.device_synchronize(local_rank)
 
     frames_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'frames.json')))
     search_fixture = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'search_tree_frames.json')))

@@ -83,6 +83,7 @@ const char* rt_last_error(const rt_ctx* ctx);       /* valid until the next fail
 int         rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
 void*       rt_ctx_get_stream(const rt_ctx* ctx);
 int         rt_ctx_synchronize(rt_ctx* ctx);        /* flushQueue + finishQueue, CLExecutionContext.h:436-445 */
+int         rt_device_synchronize(int device_ordinal);   /* every stream of the device (several contexts = several streams): hipDeviceSynchronize */
 int         rt_ctx_device_info(const rt_ctx* ctx, int* compute_units, int* wave_size, uint64_t* lds_bytes,
                                char* name, size_t name_len);
 

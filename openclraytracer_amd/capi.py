@@ -33,7 +33,7 @@ assert CAMERA.itemsize == 64 and RAY.itemsize == 48 and CONTACT.itemsize == 32 a
 # every symbol include/rtmi.h declares (tests check the library exports all of them)
 SYMBOLS = [
     'rt_abi_version', 'rt_ctx_create', 'rt_ctx_destroy', 'rt_last_error', 'rt_ctx_set_stream', 'rt_ctx_get_stream',
-    'rt_ctx_synchronize', 'rt_ctx_device_info', 'rt_buf_alloc', 'rt_buf_free', 'rt_buf_upload', 'rt_buf_download',
+    'rt_ctx_synchronize', 'rt_device_synchronize', 'rt_ctx_device_info', 'rt_buf_alloc', 'rt_buf_free', 'rt_buf_upload', 'rt_buf_download',
     'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_upload_indexed', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     L.rt_ctx_set_stream.argtypes = [vp, vp]
     L.rt_ctx_get_stream.argtypes = [vp]; L.rt_ctx_get_stream.restype = vp
     L.rt_ctx_synchronize.argtypes = [vp]
+    L.rt_device_synchronize.argtypes = [i32]
     L.rt_ctx_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64), C.c_char_p, C.c_size_t]
     L.rt_buf_alloc.argtypes = [vp, u64, pvp]
     L.rt_buf_free.argtypes = [vp, vp]
@@ -155,6 +156,13 @@ def load_library() -> C.CDLL:
 
 def _p(a: np.ndarray) -> C.c_void_p:
     return a.ctypes.data_as(C.c_void_p)
+
+
+def device_synchronize(device: int = 0):
+    """every stream of the device (hipDeviceSynchronize)"""
+    L = load_library()
+    if L.rt_device_synchronize(device):
+        raise RtError(L.rt_last_error(None).decode())
 
 
 class Context:

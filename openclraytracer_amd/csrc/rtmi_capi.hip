@@ -647,6 +647,9 @@ struct FrameMode {
     bool force_prepare = false;            // (re)compute the per-camera records whatever the BVH's marks say (the graph with the preparation in it)
     uint32_t plane_bits_known = 0;         // 0x80000000 | bits: the host knows the camera-on-a-plane bits
     uint32_t parts_drop = 0;               // RT_PREP_* this frame's kernels do not read although their strategy normally does
+    // a captured frame keeps the strategy it was captured with (the BVH remembers one calibration, for the last resolution / tiling traced)
+    bool fixed_strategy = false, packet = false, quad = false;
+    uint32_t budget = 0;
 };
 
 static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32_t parts = 0, const FrameMode* mode = nullptr)
@@ -701,7 +704,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
 {
     rt_ctx* ctx = b->ctx;
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
-    if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key)) {
+    if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key) && !(mode && mode->fixed_strategy)) {
         if (mode && (mode->record || mode->update)) return RT_FAIL(ctx, "a frame graph needs a calibrated strategy (trace one frame eagerly first)");
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
@@ -845,12 +848,21 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     bool packet = false, quad = false; uint32_t budget = ctx->defer_budget;
     if (ctx->defer_budget == 0 && b->tuned) { budget = b->tuned_budget; packet = b->tuned_packet; quad = b->tuned_quad; }
     if (ctx->defer_budget != 0 && ctx->force_packet) { packet = true; quad = ctx->force_packet4 && b->d_quad; }
+    if (mode && mode->fixed_strategy) { packet = mode->packet; quad = mode->quad; budget = mode->budget; }
     TraceLaunch t = make_launch(b, cam, strategy_parts(b, cam, packet, quad) & ~(mode ? mode->parts_drop : 0u), mode);
     t.defer_budget = budget; t.packet = packet; t.packet4 = quad;
     if (mode && mode->fused) { t.fused_rgba = mode->fused->rgba; t.fused_plane_stride = mode->fused->plane_stride; t.fused_done = &mode->fused->done; }
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
     if (mode && mode->update) return mode->update->failed ? RT_FAIL(ctx, "frame graph: a kernel node could not be updated") : RT_SUCCESS;
     RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_device_synchronize(int device_ordinal)
+{
+    hipError_t e = hipSetDevice(device_ordinal);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return RT_FAIL(nullptr, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
     return RT_SUCCESS;
 }
 
@@ -1074,16 +1086,24 @@ struct rt_frame_graph {
     void* d_contacts = nullptr; void* d_out = nullptr;
     // [0] the steady-state frame; [1] the same behind the per-camera preparation (k_prepare_camera): what a frame costs whose
     // camera has moved.  Moving the camera re-sets the arguments of the captured kernels, it does not capture again.
+    // Two executable instances of each: the arguments of an instance are only re-set once its last launch has finished (an event
+    // behind every launch), so a frame in flight is never touched -- with two, the host prepares the next camera's frame while
+    // the GPU still runs the previous one.
     hipGraph_t graph[2] = { nullptr, nullptr };
-    hipGraphExec_t exec[2] = { nullptr, nullptr };
+    hipGraphExec_t exec[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
+    hipEvent_t done[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
+    bool launched[2][2] = { { false, false }, { false, false } };
+    bool dirty[2][2] = { { false, false }, { false, false } };   // the camera changed since this instance's arguments were set
+    int slot[2] = { 0, 0 };                  // the instance of each kind that was launched last
     GraphNodes nodes[2];
-    bool dirty[2] = { false, false };        // the camera changed since this exec's arguments were set
     // what the captured launches depend on besides the caller's buffers: addresses of the context's scratch lists and of the
     // BVH's records (generations), and the per-camera records of this camera position (origin, parts)
     uint64_t scratch_generation = 0, build_generation = 0;
     float origin[3] = { 0, 0, 0 };
     uint32_t parts = 0;                      // RT_PREP_* this frame's kernels read
-    bool four_wide = false, octant_records = false;   // strategy: the four-wide packet kernel (on per-octant records: x-plane rays stay)
+    bool packet = false, quad = false;       // the strategy the frame was captured with (kept whatever the BVH is calibrated to later)
+    uint32_t budget = 0;
+    bool four_wide = false, octant_records = false;   // ... the four-wide packet kernel (on per-octant records: x-plane rays stay)
     bool no_unsafe = false;                  // captured without the wave-per-ray launch (and, unless switched off, with fused shading)
     bool eager = false;                      // the current camera cannot be served by the captured sequence: launch issues the frame eagerly
     uint32_t plane_bits_known = 0;
@@ -1164,6 +1184,7 @@ static FrameMode graph_mode(rt_frame_graph* g, int which, bool update)
     m.plane_bits_known = g->plane_bits_known;
     // without the wave-per-ray kernel nothing reads the marks of the binary records, and the plane bits come by value
     m.parts_drop = (g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u;
+    m.fixed_strategy = true; m.packet = g->packet; m.quad = g->quad; m.budget = g->budget;
     return m;
 }
 
@@ -1189,9 +1210,11 @@ static int capture_frame(rt_frame_graph* g, int which)
         return rc != RT_SUCCESS ? RT_ERROR : RT_FAIL(ctx, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     }
     if (g->nodes[which].failed) return RT_FAIL(ctx, "frame graph: the captured kernel nodes could not be identified");
-    e = hipGraphInstantiate(&g->exec[which], g->graph[which], nullptr, nullptr, 0);
-    if (e != hipSuccess) return RT_FAIL(ctx, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-    g->nodes[which].exec = g->exec[which];
+    for (int k = 0; k < 2; k++) {
+        e = hipGraphInstantiate(&g->exec[which][k], g->graph[which], nullptr, nullptr, 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done[which][k], hipEventDisableTiming);
+        if (e != hipSuccess) return RT_FAIL(ctx, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
     return RT_SUCCESS;
 }
 
@@ -1226,6 +1249,8 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
     bool packet = false, quad = false;
     current_strategy(b, packet, quad);
+    g->packet = packet; g->quad = quad;
+    g->budget = (ctx->defer_budget == 0 && b->tuned) ? b->tuned_budget : ctx->defer_budget;
     g->four_wide = packet && quad;
     g->octant_records = g->four_wide && b->quad_cam_variants == 9u;
     // The four-wide packet kernel hands rays to the wave-per-ray kernel only when the camera sits on a box plane (ray_root; on its
@@ -1263,7 +1288,7 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
     RT_ENTER(ctx);
     g->cam = *cam;
     g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
-    g->dirty[0] = g->dirty[1] = true;
+    for (int a = 0; a < 2; a++) for (int k = 0; k < 2; k++) g->dirty[a][k] = true;
     g->eager = false;
     if (g->four_wide) {
         if (ensure_host_planes(b)) return RT_ERROR;
@@ -1275,9 +1300,7 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
     } else {
         g->plane_bits_known = 0;              // the preparation node computes the bits on the device, the kernels read them there
     }
-    bool packet = false, quad = false;
-    current_strategy(b, packet, quad);
-    g->parts = strategy_parts(b, cam, packet, quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
+    g->parts = strategy_parts(b, cam, g->packet, g->quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
     return RT_SUCCESS;
 }
 
@@ -1302,13 +1325,29 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     // this BVH in between, another strategy prepared other parts), replay the sequence that starts with the preparation
     const bool same = b->marked_valid && std::memcmp(b->marked_origin, g->origin, sizeof g->origin) == 0;
     const int which = (same && (b->marked_parts & g->parts) == g->parts) ? 0 : 1;
-    if (g->dirty[which]) {
-        FrameMode m = graph_mode(g, which, true);
-        g->nodes[which].failed = false;
-        if (graph_issue(g, &m) != RT_SUCCESS) return RT_ERROR;
-        g->dirty[which] = false;
+    static const bool debug = [] { const char* e = std::getenv("RTMI_GRAPH_DEBUG"); return e && e[0] == '1'; }();
+    if (debug)
+        std::fprintf(stderr, "rtmi graph %p: launch exec[%d] dirty %d parts %#x marked %#x same %d strategy %d%d/%u no_unsafe %d plane %#x origin %.9g %.9g %.9g\n", (void*)g, which,
+                     (int)g->dirty[which][g->slot[which]], g->parts, b->marked_parts, (int)same, (int)g->packet, (int)g->quad, g->budget, (int)g->no_unsafe, g->plane_bits_known,
+                     g->origin[0], g->origin[1], g->origin[2]);
+    // the instance to launch: the one launched last if its arguments are current, else the other one (its last launch is the older
+    // one); its arguments are re-set only behind that launch
+    int k = g->slot[which];
+    if (g->dirty[which][k]) {
+        k ^= 1;
+        if (g->dirty[which][k]) {
+            if (g->launched[which][k]) RT_HIP(ctx, hipEventSynchronize(g->done[which][k]));
+            FrameMode m = graph_mode(g, which, true);
+            g->nodes[which].failed = false;
+            g->nodes[which].exec = g->exec[which][k];
+            if (graph_issue(g, &m) != RT_SUCCESS) return RT_ERROR;
+            g->dirty[which][k] = false;
+        }
     }
-    RT_HIP(ctx, hipGraphLaunch(g->exec[which], ctx->stream));
+    RT_HIP(ctx, hipGraphLaunch(g->exec[which][k], ctx->stream));
+    RT_HIP(ctx, hipEventRecord(g->done[which][k], ctx->stream));
+    g->launched[which][k] = true;
+    g->slot[which] = k;
     if (which == 1) {
         std::memcpy(b->marked_origin, g->origin, sizeof g->origin);
         b->marked_parts = same ? (b->marked_parts | g->parts) : g->parts;
@@ -1324,9 +1363,12 @@ void rt_frame_graph_destroy(rt_frame_graph* g)
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    for (int k = 0; k < 2; k++) {
-        if (g->exec[k]) (void)hipGraphExecDestroy(g->exec[k]);
-        if (g->graph[k]) (void)hipGraphDestroy(g->graph[k]);
+    for (int a = 0; a < 2; a++) {
+        for (int k = 0; k < 2; k++) {
+            if (g->exec[a][k]) (void)hipGraphExecDestroy(g->exec[a][k]);
+            if (g->done[a][k]) (void)hipEventDestroy(g->done[a][k]);
+        }
+        if (g->graph[a]) (void)hipGraphDestroy(g->graph[a]);
     }
     delete g;
 }
