@@ -111,8 +111,8 @@ def demo_camera(scene_bytes, resx, resy):
 
 
 def moving_cameras(scene_bytes, resx, resy, count):
-    """`count` camera poses around the Demo's default one: the position moves on a small closed curve (2 % of the model's box),
-    the orientation turns by up to +-3 degrees about y and x -- what a user dragging the mouse / holding a key does to the camera
+    """`count` camera poses around the Demo's default one: the position moves on a small closed curve (0.5 % of the model's box),
+    the orientation turns by up to +-1 degree about y and x -- what a user dragging the mouse / holding a key does to the camera
     between frames (OpenCLRayTracerDemo.cpp:378-460).  Pose 0 is the default camera itself (for ClumsyDragon: on a box plane)."""
     from openclraytracer_amd import capi
     base = demo_camera(scene_bytes, resx, resy)
@@ -124,15 +124,15 @@ def moving_cameras(scene_bytes, resx, resy, count):
         if k == 0:
             continue
         t = 2.0 * np.pi * k / count
-        a, b = np.radians(3.0) * np.sin(t), np.radians(3.0) * np.sin(2.0 * t + 0.5)
+        a, b = np.radians(1.0) * np.sin(t), np.radians(1.0) * np.sin(2.0 * t + 0.5)
         ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
         rot = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]]) @ np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
         m = cams[k]['viewTransform']
         for r in range(3):
             m[4 * r:4 * r + 3] = rot[r].astype(np.float32)
-        m[3] += np.float32(0.02 * size[0] * np.sin(t) + 1e-3 * size[0])
-        m[7] += np.float32(0.02 * size[1] * np.sin(3.0 * t))
-        m[11] += np.float32(0.02 * size[2] * (np.cos(t) - 1.0))
+        m[3] += np.float32(0.005 * size[0] * np.sin(t) + 1e-3 * size[0])
+        m[7] += np.float32(0.005 * size[1] * np.sin(3.0 * t))
+        m[11] += np.float32(0.005 * size[2] * (np.cos(t) - 1.0))
     return cams
 
 

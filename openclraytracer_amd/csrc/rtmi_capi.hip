@@ -4,6 +4,7 @@
 #include "rtmi_internal.h"
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 
 #include <cstdlib>
@@ -29,6 +30,7 @@ static void free_ctx_buffers(rt_ctx* ctx)
     if (ctx->d_long_list) (void)hipFree(ctx->d_long_list);
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
     if (ctx->d_split_list) (void)hipFree(ctx->d_split_list);
+    if (ctx->d_clock) (void)hipFree(ctx->d_clock);
     if (ctx->d_task_list) (void)hipFree(ctx->d_task_list);
     ctx->d_task_list = nullptr;
     ctx->d_trace_ctrl = nullptr; ctx->d_long_list = nullptr; ctx->long_cap = 0;
@@ -725,6 +727,24 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         uint32_t launches = 0;
         float gpu_ms = 0.f;               // device time of all calibration launches (events on the stream)
         const uint32_t cal_parts = calibration_parts(b, cam);
+        // Deadlines of the candidates on the device's own clock (trace_kernels.hip, cal_expired): a sample of that clock next to a
+        // host time stamp maps "now + limit" onto it.  The sample is taken behind the warm-up launch; its kernel ran before the
+        // read-back returned, so the mapped deadlines come a few tens of microseconds early: a slack is added.
+        unsigned long long clock0 = 0; double clock_rate = 0.0;        // ticks per millisecond
+        std::chrono::steady_clock::time_point host0;
+        float limit_ms = 0.f;                                          // 0 = the next launch has no deadline
+        auto sample_clock = [&]() {
+            static const bool off = [] { const char* e = std::getenv("RTMI_CALIBRATION_DEADLINE"); return e && e[0] == '0'; }();
+            if (off) return;
+            if (!ctx->d_clock && hipMalloc((void**)&ctx->d_clock, 8) != hipSuccess) { (void)hipGetLastError(); ctx->d_clock = nullptr; return; }
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); return; }
+            launch_device_clock(ctx->stream, ctx->d_clock);
+            unsigned long long v = 0;
+            if (hipMemcpyAsync(&v, ctx->d_clock, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+            host0 = std::chrono::steady_clock::now();
+            clock0 = v; clock_rate = (double)khz;
+        };
         // one launch of one candidate; false = runtime failure
         auto run_once = [&](int ci, float& ms, bool& valid) -> bool {
             const auto& cand = candidates[ci];
@@ -732,6 +752,10 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
             t.tag = 1;
+            if (clock_rate > 0.0 && limit_ms > 0.f) {
+                const double now_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count();
+                t.cal_deadline = clock0 + (unsigned long long)((now_ms + (double)limit_ms + 0.1) * clock_rate);
+            }
             ms = 0.f;
             (void)hipEventRecord(e0, ctx->stream);
             launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
@@ -776,6 +800,12 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // one more sample of a candidate: the fastest of its samples counts
         auto sample = [&](int ci) {
             if (broken || ci < 0 || ci >= N_CAND || cand_n[ci] < 0) return;
+            // a candidate that needs more than 1.6 x the best time so far will not win: it stops there
+            {
+                float best = 0.f;
+                for (int k = 0; k < N_CAND; k++) if (cand_n[k] > 0 && (best == 0.f || cand_ms[k] < best)) best = cand_ms[k];
+                limit_ms = best > 0.f ? 1.6f * best + 0.02f : 0.f;
+            }
             float m = 0.f; bool valid = false;
             if (!run_once(ci, m, valid)) { broken = true; return; }
             if (!valid) { cand_n[ci] = -1; return; }
@@ -798,10 +828,15 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // walk ~80 records per ray against a mean of 3.6, and one wave per such ray (wave-per-ray kernel behind a lane-per-ray
         // budget of 16 steps) beats eight of them in one packet.  RTMI_CALIBRATE_ALL=1 restores the exhaustive pass over all 25.
         static const bool calibrate_all = [] { const char* e = std::getenv("RTMI_CALIBRATE_ALL"); return e && e[0] == '1'; }();
+        // The first candidate runs without a deadline, twice (an untimed warm-up, then its sample), so it should never be a
+        // hopeless one: sharing after 128 steps is within ~2.5 x of the best strategy on every BVH seen so far (it has no tail),
+        // whole blocks and the lane-per-ray budgets can be six times behind.
+        const int first_cand = cand_n[P4_128] == 0 ? P4_128 : cand_n[P4_NONE] == 0 ? P4_NONE : cand_n[LANE_128] == 0 ? LANE_128 : -1;
         {
-            int warm = -1;
+            int warm = first_cand;
             for (int ci = 0; ci < N_CAND && warm < 0; ci++) if (cand_n[ci] == 0) warm = ci;
             if (warm >= 0) { float m; bool v = false; if (!run_once(warm, m, v)) broken = true; }
+            if (!broken) sample_clock();
         }
         auto refine_lane = [&](int first) {
             // the neighbours of the best lane-per-ray budget, two candidates away on either side (the list is ~sqrt(2) apart)
@@ -812,7 +847,8 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             for (int ci = 0; ci < N_CAND; ci++) { sample(ci); sample(ci); }
             for (int round = 0, a = best_of(-1); round < 2 && a >= 0; round++) { const int c = best_of(a); sample(a); sample(c); a = best_of(-1); }
         } else if (cand_n[P4_NONE] == 0) {
-            sample(P4_NONE); sample(P4_1024); sample(P4_128); sample(LANE_16); sample(LANE_128);
+            for (int ci : { first_cand, (int)LANE_16, (int)P4_NONE, (int)P4_1024, (int)P4_128, (int)LANE_128 })
+                if (ci >= 0 && cand_n[ci] == 0) sample(ci);
             const int first = best_of(-1);
             if (first == P4_128) sample(P4_256);
             else if (first == P4_1024) { sample(P4_2048); sample(P4_256); }
@@ -823,7 +859,8 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             sample(best_of(-1));
         } else {
             // no four-wide records (LITERAL_ZERO mode, RTMI_SEARCH_TREE=0 / RTMI_PACKET4=0): lane-per-ray budgets and the binary packet kernel
-            sample(LANE_16); sample(LANE_128); sample(LANE_NONE); sample(PK_256); sample(PK_NONE);
+            for (int ci : { first_cand, (int)LANE_16, (int)LANE_128, (int)LANE_NONE, (int)PK_256, (int)PK_NONE })
+                if (ci >= 0 && cand_n[ci] == 0) sample(ci);
             const int first = best_of(-1);
             if (first >= LANE_8 && first < LANE_NONE) refine_lane(first);
             else if (first >= 5 && first < LANE_8) {
@@ -1108,7 +1145,10 @@ struct rt_frame_graph {
     bool eager = false;                      // the current camera cannot be served by the captured sequence: launch issues the frame eagerly
     uint32_t plane_bits_known = 0;
     int last_launch = -1;                    // 0 steady state, 1 with the preparation, 2 eager
+    double host_update_us = 0.0, host_launch_us = 0.0, host_set_camera_us = 0.0;   // RTMI_GRAPH_DEBUG=1: host time per stage
+    uint64_t host_updates = 0, host_launches = 0, host_set_cameras = 0;
 };
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void current_strategy(const rt_bvh* b, bool& packet, bool& quad)
 {
@@ -1326,7 +1366,7 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     const bool same = b->marked_valid && std::memcmp(b->marked_origin, g->origin, sizeof g->origin) == 0;
     const int which = (same && (b->marked_parts & g->parts) == g->parts) ? 0 : 1;
     static const bool debug = [] { const char* e = std::getenv("RTMI_GRAPH_DEBUG"); return e && e[0] == '1'; }();
-    if (debug)
+    if (debug && std::getenv("RTMI_GRAPH_DEBUG_VERBOSE"))
         std::fprintf(stderr, "rtmi graph %p: launch exec[%d] dirty %d parts %#x marked %#x same %d strategy %d%d/%u no_unsafe %d plane %#x origin %.9g %.9g %.9g\n", (void*)g, which,
                      (int)g->dirty[which][g->slot[which]], g->parts, b->marked_parts, (int)same, (int)g->packet, (int)g->quad, g->budget, (int)g->no_unsafe, g->plane_bits_known,
                      g->origin[0], g->origin[1], g->origin[2]);
@@ -1336,16 +1376,20 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     if (g->dirty[which][k]) {
         k ^= 1;
         if (g->dirty[which][k]) {
+            const double t0 = debug ? now_us() : 0.0;
             if (g->launched[which][k]) RT_HIP(ctx, hipEventSynchronize(g->done[which][k]));
             FrameMode m = graph_mode(g, which, true);
             g->nodes[which].failed = false;
             g->nodes[which].exec = g->exec[which][k];
             if (graph_issue(g, &m) != RT_SUCCESS) return RT_ERROR;
             g->dirty[which][k] = false;
+            if (debug) { g->host_update_us += now_us() - t0; g->host_updates++; }
         }
     }
+    const double t1 = debug ? now_us() : 0.0;
     RT_HIP(ctx, hipGraphLaunch(g->exec[which][k], ctx->stream));
     RT_HIP(ctx, hipEventRecord(g->done[which][k], ctx->stream));
+    if (debug) { g->host_launch_us += now_us() - t1; g->host_launches++; }
     g->launched[which][k] = true;
     g->slot[which] = k;
     if (which == 1) {
@@ -1361,6 +1405,10 @@ int rt_frame_graph_launch(rt_frame_graph* g)
 void rt_frame_graph_destroy(rt_frame_graph* g)
 {
     if (!g) return;
+    if (g->host_launches && std::getenv("RTMI_GRAPH_DEBUG"))
+        std::fprintf(stderr, "rtmi graph %p (n = %u): host time per argument update %.2f us (%llu), per launch %.2f us (%llu)\n", (void*)g, g->bvh->n,
+                     g->host_updates ? g->host_update_us / g->host_updates : 0.0, (unsigned long long)g->host_updates,
+                     g->host_launch_us / g->host_launches, (unsigned long long)g->host_launches);
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     for (int a = 0; a < 2; a++) {

@@ -109,6 +109,7 @@ struct rt_ctx {
     bool calibration_log = false; // knob (env RTMI_CALIBRATION_LOG=1): one stderr line per calibration candidate
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
+    unsigned long long* d_clock = nullptr;  // one word: the device clock sample of a calibration
 };
 
 struct rt_scene {
@@ -286,6 +287,7 @@ struct TraceLaunch {
     uint32_t prepare_parts;       // RT_PREP_* to (re)compute before the trace (0: nothing)
     uint32_t octant_mask;         // primary rays, four-wide kernel on per-octant records: the octant copies that are valid
     uint32_t plane_bits_known;    // 0x80000000 | bits: the host knows the camera-on-a-plane bits (else the kernels read tree_select)
+    unsigned long long cal_deadline;   // calibration launches (tag 1): device clock value after which the kernels stop walking, 0 = none
     const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)
     const QuadNode* quad;         // four-wide records (null: the packet kernel walks the binary records)
     const QuadNode* quad_cam;     // primary rays: the same records with the camera position subtracted from the boxes (+ thresholds)
@@ -329,6 +331,7 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);   // t.prepare_parts
+void launch_device_clock(hipStream_t s, unsigned long long* d_out);      // the clock the calibration deadlines are on (s_memrealtime)
 size_t trace_ctrl_bytes();
 size_t trace_task_bytes(uint32_t cap_per_shard);
 size_t trace_ctrl_error_offset();

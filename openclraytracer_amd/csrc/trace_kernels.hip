@@ -133,6 +133,7 @@ struct TraceArgs {
     uint32_t plane_bits_known;                  // 0x80000000 | those bits when the host knows them (movable frame graphs): tree_select is not read
     uint32_t octant_mask;                       // four-wide kernel on per-octant records: bit o = the copy of octant o is valid for this camera
     uint32_t no_unsafe_rays;                    // the launcher left the wave-per-ray kernel out: a ray handed over would be lost (error bit 6)
+    unsigned long long cal_deadline;            // calibration launches (CAL = 1) only: device time (s_memrealtime) after which waves stop walking, 0 = none
     const float4* __restrict__ v0;
     const float4* __restrict__ e1;
     const float4* __restrict__ e2;
@@ -462,6 +463,19 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayStat
     return true;
 }
 
+// Calibration launches (the <.., 1> instances, never the frames that count) carry a deadline on the clock all XCDs share: a
+// candidate strategy that has fallen clearly behind the best one so far stops walking -- its frame is thrown away anyway -- so that
+// the first frame on a BVH costs a bounded multiple of a steady one whatever the hopeless candidates would have taken
+// (round 2: up to 55 ms for one of them against 0.1-7.5 ms frames).  Compiled out of every other instance.
+template <int CAL>
+__device__ __forceinline__ bool cal_expired(unsigned long long deadline)
+{
+    if (CAL != 1) return false;
+    return deadline != 0ull && __builtin_amdgcn_s_memrealtime() > deadline;
+}
+__global__ void k_device_clock(unsigned long long* out) { *out = __builtin_amdgcn_s_memrealtime(); }
+void launch_device_clock(hipStream_t s, unsigned long long* d_out) { hipLaunchKernelGGL(k_device_clock, dim3(1), dim3(1), 0, s, d_out); }
+
 // the camera-on-a-plane bits of this frame: computed by k_prepare_camera on the device, or handed over by a host that knows them
 __device__ __forceinline__ uint32_t camera_plane_bits(const TraceArgs& a)
 {
@@ -576,9 +590,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
             }
         }
     }
+    if (cal_expired<CAL>(a.cal_deadline)) return;
+    uint32_t cal_tick = 0;
     if (__ballot(active) != 0ull) {
         // ---------------- traversal steps until every ray of the block has finished or moved on ----------------
         for (;;) {
+            if (CAL == 1 && (++cal_tick & 15u) == 0u && cal_expired<CAL>(a.cal_deadline)) break;
             uint32_t extra = RT_SENTINEL;     // child that did not fit on the stack (forces a deferral)
             if (active) {
                 iters++;
@@ -903,7 +920,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
         uint32_t steps = 0;                              // nodes this block has walked
         bool walking = __ballot(in) != 0ull;
         NodeRec cur = ld_record(a.trav, node);           // record of `node`, kept in registers across steps
+        if (cal_expired<CAL>(a.cal_deadline)) walking = false;
         while (walking) {
+            if (CAL == 1 && (steps & 15u) == 15u && cal_expired<CAL>(a.cal_deadline)) break;
             // A block that keeps walking with a handful of lanes wastes the wave, and a block that walks thousands of
             // nodes sets the frame time.  After PACKET_LOW_RUN low-occupancy steps the current node -- after `defer_budget`
             // steps everything the block has left (current node and every stack entry) -- is handed, per taking-part lane,
@@ -1221,6 +1240,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
         // OCT: the lanes walk in groups of one direction octant each, on that octant's copy of the records (near / far planes in
         // place, child_mask_octant).  All but the blocks on the image's centre lines are one group; a task's lanes come out
         // of one group and are one again.  Without the copies: one group on the general records.
+        if (cal_expired<CAL>(a.cal_deadline)) todo = 0ull;          // (the wave still goes through its exit: counters of the sharing protocol)
+        uint32_t cal_tick = 0;
         while (todo != 0ull) {
         uint64_t in = todo;                              // the lanes that walk the current node
         const QuadNode* quad = quad_general;
@@ -1238,6 +1259,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
         bool walking = true;
         while (walking) {
             P4_STAMP(T0);
+            if (CAL == 1 && (++cal_tick & 31u) == 0u && cal_expired<CAL>(a.cal_deadline)) { todo = 0ull; break; }
             if (SHARE && ++steps > share_after) {
                 steps = 0;
                 share_after = share_after >> 1 > SHARE_MIN_STEPS ? share_after >> 1 : SHARE_MIN_STEPS;
@@ -1557,6 +1579,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
     uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
     for (;;) {
         if (bi >= n_batches) break;
+        if (cal_expired<CAL>(a.cal_deadline)) break;
         // ---------------- set the batch up: lane s < batch prepares slot s ----------------
         if (lane < batch) {
             const uint32_t i = bi * batch + lane;
@@ -1614,6 +1637,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         uint32_t pool_steps = 0, pool_nodes = 0;
         while (n_inner != 0u || n_leaf != 0u) {
             pool_steps++;
+            if (CAL == 1 && (pool_steps & 15u) == 0u && cal_expired<CAL>(a.cal_deadline)) break;
             // ---- leaves, 64 at a time, when the pool is filling up or nothing else is left ----
             if (n_leaf >= POOL_LEAF - 128u || n_inner == 0u) {
                 uint32_t k = n_leaf < 64u ? n_leaf : 64u;
@@ -1918,7 +1942,7 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.out = out;
     if (a.quad) a.quad = t.quad_cam;                  // boxes minus the camera position (k_prepare_camera)
     a.quad_octant_records = (a.quad && t.quad_cam_variants == 9u) ? (t.n_leaves - 1u) * (t.search_root ? 2u : 1u) : 0u;
-    a.octant_mask = t.octant_mask; a.plane_bits_known = t.plane_bits_known;
+    a.octant_mask = t.octant_mask; a.plane_bits_known = t.plane_bits_known; a.cal_deadline = t.tag == 1 ? t.cal_deadline : 0ull;
     if (t.prepare_parts) {
         const float origin[3] = { cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11] };
         launch_prepare_camera(s, t, origin);
