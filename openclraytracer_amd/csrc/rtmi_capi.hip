@@ -819,7 +819,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
                 if (ci != skip && cand_n[ci] > 0 && (best < 0 || cand_ms[ci] < cand_ms[best])) best = ci;
             return best;
         };
-        // The first frame is bounded: about a dozen full-size launches instead of round 2's ~65 (25 candidates x 2 + warm-up + a
+        // The first frame is bounded: about ten full-size launches instead of round 2's ~65 (25 candidates x 2 + warm-up + a
         // final round; 1.2 s of GPU time over the bench's six BVHs against 0.1-7.5 ms frames).  A coarse pass over few, widely
         // spaced candidates, one sample each; then the neighbours of the best; then the two fastest once more -- a 0.1 ms frame
         // cannot rank strategies 10 % apart on one sample, and the first launches run on idle clocks, hence an untimed
@@ -829,9 +829,10 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // budget of 16 steps) beats eight of them in one packet.  RTMI_CALIBRATE_ALL=1 restores the exhaustive pass over all 25.
         static const bool calibrate_all = [] { const char* e = std::getenv("RTMI_CALIBRATE_ALL"); return e && e[0] == '1'; }();
         // The first candidate runs without a deadline, twice (an untimed warm-up, then its sample), so it should never be a
-        // hopeless one: sharing after 128 steps is within ~2.5 x of the best strategy on every BVH seen so far (it has no tail),
-        // whole blocks and the lane-per-ray budgets can be six times behind.
-        const int first_cand = cand_n[P4_128] == 0 ? P4_128 : cand_n[P4_NONE] == 0 ? P4_NONE : cand_n[LANE_128] == 0 ? LANE_128 : -1;
+        // hopeless one: sharing after 256 steps is within ~1.3 x of the best four-wide strategy on every BVH seen so far (it has
+        // no tail; measured: Tenryuu 1.3 x, ManFigure 1.0, atrium 4K 1.0, against 1.8-2.9 x for 128 steps on the atrium and
+        // ClumsyDragon and 2.1 x for 1 024 on Tenryuu), whole blocks and the lane-per-ray budgets can be six times behind.
+        const int first_cand = cand_n[P4_256] == 0 ? P4_256 : cand_n[P4_NONE] == 0 ? P4_NONE : cand_n[LANE_128] == 0 ? LANE_128 : -1;
         {
             int warm = first_cand;
             for (int ci = 0; ci < N_CAND && warm < 0; ci++) if (cand_n[ci] == 0) warm = ci;
@@ -847,16 +848,15 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             for (int ci = 0; ci < N_CAND; ci++) { sample(ci); sample(ci); }
             for (int round = 0, a = best_of(-1); round < 2 && a >= 0; round++) { const int c = best_of(a); sample(a); sample(c); a = best_of(-1); }
         } else if (cand_n[P4_NONE] == 0) {
-            for (int ci : { first_cand, (int)LANE_16, (int)P4_NONE, (int)P4_1024, (int)P4_128, (int)LANE_128 })
+            // coarse: one of each family -- sub-trees shared, whole blocks, lane-per-ray with an early hand-over
+            for (int ci : { first_cand, (int)P4_NONE, (int)LANE_16 })
                 if (ci >= 0 && cand_n[ci] == 0) sample(ci);
             const int first = best_of(-1);
-            if (first == P4_128) sample(P4_256);
-            else if (first == P4_1024) { sample(P4_2048); sample(P4_256); }
+            if (first == P4_256) { sample(P4_128); sample(P4_1024); if (best_of(-1) == P4_1024) sample(P4_2048); }
             else if (first >= LANE_8 && first < LANE_NONE) refine_lane(first);
-            // (whole blocks won: the sharing candidates lost with their handicap, a budget between or beyond them would too)
+            // (whole blocks won: a sharing budget lost with its handicap, the others would too)
             const int a = best_of(-1), c = best_of(a);
             sample(a); sample(c);
-            sample(best_of(-1));
         } else {
             // no four-wide records (LITERAL_ZERO mode, RTMI_SEARCH_TREE=0 / RTMI_PACKET4=0): lane-per-ray budgets and the binary packet kernel
             for (int ci : { first_cand, (int)LANE_16, (int)LANE_128, (int)LANE_NONE, (int)PK_256, (int)PK_NONE })
