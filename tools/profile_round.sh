@@ -5,7 +5,7 @@
 # 2) kernel trace + stats of the same bench command (without the nested counter passes), 3) config 4 and config 3 with their own stats,
 # 4) the host floor of the tiled path (four ranks in one process on this one GPU).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$R
 mkdir -p $OUT
@@ -17,6 +17,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tlg_stats -- python
 echo "tlg done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config3_stats -- python3 tools/config_report.py config3 > $OUT/config3.log 2>&1 || echo "config3 stats pass failed"
 echo "config3 done"
+# counter passes of configs 3 and 4 (BASELINE configs[2] asks for the HBM-bandwidth run of the Bunny-class frame): the scenes are
+# packed beforehand, the profiled program (directly behind `--`) starts no process; one pass per counter group
+apps/bin/scene_pack_tool assets/synth/synth_bunny.txt /tmp/_synth_bunny.bin && apps/bin/scene_pack_tool assets/synth/synth_atrium.txt /tmp/_synth_atrium.bin
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
+  set -- $pass; tag=$1; shift
+  RTMI_PACKED=1 timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/config3_pmc_$tag -- python3 tools/config_report.py config3 > $OUT/config3_pmc_$tag.log 2>&1 || echo "config3 counter pass $tag failed"
+  RTMI_PACKED=1 timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/tlg_pmc_$tag -- python3 tools/tlg_config4.py > $OUT/tlg_pmc_$tag.log 2>&1 || echo "config4 counter pass $tag failed"
+done
+echo "config counter passes done"
 python3 tools/config_report.py > $OUT/config_report.json 2> $OUT/config_report.err || echo "config report failed"
 RTMI_BENCH_GROUP=4 python3 bench.py --steps 100 --warmup 5 --no-extra-legs > $OUT/bench_group4.json 2> $OUT/bench_group4.err || echo "group run failed"
 echo "group done"

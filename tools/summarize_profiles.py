@@ -3,7 +3,7 @@ import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as bench_mod
 newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
-R = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src = 'gpurun_out/%s' % R
 stats = newest(src + '/stats/**/*_kernel_stats.csv')
 shutil.copy(stats, 'profiles/%s_bench_kernel_stats.csv' % R)
@@ -47,6 +47,54 @@ for name, sub, log in (('tlg_config4', 'tlg_stats', 'tlg_config4.log'), ('config
         open('profiles/%s_%s_line.json' % (R, name), 'w').write(txt[a:b + 1] + '\n')
     except Exception as e:
         print('no %s profile: %s' % (name, e))
+# counter passes of configs 3 and 4 (tools/profile_round.sh): measured HBM bytes and VALU issue of the steady-state trace launches,
+# folded into the _line.json of the configuration (FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md)
+def counter_pass(prefix, kernel_prefixes, skip_first):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for tag in ('fetch', 'write', 'sq'):
+        try:
+            f = newest(src + '/%s_%s/**/*counter_collection.csv' % (prefix, tag))
+        except ValueError:
+            return None
+        for row in csv.DictReader(open(f)):
+            k = row['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+            if k.startswith(kernel_prefixes):
+                per[k][row['Counter_Name']].append((int(row['Dispatch_Id']), float(row['Counter_Value'])))
+    out = {}
+    for k, cs in per.items():
+        d = {}
+        for c, vals in cs.items():
+            by = collections.defaultdict(float)
+            for disp, v in vals:
+                by[disp] += v
+            steady = [by[x] for x in sorted(by)][skip_first:] or [by[x] for x in sorted(by)]     # (the first launches calibrate / warm up)
+            d[c] = sum(steady) / len(steady)
+        out[k] = d
+    return out
+for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve'), 40), ('tlg_config4', 'tlg_pmc', ('k_tlg_trace',), 1)):
+    try:
+        pk = counter_pass(prefix, kp, skip)
+        if not pk:
+            raise RuntimeError('no counter files')
+        line_path = 'profiles/%s_%s_line.json' % (R, name)
+        line = json.load(open(line_path))
+        # the kernel with the most device time carries the launch
+        dom = max(pk, key=lambda k: pk[k].get('GRBM_GUI_ACTIVE', 0.0))
+        c = pk[dom]
+        cycles = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+        hbm = sum((2.0 * v.get('FETCH_SIZE', 0.0) + v.get('WRITE_SIZE', 0.0)) * 1024 for v in pk.values())
+        ms = line.get('trace_ms') or line.get('ms_per_frame') or 0.0
+        line['counters'] = dict(source='rocprofv3 --pmc passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE, SQ group: one pass each), steady-state launches',
+                                dominant_kernel=dom, per_launch={k: {a: round(b, 1) for a, b in v.items()} for k, v in pk.items()},
+                                hbm_bytes_per_launch=int(hbm), measured_hbm_gbps=(round(hbm / (ms * 1e-3) / 1e9, 1) if ms else None),
+                                hbm_frac_of_8tbps=(round(hbm / (ms * 1e-3) / 1e9 / 8000.0, 4) if ms else None),
+                                valu_issue_frac=(round(c.get('SQ_INSTS_VALU', 0.0) * 2.0 / (1024 * cycles), 4) if cycles else None),
+                                wave_time_split=(dict(executing=round(c.get('SQ_ACTIVE_INST_ANY', 0) / c['SQ_WAVE_CYCLES'], 3), parked_on_waitcnt=round(c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES'], 3),
+                                                      issue_stall=round(c.get('SQ_WAIT_INST_ANY', 0) / c['SQ_WAVE_CYCLES'], 3)) if c.get('SQ_WAVE_CYCLES') else None))
+        json.dump(line, open(line_path, 'w'), indent=1)
+        print(name, 'counters:', json.dumps({k: line['counters'][k] for k in ('dominant_kernel', 'hbm_bytes_per_launch', 'measured_hbm_gbps', 'hbm_frac_of_8tbps', 'valu_issue_frac', 'wave_time_split')}))
+    except Exception as e:
+        print('no %s counters: %s' % (name, e))
 for f, dst in (('config_report.json', '%s_config_report.json' % R), ('bench_group4.json', '%s_bench_group4_rehearsal.json' % R)):
     try:
         txt = open(src + '/' + f).read()

@@ -12,7 +12,8 @@ from openclraytracer_amd import capi
 name, res = 'synth_atrium', (1920, 1080)
 txt = gen_scenes.ensure()[name]
 tmp = '/tmp/_%s.bin' % name
-subprocess.check_call([os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool'), os.path.relpath(txt, ROOT), tmp], cwd=ROOT)
+if not (os.environ.get('RTMI_PACKED') == '1' and os.path.exists(tmp)):      # (under rocprofv3 --pmc the scene comes packed: no child process)
+    subprocess.check_call([os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool'), os.path.relpath(txt, ROOT), tmp], cwd=ROOT)
 buf = open(tmp, 'rb').read()
 ctx = capi.Context(0)
 sc = capi.DeviceScene(ctx, buf)
