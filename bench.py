@@ -358,7 +358,10 @@ def main():
                 it['comms'] = [main_comm]
             else:
                 it['comms'] = [main_comm.share(it['ctx'])]
-            it['frames'] = [capi.MultiFrame(c, b, s, cam, root_extra) for c, b, s in zip(it['comms'], it['bvhs'], it['scenes'])]
+            # every scene's frame is assembled on another rank (scene i -> rank i mod N): what crosses the links into one GPU is one
+            # frame's colour per step, not all five; RTMI_BENCH_ONE_ROOT=1 gathers everything into rank 0
+            it['root'] = 0 if os.environ.get('RTMI_BENCH_ONE_ROOT') == '1' else len(work) % nranks
+            it['frames'] = [capi.MultiFrame(c, b, s, cam, root_extra, it['root']) for c, b, s in zip(it['comms'], it['bvhs'], it['scenes'])]
             it['slots'] = it['frames'][0].layout()['own_slots']
         else:
             it['slots'] = npx
@@ -402,20 +405,32 @@ def main():
                 it['ctx'].synchronize()
 
     def check_frames(when):
-        # rank 0 traces and shades every frame untiled, on a context of its own, and compares with the assembled frame
-        if rank == 0:
-            cctx = capi.Context(local_rank)
-            for it in work:
-                cscene = capi.DeviceScene(cctx, it['bytes'])
-                cbvh = capi.DeviceBVH(cctx, cscene).build()
-                want = capi.shade_blinn_phong(cctx, cscene, it['cam'], cbvh.generate_contacts_primary(it['cam'])).reshape(-1, 4)
-                it['frames'][0].wait()
-                got = it['frames'][0].download_frame()
-                cbvh.close(); cscene.close()
-                if got.tobytes() != want.tobytes():
-                    raise SystemExit('frame check failed for %s (%s): the assembled frame differs from the untiled one' % (it['name'], when))
+        # the rank that assembles a scene's frame also traces and shades it untiled, on a context of its own, and compares
+        checked = 0
+        cctx = None
+        for it in work:
+            root_frame = it['frames'][it['root']] if group_ranks else (it['frames'][0] if rank == it['root'] else None)
+            if root_frame is None:
+                continue
+            if cctx is None:
+                cctx = capi.Context(local_rank)
+            cscene = capi.DeviceScene(cctx, it['bytes'])
+            cbvh = capi.DeviceBVH(cctx, cscene).build()
+            want = capi.shade_blinn_phong(cctx, cscene, it['cam'], cbvh.generate_contacts_primary(it['cam'])).reshape(-1, 4)
+            root_frame.wait()
+            got = root_frame.download_frame()
+            cbvh.close(); cscene.close()
+            if got.tobytes() != want.tobytes():
+                raise SystemExit('frame check failed for %s (%s): the assembled frame differs from the untiled one' % (it['name'], when))
+            checked += 1
+        if cctx is not None:
             cctx.close()
-            print('frame check ok (%s): %d assembled frames equal the untiled ones' % (when, len(work)), file=sys.stderr)
+        if dist is not None:
+            box = [None] * world
+            dist.all_gather_object(box, checked)
+            checked = sum(box)
+        if rank == 0:
+            print('frame check ok (%s): %d assembled frames equal the untiled ones' % (when, checked), file=sys.stderr)
         fence()
 
     note('warm-up and timed steps')
@@ -441,6 +456,41 @@ def main():
         elapsed = float(t.item())
     rays_per_step = npx * len(SCENES)
     value = rays_per_step * args.steps / elapsed / 1e6
+
+    # ---- N > 1: where a step's time goes on every rank (untimed extra pass: events around each rank's trace + shade and around its
+    # part of the gather; host time to issue a step) -- so that a scaling run explains itself
+    per_rank = None
+    if tiled:
+        K = max(10, min(args.steps, 100))
+        for it in work:
+            for f in it['frames']:
+                f.set_timing(True)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(K):
+            step()
+        host_issue = (time.perf_counter() - t1) * 1e3 / K
+        fence()
+        wall = (time.perf_counter() - t1) * 1e3 / K
+        mine = []
+        for i, f0 in enumerate(work[0]['frames']):
+            tr = ga = 0.0
+            for it in work:
+                t = it['frames'][i].times()
+                tr += t['trace_ms'] / max(t['frames'], 1); ga += t['gather_ms'] / max(t['frames'], 1)
+            c = work[0]['comms'][i]
+            mine.append(dict(rank=(i if group_ranks else rank), trace_shade_ms_per_step=round(tr, 4), gather_ms_per_step=round(ga, 4),
+                             host_issue_ms_per_step=round(host_issue / (len(work[0]['frames'])), 4), step_ms=round(wall, 4),
+                             uses_rccl=c.uses_rccl(), rccl_ranks=c.rccl_ranks(), roots_here=[it['name'] for it in work if it['root'] == (i if group_ranks else rank)]))
+        for it in work:
+            for f in it['frames']:
+                f.set_timing(False)
+        if dist is not None:
+            box = [None] * world
+            dist.all_gather_object(box, mine)
+            per_rank = [x for b in box for x in b]
+        else:
+            per_rank = mine
 
     # ---- per-scene device times (untimed extra pass, HIP events on the stream the kernels run on; one scene at a time: what a
     # frame costs when it has the device to itself) -- the launches rocprofv3 lists as <1, 2>
@@ -756,9 +806,10 @@ def main():
 
     par = 'single GPU, the five frames of a step on five HIP streams'
     if tiled:
-        par = ('64x64 frame tiles dealt over %d ranks (rank 0 owns %d extra per period of %d tiles), one gather of shaded colour per frame to rank 0 '
-               '(12 B per pixel, grouped RCCL send/recv issued by librtmi), the five frames of a step on five HIP streams per rank'
-               % (nranks, root_extra, nranks + root_extra))
+        par = ('64x64 frame tiles dealt over %d ranks (the rank that assembles a frame owns %d extra per period of %d tiles), ONE gather of shaded colour per '
+               'frame (12 B per pixel, grouped RCCL send/recv issued by librtmi) into that rank: scene i is assembled on rank i mod N (roots %s), '
+               'the five frames of a step on five HIP streams per rank'
+               % (nranks, root_extra, nranks + root_extra, [it['root'] for it in work]))
         if group_ranks:
             par += '; REHEARSAL: all ranks in one process on one device, gather by device copies'
     out = dict(metric='Mrays/s (primary rays, BVH trace + shade, bundled TestModels, 1920x1080)', value=round(value, 1),
@@ -769,7 +820,7 @@ def main():
                            rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES, parallelism=par),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
-               roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, config5=config5, per_scene=per_scene)
+               roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, config5=config5, per_rank=per_rank, per_scene=per_scene)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

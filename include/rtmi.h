@@ -268,9 +268,22 @@ void  rt_comm_destroy(rt_comm* comm);
 int   rt_comm_rank(const rt_comm* comm);
 int   rt_comm_size(const rt_comm* comm);
 int   rt_comm_uses_rccl(const rt_comm* comm);        /* 0: one rank, or a group whose contexts share a device (copies) */
+int   rt_comm_rccl_ranks(const rt_comm* comm);       /* ncclCommCount of the communicator (0 without RCCL): what RCCL says it spans */
 int   rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t root_extra,
                             rt_multi_frame** out);
+/* The same with another rank than 0 assembling the frame: the tiles are dealt by virtual rank (rank - root) mod N, the root being
+ * virtual rank 0 with its extra share.  Several frames in flight (several viewports / scenes, each on a context of its own) can so
+ * gather into different GPUs: what crosses the links of one root is one frame's colour, not all of them.
+ * Collective: every rank passes the same root.                                                                             */
+int   rt_multi_frame_create_rooted(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t root_extra, int root,
+                                   rt_multi_frame** out);
+int   rt_multi_frame_root(const rt_multi_frame* frame);
 int   rt_multi_frame_render(rt_multi_frame** frames, int n);
+/* measurement: HIP events around this rank's trace + shade (context stream) and around its part of the gather -- the RCCL group, on the
+ * root also the untile -- (communicator stream); sums over the frames rendered since the last query, read back two frames late so
+ * that nothing waits.  Off by default.                                                                                       */
+int   rt_multi_frame_set_timing(rt_multi_frame* frame, int enable);
+int   rt_multi_frame_times(rt_multi_frame* frame, double* trace_ms, double* gather_ms, uint64_t* frames);
 int   rt_multi_frame_wait(rt_multi_frame* frame);
 void* rt_multi_frame_pixels(const rt_multi_frame* frame);
 int   rt_multi_frame_layout(const rt_multi_frame* frame, uint32_t* tiling, uint32_t* own_slots, uint32_t* root_slots, uint32_t* peer_slots);

@@ -44,7 +44,7 @@ SYMBOLS = [
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
     'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
-    'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl',
+    'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl', 'rt_comm_rccl_ranks', 'rt_multi_frame_create_rooted', 'rt_multi_frame_root', 'rt_multi_frame_set_timing', 'rt_multi_frame_times',
     'rt_multi_frame_create', 'rt_multi_frame_render', 'rt_multi_frame_wait', 'rt_multi_frame_pixels', 'rt_multi_frame_layout', 'rt_multi_frame_destroy',
     'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays',
 ]
@@ -642,6 +642,11 @@ class Comm:
     def uses_rccl(self) -> bool:
         return bool(self.ctx.lib.rt_comm_uses_rccl(self.h))
 
+    def rccl_ranks(self) -> int:
+        """ncclCommCount of the communicator (0 without RCCL)"""
+        self.ctx.lib.rt_comm_rccl_ranks.argtypes = [C.c_void_p]
+        return int(self.ctx.lib.rt_comm_rccl_ranks(self.h))
+
     def close(self):
         if self.h:
             self.ctx.lib.rt_comm_destroy(self.h)
@@ -651,12 +656,25 @@ class Comm:
 class MultiFrame:
     """rt_multi_frame: this rank's part of the tiled frame + the gather + (rank 0) the untile"""
 
-    def __init__(self, comm: Comm, bvh, scene, cam: np.ndarray, root_extra: int = 1):
+    def __init__(self, comm: Comm, bvh, scene, cam: np.ndarray, root_extra: int = 1, root: int = 0):
         self.comm, self.ctx = comm, comm.ctx
         self.cam = np.array(cam, copy=True)
         h = C.c_void_p()
-        self.ctx.check(self.ctx.lib.rt_multi_frame_create(comm.h, bvh.h, scene.h, _p(self.cam), root_extra, C.byref(h)))
+        L = self.ctx.lib
+        L.rt_multi_frame_create_rooted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        self.ctx.check(L.rt_multi_frame_create_rooted(comm.h, bvh.h, scene.h, _p(self.cam), root_extra, root, C.byref(h)))
         self.h = h
+        self.root = root
+
+    def set_timing(self, on: bool = True):
+        self.ctx.lib.rt_multi_frame_set_timing.argtypes = [C.c_void_p, C.c_int]
+        self.ctx.check(self.ctx.lib.rt_multi_frame_set_timing(self.h, 1 if on else 0))
+
+    def times(self) -> dict:
+        a, g, n = C.c_double(), C.c_double(), C.c_uint64()
+        self.ctx.lib.rt_multi_frame_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        self.ctx.check(self.ctx.lib.rt_multi_frame_times(self.h, C.byref(a), C.byref(g), C.byref(n)))
+        return dict(trace_ms=a.value, gather_ms=g.value, frames=n.value)
 
     def layout(self) -> dict:
         v = [C.c_uint32() for _ in range(4)]

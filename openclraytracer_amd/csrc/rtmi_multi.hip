@@ -34,6 +34,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -52,7 +53,7 @@ static const char* load_rccl()
     a.lib = h;
 #define RT_SYM(field, name) *(void**)(&a.field) = dlsym(h, name); if (!a.field) return "RCCL lacks " name;
     RT_SYM(GetUniqueId, "ncclGetUniqueId") RT_SYM(CommInitRank, "ncclCommInitRank") RT_SYM(CommInitAll, "ncclCommInitAll")
-    RT_SYM(CommDestroy, "ncclCommDestroy") RT_SYM(Send, "ncclSend") RT_SYM(Recv, "ncclRecv") RT_SYM(GroupStart, "ncclGroupStart")
+    RT_SYM(CommDestroy, "ncclCommDestroy") RT_SYM(CommCount, "ncclCommCount") RT_SYM(Send, "ncclSend") RT_SYM(Recv, "ncclRecv") RT_SYM(GroupStart, "ncclGroupStart")
     RT_SYM(GroupEnd, "ncclGroupEnd") RT_SYM(GetErrorString, "ncclGetErrorString")
 #undef RT_SYM
     g_rccl = a;
@@ -92,7 +93,28 @@ struct rt_multi_frame {
     hipEvent_t traced[2] = { nullptr, nullptr }, gathered[2] = { nullptr, nullptr };
     bool gathered_valid[2] = { false, false };
     uint64_t frames = 0;
+    // which rank assembles this frame, and this rank's place counted from it: the tiles are dealt by VIRTUAL rank (the root is virtual
+    // rank 0 and owns the extra share), so several frames in flight can gather into different GPUs (bench.py: scene i -> rank i mod N)
+    int root = 0, vrank = 0;
+    // optional timing (rt_multi_frame_set_timing): events around this rank's trace + shade and around the gather (+ untile on the root)
+    bool timing = false;
+    hipEvent_t tev[2][4] = { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } };
+    bool tev_pending[2] = { false, false };
+    double trace_ms_sum = 0.0, gather_ms_sum = 0.0;
+    uint64_t timed_frames = 0;
 };
+
+static void harvest_timing(rt_multi_frame* f, int b)
+{
+    if (!f->tev_pending[b]) return;
+    float a = 0.f, g = 0.f;
+    if (hipEventSynchronize(f->tev[b][3]) == hipSuccess && hipEventElapsedTime(&a, f->tev[b][0], f->tev[b][1]) == hipSuccess &&
+        hipEventElapsedTime(&g, f->tev[b][2], f->tev[b][3]) == hipSuccess) {
+        f->trace_ms_sum += a; f->gather_ms_sum += g; f->timed_frames++;
+    }
+    (void)hipGetLastError();
+    f->tev_pending[b] = false;
+}
 
 extern "C" {
 
@@ -187,6 +209,12 @@ int rt_comm_share(const rt_comm* owner, rt_ctx* ctx, rt_comm** out)
 int rt_comm_rank(const rt_comm* c) { return c ? c->rank : -1; }
 int rt_comm_size(const rt_comm* c) { return c ? c->nranks : 0; }
 int rt_comm_uses_rccl(const rt_comm* c) { return c && c->nccl ? 1 : 0; }
+int rt_comm_rccl_ranks(const rt_comm* c)
+{
+    int n = 0;
+    if (!c || !c->nccl || !g_rccl.CommCount || g_rccl.CommCount(c->nccl, &n) != 0) return 0;
+    return n;                                      // what RCCL itself says the communicator spans
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 void rt_multi_frame_destroy(rt_multi_frame* f)
@@ -201,6 +229,7 @@ void rt_multi_frame_destroy(rt_multi_frame* f)
         if (f->traced[b]) (void)hipEventDestroy(f->traced[b]);
         if (f->gathered[b]) (void)hipEventDestroy(f->gathered[b]);
         if (f->d_send[b]) (void)hipFree(f->d_send[b]);
+        for (int k = 0; k < 4; k++) if (f->tev[b][k]) (void)hipEventDestroy(f->tev[b][k]);
     }
     if (f->d_contacts) (void)hipFree(f->d_contacts);
     if (f->d_peers) (void)hipFree(f->d_peers);
@@ -210,9 +239,15 @@ void rt_multi_frame_destroy(rt_multi_frame* f)
 
 int rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t root_extra, rt_multi_frame** out)
 {
+    return rt_multi_frame_create_rooted(comm, bvh, scene, cam, root_extra, 0, out);
+}
+
+int rt_multi_frame_create_rooted(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t root_extra, int root, rt_multi_frame** out)
+{
     if (!comm || !bvh || !scene || !out) return RT_FAIL(comm ? comm->ctx : nullptr, "null argument");
     rt_ctx* ctx = comm->ctx;
     *out = nullptr;
+    if (root < 0 || root >= comm->nranks) return RT_FAIL(ctx, "root rank outside the communicator");
     if (bvh->ctx != ctx || scene->ctx != ctx) return RT_FAIL(ctx, "the BVH and the scene must live on the communicator's context");
     if (rt_check_camera(ctx, cam)) return RT_ERROR;
     if (root_extra > 0xFFFFu) return RT_FAIL(ctx, "root_extra too large");
@@ -221,11 +256,12 @@ int rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, con
     if (!f) return RT_FAIL(ctx, "out of host memory");
     f->comm = comm; f->bvh = bvh; f->scene = scene; f->cam = *cam;
     const uint32_t N = (uint32_t)comm->nranks;
+    f->root = root; f->vrank = (comm->rank - root + comm->nranks) % comm->nranks;
     f->tiling = RT_TILING(N, N > 1 ? root_extra : 0u);
-    f->own_slots = rt_tiles_owned_pixels(cam, (uint32_t)comm->rank, f->tiling);
+    f->own_slots = rt_tiles_owned_pixels(cam, (uint32_t)f->vrank, f->tiling);
     f->root_slots = rt_tiles_owned_pixels(cam, 0, f->tiling);
     for (uint32_t r = 1; r < N; r++) { const uint32_t s = rt_tiles_owned_pixels(cam, r, f->tiling); if (s > f->peer_slots) f->peer_slots = s; }
-    const uint32_t plane = comm->rank == 0 ? f->root_slots : f->peer_slots;        // plane stride of this rank's send buffers
+    const uint32_t plane = f->vrank == 0 ? f->root_slots : f->peer_slots;        // plane stride of this rank's send buffers
     hipError_t e = hipMalloc(&f->d_contacts, (size_t)(f->own_slots ? f->own_slots : 1u) * sizeof(rt_contact));
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
         e = hipMalloc((void**)&f->d_send[b], (size_t)(plane ? plane : 1u) * 3u * sizeof(float));
@@ -233,7 +269,7 @@ int rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, con
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->traced[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->gathered[b], hipEventDisableTiming);
     }
-    if (e == hipSuccess && comm->rank == 0) {
+    if (e == hipSuccess && f->vrank == 0) {
         e = hipMalloc((void**)&f->d_frame, (size_t)cam->resX * cam->resY * sizeof(float4));
         if (e == hipSuccess && N > 1) e = hipMalloc((void**)&f->d_peers, (size_t)(N - 1) * 3u * f->peer_slots * sizeof(float));
     }
@@ -241,7 +277,7 @@ int rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, con
     // one frame graph per send buffer: trace of this rank's tiles with the calibrated strategy + shading into the planes
     if (f->own_slots) {
         for (int b = 0; b < 2; b++)
-            if (rt_frame_graph_create(bvh, scene, cam, (uint32_t)comm->rank, f->tiling, RT_FRAME_TILED_PACKED, f->d_contacts, f->d_send[b], plane,
+            if (rt_frame_graph_create(bvh, scene, cam, (uint32_t)f->vrank, f->tiling, RT_FRAME_TILED_PACKED, f->d_contacts, f->d_send[b], plane,
                                       &f->graph[b])) { rt_multi_frame_destroy(f); return RT_ERROR; }
     }
     *out = f;
@@ -260,6 +296,7 @@ int rt_multi_frame_render(rt_multi_frame** frames, int n)
     for (int i = 0; i < n; i++) {
         if (frames[i] && frames[i]->comm->broken) return RT_FAIL(ctx0, "this communicator is broken: an earlier gather failed half way");
         if (!frames[i] || frames[i]->comm->nranks != c0->nranks || frames[i]->frames != frames[0]->frames) return RT_FAIL(ctx0, "frames of different groups or out of step");
+        if (frames[i]->root != frames[0]->root) return RT_FAIL(ctx0, "the frames of one render call gather into one root");
         if (!c0->group.empty() && frames[i]->comm != c0->group[(size_t)i]) return RT_FAIL(ctx0, "frames must be given in rank order");
     }
     const int b = (int)(frames[0]->frames & 1u);
@@ -269,10 +306,14 @@ int rt_multi_frame_render(rt_multi_frame** frames, int n)
         rt_multi_frame* f = frames[i];
         rt_ctx* ctx = f->comm->ctx;
         RT_ENTER(ctx);
+        if (f->timing) harvest_timing(f, b);
         if (f->gathered_valid[b]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, f->gathered[b], 0));
+        if (f->timing) RT_HIP(ctx, hipEventRecord(f->tev[b][0], ctx->stream));
         if (f->graph[b] && rt_frame_graph_launch(f->graph[b])) return RT_ERROR;
+        if (f->timing) RT_HIP(ctx, hipEventRecord(f->tev[b][1], ctx->stream));
         RT_HIP(ctx, hipEventRecord(f->traced[b], ctx->stream));
         RT_HIP(ctx, hipStreamWaitEvent(f->comm->stream, f->traced[b], 0));
+        if (f->timing) RT_HIP(ctx, hipEventRecord(f->tev[b][2], f->comm->stream));
     }
     // 2. the one collective: the peers' planes to the root
     if (N > 1 && c0->nccl) {
@@ -286,13 +327,13 @@ int rt_multi_frame_render(rt_multi_frame** frames, int n)
             rt_comm* c = f->comm;
             const size_t count = (size_t)3u * f->peer_slots;
             (void)hipSetDevice(c->ctx->device);
-            if (c->rank == 0) {
-                for (uint32_t r = 1; r < N && !bad; r++) {
-                    bad = g_rccl.Recv(f->d_peers + (size_t)(r - 1u) * count, count, rtNcclFloat32, (int)r, c->nccl, c->stream);
+            if (f->vrank == 0) {
+                for (uint32_t r = 1; r < N && !bad; r++) {        // virtual rank r = communicator rank (r + root) mod N
+                    bad = g_rccl.Recv(f->d_peers + (size_t)(r - 1u) * count, count, rtNcclFloat32, (int)((r + (uint32_t)f->root) % N), c->nccl, c->stream);
                     if (bad) { what = "ncclRecv"; bad_ctx = c->ctx; }
                 }
             } else if (count) {
-                bad = g_rccl.Send(f->d_send[b], count, rtNcclFloat32, 0, c->nccl, c->stream);
+                bad = g_rccl.Send(f->d_send[b], count, rtNcclFloat32, f->root, c->nccl, c->stream);
                 if (bad) { what = "ncclSend"; bad_ctx = c->ctx; }
             }
         }
@@ -304,13 +345,14 @@ int rt_multi_frame_render(rt_multi_frame** frames, int n)
         }
     } else if (N > 1) {
         // contexts that share a device (one-GPU tests): the root's stream copies every peer's planes once that peer has traced
-        rt_multi_frame* root = frames[0];
+        rt_multi_frame* root = frames[frames[0]->root];
         rt_ctx* rctx = root->comm->ctx;
         RT_ENTER(rctx);
         const size_t count = (size_t)3u * root->peer_slots;
-        for (int i = 1; i < n; i++) {
+        for (int i = 0; i < n; i++) {
+            if (frames[i] == root) continue;
             RT_HIP(rctx, hipStreamWaitEvent(root->comm->stream, frames[i]->traced[b], 0));
-            if (count) RT_HIP(rctx, hipMemcpyAsync(root->d_peers + (size_t)(i - 1) * count, frames[i]->d_send[b], count * sizeof(float), hipMemcpyDeviceToDevice, root->comm->stream));
+            if (count) RT_HIP(rctx, hipMemcpyAsync(root->d_peers + (size_t)(frames[i]->vrank - 1) * count, frames[i]->d_send[b], count * sizeof(float), hipMemcpyDeviceToDevice, root->comm->stream));
         }
     }
     // 3. root: planes -> pixel order; everybody: send[b] is free again after this point of the communicator's stream
@@ -318,13 +360,14 @@ int rt_multi_frame_render(rt_multi_frame** frames, int n)
         rt_multi_frame* f = frames[i];
         rt_comm* c = f->comm;
         RT_ENTER(c->ctx);
-        if (c->rank == 0) {
+        if (f->vrank == 0) {
             launch_untile_rgba_split(c->stream, f->cam, f->tiling, f->d_send[b], f->root_slots, f->d_peers, f->peer_slots, (uint64_t)3u * f->peer_slots, f->d_frame);
             RT_HIP(c->ctx, hipGetLastError());
         }
         // (copy transport: a peer's buffer is read by the ROOT's stream, so that is where its event goes)
-        hipStream_t reader = (c->by_copies && c->rank != 0) ? frames[0]->comm->stream : c->stream;
+        hipStream_t reader = (c->by_copies && f->vrank != 0) ? frames[f->root]->comm->stream : c->stream;
         RT_HIP(c->ctx, hipEventRecord(f->gathered[b], reader));
+        if (f->timing) { RT_HIP(c->ctx, hipEventRecord(f->tev[b][3], reader)); f->tev_pending[b] = true; }
         f->gathered_valid[b] = true;
         f->frames++;
     }
@@ -341,6 +384,32 @@ int rt_multi_frame_wait(rt_multi_frame* f)
 }
 
 void* rt_multi_frame_pixels(const rt_multi_frame* f) { return f ? (void*)f->d_frame : nullptr; }
+
+int rt_multi_frame_set_timing(rt_multi_frame* f, int enable)
+{
+    if (!f) return RT_FAIL(nullptr, "frame is null");
+    rt_ctx* ctx = f->comm->ctx;
+    RT_ENTER(ctx);
+    for (int b = 0; b < 2; b++) { harvest_timing(f, b); }
+    if (enable)
+        for (int b = 0; b < 2; b++) for (int k = 0; k < 4; k++) if (!f->tev[b][k]) RT_HIP(ctx, hipEventCreate(&f->tev[b][k]));
+    f->timing = enable != 0;
+    f->trace_ms_sum = f->gather_ms_sum = 0.0; f->timed_frames = 0;
+    return RT_SUCCESS;
+}
+
+int rt_multi_frame_times(rt_multi_frame* f, double* trace_ms, double* gather_ms, uint64_t* frames)
+{
+    if (!f) return RT_FAIL(nullptr, "frame is null");
+    RT_ENTER(f->comm->ctx);
+    for (int b = 0; b < 2; b++) harvest_timing(f, b);
+    if (trace_ms) *trace_ms = f->trace_ms_sum;
+    if (gather_ms) *gather_ms = f->gather_ms_sum;
+    if (frames) *frames = f->timed_frames;
+    f->trace_ms_sum = f->gather_ms_sum = 0.0; f->timed_frames = 0;
+    return RT_SUCCESS;
+}
+int rt_multi_frame_root(const rt_multi_frame* f) { return f ? f->root : -1; }
 
 int rt_multi_frame_layout(const rt_multi_frame* f, uint32_t* tiling, uint32_t* own_slots, uint32_t* root_slots, uint32_t* peer_slots)
 {

@@ -94,8 +94,19 @@ def untile_host_packed(gathered: np.ndarray, resx: int, resy: int, nranks: int =
     return per_rank[r, s]
 
 
-def gather_to_root(send, world: int, rank: int, out=None, async_op: bool = False):
-    """THE collective of the path: one gather of equally sized compact buffers to rank 0
+def virtual_rank(rank: int, root: int, world: int) -> int:
+    """== rt_multi_frame_create_rooted: the tiles are dealt by virtual rank, the rank that assembles the frame being virtual rank 0"""
+    return (rank - root + world) % world
+
+
+def by_virtual_rank(gathered, root: int):
+    """a buffer gathered in communicator-rank order, re-ordered by virtual rank (what the untile functions index by)"""
+    world = gathered.shape[0]
+    return gathered[[(v + root) % world for v in range(world)]]
+
+
+def gather_to_root(send, world: int, rank: int, out=None, async_op: bool = False, root: int = 0):
+    """THE collective of the path: one gather of equally sized compact buffers to the rank that assembles the frame
     (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU).
 
     async_op=True returns (out, work): the gather runs on the communicator's own stream behind the work already queued
@@ -104,8 +115,8 @@ def gather_to_root(send, world: int, rank: int, out=None, async_op: bool = False
     import torch.distributed as dist
     if dist.get_backend() == 'gloo' and send.is_cuda:
         # gloo has no device gather: stage through the host (rehearsals of the N > 1 path on a one-GPU box only)
-        host = gather_to_root(send.cpu(), world, rank)
-        if rank == 0:
+        host = gather_to_root(send.cpu(), world, rank, root=root)
+        if rank == root:
             if out is None:
                 out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
             out.copy_(host)
@@ -113,12 +124,12 @@ def gather_to_root(send, world: int, rank: int, out=None, async_op: bool = False
         class _Done:
             def wait(self):
                 return True
-        return (out if rank == 0 else None, _Done()) if async_op else (out if rank == 0 else None)
-    if rank == 0:
+        return (out if rank == root else None, _Done()) if async_op else (out if rank == root else None)
+    if rank == root:
         if out is None:
             out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-        work = dist.gather(send, list(out.unbind(0)), dst=0, async_op=async_op)
+        work = dist.gather(send, list(out.unbind(0)), dst=root, async_op=async_op)
     else:
-        work = dist.gather(send, None, dst=0, async_op=async_op)
+        work = dist.gather(send, None, dst=root, async_op=async_op)
         out = None
     return (out, work) if async_op else out

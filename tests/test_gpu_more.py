@@ -857,11 +857,12 @@ def test_frame_graph_survives_another_camera_on_the_same_bvh(gpu_ctx):
 
 # ---- round 2: the native multi-GPU frame driver (rt_comm_* / rt_multi_frame_*) ----------------------------------------------
 
-@pytest.mark.parametrize('nranks,root_extra', [(1, 0), (2, 1), (3, 0), (4, 1), (6, 2)])
-def test_native_multi_frame_group_on_one_device(nranks, root_extra):
+@pytest.mark.parametrize('nranks,root_extra,root', [(1, 0, 0), (2, 1, 0), (3, 0, 0), (4, 1, 0), (6, 2, 0), (2, 1, 1), (4, 1, 3), (6, 2, 2)])
+def test_native_multi_frame_group_on_one_device(nranks, root_extra, root):
     """one process, N contexts, all on device 0 (the group then exchanges by device copies: RCCL refuses two ranks on a device):
     tiling, frame graphs per send buffer, double buffering, stream order and the untile are the code a multi-GPU node runs.
-    The assembled frame must equal the untiled one bit for bit, frame after frame, also when the camera of the group changes."""
+    The assembled frame must equal the untiled one bit for bit, frame after frame, also when the camera of the group changes --
+    and whichever rank assembles it (round 3: rt_multi_frame_create_rooted, tiles dealt by virtual rank)."""
     from openclraytracer_amd import capi
     import oracle as orc
     from conftest import packed_scene
@@ -876,8 +877,11 @@ def test_native_multi_frame_group_on_one_device(nranks, root_extra):
         assert not comms[0].uses_rccl()
         for res in ((640, 360), (333, 251)):
             cam = as_capi_camera(osc.demo_camera(*res))
-            frames = [capi.MultiFrame(comms[r], bvhs[r], scenes[r], cam, root_extra) for r in range(nranks)]
+            frames = [capi.MultiFrame(comms[r], bvhs[r], scenes[r], cam, root_extra, root) for r in range(nranks)]
             lay = frames[0].layout()
+            if res == (640, 360):
+                for f in frames:
+                    f.set_timing(True)
             assert lay['tiling'] == capi.tiling(nranks, root_extra if nranks > 1 else 0)
             assert sum(f.layout()['own_slots'] for f in frames) >= res[0] * res[1]
             # reference frame: untiled trace + shade on a context of its own
@@ -891,9 +895,14 @@ def test_native_multi_frame_group_on_one_device(nranks, root_extra):
                 if k in (0, 3, 4):
                     for f in frames:
                         f.wait()
-                    got = frames[0].download_frame()
+                    got = frames[root].download_frame()
                     assert got.tobytes() == want.reshape(-1, 4).tobytes(), 'frame %d' % k
-            assert frames[0].pixels_ptr() != 0 and all(f.pixels_ptr() == 0 for f in frames[1:])
+            assert frames[root].pixels_ptr() != 0 and all(f.pixels_ptr() == 0 for r, f in enumerate(frames) if r != root)
+            if res == (640, 360):
+                for f in frames:
+                    t = f.times()
+                    assert t['frames'] == 5 and t['trace_ms'] > 0 and t['gather_ms'] >= 0
+            assert comms[0].rccl_ranks() == 0                     # no RCCL communicator in a group that shares a device
             for f in frames:
                 f.close()
         for c in comms:

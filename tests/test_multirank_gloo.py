@@ -55,6 +55,19 @@ def _worker(rank, world, port, res, name, ret):
             gotp = ft.untile_host_packed(outp.numpy(), res[0], res[1], til)
             ret['equal'] = bool(np.array_equal(got, frame)) and gotp.tobytes() == frame.tobytes()
             ret['hits'] = int((frame[:, 3] > 0).sum())
+        # round 3: another rank assembles the frame (rt_multi_frame_create_rooted; bench.py: scene i gathers into rank i mod N) --
+        # the tiles are dealt by virtual rank (rank - root) mod N, the gather lands on `root`
+        root = 1
+        v = ft.virtual_rank(rank, root, world)
+        mine_v = ft.owned_slots(res[0], res[1], v, til)
+        planes_v = np.zeros((3, slots0), dtype=np.float32)
+        planes_v[:, :mine_v] = ft.pack_planes(ft.compact_from_frame(frame, res[0], res[1], v, til, mine_v))
+        outr = ft.gather_to_root(torch.from_numpy(planes_v), world, rank, root=root)
+        if rank == root:
+            gotr = ft.untile_host_packed(ft.by_virtual_rank(outr.numpy(), root), res[0], res[1], til)
+            ret['equal_rooted'] = gotr.tobytes() == frame.tobytes()
+        else:
+            assert outr is None
     finally:
         dist.destroy_process_group()
 
@@ -73,7 +86,7 @@ def test_two_rank_gather_reassembles_the_frame(res):
     for p in procs:
         p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs)
-    assert ret['equal'] and ret['hits'] > 0
+    assert ret['equal'] and ret['hits'] > 0 and ret['equal_rooted']
 
 
 def test_slot_contract_matches_c_abi():

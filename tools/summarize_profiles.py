@@ -58,7 +58,7 @@ def counter_pass(prefix, kernel_prefixes, skip_first):
             return None
         for row in csv.DictReader(open(f)):
             k = row['Kernel_Name'].split('(')[0].replace('void ', '').strip()
-            if k.startswith(kernel_prefixes):
+            if k.startswith(kernel_prefixes) and (not k.startswith(('k_trace', 'k_resolve')) or bench_mod.kernel_tag(k) == (1, 0)):   # (<1, 1> = calibration)
                 per[k][row['Counter_Name']].append((int(row['Dispatch_Id']), float(row['Counter_Value'])))
     out = {}
     for k, cs in per.items():
@@ -71,7 +71,7 @@ def counter_pass(prefix, kernel_prefixes, skip_first):
             d[c] = sum(steady) / len(steady)
         out[k] = d
     return out
-for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve'), 40), ('tlg_config4', 'tlg_pmc', ('k_tlg_trace',), 1)):
+for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve'), 1), ('tlg_config4', 'tlg_pmc', ('k_tlg_trace',), 1)):
     try:
         pk = counter_pass(prefix, kp, skip)
         if not pk:
