@@ -499,7 +499,10 @@ def main():
     note('timed region done: %.4f ms per step; isolated pass per scene' % (elapsed / args.steps * 1e3))
     for it in work:
         sctx = it['ctx']
-        r0 = 0 if group_ranks else rank
+        # (tiled: this rank's place in the scene's frame, counted from the rank that assembles it)
+        r0 = ((0 if group_ranks else rank) - it.get('root', 0)) % nranks
+        if tiled:
+            it['slots'] = capi.tiles_owned_pixels(it['cam'], r0, tiling)
         dc = sctx.alloc(max(it['slots'], 1) * 32) if tiled else it['contacts']
         if tiled:
             trace = lambda it=it, dc=dc: it['bvh'].generate_contacts_primary_tiled_d(it['cam'], r0, tiling, dc)
