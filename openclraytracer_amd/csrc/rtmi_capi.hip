@@ -1130,6 +1130,8 @@ struct rt_frame_graph {
     hipGraphExec_t exec[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
     hipEvent_t done[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
     bool launched[2][2] = { { false, false }, { false, false } };
+    bool has_event[2][2] = { { false, false }, { false, false } };   // a `done` event stands behind the instance's last launch
+    bool moved = false;                      // rt_frame_graph_set_camera was called: launches leave events behind (a graph whose camera never moves pays nothing)
     bool dirty[2][2] = { { false, false }, { false, false } };   // the camera changed since this instance's arguments were set
     int slot[2] = { 0, 0 };                  // the instance of each kind that was launched last
     GraphNodes nodes[2];
@@ -1330,6 +1332,7 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
     g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
     for (int a = 0; a < 2; a++) for (int k = 0; k < 2; k++) g->dirty[a][k] = true;
     g->eager = false;
+    g->moved = true;
     if (g->four_wide) {
         if (ensure_host_planes(b)) return RT_ERROR;
         const uint32_t bits = host_plane_bits(b, g->origin);
@@ -1377,7 +1380,10 @@ int rt_frame_graph_launch(rt_frame_graph* g)
         k ^= 1;
         if (g->dirty[which][k]) {
             const double t0 = debug ? now_us() : 0.0;
-            if (g->launched[which][k]) RT_HIP(ctx, hipEventSynchronize(g->done[which][k]));
+            if (g->launched[which][k]) {
+                if (g->has_event[which][k]) RT_HIP(ctx, hipEventSynchronize(g->done[which][k]));
+                else RT_HIP(ctx, hipStreamSynchronize(ctx->stream));          // launched before the camera first moved: no event behind it
+            }
             FrameMode m = graph_mode(g, which, true);
             g->nodes[which].failed = false;
             g->nodes[which].exec = g->exec[which][k];
@@ -1388,7 +1394,8 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     }
     const double t1 = debug ? now_us() : 0.0;
     RT_HIP(ctx, hipGraphLaunch(g->exec[which][k], ctx->stream));
-    RT_HIP(ctx, hipEventRecord(g->done[which][k], ctx->stream));
+    g->has_event[which][k] = g->moved;
+    if (g->moved) RT_HIP(ctx, hipEventRecord(g->done[which][k], ctx->stream));
     if (debug) { g->host_launch_us += now_us() - t1; g->host_launches++; }
     g->launched[which][k] = true;
     g->slot[which] = k;

@@ -7,6 +7,8 @@
 // Data the reference re-reads from the packed scene buffer per pair / per ray comes from the SoA triangle table.
 #include "rtmi_internal.h"
 #include "device_math.h"
+#include <cstdio>
+#include <cstdlib>
 #include "tlg_math.h"
 
 #define TLG_BLOCK 256
@@ -371,6 +373,18 @@ __device__ __forceinline__ bool dda_advance(Dda& s, int axis)
     return (a0 & hx) | (a1 & hy) | (a2 & hz);
 }
 
+// -DRTMI_TLG_DIAG (experiment twin only, `make exp EXPSRC=tlg_kernels EXPFLAGS=-DRTMI_TLG_DIAG`): loop trip counts per WAVE (what the
+// wave executes: the longest lane sets every loop) and per LANE (what the rays need), and the sizes of the leaf ranges met
+#ifdef RTMI_TLG_DIAG
+__device__ unsigned long long g_tlg_diag[96];
+#define TLG_DIAG(W, L) do { const unsigned long long m__ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m__) - 1)) { \
+        atomicAdd(&g_tlg_diag[W], 1ull); atomicAdd(&g_tlg_diag[L], (unsigned long long)__popcll(m__)); } } while (0)
+#define TLG_DIAG_HIST(n) atomicAdd(&g_tlg_diag[16u + ((n) < 63u ? (n) : 63u)], 1ull)
+#else
+#define TLG_DIAG(W, L)
+#define TLG_DIAG_HIST(n)
+#endif
+
 template <int PRIMARY>
 __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_tlg_trace(TlgTraceArgs a)
 {
@@ -421,9 +435,11 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
     dda_setup(o, d, glo, ghi, g.resX, g.resY, g.resZ, T);
     bool done = T.t0 > T.tmaxmax;            // TwoLevelGrid.h:590-591
     while (!done) {
+        TLG_DIAG(0, 1);
         const rt_top_cell tc = a.top[(uint32_t)T.iz * g.resX * g.resY + (uint32_t)T.iy * g.resX + (uint32_t)T.ix];
         const int taxis = dda_axis(T);
         if (!(tc.resX == 0 || tc.resY == 0 || tc.resZ == 0)) {
+            TLG_DIAG(2, 3);
             // processTopLevelCell, TwoLevelGrid.h:419-545
             f3 clo, chi;
             clo.x = glo.x + (float)T.ix * g.stepX; clo.y = glo.y + (float)T.iy * g.stepY; clo.z = glo.z + (float)T.iz * g.stepZ;
@@ -433,14 +449,18 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
             float cell_t = FLT_MAX;
             uint32_t cell_tri = 0xFFFFFFFFu;
             for (;;) {
+                TLG_DIAG(4, 5);
                 const int laxis = dda_axis(Lf);
                 const uint32_t leaf = (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
                 const uint2 range = a.leaf_ranges[leaf];
+                TLG_DIAG_HIST(range.y - range.x);
                 for (uint32_t i = range.x; i < range.y; i++) {
+                    TLG_DIAG(6, 7);
                     const uint32_t tri = a.leaf_pairs[i].y;
                     uint32_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
                     if (*slot == tri) continue;                               // tested in an earlier cell: a miss, again
                     *slot = tri;
+                    TLG_DIAG(8, 9);
                     // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
                     // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
                     f3 edge1, edge2, tvec, qvec;
@@ -575,7 +595,25 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
     if (t.tricam && t.prepare_tricam && t.scene->n_tris)
         hipLaunchKernelGGL(k_tlg_prepare_triangles, blocks_for(t.scene->n_tris), dim3(TLG_BLOCK), 0, s, t.scene->v0, t.scene->e1, t.scene->e2,
                            const_cast<TriCam*>(t.tricam), t.scene->n_tris, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11]);
+#ifdef RTMI_TLG_DIAG
+    static unsigned long long zero[96] = { 0 };
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tlg_diag), zero, sizeof zero, 0, hipMemcpyHostToDevice, s);
+#endif
     if (a.total_work) hipLaunchKernelGGL(k_tlg_trace<1>, blocks_for(a.total_work), dim3(TLG_BLOCK), 0, s, a);
+#ifdef RTMI_TLG_DIAG
+    if (getenv("RTMI_TLG_DIAG_PRINT")) {
+        unsigned long long h[96];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tlg_diag), sizeof h);
+        const char* nm[5] = { "top cells", "non-empty top cells", "leaf cells", "range entries", "triangle tests" };
+        for (int k = 0; k < 5; k++)
+            fprintf(stderr, "tlg diag %-20s wave iterations %12llu  lane iterations %14llu  lanes per wave iteration %.1f\n", nm[k], h[2 * k], h[2 * k + 1],
+                    h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
+        fprintf(stderr, "tlg diag leaf range sizes (lane visits):");
+        for (int k = 0; k < 64; k++) fprintf(stderr, " %llu", h[16 + k]);
+        fprintf(stderr, "\n");
+    }
+#endif
 }
 
 void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)
