@@ -507,10 +507,15 @@ __global__ __launch_bounds__(256) void k_refit_literal(rt_bvh_node* nodes, uint3
     uint32_t current = nodes[leaf].data[0];
     while (current != UINT_MAX) {
         if (current < n || current >= 2u * n - 1u) break;
+        // (as in k_refit: the write-back of the release and the invalidate of the acquire complete asynchronously, MI355X_MICROARCH.md;
+        //  without the waits a second arriver read a child box of before the first arriver's merge once in some thousand builds --
+        //  round 3, test_literal_zero_mode_on_the_device[clumsydragon]: three nodes with boxes too small)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t old = atomicAdd(&counters[current - n], 1u);
         if (old == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         literal_merge(nodes, current);
         current = nodes[current].data[0];
     }
