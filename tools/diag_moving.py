@@ -76,6 +76,8 @@ def main():
         for it in work:
             it['ctx'].synchronize(); log('  synced', it['name'])
         log('all streams moving: %.4f ms per step' % ((time.perf_counter() - t) * 1e3 / 64))
+    for it in work:
+        it['g'].close()
     log('done')
 
 
