@@ -83,7 +83,7 @@ for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve
         c = pk[dom]
         cycles = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
         hbm = sum((2.0 * v.get('FETCH_SIZE', 0.0) + v.get('WRITE_SIZE', 0.0)) * 1024 for v in pk.values())
-        ms = line.get('trace_ms') or line.get('ms_per_frame') or 0.0
+        ms = line.get('trace_ms') or line.get('ms_per_frame') or next((v['ms_per_frame'] for v in line.values() if isinstance(v, dict) and 'ms_per_frame' in v), 0.0)
         line['counters'] = dict(source='rocprofv3 --pmc passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE, SQ group: one pass each), steady-state launches',
                                 dominant_kernel=dom, per_launch={k: {a: round(b, 1) for a, b in v.items()} for k, v in pk.items()},
                                 hbm_bytes_per_launch=int(hbm), measured_hbm_gbps=(round(hbm / (ms * 1e-3) / 1e9, 1) if ms else None),
