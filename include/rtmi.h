@@ -278,6 +278,9 @@ int   rt_multi_frame_create(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, c
 int   rt_multi_frame_create_rooted(rt_comm* comm, rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t root_extra, int root,
                                    rt_multi_frame** out);
 int   rt_multi_frame_root(const rt_multi_frame* frame);
+/* the camera moves (OpenCLRayTracerDemo.cpp:275-276): as rt_frame_graph_set_camera, for both send buffers' graphs; every rank
+ * passes the same camera, same resolution as at creation                                                                       */
+int   rt_multi_frame_set_camera(rt_multi_frame* frame, const rt_camera* cam);
 int   rt_multi_frame_render(rt_multi_frame** frames, int n);
 /* measurement: HIP events around this rank's trace + shade (context stream) and around its part of the gather -- the RCCL group, on the
  * root also the untile -- (communicator stream); sums over the frames rendered since the last query, read back two frames late so

@@ -44,7 +44,7 @@ SYMBOLS = [
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
     'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
-    'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl', 'rt_comm_rccl_ranks', 'rt_multi_frame_create_rooted', 'rt_multi_frame_root', 'rt_multi_frame_set_timing', 'rt_multi_frame_times',
+    'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl', 'rt_comm_rccl_ranks', 'rt_multi_frame_create_rooted', 'rt_multi_frame_root', 'rt_multi_frame_set_camera', 'rt_multi_frame_set_timing', 'rt_multi_frame_times',
     'rt_multi_frame_create', 'rt_multi_frame_render', 'rt_multi_frame_wait', 'rt_multi_frame_pixels', 'rt_multi_frame_layout', 'rt_multi_frame_destroy',
     'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays',
 ]
@@ -665,6 +665,12 @@ class MultiFrame:
         self.ctx.check(L.rt_multi_frame_create_rooted(comm.h, bvh.h, scene.h, _p(self.cam), root_extra, root, C.byref(h)))
         self.h = h
         self.root = root
+
+    def set_camera(self, cam: np.ndarray):
+        """rt_multi_frame_set_camera: the next frames render this camera (every rank passes the same one)"""
+        self.ctx.lib.rt_multi_frame_set_camera.argtypes = [C.c_void_p, C.c_void_p]
+        self.cam = np.array(cam, copy=True)
+        self.ctx.check(self.ctx.lib.rt_multi_frame_set_camera(self.h, _p(self.cam)))
 
     def set_timing(self, on: bool = True):
         self.ctx.lib.rt_multi_frame_set_timing.argtypes = [C.c_void_p, C.c_int]

@@ -23,6 +23,9 @@ public:
     /** forms the communicator group (RCCL when the contexts' devices differ) and prepares the frame for `cam`;
      *  rootExtra = extra tiles per period that GPU 0, which gathers the frame, traces itself */
     Common::Result initialize(Camera& cam, unsigned int rootExtra, Common::Errata& err);
+    /** the camera of the following frames (the Demo updates its camera before every frame, OpenCLRayTracerDemo.cpp:275-276);
+     *  same resolution as at initialize */
+    Common::Result setCamera(Camera& cam, Common::Errata& err);
     /** one frame: asynchronous (trace + shade on every GPU, gather, untile on GPU 0) */
     Common::Result render(Common::Errata& err);
     /** waits for the frames issued so far */

@@ -298,6 +298,15 @@ Result MultiGPUFrame::initialize(Camera& cam, unsigned int rootExtra, Errata& er
     return Success;
 }
 
+Result MultiGPUFrame::setCamera(Camera& cam, Errata& err)
+{
+    if (_frames.empty()) { FILL_ERRATA(err, "initialize must precede setCamera"); return Error; }
+    for (size_t r = 0; r < _frames.size(); r++)
+        RTMI_CHECK(*_contexts[r], rt_multi_frame_set_camera(_frames[r], reinterpret_cast<const rt_camera*>(&cam)), err);
+    _camera = cam;
+    return Success;
+}
+
 Result MultiGPUFrame::render(Errata& err)
 {
     if (_frames.empty()) { FILL_ERRATA(err, "initialize must precede render"); return Error; }

@@ -411,6 +411,20 @@ int rt_multi_frame_times(rt_multi_frame* f, double* trace_ms, double* gather_ms,
 }
 int rt_multi_frame_root(const rt_multi_frame* f) { return f ? f->root : -1; }
 
+// The camera of a tiled frame moves like the camera of any captured frame (rt_frame_graph_set_camera): both send buffers' graphs get
+// the new camera as new kernel arguments; every rank passes the same camera (same resolution as at creation).
+int rt_multi_frame_set_camera(rt_multi_frame* f, const rt_camera* cam)
+{
+    if (!f) return RT_FAIL(nullptr, "frame is null");
+    rt_ctx* ctx = f->comm->ctx;
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (cam->resX != f->cam.resX || cam->resY != f->cam.resY) return RT_FAIL(ctx, "multi-GPU frame: the resolution is part of the frame; create a new one");
+    for (int b = 0; b < 2; b++)
+        if (f->graph[b] && rt_frame_graph_set_camera(f->graph[b], cam)) return RT_ERROR;
+    f->cam = *cam;
+    return RT_SUCCESS;
+}
+
 int rt_multi_frame_layout(const rt_multi_frame* f, uint32_t* tiling, uint32_t* own_slots, uint32_t* root_slots, uint32_t* peer_slots)
 {
     if (!f) return RT_FAIL(nullptr, "frame is null");

@@ -898,6 +898,22 @@ def test_native_multi_frame_group_on_one_device(nranks, root_extra, root):
                     got = frames[root].download_frame()
                     assert got.tobytes() == want.reshape(-1, 4).tobytes(), 'frame %d' % k
             assert frames[root].pixels_ptr() != 0 and all(f.pixels_ptr() == 0 for r, f in enumerate(frames) if r != root)
+            if res == (333, 251):
+                # the group's camera moves (rt_multi_frame_set_camera on every rank): the assembled frames follow, both send buffers
+                for step in range(3):
+                    cam2 = cam.copy()
+                    cam2['viewTransform'][0][3] += np.float32(0.11 * (step + 1)); cam2['viewTransform'][0][11] += np.float32(0.07 * (step + 1))
+                    rctx = capi.Context(0)
+                    rsc = capi.DeviceScene(rctx, buf)
+                    rb = capi.DeviceBVH(rctx, rsc).build()
+                    want2 = capi.shade_blinn_phong(rctx, rsc, cam2, rb.generate_contacts_primary(cam2))
+                    rb.close(); rsc.close(); rctx.close()
+                    for f in frames:
+                        f.set_camera(cam2)
+                    capi.multi_frame_render(frames)
+                    for f in frames:
+                        f.wait()
+                    assert frames[root].download_frame().tobytes() == want2.reshape(-1, 4).tobytes(), 'moved camera, frame %d' % step
             if res == (640, 360):
                 for f in frames:
                     t = f.times()
