@@ -309,12 +309,13 @@ def main():
     # loads torch FIRST, as in round 2, so that the library, RCCL and torch share ONE runtime; that path replays captured frames
     # only.
     torch, dist, dev = None, None, None
-    if world > 1:
+    if world > 1 or os.environ.get('RTMI_BENCH_TORCH_FIRST') == '1':     # (the knob: rehearse the N > 1 runtime combination with one rank)
         import torch
-        import torch.distributed as dist
-        dist.init_process_group('gloo')          # control plane only
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo')          # control plane only
     from openclraytracer_amd import capi
 
     def fence():

@@ -1131,6 +1131,7 @@ struct rt_frame_graph {
     hipEvent_t done[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
     bool launched[2][2] = { { false, false }, { false, false } };
     bool has_event[2][2] = { { false, false }, { false, false } };   // a `done` event stands behind the instance's last launch
+    bool nodes_known = true;                 // the kernel nodes of both captured sequences were identified (else a moved camera is rendered eagerly)
     bool moved = false;                      // rt_frame_graph_set_camera was called: launches leave events behind (a graph whose camera never moves pays nothing)
     bool dirty[2][2] = { { false, false }, { false, false } };   // the camera changed since this instance's arguments were set
     int slot[2] = { 0, 0 };                  // the instance of each kind that was launched last
@@ -1251,7 +1252,9 @@ static int capture_frame(rt_frame_graph* g, int which)
         (void)hipGetLastError();
         return rc != RT_SUCCESS ? RT_ERROR : RT_FAIL(ctx, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     }
-    if (g->nodes[which].failed) return RT_FAIL(ctx, "frame graph: the captured kernel nodes could not be identified");
+    // (a runtime that does not report the captured nodes -- hipStreamGetCaptureInfo_v2 -- still replays the frame; only a camera that
+    //  moves is then served by the eager sequence, rt_frame_graph_set_camera)
+    if (g->nodes[which].failed) g->nodes_known = false;
     for (int k = 0; k < 2; k++) {
         e = hipGraphInstantiate(&g->exec[which][k], g->graph[which], nullptr, nullptr, 0);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done[which][k], hipEventDisableTiming);
@@ -1331,7 +1334,7 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
     g->cam = *cam;
     g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
     for (int a = 0; a < 2; a++) for (int k = 0; k < 2; k++) g->dirty[a][k] = true;
-    g->eager = false;
+    g->eager = !g->nodes_known;
     g->moved = true;
     if (g->four_wide) {
         if (ensure_host_planes(b)) return RT_ERROR;
@@ -1340,6 +1343,7 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
         // a frame captured without the wave-per-ray kernel cannot walk rays that must use the reference tree: such a camera
         // position (measure zero, but "x = 0" happens) gets the eager sequence until the camera leaves the plane
         if (g->no_unsafe && (bits & (g->octant_records ? 6u : 7u)) != 0u) g->eager = true;
+        if (!g->nodes_known) g->eager = true;
     } else {
         g->plane_bits_known = 0;              // the preparation node computes the bits on the device, the kernels read them there
     }

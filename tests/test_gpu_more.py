@@ -607,6 +607,23 @@ def test_bench_tiled_path_with_one_rank():
     assert len(line) == 1 and json.loads(line[0])['value'] > 0
 
 
+def test_bench_tiled_path_under_the_runtime_torch_bundles():
+    """N > 1 loads torch first (torch.distributed), so the library, RCCL and torch share the HIP runtime torch bundles -- an older
+    ROCm than the one librtmi.so is linked against.  One rank rehearses that combination: frame graphs are captured, their nodes
+    noted (or not: then moved cameras fall back to the eager sequence), frames are assembled and checked."""
+    import subprocess
+    import sys as _sys
+    env = dict(os.environ, RTMI_BENCH_FORCE_TILED='1', RTMI_BENCH_TORCH_FIRST='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RTMI_BENCH_GROUP'):
+        env.pop(k, None)
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '7', '--warmup', '2', '--check-frames',
+                        '--no-cpu-baseline', '--no-extra-legs'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'frame check ok (after the timed steps): 5 assembled frames equal the untiled ones' in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert line['value'] > 0 and line['per_rank'] and line['per_rank'][0]['trace_shade_ms_per_step'] > 0
+
+
 def test_bench_default_line_has_measured_rooflines():
     """the N = 1 line: the counters are collected by the run itself (rocprofv3 child processes), every fraction is <= 1 and
     recomputes from the fields beside it"""
