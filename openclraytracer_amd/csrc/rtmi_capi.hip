@@ -587,7 +587,7 @@ int rt_bvh_construct(rt_bvh* b)
     // Dynamic scenes rebuild every frame (OpenCLRayTracerDemo.cpp:230-234).  The calibrated strategy is a property of how the
     // model fills the frame, not of one build: it is kept while the triangle count stays (the key holds resolution and tiling),
     // and every strategy produces the same contacts anyway.  RTMI_RECALIBRATE=1 restores a calibration per construct().
-    if (b->tuned_n != b->n || ctx->recalibrate) b->tuned = false;
+    if (b->tuned_n != b->n || ctx->recalibrate) { b->tuned = false; for (auto& e : b->tuned_cache) e.valid = false; }
     b->tuned_n = b->n;
     return RT_SUCCESS;
 }
@@ -706,6 +706,20 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
 {
     rt_ctx* ctx = b->ctx;
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
+    if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key) && !(mode && mode->fixed_strategy)) {
+        // another resolution / tiling than the last frame's: known from before?
+        for (auto& e : b->tuned_cache)
+            if (e.valid && e.key == key) {
+                if (b->tuned) {                     // the current one changes places with it
+                    rt_bvh::TunedEntry cur; cur.key = b->tuned_key; cur.budget = b->tuned_budget; cur.packet = b->tuned_packet; cur.quad = b->tuned_quad; cur.valid = true;
+                    const rt_bvh::TunedEntry hit = e; e = cur;
+                    b->tuned_key = hit.key; b->tuned_budget = hit.budget; b->tuned_packet = hit.packet; b->tuned_quad = hit.quad;
+                } else {
+                    b->tuned = true; b->tuned_key = e.key; b->tuned_budget = e.budget; b->tuned_packet = e.packet; b->tuned_quad = e.quad; e.valid = false;
+                }
+                break;
+            }
+    }
     if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key) && !(mode && mode->fixed_strategy)) {
         if (mode && (mode->record || mode->update)) return RT_FAIL(ctx, "a frame graph needs a calibrated strategy (trace one frame eagerly first)");
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
@@ -876,6 +890,10 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         const bool best_packet = have && candidates[best_ci].packet, best_quad = have && candidates[best_ci].quad;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (!have) return RT_FAIL(ctx, "trace calibration: no strategy produced a valid frame");
+        if (b->tuned) {                            // the calibration it replaces is kept for later
+            rt_bvh::TunedEntry& slot = b->tuned_cache[b->tuned_cache_next++ % 4u];
+            slot.key = b->tuned_key; slot.budget = b->tuned_budget; slot.packet = b->tuned_packet; slot.quad = b->tuned_quad; slot.valid = true;
+        }
         b->tuned = true; b->tuned_key = key; b->tuned_budget = best; b->tuned_packet = best_packet; b->tuned_quad = best_quad;
         b->calibration_launches = launches; b->calibration_gpu_ms = gpu_ms;
         (void)last_failed;

@@ -166,6 +166,11 @@ struct rt_bvh {
     uint32_t tuned_budget = 0;              // 0 = packet kernel, else deferral budget of the two-phase kernels
     bool tuned_packet = false;
     bool tuned_quad = false;                // with tuned_packet: the four-wide packet kernel
+    // the last few other calibrations (resolution / tiling keys): a BVH that serves several viewports or a tiled and an untiled frame
+    // in turns does not calibrate again at every switch
+    struct TunedEntry { uint64_t key = 0; uint32_t budget = 0; bool packet = false, quad = false, valid = false; };
+    TunedEntry tuned_cache[4];
+    uint32_t tuned_cache_next = 0;
     uint32_t calibration_launches = 0;      // full-size launches the last calibration took (diagnostic)
     float calibration_gpu_ms = 0.f;         // ... and their device time
     uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)

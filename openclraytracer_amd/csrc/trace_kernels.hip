@@ -1323,6 +1323,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
             // (an unused slot's camera-relative box is empty and unmarked, k_prepare_camera: no test of its id here)
             uint64_t m[4];
             if (OCT) {
+                // (round 3, tried and not kept: the set `in` and the threshold compare folded into ONE compare per slot -- lanes that do not
+                //  walk the node, or whose near is not beyond the threshold, compared as NaN: one scalar AND less, one vector select more
+                //  per slot -- and, separately, the leaf slots ordered first so that one test of slot 0 replaces the four leaf checks:
+                //  neither moved an isolated frame nor the five-stream step (21 670 / 21 560-21 620 Mrays/s in alternating runs).  At
+                //  full occupancy the kernel is bound by the latency of a step's dependent chain times the eight waves a SIMD holds
+                //  (8 192 waves x ~1 step per microsecond = the 3.5 M steps of a bench step in 0.43 ms), not by instruction issue.)
                 m[0] = in & child_mask_octant(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, q4.w);
                 m[1] = in & child_mask_octant(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, q5.w);
                 m[2] = in & child_mask_octant(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w);
