@@ -152,6 +152,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     ctx->task_cap = 64; ctx->task_cap_auto = true;     // per queue, 256 queues; grows with the frame (ensure_long_list)
     if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
     if (const char* env = std::getenv("RTMI_FUSED_FRAMES")) ctx->no_fused_frames = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_BLOCK_ORDER")) ctx->no_block_order = env[0] == '0';
     if (const char* env = std::getenv("RTMI_SHARE_MIN_BUDGET")) ctx->share_min_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
@@ -396,6 +397,8 @@ int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** 
     return RT_SUCCESS;
 }
 
+static void block_order_free(BlockOrder& o);
+
 static void free_build_buffers(rt_bvh* b)
 {
     if (b->d_nodes) (void)hipFree(b->d_nodes);
@@ -433,6 +436,7 @@ void rt_bvh_destroy(rt_bvh* b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     free_build_buffers(b);
+    block_order_free(b->block_order);
     delete b;
 }
 
@@ -640,6 +644,38 @@ static uint32_t calibration_parts(const rt_bvh* b, const rt_camera* cam)
     return strategy_parts(b, cam, true, true) | strategy_parts(b, cam, false, false) | strategy_parts(b, cam, true, false);
 }
 
+// ---- start order of the blocks (BlockOrder, rtmi_internal.h) -------------------------------------------------------------------
+#define RT_BLOCK_ORDER_REFRESH 32u          // frames between two sorts (a sort of 32 768 pairs is a handful of small launches)
+static void block_order_free(BlockOrder& o)
+{
+    if (o.d_cost) (void)hipFree(o.d_cost);
+    if (o.d_order) (void)hipFree(o.d_order);
+    if (o.d_pairs) (void)hipFree(o.d_pairs);
+    o = BlockOrder();
+}
+// buffers for a frame of `blocks` blocks; false: none (allocation failed): the frame runs in index order
+static bool block_order_fit(rt_ctx* ctx, BlockOrder& o, uint32_t blocks)
+{
+    if (blocks == 0) return false;
+    if (blocks > o.cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        block_order_free(o);
+        uint32_t p2 = 1; while (p2 < blocks) p2 <<= 1;
+        if (hipMalloc((void**)&o.d_cost, (size_t)blocks * 4) != hipSuccess || hipMalloc((void**)&o.d_order, (size_t)blocks * 4) != hipSuccess ||
+            hipMalloc((void**)&o.d_pairs, (size_t)p2 * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); block_order_free(o); return false; }
+        o.cap = blocks; o.cap_pow2 = p2;
+    }
+    if (o.count != blocks) { o.count = blocks; o.valid = false; o.age = 0; }
+    return true;
+}
+// the costs the frame just enqueued will have counted -> the order of the following frames (stream-ordered behind that frame)
+static void block_order_refresh(rt_ctx* ctx, BlockOrder& o)
+{
+    uint32_t p2 = 1; while (p2 < o.count) p2 <<= 1;
+    launch_block_order(ctx->stream, o.d_cost, o.d_pairs, o.d_order, o.count, p2, false);
+    o.valid = true; o.age = 0;
+}
+
 // Per-launch options of a primary frame beyond the strategy: a captured / updated frame graph, a fused colour buffer
 struct FusedShade { void* rgba; uint32_t plane_stride; bool done; };
 struct FrameMode {
@@ -652,6 +688,7 @@ struct FrameMode {
     // a captured frame keeps the strategy it was captured with (the BVH remembers one calibration, for the last resolution / tiling traced)
     bool fixed_strategy = false, packet = false, quad = false;
     uint32_t budget = 0;
+    BlockOrder* block_order = nullptr;     // a captured frame's own start-order buffers (null: the BVH's)
 };
 
 static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32_t parts = 0, const FrameMode* mode = nullptr)
@@ -705,6 +742,11 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32
 static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out, const FrameMode* mode = nullptr)
 {
     rt_ctx* ctx = b->ctx;
+    // start order of the blocks (four-wide kernel): the buffers of this frame shape
+    BlockOrder* const bo = (mode && mode->block_order) ? mode->block_order : &b->block_order;
+    const bool captured = mode && (mode->record || mode->update);
+    const bool order_ok = !ctx->no_block_order && b->d_quad && b->have_search_tree &&
+                          (captured ? bo->count != 0 : block_order_fit(ctx, *bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u));
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
     if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key) && !(mode && mode->fixed_strategy)) {
         // another resolution / tiling than the last frame's: known from before?
@@ -766,6 +808,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
             t.tag = 1;
+            if (cand.packet && cand.quad && order_ok) { t.block_cost = bo->d_cost; t.block_order = bo->valid ? bo->d_order : nullptr; }
             if (clock_rate > 0.0 && limit_ms > 0.f) {
                 const double now_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count();
                 t.cal_deadline = clock0 + (unsigned long long)((now_ms + (double)limit_ms + 0.1) * clock_rate);
@@ -851,6 +894,8 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             int warm = first_cand;
             for (int ci = 0; ci < N_CAND && warm < 0; ci++) if (cand_n[ci] == 0) warm = ci;
             if (warm >= 0) { float m; bool v = false; if (!run_once(warm, m, v)) broken = true; }
+            // the warm-up ran to its end: its block costs give the candidates the start order the frames will have
+            if (!broken && warm >= 0 && candidates[warm].packet && candidates[warm].quad && order_ok) block_order_refresh(ctx, *bo);
             if (!broken) sample_clock();
         }
         auto refine_lane = [&](int first) {
@@ -907,8 +952,12 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     TraceLaunch t = make_launch(b, cam, strategy_parts(b, cam, packet, quad) & ~(mode ? mode->parts_drop : 0u), mode);
     t.defer_budget = budget; t.packet = packet; t.packet4 = quad;
     if (mode && mode->fused) { t.fused_rgba = mode->fused->rgba; t.fused_plane_stride = mode->fused->plane_stride; t.fused_done = &mode->fused->done; }
+    const bool ordered = packet && quad && order_ok;
+    if (ordered) { t.block_cost = bo->d_cost; t.block_order = (bo->valid || captured) ? bo->d_order : nullptr; }
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
     if (mode && mode->update) return mode->update->failed ? RT_FAIL(ctx, "frame graph: a kernel node could not be updated") : RT_SUCCESS;
+    // every few frames the order follows the costs the frame just enqueued will have counted (a captured frame: rt_frame_graph_launch)
+    if (ordered && !captured && (!bo->valid || ++bo->age >= RT_BLOCK_ORDER_REFRESH)) block_order_refresh(ctx, *bo);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }
@@ -1165,6 +1214,8 @@ struct rt_frame_graph {
     bool no_unsafe = false;                  // captured without the wave-per-ray launch (and, unless switched off, with fused shading)
     bool eager = false;                      // the current camera cannot be served by the captured sequence: launch issues the frame eagerly
     uint32_t plane_bits_known = 0;
+    BlockOrder bo;                           // this frame's start order of the blocks (its buffers' addresses are arguments of the captured kernel)
+    bool bo_sorted = false;
     int last_launch = -1;                    // 0 steady state, 1 with the preparation, 2 eager
     double host_update_us = 0.0, host_launch_us = 0.0, host_set_camera_us = 0.0;   // RTMI_GRAPH_DEBUG=1: host time per stage
     uint64_t host_updates = 0, host_launches = 0, host_set_cameras = 0;
@@ -1246,6 +1297,7 @@ static FrameMode graph_mode(rt_frame_graph* g, int which, bool update)
     // without the wave-per-ray kernel nothing reads the marks of the binary records, and the plane bits come by value
     m.parts_drop = (g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u;
     m.fixed_strategy = true; m.packet = g->packet; m.quad = g->quad; m.budget = g->budget;
+    m.block_order = &g->bo;
     return m;
 }
 
@@ -1328,6 +1380,11 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     g->plane_bits_known = 0x80000000u | (plane_bits & 7u);
     g->no_unsafe = g->four_wide && (plane_bits & (g->octant_records ? 6u : 7u)) == 0u;
     g->parts = strategy_parts(b, cam, packet, quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
+    if (g->four_wide && !ctx->no_block_order && block_order_fit(ctx, g->bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u)) {
+        // the captured kernel reads its start order from this graph's own buffer: index order until the first launches have been counted
+        launch_block_order(ctx->stream, g->bo.d_cost, g->bo.d_pairs, g->bo.d_order, g->bo.count, g->bo.cap_pow2, true);
+        g->bo.valid = true;
+    }
     for (int which = 0; which < 2; which++) {
         if (capture_frame(g, which) != RT_SUCCESS) { rt_frame_graph_destroy(g); return RT_ERROR; }
     }
@@ -1421,6 +1478,8 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     if (debug) { g->host_launch_us += now_us() - t1; g->host_launches++; }
     g->launched[which][k] = true;
     g->slot[which] = k;
+    // the blocks' start order follows the costs the kernel counts: sorted behind the first replay, then every few frames
+    if (g->bo.count && g->four_wide && (!g->bo_sorted || ++g->bo.age >= RT_BLOCK_ORDER_REFRESH)) { block_order_refresh(ctx, g->bo); g->bo_sorted = true; }
     if (which == 1) {
         std::memcpy(b->marked_origin, g->origin, sizeof g->origin);
         b->marked_parts = same ? (b->marked_parts | g->parts) : g->parts;
@@ -1447,6 +1506,7 @@ void rt_frame_graph_destroy(rt_frame_graph* g)
         }
         if (g->graph[a]) (void)hipGraphDestroy(g->graph[a]);
     }
+    block_order_free(g->bo);
     delete g;
 }
 

@@ -110,6 +110,17 @@ struct rt_ctx {
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
     unsigned long long* d_clock = nullptr;  // one word: the device clock sample of a calibration
+    bool no_block_order = false;            // knob RTMI_BLOCK_ORDER=0: waves walk the blocks in index order
+};
+
+// Start order of a frame's 8x8 blocks by their cost in an earlier frame (trace_kernels.hip, launch_block_order): the buffers of one
+// frame shape -- the BVH's for eager frames, a frame graph's own for captured ones (their addresses are kernel arguments)
+struct BlockOrder {
+    uint32_t* d_cost = nullptr; uint32_t* d_order = nullptr; uint2* d_pairs = nullptr;
+    uint32_t cap = 0, cap_pow2 = 0;         // blocks the buffers hold / pairs
+    uint32_t count = 0;                     // blocks of the frame shape the order is for
+    bool valid = false;                     // d_order holds a permutation of [0, count)
+    uint32_t age = 0;                       // frames since the order was last derived from the costs
 };
 
 struct rt_scene {
@@ -171,6 +182,7 @@ struct rt_bvh {
     struct TunedEntry { uint64_t key = 0; uint32_t budget = 0; bool packet = false, quad = false, valid = false; };
     TunedEntry tuned_cache[4];
     uint32_t tuned_cache_next = 0;
+    BlockOrder block_order;                 // eager frames
     uint32_t calibration_launches = 0;      // full-size launches the last calibration took (diagnostic)
     float calibration_gpu_ms = 0.f;         // ... and their device time
     uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)
@@ -292,6 +304,8 @@ struct TraceLaunch {
     uint32_t prepare_parts;       // RT_PREP_* to (re)compute before the trace (0: nothing)
     uint32_t octant_mask;         // primary rays, four-wide kernel on per-octant records: the octant copies that are valid
     uint32_t plane_bits_known;    // 0x80000000 | bits: the host knows the camera-on-a-plane bits (else the kernels read tree_select)
+    const uint32_t* block_order;  // four-wide kernel: wave -> block permutation (null: identity)
+    uint32_t* block_cost;         // ... and where it counts this frame's steps per block (null: not counted)
     unsigned long long cal_deadline;   // calibration launches (tag 1): device clock value after which the kernels stop walking, 0 = none
     const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)
     const QuadNode* quad;         // four-wide records (null: the packet kernel walks the binary records)
@@ -336,7 +350,8 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);   // t.prepare_parts
-void launch_device_clock(hipStream_t s, unsigned long long* d_out);      // the clock the calibration deadlines are on (s_memrealtime)
+void launch_device_clock(hipStream_t s, unsigned long long* d_out);
+void launch_block_order(hipStream_t s, const uint32_t* cost, uint2* pairs, uint32_t* order, uint32_t blocks, uint32_t n_pow2, bool identity);      // the clock the calibration deadlines are on (s_memrealtime)
 size_t trace_ctrl_bytes();
 size_t trace_task_bytes(uint32_t cap_per_shard);
 size_t trace_ctrl_error_offset();

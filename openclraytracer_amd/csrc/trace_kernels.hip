@@ -133,6 +133,8 @@ struct TraceArgs {
     uint32_t plane_bits_known;                  // 0x80000000 | those bits when the host knows them (movable frame graphs): tree_select is not read
     uint32_t octant_mask;                       // four-wide kernel on per-octant records: bit o = the copy of octant o is valid for this camera
     uint32_t no_unsafe_rays;                    // the launcher left the wave-per-ray kernel out: a ray handed over would be lost (error bit 6)
+    const uint32_t* __restrict__ block_order;   // four-wide kernel: wave -> 8x8 block (null: identity), the most expensive blocks of an earlier frame first
+    uint32_t* block_cost;                       // ... steps per block of this frame, tasks included (null: not counted)
     unsigned long long cal_deadline;            // calibration launches (CAL = 1) only: device time (s_memrealtime) after which waves stop walking, 0 = none
     const float4* __restrict__ v0;
     const float4* __restrict__ e1;
@@ -1156,6 +1158,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
     const bool helper = wave_gid >= n_block_waves;       // SHARE only: the grid ends with waves that have no block of their own
     // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
     uint32_t job_w0 = wave_gid << 6, job_node = 0u;
+    if (!helper && a.block_order != nullptr) job_w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.block_order[wave_gid]) << 6;
     unsigned long long job_mask = 0ull;
     bool is_task = false, have = !helper;
 #if RTMI_P4_VARIANT == 3
@@ -1237,6 +1240,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 #if RTMI_P4_VARIANT >= 2
         uint32_t nsteps = 0;
 #endif
+        uint32_t cost_steps = 0;
         // OCT: the lanes walk in groups of one direction octant each, on that octant's copy of the records (near / far planes in
         // place, child_mask_octant).  All but the blocks on the image's centre lines are one group; a task's lanes come out
         // of one group and are one again.  Without the copies: one group on the general records.
@@ -1410,9 +1414,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
 #if RTMI_P4_VARIANT >= 2
             nsteps++;
 #endif
+            cost_steps++;
         }
         }                                                // next octant group
         const TraceArgs& A = SHARE ? rare_args<4>() : a;
+        // what this block cost, for the start order of later frames (launch_block_order): its own steps; a block that shared sub-trees
+        // ranks before every block that did not
+        if (A.block_cost != nullptr && lane == 0 && !(SHARE && is_task)) A.block_cost[job_w0 >> 6] = cost_steps + (split ? 0x10000u : 0u);
 #if RTMI_P4_VARIANT == 2
         if (lane == 0) {
             __hip_atomic_fetch_add((gu32*)&A.ctrl->long_steps, (uint32_t)(tA >> 6), RLX_AGENT);
@@ -1952,6 +1960,7 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     if (a.quad) a.quad = t.quad_cam;                  // boxes minus the camera position (k_prepare_camera)
     a.quad_octant_records = (a.quad && t.quad_cam_variants == 9u) ? (t.n_leaves - 1u) * (t.search_root ? 2u : 1u) : 0u;
     a.octant_mask = t.octant_mask; a.plane_bits_known = t.plane_bits_known; a.cal_deadline = t.tag == 1 ? t.cal_deadline : 0ull;
+    a.block_order = t.block_order; a.block_cost = t.block_cost;
     if (t.prepare_parts) {
         const float origin[3] = { cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11] };
         launch_prepare_camera(s, t, origin);
@@ -1983,6 +1992,35 @@ void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float orig
     if (grid == 0u) return;
     if ((a.parts & RT_PREP_MARKS) && !t.graph_update) (void)hipMemsetAsync(a.select, 0, sizeof(uint32_t), s);
     rt_launch_node(t.graph_record, t.graph_update, RT_NODE_PREP_CAMERA, k_prepare_camera, dim3(grid), dim3(256), s, a);
+}
+
+// Start order of the 8x8 blocks: a launch of one wave per block ends with its longest blocks, which the dispatcher hands out
+// wherever they stand in index order (wave timelines: ManFigure's heaviest blocks start 44-75 us into a 277 us launch and end it).
+// Frames follow each other, so the previous frame knows: the four-wide kernel notes every block's steps, and every few frames
+// the blocks are sorted by that cost, longest first (the library's bitonic network on (~cost, block) pairs); wave w then walks
+// block order[w].  Which block a wave walks changes nothing in any contact.
+__global__ __launch_bounds__(256) void k_block_keys(const uint32_t* __restrict__ cost, uint2* __restrict__ pairs, uint32_t blocks, uint32_t n_pow2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    // (keys ascending = costs descending; a real block's key stays below the padding's, so the first `blocks` sorted values are
+    //  exactly the blocks whatever the network does with equal keys)
+    const uint32_t c = i < blocks ? cost[i] : 0u;
+    pairs[i] = i < blocks ? make_uint2(0xFFFFFFFEu - (c < 0xFFFFFFFEu ? c : 0xFFFFFFFEu), i) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+}
+__global__ __launch_bounds__(256) void k_block_order(const uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t blocks, uint32_t identity)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < blocks) order[i] = identity ? i : pairs[i].y;
+}
+void launch_block_order(hipStream_t s, const uint32_t* cost, uint2* pairs, uint32_t* order, uint32_t blocks, uint32_t n_pow2, bool identity)
+{
+    if (!blocks) return;
+    if (!identity) {
+        hipLaunchKernelGGL(k_block_keys, dim3((n_pow2 + 255) / 256), dim3(256), 0, s, cost, pairs, blocks, n_pow2);
+        launch_bitonic_sort(s, pairs, n_pow2);
+    }
+    hipLaunchKernelGGL(k_block_order, dim3((blocks + 255) / 256), dim3(256), 0, s, pairs, order, blocks, identity ? 1u : 0u);
 }
 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)
