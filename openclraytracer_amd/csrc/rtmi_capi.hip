@@ -153,6 +153,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
     if (const char* env = std::getenv("RTMI_FUSED_FRAMES")) ctx->no_fused_frames = env[0] == '0';
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER")) ctx->no_block_order = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_BLOCK_ORDER_GROUP")) { const uint32_t g = (uint32_t)std::strtoul(env, nullptr, 10); if (g && g <= 64u && !(g & (g - 1u))) { ctx->block_order_group_log = 0; while ((1u << ctx->block_order_group_log) < g) ctx->block_order_group_log++; } }
     if (const char* env = std::getenv("RTMI_SHARE_MIN_BUDGET")) ctx->share_min_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
@@ -645,25 +646,22 @@ static uint32_t calibration_parts(const rt_bvh* b, const rt_camera* cam)
 }
 
 // ---- start order of the blocks (BlockOrder, rtmi_internal.h) -------------------------------------------------------------------
-#define RT_BLOCK_ORDER_REFRESH 32u          // frames between two sorts (a sort of 32 768 pairs is a handful of small launches)
+#define RT_BLOCK_ORDER_REFRESH 32u          // frames between two sorts (one launch of one workgroup, k_block_order)
 static void block_order_free(BlockOrder& o)
 {
     if (o.d_cost) (void)hipFree(o.d_cost);
     if (o.d_order) (void)hipFree(o.d_order);
-    if (o.d_pairs) (void)hipFree(o.d_pairs);
     o = BlockOrder();
 }
 // buffers for a frame of `blocks` blocks; false: none (allocation failed): the frame runs in index order
 static bool block_order_fit(rt_ctx* ctx, BlockOrder& o, uint32_t blocks)
 {
-    if (blocks == 0) return false;
+    if (blocks == 0 || (blocks & 63u) || blocks > (4096u << 6)) return false;     // (what one launch of k_block_order sorts: frames up to 16.7 M pixels)
     if (blocks > o.cap) {
         (void)hipStreamSynchronize(ctx->stream);
         block_order_free(o);
-        uint32_t p2 = 1; while (p2 < blocks) p2 <<= 1;
-        if (hipMalloc((void**)&o.d_cost, (size_t)blocks * 4) != hipSuccess || hipMalloc((void**)&o.d_order, (size_t)blocks * 4) != hipSuccess ||
-            hipMalloc((void**)&o.d_pairs, (size_t)p2 * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); block_order_free(o); return false; }
-        o.cap = blocks; o.cap_pow2 = p2;
+        if (hipMalloc((void**)&o.d_cost, (size_t)blocks * 4) != hipSuccess || hipMalloc((void**)&o.d_order, (size_t)blocks * 4) != hipSuccess) { (void)hipGetLastError(); block_order_free(o); return false; }
+        o.cap = blocks;
     }
     if (o.count != blocks) { o.count = blocks; o.valid = false; o.age = 0; }
     return true;
@@ -671,9 +669,8 @@ static bool block_order_fit(rt_ctx* ctx, BlockOrder& o, uint32_t blocks)
 // the costs the frame just enqueued will have counted -> the order of the following frames (stream-ordered behind that frame)
 static void block_order_refresh(rt_ctx* ctx, BlockOrder& o)
 {
-    uint32_t p2 = 1; while (p2 < o.count) p2 <<= 1;
-    launch_block_order(ctx->stream, o.d_cost, o.d_pairs, o.d_order, o.count, p2, false);
-    o.valid = true; o.age = 0;
+    o.valid = launch_block_order(ctx->stream, o.d_cost, o.d_order, o.count, ctx->block_order_group_log, false);
+    o.age = 0;
 }
 
 // Per-launch options of a primary frame beyond the strategy: a captured / updated frame graph, a fused colour buffer
@@ -1044,6 +1041,20 @@ int rt_bvh_trace_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget)
     return RT_SUCCESS;
 }
 
+int rt_bvh_block_order(rt_bvh* b, uint32_t* h_order, uint32_t* h_cost, uint32_t capacity, uint32_t* blocks)
+{
+    if (!b || !blocks) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
+    rt_ctx* ctx = b->ctx;
+    const BlockOrder& o = b->block_order;
+    *blocks = (o.valid && !ctx->no_block_order) ? o.count : 0u;
+    if (*blocks == 0) return RT_SUCCESS;
+    if (*blocks > capacity) return RT_FAIL(ctx, "rt_bvh_block_order: capacity too small");
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_order) RT_HIP(ctx, hipMemcpy(h_order, o.d_order, (size_t)o.count * 4, hipMemcpyDeviceToHost));
+    if (h_cost) RT_HIP(ctx, hipMemcpy(h_cost, o.d_cost, (size_t)o.count * 4, hipMemcpyDeviceToHost));
+    return RT_SUCCESS;
+}
+
 uint32_t rt_bvh_calibration_launches(const rt_bvh* b) { return b ? b->calibration_launches : 0u; }
 float rt_bvh_calibration_gpu_ms(const rt_bvh* b) { return b ? b->calibration_gpu_ms : 0.f; }
 
@@ -1382,8 +1393,8 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     g->parts = strategy_parts(b, cam, packet, quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
     if (g->four_wide && !ctx->no_block_order && block_order_fit(ctx, g->bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u)) {
         // the captured kernel reads its start order from this graph's own buffer: index order until the first launches have been counted
-        launch_block_order(ctx->stream, g->bo.d_cost, g->bo.d_pairs, g->bo.d_order, g->bo.count, g->bo.cap_pow2, true);
-        g->bo.valid = true;
+        g->bo.valid = launch_block_order(ctx->stream, g->bo.d_cost, g->bo.d_order, g->bo.count, ctx->block_order_group_log, true);
+        if (!g->bo.valid) block_order_free(g->bo);
     }
     for (int which = 0; which < 2; which++) {
         if (capture_frame(g, which) != RT_SUCCESS) { rt_frame_graph_destroy(g); return RT_ERROR; }
@@ -1577,6 +1588,14 @@ static void drop_trace_events(rt_ctx* ctx)
 {
     for (hipEvent_t e : ctx->trace_events) if (e) (void)hipEventDestroy(e);
     ctx->trace_events.clear();
+}
+
+int rt_ctx_set_block_order(rt_ctx* ctx, int mode)
+{
+    if (!ctx) return RT_ERROR;
+    if (mode != 0 && mode != 1) return RT_FAIL(ctx, "rt_ctx_set_block_order: mode is 0 (index order) or 1 (longest first)");
+    ctx->no_block_order = mode == 0;
+    return RT_SUCCESS;
 }
 
 int rt_ctx_set_profiling(rt_ctx* ctx, int enable)

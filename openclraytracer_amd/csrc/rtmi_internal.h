@@ -111,13 +111,14 @@ struct rt_ctx {
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
     unsigned long long* d_clock = nullptr;  // one word: the device clock sample of a calibration
     bool no_block_order = false;            // knob RTMI_BLOCK_ORDER=0: waves walk the blocks in index order
+    uint32_t block_order_group_log = 4;     // knob RTMI_BLOCK_ORDER_GROUP=1..64: consecutive blocks that stay together (a power of two)
 };
 
 // Start order of a frame's 8x8 blocks by their cost in an earlier frame (trace_kernels.hip, launch_block_order): the buffers of one
 // frame shape -- the BVH's for eager frames, a frame graph's own for captured ones (their addresses are kernel arguments)
 struct BlockOrder {
-    uint32_t* d_cost = nullptr; uint32_t* d_order = nullptr; uint2* d_pairs = nullptr;
-    uint32_t cap = 0, cap_pow2 = 0;         // blocks the buffers hold / pairs
+    uint32_t* d_cost = nullptr; uint32_t* d_order = nullptr;
+    uint32_t cap = 0;                       // blocks the buffers hold
     uint32_t count = 0;                     // blocks of the frame shape the order is for
     bool valid = false;                     // d_order holds a permutation of [0, count)
     uint32_t age = 0;                       // frames since the order was last derived from the costs
@@ -350,8 +351,8 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);   // t.prepare_parts
-void launch_device_clock(hipStream_t s, unsigned long long* d_out);
-void launch_block_order(hipStream_t s, const uint32_t* cost, uint2* pairs, uint32_t* order, uint32_t blocks, uint32_t n_pow2, bool identity);      // the clock the calibration deadlines are on (s_memrealtime)
+void launch_device_clock(hipStream_t s, unsigned long long* d_out);      // the clock the calibration deadlines are on (s_memrealtime)
+bool launch_block_order(hipStream_t s, const uint32_t* cost, uint32_t* order, uint32_t blocks, uint32_t group_log, bool identity);
 size_t trace_ctrl_bytes();
 size_t trace_task_bytes(uint32_t cap_per_shard);
 size_t trace_ctrl_error_offset();

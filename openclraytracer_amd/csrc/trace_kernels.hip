@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
     const bool helper = wave_gid >= n_block_waves;       // SHARE only: the grid ends with waves that have no block of their own
     // one wave per 8x8-pixel block: the hardware dispatcher is the work queue
     uint32_t job_w0 = wave_gid << 6, job_node = 0u;
-    if (!helper && a.block_order != nullptr) job_w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.block_order[wave_gid]) << 6;
+    if (!helper && a.block_order != nullptr) job_w0 = a.block_order[__builtin_amdgcn_readfirstlane((int)wave_gid)] << 6;      // (uniform index: a scalar load)
     unsigned long long job_mask = 0ull;
     bool is_task = false, have = !helper;
 #if RTMI_P4_VARIANT == 3
@@ -1999,28 +1999,44 @@ void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float orig
 // Frames follow each other, so the previous frame knows: the four-wide kernel notes every block's steps, and every few frames
 // the blocks are sorted by that cost, longest first (the library's bitonic network on (~cost, block) pairs); wave w then walks
 // block order[w].  Which block a wave walks changes nothing in any contact.
-__global__ __launch_bounds__(256) void k_block_keys(const uint32_t* __restrict__ cost, uint2* __restrict__ pairs, uint32_t blocks, uint32_t n_pow2)
+#define BLOCK_ORDER_GROUPS 4096u          // groups one workgroup sorts in LDS (32 KB of pairs)
+// One workgroup, one launch: the groups' costs -> keys -> bitonic network in LDS -> order[].  `1 << group_log` consecutive blocks
+// keep their places next to each other: neighbouring blocks walk the same records, and consecutive waves land on the same CU
+// (scalar cache) and XCD (L2).  Keys ascending = costs descending, ties by index (the pair is compared as a whole, so the network's
+// result does not depend on its shape); p2 = groups rounded up to a power of two, the padding sorts behind every group.
+__global__ __launch_bounds__(1024) void k_block_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t blocks,
+                                                      uint32_t group_log, uint32_t groups, uint32_t p2, uint32_t identity)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pow2) return;
-    // (keys ascending = costs descending; a real block's key stays below the padding's, so the first `blocks` sorted values are
-    //  exactly the blocks whatever the network does with equal keys)
-    const uint32_t c = i < blocks ? cost[i] : 0u;
-    pairs[i] = i < blocks ? make_uint2(0xFFFFFFFEu - (c < 0xFFFFFFFEu ? c : 0xFFFFFFFEu), i) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-}
-__global__ __launch_bounds__(256) void k_block_order(const uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t blocks, uint32_t identity)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < blocks) order[i] = identity ? i : pairs[i].y;
-}
-void launch_block_order(hipStream_t s, const uint32_t* cost, uint2* pairs, uint32_t* order, uint32_t blocks, uint32_t n_pow2, bool identity)
-{
-    if (!blocks) return;
-    if (!identity) {
-        hipLaunchKernelGGL(k_block_keys, dim3((n_pow2 + 255) / 256), dim3(256), 0, s, cost, pairs, blocks, n_pow2);
-        launch_bitonic_sort(s, pairs, n_pow2);
+    __shared__ uint2 t[BLOCK_ORDER_GROUPS];
+    if (identity) { for (uint32_t i = threadIdx.x; i < blocks; i += 1024u) order[i] = i; return; }
+    for (uint32_t i = threadIdx.x; i < p2; i += 1024u) {
+        uint32_t c = 0;
+        if (i < groups) for (uint32_t k = 0; k < (1u << group_log); k++) { const uint32_t v = cost[(i << group_log) + k]; c = c + v < c ? 0xFFFFFFFEu : c + v; }
+        t[i] = i < groups ? make_uint2(0xFFFFFFFEu - (c < 0xFFFFFFFEu ? c : 0xFFFFFFFEu), i) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     }
-    hipLaunchKernelGGL(k_block_order, dim3((blocks + 255) / 256), dim3(256), 0, s, pairs, order, blocks, identity ? 1u : 0u);
+    __syncthreads();
+    for (uint32_t len = 2; len <= p2; len <<= 1)
+        for (uint32_t inc = len >> 1; inc; inc >>= 1) {
+            for (uint32_t i = threadIdx.x; i < (p2 >> 1); i += 1024u) {
+                const uint32_t lo = (i << 1) - (i & (inc - 1u)), hi = lo + inc;
+                const uint2 a = t[lo], b = t[hi];
+                const bool greater = a.x > b.x || (a.x == b.x && a.y > b.y);
+                if (greater == !(lo & len)) { t[lo] = b; t[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < blocks; i += 1024u) order[i] = (t[i >> group_log].y << group_log) | (i & ((1u << group_log) - 1u));
+}
+// group_log: as asked for, raised until the frame's groups fit one workgroup; false = a frame too large for that (blocks stay in index order)
+bool launch_block_order(hipStream_t s, const uint32_t* cost, uint32_t* order, uint32_t blocks, uint32_t group_log, bool identity)
+{
+    if (!blocks) return false;
+    while (group_log < 6u && (blocks >> group_log) > BLOCK_ORDER_GROUPS) group_log++;
+    const uint32_t groups = blocks >> group_log;             // the tiled enumeration's blocks come in multiples of 64 (one 64x64 tile)
+    if (groups > BLOCK_ORDER_GROUPS || (groups << group_log) != blocks) return false;
+    uint32_t p2 = 1; while (p2 < groups) p2 <<= 1;
+    hipLaunchKernelGGL(k_block_order, dim3(1), dim3(1024), 0, s, cost, order, blocks, group_log, groups, p2, identity ? 1u : 0u);
+    return true;
 }
 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)

@@ -1287,3 +1287,72 @@ def test_cpp_reference_frame_loop(gpu_ctx, tmp_path):
     assert ((a != 0).any(axis=2) == (b != 0).any(axis=2)).all() and (b != 0).any()
     err = np.abs(a - b) / np.maximum(np.abs(a), 1e-30)
     assert float(np.where(a == b, 0.0, err).max()) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('group', ['1', '16', '64'])
+def test_block_start_order_changes_no_bit(group, monkeypatch):
+    """The four-wide kernel starts a frame's blocks in the order of their step counts in earlier frames (rt_ctx_set_block_order,
+    k_block_order): the order is a permutation of the blocks in groups of `group` neighbours, most expensive group first, and
+    contacts and colours are the bits of the index-order frames -- eager frames over two refreshes of the order with a camera
+    that moves, a frame graph replayed over two refreshes, and the sub-tree sharing (budget 128) included."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    monkeypatch.setenv('RTMI_PACKET', '4')
+    monkeypatch.setenv('RTMI_DEFER_BUDGET', '128')
+    monkeypatch.setenv('RTMI_BLOCK_ORDER_GROUP', group)
+    name, res = 'man', (448, 320)
+    npx = res[0] * res[1]
+    osc, ob = oracle_bvh(name)
+    cams = []
+    for i in range(4):
+        cam = osc.demo_camera(*res).copy()
+        cam['m'][0][3] += np.float32(0.03 * i)
+        cams.append(as_capi_camera(cam))
+    ctxs = [capi.Context(0), capi.Context(0)]
+    try:
+        ctxs[1].set_block_order(False)
+        scs = [capi.DeviceScene(c, packed_scene(name)) for c in ctxs]
+        bvhs = [capi.DeviceBVH(c, s).build() for c, s in zip(ctxs, scs)]
+        assert bvhs[1].block_order() is None
+        g = int(group)
+        for k in range(70):                                   # refreshes behind frames 1, 33 and 65
+            cam = cams[(k // 9) % 4]
+            a = bvhs[0].generate_contacts_primary(cam)
+            if k in (0, 1, 2, 32, 33, 34, 66, 69):
+                b = bvhs[1].generate_contacts_primary(cam)
+                assert a.tobytes() == b.tobytes(), k
+            if k in (1, 40, 69):
+                order, cost = bvhs[0].block_order()
+                blocks = len(order)
+                assert blocks % 64 == 0 and blocks * 64 >= npx
+                assert np.array_equal(np.sort(order), np.arange(blocks, dtype=np.uint32))
+                assert np.array_equal(order.reshape(-1, g) - order.reshape(-1, g)[:, :1], np.tile(np.arange(g, dtype=np.uint32), (blocks // g, 1)))
+                assert not np.array_equal(order, np.arange(blocks, dtype=np.uint32))
+                assert cost.max() > 4 * max(1, int(np.median(cost)))          # what the order is for: a few blocks cost a multiple
+        # the order in use is the one sorted from the costs counted 6 frames ago, same camera since frame 63: most expensive group first
+        order, cost = bvhs[0].block_order()
+        sums = cost.astype(np.int64).reshape(-1, g).sum(1)
+        first = order[::g] // g
+        assert sums[first[0]] == sums.max()
+        assert sums[first[:len(first) // 8]].mean() > sums.mean()
+        # a frame graph (its own order, sorted behind its first replay and every 32 after that) against the index-order graph
+        outs = []
+        for c, s, b in zip(ctxs, scs, bvhs):
+            d_c, d_o = c.alloc(npx * 32), c.alloc(npx * 16)
+            fg = capi.FrameGraph(b, s, cams[0], d_c, d_o)
+            frames = []
+            for k in range(36):
+                fg.launch()
+                if k in (0, 1, 35):
+                    c.synchronize()
+                    frames.append((c.download(d_c, npx * 32, np.uint8).tobytes(), c.download(d_o, npx * 16, np.uint8).tobytes()))
+            outs.append(frames)
+            fg.close()
+            c.free(d_c); c.free(d_o)
+        assert outs[0] == outs[1]
+        assert outs[0][0] == outs[0][2]
+        assert outs[0][0][0] == bvhs[1].generate_contacts_primary(cams[0]).tobytes()
+    finally:
+        for c in ctxs:
+            c.close()
