@@ -308,10 +308,12 @@ struct Dda {
     float nx, ny, nz;        // next[]
     float dtx, dty, dtz;     // dt[]
     int ix, iy, iz;          // idx[]
-    int sx, sy, sz;          // step[]
-    int ex, ey, ez;          // stop[]
     float t0, tmaxmax;
 };
+// step[] and stop[] (TwoLevelGrid.h:470-490 / :610-630) are functions of the direction's sign and the resolution alone
+// (d > 0: +1 / res, else -1 / -1) and the same at both levels: not kept in registers (18 VGPRs = one wave per SIMD), evaluated
+// from these three bits when an index advances
+struct DdaSigns { bool px, py, pz; };
 
 __device__ __forceinline__ void dda_axis_setup(float o, float d, float lo, float hi, uint32_t res, float& tmin, float& tmax)
 {
@@ -321,7 +323,7 @@ __device__ __forceinline__ void dda_axis_setup(float o, float d, float lo, float
 }
 
 __device__ __forceinline__ void dda_axis_finish(float p, float d, float lo, float hi, uint32_t res, float tmin, float tmax,
-                                                float& next, float& dt, int& idx, int& step, int& stop)
+                                                float& next, float& dt, int& idx)
 {
     float f = (p - lo) * (float)res / (hi - lo);
     const float top = (float)res - 1;
@@ -330,10 +332,8 @@ __device__ __forceinline__ void dda_axis_finish(float p, float d, float lo, floa
     dt = (tmax - tmin) / (float)res;
     if (d > 0.0f) {
         next = tmin + (float)(idx + 1) * dt;
-        step = 1; stop = (int)res;
     } else {
         next = d == 0.0f ? FLT_MAX : tmin + (float)(res - (uint32_t)idx) * dt;
-        step = -1; stop = -1;
     }
 }
 
@@ -348,9 +348,9 @@ __device__ __forceinline__ void dda_setup(f3 o, f3 d, f3 lo, f3 hi, uint32_t rx,
     const bool inside = (lo.x <= o.x) && (o.x <= hi.x) && (lo.y <= o.y) && (o.y <= hi.y) && (lo.z <= o.z) && (o.z <= hi.z);
     f3 p = o;
     if (!inside) p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
-    dda_axis_finish(p.x, d.x, lo.x, hi.x, rx, txmin, txmax, s.nx, s.dtx, s.ix, s.sx, s.ex);
-    dda_axis_finish(p.y, d.y, lo.y, hi.y, ry, tymin, tymax, s.ny, s.dty, s.iy, s.sy, s.ey);
-    dda_axis_finish(p.z, d.z, lo.z, hi.z, rz, tzmin, tzmax, s.nz, s.dtz, s.iz, s.sz, s.ez);
+    dda_axis_finish(p.x, d.x, lo.x, hi.x, rx, txmin, txmax, s.nx, s.dtx, s.ix);
+    dda_axis_finish(p.y, d.y, lo.y, hi.y, ry, tymin, tymax, s.ny, s.dty, s.iy);
+    dda_axis_finish(p.z, d.z, lo.z, hi.z, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
 }
 
 // `minimal = min(next[x], min(next[y], next[z])); while (minimal != next[axis]) axis++`; -1: no axis (all NaN), the
@@ -363,13 +363,13 @@ __device__ __forceinline__ int dda_axis(const Dda& s)
 
 // next[axis] += dt[axis]; idx[axis] += step[axis]; returns idx[axis] == stop[axis]
 // (value selects on purpose: with branches the compiler turns next[] / dt[] / idx[] back into a scratch array indexed by axis)
-__device__ __forceinline__ bool dda_advance(Dda& s, int axis)
+__device__ __forceinline__ bool dda_advance(Dda& s, int axis, const DdaSigns& g, uint32_t rx, uint32_t ry, uint32_t rz)
 {
     const bool a0 = axis == 0, a1 = axis == 1, a2 = !(a0 | a1);
     const float nx = s.nx + s.dtx, ny = s.ny + s.dty, nz = s.nz + s.dtz;
     s.nx = a0 ? nx : s.nx; s.ny = a1 ? ny : s.ny; s.nz = a2 ? nz : s.nz;
-    s.ix += a0 ? s.sx : 0; s.iy += a1 ? s.sy : 0; s.iz += a2 ? s.sz : 0;
-    const bool hx = s.ix == s.ex, hy = s.iy == s.ey, hz = s.iz == s.ez;
+    s.ix += a0 ? (g.px ? 1 : -1) : 0; s.iy += a1 ? (g.py ? 1 : -1) : 0; s.iz += a2 ? (g.pz ? 1 : -1) : 0;
+    const bool hx = s.ix == (g.px ? (int)rx : -1), hy = s.iy == (g.py ? (int)ry : -1), hz = s.iz == (g.pz ? (int)rz : -1);
     return (a0 & hx) | (a1 & hy) | (a2 & hz);
 }
 
@@ -385,45 +385,58 @@ __device__ unsigned long long g_tlg_diag[96];
 #define TLG_DIAG_HIST(n)
 #endif
 
+// Registers set this kernel's occupancy (round 3's counters: a wave issues for 35 % of its life and is parked on loads for 43 %; five
+// waves per SIMD kept the vector unit 50 % busy).  Six waves per SIMD = 80 VGPRs (86 before), reached by (a) step[] / stop[] as
+// functions of three sign bits (DdaSigns) and (b) the pixel located again for the store instead of kept: config 4's trace 3.57 ->
+// 3.36-3.41 ms.  Measured beyond that and not kept: seven waves (72 VGPRs: the top level's next[] / dt[] / idx[] in LDS, [k][lane]
+// with the axis as the index, 16-bit mailbox tags so that nine blocks fit a CU's LDS) 3.35-3.47; eight (spills) 3.77; fetching the next
+// top-level cell / the next leaf range before the current one is worked on 3.62 / 3.63 (the copies of the DDA state cost what the
+// overlap gains) -- only the next PAIR id is fetched early (3.56 -> 3.48).
+#ifndef TLG_WAVES
+#define TLG_WAVES 6
+#endif
 template <int PRIMARY>
-__global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_tlg_trace(TlgTraceArgs a)
+__global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_WAVES, TLG_WAVES))) void k_tlg_trace(TlgTraceArgs a)
 {
     // Mailbox: a triangle lies in every leaf cell it overlaps, so a ray marching through the grid meets it again and again
     // (61 % of all tests on the atrium).  The reference returns from the first leaf cell in which ANY triangle is hit
     // (TwoLevelGrid.h:528-540), so whatever this ray tested before the current cell was a miss, and testing it again gives
     // the same miss: the test is skipped when the triangle sits in a 16-entry direct-mapped table of tested triangles
-    // (per lane, LDS [entry][lane]: conflict free).  Results are unchanged by construction.
-    __shared__ uint32_t s_mailbox[16][TLG_BLOCK];
+    // (per lane, LDS [entry][lane]; entry = id & 15, tag = id >> 4).  Results are unchanged by construction.
+    typedef uint32_t mail_t;
+    __shared__ mail_t s_mailbox[16][TLG_BLOCK];
     const uint32_t w = blockIdx.x * TLG_BLOCK + threadIdx.x;
     if (w >= a.total_work) return;
 #pragma unroll
-    for (int k = 0; k < 16; k++) s_mailbox[k][threadIdx.x] = 0xFFFFFFFFu;
+    for (int k = 0; k < 16; k++) s_mailbox[k][threadIdx.x] = (mail_t)~0u;
     f3 o, d;
-    uint32_t pixel, out_index;
-    if (PRIMARY) {
-        // work item -> pixel: this rank's 64x64 tiles, inside a tile 8x8 blocks (one wave = one block), as in trace_kernels.hip
+    // work item -> pixel: this rank's 64x64 tiles, inside a tile 8x8 blocks (one wave = one block), as in trace_kernels.hip; evaluated
+    // here for the ray and again for the store (two registers that would live through the whole walk otherwise)
+    auto locate = [&](uint32_t& x, uint32_t& y, uint32_t& slot) {
         const uint32_t ordinal = w >> 12, within = w & 4095u;
         const uint32_t tile = rt_tile_of(a.rank, ordinal, a.nranks);
         const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const uint32_t blk = within >> 6, lp = within & 63u;
         const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3), lx = ((blk & 7u) << 3) + (lp & 7u);
-        const uint32_t x = tx * RT_TILE + lx, y = ty * RT_TILE + ly;
+        x = tx * RT_TILE + lx; y = ty * RT_TILE + ly;
+        slot = (ordinal << 12) + ly * RT_TILE + lx;
+    };
+    if (PRIMARY) {
+        uint32_t x, y, slot;
+        locate(x, y, slot);
         if (x >= a.cam.resX || y >= a.cam.resY) {
             if (a.compact) {         // slot of a border tile outside the frame: defined as "no contact", as in the BVH kernels
-                float4* z = reinterpret_cast<float4*>(a.out + ((ordinal << 12) + ly * RT_TILE + lx));
+                float4* z = reinterpret_cast<float4*>(a.out + slot);
                 z[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 z[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             return;
         }
         generate_ray_xy(a.cam, x, y, o, d);
-        pixel = y * a.cam.resX + x;
-        out_index = a.compact ? (ordinal << 12) + ly * RT_TILE + lx : pixel;
     } else {
         const float4* p = reinterpret_cast<const float4*>(a.rays + w);
         const float4 ro = p[1], rd = p[2];
         o = f3{ ro.x, ro.y, ro.z }; d = f3{ rd.x, rd.y, rd.z };
-        pixel = w; out_index = w;
     }
     const rt_grid_data& g = a.grid;
     const f3 glo = f3{ g.box_lo[0], g.box_lo[1], g.box_lo[2] }, ghi = f3{ g.box_hi[0], g.box_hi[1], g.box_hi[2] };
@@ -431,18 +444,20 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
     float best_t = 0.0f;                    // NO_CONTACT (CLStructs.h:124)
     uint32_t best_tri = 0xFFFFFFFFu;
 
+    const DdaSigns sg = DdaSigns{ d.x > 0.0f, d.y > 0.0f, d.z > 0.0f };
+    bool done;
     Dda T;
     dda_setup(o, d, glo, ghi, g.resX, g.resY, g.resZ, T);
-    bool done = T.t0 > T.tmaxmax;            // TwoLevelGrid.h:590-591
+    done = T.t0 > T.tmaxmax;
     while (!done) {
         TLG_DIAG(0, 1);
-        const rt_top_cell tc = a.top[(uint32_t)T.iz * g.resX * g.resY + (uint32_t)T.iy * g.resX + (uint32_t)T.ix];
-        const int taxis = dda_axis(T);
+        const int tix = T.ix, tiy = T.iy, tiz = T.iz;
+        const rt_top_cell tc = a.top[(uint32_t)tiz * g.resX * g.resY + (uint32_t)tiy * g.resX + (uint32_t)tix];
         if (!(tc.resX == 0 || tc.resY == 0 || tc.resZ == 0)) {
             TLG_DIAG(2, 3);
             // processTopLevelCell, TwoLevelGrid.h:419-545
             f3 clo, chi;
-            clo.x = glo.x + (float)T.ix * g.stepX; clo.y = glo.y + (float)T.iy * g.stepY; clo.z = glo.z + (float)T.iz * g.stepZ;
+            clo.x = glo.x + (float)tix * g.stepX; clo.y = glo.y + (float)tiy * g.stepY; clo.z = glo.z + (float)tiz * g.stepZ;
             chi.x = clo.x + g.stepX; chi.y = clo.y + g.stepY; chi.z = clo.z + g.stepZ;
             Dda Lf;
             dda_setup(o, d, clo, chi, tc.resX, tc.resY, tc.resZ, Lf);
@@ -454,12 +469,16 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
                 const uint32_t leaf = (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
                 const uint2 range = a.leaf_ranges[leaf];
                 TLG_DIAG_HIST(range.y - range.x);
+                // (the next pair id is fetched while this triangle is tested: one dependent load less per entry)
+                uint32_t tri_next = range.x < range.y ? a.leaf_pairs[range.x].y : 0u;
                 for (uint32_t i = range.x; i < range.y; i++) {
                     TLG_DIAG(6, 7);
-                    const uint32_t tri = a.leaf_pairs[i].y;
-                    uint32_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
-                    if (*slot == tri) continue;                               // tested in an earlier cell: a miss, again
-                    *slot = tri;
+                    const uint32_t tri = tri_next;
+                    if (i + 1u < range.y) tri_next = a.leaf_pairs[i + 1u].y;
+                    mail_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
+                    const mail_t tag = (mail_t)(tri >> 4);
+                    if (*slot == tag) continue;                // tested in an earlier cell: a miss, again
+                    *slot = tag;
                     TLG_DIAG(8, 9);
                     // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
                     // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
@@ -490,12 +509,15 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
                 }
                 if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
                 if (laxis < 0) break;
-                if (dda_advance(Lf, laxis)) break;                        // :542-545
+                if (dda_advance(Lf, laxis, sg, tc.resX, tc.resY, tc.resZ)) break;   // :542-545
             }
             if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
         }
+        // :660-676 -- the axis of the smallest next[] (chosen before the cell is processed in the reference; nothing in between changes
+        // next[]), `next[axis] += dt[axis]; idx[axis] += step[axis]; if (idx[axis] == stop[axis]) break`
+        const int taxis = dda_axis(T);
         if (taxis < 0) break;
-        if (dda_advance(T, taxis)) break;                                 // :672-676
+        if (dda_advance(T, taxis, sg, g.resX, g.resY, g.resZ)) break;
     }
 
     float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -504,6 +526,13 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 5)
         const float4 n = a.nrm[best_tri];
         nt = make_float4(n.x, n.y, n.z, best_t);
         material = __float_as_uint(a.v0[best_tri].w);
+    }
+    uint32_t pixel = w, out_index = w;
+    if (PRIMARY) {
+        uint32_t x, y, slot;
+        locate(x, y, slot);
+        pixel = y * a.cam.resX + x;
+        out_index = a.compact ? slot : pixel;
     }
     const uint4 head = make_uint4(pixel, material, 0u, 0u);
     float4* dst = reinterpret_cast<float4*>(a.out + out_index);
