@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
     if (i >= a.count) return;
     // contacts are 32 B: two float4 loads
     const float4* p = reinterpret_cast<const float4*>(a.contacts + i);
-    float4 h = p[0], nt = p[1];
+    const float4 h = load16_stream(p), nt = load16_stream(p + 1);
     rt_contact c;
     c.pixelIndex = __float_as_uint(h.x); c.materialIndex = __float_as_uint(h.y); c.pad[0] = 0; c.pad[1] = 0;
     c.normalAndDistance[0] = nt.x; c.normalAndDistance[1] = nt.y; c.normalAndDistance[2] = nt.z; c.normalAndDistance[3] = nt.w;
@@ -39,13 +39,13 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
         float* planes = reinterpret_cast<float*>(a.rgba);
         float4 col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (nt.w > 0.0f) { col = shade_one(a.sc, a.cam, c); col.x = __uint_as_float(__float_as_uint(col.x) | 0x80000000u); }
-        planes[i] = col.x;
-        planes[(size_t)a.plane_stride + i] = col.y;
-        planes[2u * (size_t)a.plane_stride + i] = col.z;
+        store4_stream(planes + i, col.x);
+        store4_stream(planes + (size_t)a.plane_stride + i, col.y);
+        store4_stream(planes + 2u * (size_t)a.plane_stride + i, col.z);
         return;
     }
-    if (nt.w > 0.0f) a.rgba[a.tiled ? i : c.pixelIndex] = shade_one(a.sc, a.cam, c);
-    else if (a.tiled) a.rgba[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (nt.w > 0.0f) store16_stream(a.rgba + (a.tiled ? i : c.pixelIndex), shade_one(a.sc, a.cam, c));
+    else if (a.tiled) store16_stream(a.rgba + i, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 }
 
 void launch_shade(hipStream_t s, const DeviceScene& sc, const rt_camera& cam, const rt_contact* contacts,

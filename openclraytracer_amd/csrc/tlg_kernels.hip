@@ -536,8 +536,8 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     }
     const uint4 head = make_uint4(pixel, material, 0u, 0u);
     float4* dst = reinterpret_cast<float4*>(a.out + out_index);
-    dst[0] = *reinterpret_cast<const float4*>(&head);
-    dst[1] = nt;
+    store16_stream(dst, *reinterpret_cast<const float4*>(&head));
+    store16_stream(dst + 1, nt);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -521,8 +521,8 @@ __device__ __forceinline__ void store_contact(const TraceArgs& a, uint32_t out_i
     }
     uint4 head = make_uint4(pixel, material, 0u, 0u);
     float4* o = reinterpret_cast<float4*>(a.out + out_index);
-    o[0] = *reinterpret_cast<float4*>(&head);
-    o[1] = nt;
+    store16_stream(o, *reinterpret_cast<float4*>(&head));
+    store16_stream(o + 1, nt);
 }
 
 // ... and, in a fused frame, its colour: what k_shade computes from the contact just written, at the index k_shade writes it to
@@ -541,11 +541,11 @@ __device__ __forceinline__ void store_colour(const TraceArgs& a, uint32_t out_in
     if (a.fused_plane_stride) {
         float* planes = reinterpret_cast<float*>(a.fused_rgba);
         if (hit) col.x = __uint_as_float(__float_as_uint(col.x) | 0x80000000u);
-        planes[out_index] = col.x;
-        planes[(size_t)a.fused_plane_stride + out_index] = col.y;
-        planes[2u * (size_t)a.fused_plane_stride + out_index] = col.z;
+        store4_stream(planes + out_index, col.x);
+        store4_stream(planes + (size_t)a.fused_plane_stride + out_index, col.y);
+        store4_stream(planes + 2u * (size_t)a.fused_plane_stride + out_index, col.z);
     } else {
-        a.fused_rgba[out_index] = col;
+        store16_stream(a.fused_rgba + out_index, col);
     }
 }
 
