@@ -121,6 +121,9 @@ int  rt_bvh_generate_contacts_rays(rt_bvh* bvh, const void* d_rays, uint32_t ray
 /* parity/debug read-backs in the reference's own layouts (blocking) */
 int  rt_bvh_read_nodes(const rt_bvh* bvh, void* h_nodes /* (2n-1) * 48 B */);
 int  rt_bvh_read_morton_pairs(const rt_bvh* bvh, void* h_pairs /* N * 8 B */, uint32_t* n_pow2);
+/* test / inspection: the search tree primary rays walk (rt_bvh_search_tree), in the reference's node layout: the same n leaf nodes,
+ * then its own n - 1 inner nodes (root = node n); fails when the BVH has none (environment RTMI_SEARCH_TREE=0, LITERAL_ZERO mode) */
+int  rt_bvh_read_search_nodes(const rt_bvh* bvh, void* h_nodes /* (2n-1) * 48 B */);
 int  rt_bvh_info(const rt_bvh* bvh, uint32_t* leaves, uint32_t* morton_items, uint32_t* max_depth);
 /* How primary frames of this BVH are traced: *packet_kernel = 0 lane-per-ray kernel, 1 packet kernel (one 8x8 pixel block
  * per wave, node records through the scalar path), 2 four-wide packet kernel (records that hold a node's grandchildren: one

@@ -230,8 +230,18 @@ void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, ui
 // mergeBoundingBox (BVH.h:328-334) = merge3 (AABB.h:107-113) on all four lanes: child A, child B, then the node's own box,
 // which still holds what constructNode gave it: (FLT_MAX, FLT_MAX, FLT_MAX, 0) / (FLT_MIN, FLT_MIN, FLT_MIN, 0).  The
 // operand order matters for ties (RMIN / RMAX return their second operand unless the first is strictly smaller / larger).
+// TIGHT (the search tree, whose boxes are ours to choose as long as they nest): the union and nothing else.  The
+// reference's init box makes every maximum at least FLT_MIN, i.e. every box of a model's negative half reach to the plane 0 -- on
+// ManFigure (x in [-8, 8], z in [-2.2, 1.2]) that trebles the summed surface area of the inner boxes, and with it the boxes a ray
+// enters for nothing (round 3: 47 -> 13 four-wide steps per 8x8 block, tools/tree_quality.py).
+template <bool TIGHT>
 __device__ __forceinline__ void refit_merge(float4 alo, float4 ahi, float4 blo, float4 bhi, float4& rlo, float4& rhi)
 {
+    if (TIGHT) {
+        rlo.x = RMIN(alo.x, blo.x); rlo.y = RMIN(alo.y, blo.y); rlo.z = RMIN(alo.z, blo.z); rlo.w = 0.0f;
+        rhi.x = RMAX(ahi.x, bhi.x); rhi.y = RMAX(ahi.y, bhi.y); rhi.z = RMAX(ahi.z, bhi.z); rhi.w = 0.0f;
+        return;
+    }
     const float4 slo = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.0f), shi = make_float4(FLT_MIN, FLT_MIN, FLT_MIN, 0.0f);
     float4 t;
     t.x = RMIN(alo.x, blo.x); t.y = RMIN(alo.y, blo.y); t.z = RMIN(alo.z, blo.z); t.w = RMIN(alo.w, blo.w);
@@ -249,6 +259,7 @@ __device__ __forceinline__ void refit_merge(float4 alo, float4 ahi, float4 blo, 
 //     behind an agent-scope release, the second reads it after an agent-scope acquire (per-CU L1 and per-XCD L2 are not
 //     coherent, MI355X_MICROARCH "inter-workgroup visibility").
 // Same merges in the same operand order as one walker per leaf with a counter at every node, hence the same bytes.
+template <bool TIGHT>
 __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
 {
     const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
     uint32_t ca = nodes[current].data[1], cb = nodes[current].data[2];
     if (ca != leaf || cb >= n) return;                     // walkers start at (leaf, leaf) nodes, from child A
     float4 lo, hi;
-    refit_merge(*reinterpret_cast<const float4*>(nodes[ca].boundsMin), *reinterpret_cast<const float4*>(nodes[ca].boundsMax),
+    refit_merge<TIGHT>(*reinterpret_cast<const float4*>(nodes[ca].boundsMin), *reinterpret_cast<const float4*>(nodes[ca].boundsMax),
                 *reinterpret_cast<const float4*>(nodes[cb].boundsMin), *reinterpret_cast<const float4*>(nodes[cb].boundsMax), lo, hi);
     // The walker also carries the height of its sub-tree (a leaf has height 0): the root's height is the tree depth the
     // traversal stacks are sized from, and no separate pass has to climb from every leaf to the root for it.  At a node
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
 #pragma unroll
                 for (int k = 0; k < REFIT_RUN; k++) {
                     float4 rlo, rhi;
-                    refit_merge(llo[k], lhi[k], lo, hi, rlo, rhi);                   // child A = the leaf, child B = the chain below
+                    refit_merge<TIGHT>(llo[k], lhi[k], lo, hi, rlo, rhi);                   // child A = the leaf, child B = the chain below
                     lo = rlo; hi = rhi;
                     if (k + 1 < REFIT_RUN) {
                         *reinterpret_cast<float4*>(nodes[current - 1u - (uint32_t)k].boundsMin) = lo;
@@ -321,16 +332,17 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
         const float4 slo = *reinterpret_cast<const float4*>(nodes[sibling].boundsMin);
         const float4 shi = *reinterpret_cast<const float4*>(nodes[sibling].boundsMax);
         float4 rlo, rhi;
-        if (i_am_a) refit_merge(lo, hi, slo, shi, rlo, rhi);
-        else refit_merge(slo, shi, lo, hi, rlo, rhi);
+        if (i_am_a) refit_merge<TIGHT>(lo, hi, slo, shi, rlo, rhi);
+        else refit_merge<TIGHT>(slo, shi, lo, hi, rlo, rhi);
         lo = rlo; hi = rhi;
         current = parent;
     }
 }
 
-void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
+void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight)
 {
-    hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
+    if (tight) hipLaunchKernelGGL(k_refit<true>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
+    else hipLaunchKernelGGL(k_refit<false>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -153,6 +153,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
     if (const char* env = std::getenv("RTMI_FUSED_FRAMES")) ctx->no_fused_frames = env[0] == '0';
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER")) ctx->no_block_order = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_SEARCH_TREE_BOXES")) ctx->search_tree_reference_boxes = std::strcmp(env, "reference") == 0;
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER_GROUP")) { const uint32_t g = (uint32_t)std::strtoul(env, nullptr, 10); if (g && g <= 64u && !(g & (g - 1u))) { ctx->block_order_group_log = 0; while ((1u << ctx->block_order_group_log) < g) ctx->block_order_group_log++; } }
     if (const char* env = std::getenv("RTMI_SHARE_MIN_BUDGET")) ctx->share_min_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
@@ -554,7 +555,7 @@ int rt_bvh_construct(rt_bvh* b)
         launch_bitonic_sort(s, s_pairs, N);
         launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u);
         uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
-        launch_refit(s, s_nodes, s_counters, n, s_depth);
+        launch_refit(s, s_nodes, s_counters, n, s_depth, !ctx->search_tree_reference_boxes);
         launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s));
@@ -1020,6 +1021,14 @@ int rt_bvh_read_nodes(const rt_bvh* b, void* h_nodes)
     if (!b || !h_nodes) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
     if (!b->built) return RT_FAIL(b->ctx, "BVH not built");
     return rt_buf_download(b->ctx, h_nodes, b->d_nodes, (uint64_t)(2 * b->n - 1) * sizeof(rt_bvh_node));
+}
+
+int rt_bvh_read_search_nodes(const rt_bvh* b, void* h_nodes)
+{
+    if (!b || !h_nodes) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
+    if (!b->built) return RT_FAIL(b->ctx, "BVH not built");
+    if (!b->have_search_tree || !b->s_nodes) return RT_FAIL(b->ctx, "this BVH has no search tree");
+    return rt_buf_download(b->ctx, h_nodes, b->s_nodes, (uint64_t)(2 * b->n - 1) * sizeof(rt_bvh_node));
 }
 
 int rt_bvh_read_morton_pairs(const rt_bvh* b, void* h_pairs, uint32_t* n_pow2)

@@ -110,6 +110,7 @@ struct rt_ctx {
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
     unsigned long long* d_clock = nullptr;  // one word: the device clock sample of a calibration
+    bool search_tree_reference_boxes = false;   // knob RTMI_SEARCH_TREE_BOXES=reference: the search tree's boxes clamped like the reference's (round 2's)
     bool no_block_order = false;            // knob RTMI_BLOCK_ORDER=0: waves walk the blocks in index order
     uint32_t block_order_group_log = 4;     // knob RTMI_BLOCK_ORDER_GROUP=1..64: consecutive blocks that stay together (a power of two)
 };
@@ -253,7 +254,7 @@ size_t refit_rq_scratch_bytes(uint32_t n);
 void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
                      uint32_t* nan_flag_out);      // range-query refit (large scenes); *nan_flag_out != 0: NaN boxes, redo with launch_refit
 void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
-void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);   // boxes + tree depth
+void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false);   // boxes + tree depth; tight: plain unions (search tree)
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t id_offset = 0);
 void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records);
