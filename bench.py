@@ -363,10 +363,10 @@ def main():
             # frame's colour per step, not all five; RTMI_BENCH_ONE_ROOT=1 gathers everything into rank 0
             it['root'] = 0 if os.environ.get('RTMI_BENCH_ONE_ROOT') == '1' else len(work) % nranks
             for c in it['ctxs']:
-                c.set_block_order(False)                     # five scenes' frames are in flight per step (see use_graphs below)
+                c.set_frames_in_flight(len(SCENES))          # five scenes' frames are in flight per step (see use_graphs below)
             it['frames'] = [capi.MultiFrame(c, b, s, cam, root_extra, it['root']) for c, b, s in zip(it['comms'], it['bvhs'], it['scenes'])]
             for c in it['ctxs']:
-                c.set_block_order(True)
+                c.set_frames_in_flight(1)
             it['slots'] = it['frames'][0].layout()['own_slots']
         else:
             it['slots'] = npx
@@ -388,13 +388,13 @@ def main():
             first_frame_ms[it['name']] = ((time.perf_counter() - t1) * 1e3, it['bvh'].calibration_launches(), it['bvh'].calibration_gpu_ms())
     use_graphs = not tiled and not args.no_graphs and os.environ.get('RTMI_BENCH_GRAPHS', '1') != '0'
     if use_graphs:
-        # a step keeps the five scenes' frames in flight together: blocks in index order (rt_ctx_set_block_order, include/rtmi.h --
-        # longest-first is for a frame that has the device to itself; measured here it costs the five-frame step 2-5 %).  The
-        # isolated pass, the first frames and the 4K leg run one frame at a time, with the library's default (longest first).
+        # a step keeps the five scenes' frames in flight together, and says so (rt_ctx_set_frames_in_flight, include/rtmi.h: blocks in
+        # index order, sub-tree sharing only where it wins by far -- both measured here).  The isolated pass, the first frames and
+        # the 4K leg run one frame at a time, with the library's default policy.
         for it in work:
-            it['ctx'].set_block_order(False)
+            it['ctx'].set_frames_in_flight(len(SCENES))
             it['graph'] = capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'], it['rgba'])
-            it['ctx'].set_block_order(True)
+            it['ctx'].set_frames_in_flight(1)
 
     def step():
         for it in work:
@@ -582,9 +582,9 @@ def main():
         for it in work:
             it['poses'] = moving_cameras(it['bytes'], RES[0], RES[1], M)
             it['graph'].close()                             # the rebuild-per-frame leg above has rebuilt the BVH: a graph of its own
-            it['ctx'].set_block_order(False)                # five frames in flight, as in the timed region
+            it['ctx'].set_frames_in_flight(len(SCENES))     # five frames in flight, as in the timed region
             it['graph'] = capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'], it['rgba'])
-            it['ctx'].set_block_order(True)
+            it['ctx'].set_frames_in_flight(1)
         def pose(it, k):
             return it['poses'][k % M:k % M + 1]
         per = {}
@@ -833,7 +833,7 @@ def main():
                vs_baseline=None, dtype='f32', data='bundled TestModels OBJ scenes (shipped with the reference), demo default camera',
                config=dict(workload='5 bundled TestModels scenes x 1920x1080 primary rays, BVH traversal + Blinn-Phong shading',
                            rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES, parallelism=par,
-                           block_order='timed region and moving-camera leg: index order (five frames in flight); isolated frames, first frames, config5: longest first'),
+                           policy='timed region and moving-camera leg: rt_ctx_set_frames_in_flight(5); isolated frames, first frames, config5: the default (one frame at a time)'),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
                roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, config5=config5, per_rank=per_rank, per_scene=per_scene)

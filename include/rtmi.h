@@ -333,13 +333,19 @@ int  rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2);
 /* PrefixSum::computePrefixSum (Include/Algorithms/PrefixSum.h:68): inclusive uint scan          */
 int  rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n);
 
-/* ---- start order of a frame's 8x8 blocks (four-wide packet kernel) ----------------------- */
-/* mode 1 (default; environment RTMI_BLOCK_ORDER=0 makes 0 the default): the blocks that cost the most steps in earlier frames of
- * the same shape start first, so a frame that has the device to itself does not end on a few long blocks (isolated 1024x1024
- * frames 7-25 % shorter, 4K 15 %).  mode 0: index order -- for applications that keep SEVERAL frames in flight on one device
- * (streams of different contexts): other frames' waves fill the end of each frame anyway, and the bookkeeping costs 2-5 % there.
- * Read at each eager trace and at rt_frame_graph_create / rt_multi_frame_create; results are the same bits either way.          */
-int  rt_ctx_set_block_order(rt_ctx* ctx, int mode);
+/* ---- one frame at a time, or several in flight ------------------------------------------- */
+/* How many frames the application keeps in flight on this device (streams of different contexts); default 1.  Two speed policies
+ * follow it -- results are the same bits either way:
+ *   n <= 1 (the Demo's RTFrame loop: a frame has the device to itself, its LATENCY counts): the four-wide kernel starts the blocks
+ *          that cost the most steps in earlier frames of the same shape first, so a frame does not end on a few long blocks
+ *          (environment RTMI_BLOCK_ORDER=0 switches that off), and the first-frame calibration takes sub-tree sharing at face value;
+ *   n  > 1 (a server rendering many views: THROUGHPUT counts, other frames' waves fill a frame's end anyway): blocks in index order
+ *          (the bookkeeping costs the five-frame step 2-5 %), and a sharing strategy must beat whole blocks by 1.6 x to be chosen
+ *          (its helper waves and queues cost the other frames more than they gain: five bundled scenes in flight 0.284 ms per step
+ *          with whole blocks, 0.316 with Tenryuu's sub-trees shared, which alone is 0.15 against 0.19 ms).
+ * Read at each eager trace and at rt_frame_graph_create / rt_multi_frame_create; part of the calibration key, so a BVH keeps one
+ * strategy per policy.                                                                                                            */
+int  rt_ctx_set_frames_in_flight(rt_ctx* ctx, uint32_t n);
 /* test / inspection: the start order the next eager four-wide frame of this BVH will use (wave i takes block order[i]) and the step
  * counts of its last such frame; *blocks = 0: none (never traced four-wide, mode 0, or not yet sorted).  Synchronises the stream.  */
 int  rt_bvh_block_order(rt_bvh* bvh, uint32_t* h_order, uint32_t* h_cost, uint32_t capacity, uint32_t* blocks);

@@ -39,7 +39,7 @@ SYMBOLS = [
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
-    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_block_order', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
+    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_frames_in_flight', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
@@ -118,7 +118,7 @@ def load_library() -> C.CDLL:
     L.rt_sort_pairs_bitonic.argtypes = [vp, vp, u32]
     L.rt_scan_inclusive_u32.argtypes = [vp, vp, vp, u32]
     L.rt_ctx_set_profiling.argtypes = [vp, i32]
-    L.rt_ctx_set_block_order.argtypes = [vp, i32]
+    L.rt_ctx_set_frames_in_flight.argtypes = [vp, u32]
     L.rt_ctx_trace_kernel_times.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rt_ctx_last_trace_counters.argtypes = [vp, C.POINTER(C.c_uint32), u32]
     L.rt_timer_create.argtypes = [vp, pvp]
@@ -196,10 +196,11 @@ class Context:
         self.check(self.lib.rt_ctx_device_info(self.h, C.byref(cu), C.byref(ws), C.byref(lds), name, 64))
         return dict(compute_units=cu.value, wave_size=ws.value, lds_bytes=lds.value, name=name.value.decode())
 
-    def set_block_order(self, longest_first):
-        """True (default): the four-wide kernel starts a frame's most expensive blocks first; False: index order, for several
-        frames in flight on one device (rtmi.h, rt_ctx_set_block_order)."""
-        self.check(self.lib.rt_ctx_set_block_order(self.h, 1 if longest_first else 0))
+    def set_frames_in_flight(self, n):
+        """1 (default): a frame has the device to itself -- the four-wide kernel starts a frame's most expensive blocks first, sharing
+        strategies compete at face value; > 1: several frames in flight -- index order, sharing handicapped (rtmi.h,
+        rt_ctx_set_frames_in_flight)."""
+        self.check(self.lib.rt_ctx_set_frames_in_flight(self.h, int(n)))
 
     def set_profiling(self, on):
         """False/0 off, True/1 HIP events around the traversal kernels, 2 the same with the '<.., 2>' kernel names."""

@@ -743,9 +743,10 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     // start order of the blocks (four-wide kernel): the buffers of this frame shape
     BlockOrder* const bo = (mode && mode->block_order) ? mode->block_order : &b->block_order;
     const bool captured = mode && (mode->record || mode->update);
-    const bool order_ok = !ctx->no_block_order && b->d_quad && b->have_search_tree &&
+    const bool order_ok = !ctx->no_block_order && ctx->frames_in_flight <= 1u && b->d_quad && b->have_search_tree &&
                           (captured ? bo->count != 0 : block_order_fit(ctx, *bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u));
-    const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0);
+    const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0) ^
+                         (ctx->frames_in_flight > 1u ? 1ull << 62 : 0);      // (one strategy per policy, rt_ctx_set_frames_in_flight)
     if (ctx->defer_budget == 0 && (!b->tuned || b->tuned_key != key) && !(mode && mode->fixed_strategy)) {
         // another resolution / tiling than the last frame's: known from before?
         for (auto& e : b->tuned_cache)
@@ -765,10 +766,10 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // candidates: (packet kernel?, budget) -- budget = steps after which a block (packet kernel) or a ray (lane-per-ray
         // kernel) hands its remaining sub-trees to the wave-per-ray kernel
         static const struct { bool packet; uint32_t budget; bool quad; } candidates[] = {
-            { true, 1u << 20, true }, { true, 128u, true }, { true, 256u, true }, { true, 1024u, true }, { true, 2048u, true },   // four-wide: whole blocks / sub-trees shared after so many steps
+            { true, 1u << 20, true }, { true, 32u, true }, { true, 64u, true }, { true, 128u, true }, { true, 256u, true }, { true, 1024u, true },   // four-wide: whole blocks / sub-trees shared after so many steps
             { true, 64u }, { true, 256u }, { true, 1024u }, { true, 4096u }, { true, 1u << 20 },
             { false, 8u }, { false, 12u }, { false, 16u }, { false, 24u }, { false, 32u }, { false, 48u }, { false, 64u }, { false, 96u }, { false, 128u }, { false, 192u }, { false, 256u }, { false, 512u }, { false, 1024u }, { false, 2048u }, { false, 1u << 20 } };
-        enum { P4_NONE = 0, P4_128 = 1, P4_256 = 2, P4_1024 = 3, P4_2048 = 4, PK_256 = 6, PK_NONE = 9, LANE_8 = 10, LANE_16 = 12, LANE_128 = 18, LANE_NONE = 24 };
+        enum { P4_NONE = 0, P4_32 = 1, P4_64 = 2, P4_128 = 3, P4_256 = 4, P4_1024 = 5, PK_64 = 6, PK_256 = 7, PK_4096 = 9, PK_NONE = 10, LANE_8 = 11, LANE_16 = 13, LANE_128 = 19, LANE_NONE = 25 };
         hipEvent_t e0 = nullptr, e1 = nullptr;
         RT_HIP(ctx, hipEventCreate(&e0));
         RT_HIP(ctx, hipEventCreate(&e1));
@@ -840,6 +841,10 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             if (!(cand.packet && cand.quad && cand.budget < (1u << 20))) return 1.0f;
             float h = 1.03f;
             for (uint32_t bgt = cand.budget; bgt < 1024u; bgt <<= 1) h += 0.03f;
+            // several frames in flight (rt_ctx_set_frames_in_flight): the helper waves and queues of a sharing launch cost the OTHER frames
+            // more than its own shorter tail gains (the bundled five: 0.284 ms per step with whole blocks, 0.316 with Tenryuu shared
+            // after 64 steps, which alone is 0.15 against 0.19 ms) -- sharing must then win by far, as it does where whole blocks crawl
+            if (ctx->frames_in_flight > 1u) h *= 1.6f;
             return h;
         };
         auto usable = [&](int ci) {
@@ -884,10 +889,11 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
         // budget of 16 steps) beats eight of them in one packet.  RTMI_CALIBRATE_ALL=1 restores the exhaustive pass over all 25.
         static const bool calibrate_all = [] { const char* e = std::getenv("RTMI_CALIBRATE_ALL"); return e && e[0] == '1'; }();
         // The first candidate runs without a deadline, twice (an untimed warm-up, then its sample), so it should never be a
-        // hopeless one: sharing after 256 steps is within ~1.3 x of the best four-wide strategy on every BVH seen so far (it has
-        // no tail; measured: Tenryuu 1.3 x, ManFigure 1.0, atrium 4K 1.0, against 1.8-2.9 x for 128 steps on the atrium and
-        // ClumsyDragon and 2.1 x for 1 024 on Tenryuu), whole blocks and the lane-per-ray budgets can be six times behind.
-        const int first_cand = cand_n[P4_256] == 0 ? P4_256 : cand_n[P4_NONE] == 0 ? P4_NONE : cand_n[LANE_128] == 0 ? LANE_128 : -1;
+        // hopeless one: sharing after 64 steps has no tail (since the search tree's boxes are tight a 1080p block takes 3-13 steps on
+        // average and 50-900 at most: Tenryuu whole blocks 0.173 ms, shared after 256 / 128 / 64 / 32 steps 0.195 / 0.18 / 0.132 /
+        // 0.14; ManFigure 0.09 / 0.108 from 64 up; ClumsyDragon 0.61 / 0.40 / 0.31 / 0.25 / 0.22 against 0.127 for lane-per-ray 16),
+        // whole blocks and the lane-per-ray budgets can be several times behind.
+        const int first_cand = cand_n[P4_64] == 0 ? P4_64 : cand_n[P4_NONE] == 0 ? P4_NONE : cand_n[LANE_128] == 0 ? LANE_128 : -1;
         {
             int warm = first_cand;
             for (int ci = 0; ci < N_CAND && warm < 0; ci++) if (cand_n[ci] == 0) warm = ci;
@@ -909,7 +915,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             for (int ci : { first_cand, (int)P4_NONE, (int)LANE_16 })
                 if (ci >= 0 && cand_n[ci] == 0) sample(ci);
             const int first = best_of(-1);
-            if (first == P4_256) { sample(P4_128); sample(P4_1024); if (best_of(-1) == P4_1024) sample(P4_2048); }
+            if (first == P4_64) { sample(P4_32); sample(P4_128); if (best_of(-1) == P4_128) sample(P4_256); }
             else if (first >= LANE_8 && first < LANE_NONE) refine_lane(first);
             // (whole blocks won: a sharing budget lost with its handicap, the others would too)
             const int a = best_of(-1), c = best_of(a);
@@ -920,9 +926,9 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
                 if (ci >= 0 && cand_n[ci] == 0) sample(ci);
             const int first = best_of(-1);
             if (first >= LANE_8 && first < LANE_NONE) refine_lane(first);
-            else if (first >= 5 && first < LANE_8) {
-                sample(first == PK_NONE ? 8 : first + 1);
-                if (first > 5) sample(first - 1);
+            else if (first >= PK_64 && first < LANE_8) {
+                sample(first == PK_NONE ? (int)PK_4096 : first + 1);
+                if (first > PK_64) sample(first - 1);
             }
             const int a = best_of(-1), c = best_of(a);
             sample(a); sample(c);
@@ -1055,7 +1061,7 @@ int rt_bvh_block_order(rt_bvh* b, uint32_t* h_order, uint32_t* h_cost, uint32_t 
     if (!b || !blocks) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
     rt_ctx* ctx = b->ctx;
     const BlockOrder& o = b->block_order;
-    *blocks = (o.valid && !ctx->no_block_order) ? o.count : 0u;
+    *blocks = (o.valid && !ctx->no_block_order && ctx->frames_in_flight <= 1u) ? o.count : 0u;
     if (*blocks == 0) return RT_SUCCESS;
     if (*blocks > capacity) return RT_FAIL(ctx, "rt_bvh_block_order: capacity too small");
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1400,7 +1406,7 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     g->plane_bits_known = 0x80000000u | (plane_bits & 7u);
     g->no_unsafe = g->four_wide && (plane_bits & (g->octant_records ? 6u : 7u)) == 0u;
     g->parts = strategy_parts(b, cam, packet, quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
-    if (g->four_wide && !ctx->no_block_order && block_order_fit(ctx, g->bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u)) {
+    if (g->four_wide && !ctx->no_block_order && ctx->frames_in_flight <= 1u && block_order_fit(ctx, g->bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u)) {
         // the captured kernel reads its start order from this graph's own buffer: index order until the first launches have been counted
         g->bo.valid = launch_block_order(ctx->stream, g->bo.d_cost, g->bo.d_order, g->bo.count, ctx->block_order_group_log, true);
         if (!g->bo.valid) block_order_free(g->bo);
@@ -1599,11 +1605,10 @@ static void drop_trace_events(rt_ctx* ctx)
     ctx->trace_events.clear();
 }
 
-int rt_ctx_set_block_order(rt_ctx* ctx, int mode)
+int rt_ctx_set_frames_in_flight(rt_ctx* ctx, uint32_t n)
 {
     if (!ctx) return RT_ERROR;
-    if (mode != 0 && mode != 1) return RT_FAIL(ctx, "rt_ctx_set_block_order: mode is 0 (index order) or 1 (longest first)");
-    ctx->no_block_order = mode == 0;
+    ctx->frames_in_flight = n ? n : 1u;
     return RT_SUCCESS;
 }
 

@@ -1292,7 +1292,7 @@ def test_cpp_reference_frame_loop(gpu_ctx, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize('group', ['1', '16', '64'])
 def test_block_start_order_changes_no_bit(group, monkeypatch):
-    """The four-wide kernel starts a frame's blocks in the order of their step counts in earlier frames (rt_ctx_set_block_order,
+    """The four-wide kernel starts a frame's blocks in the order of their step counts in earlier frames (rt_ctx_set_frames_in_flight,
     k_block_order): the order is a permutation of the blocks in groups of `group` neighbours, most expensive group first, and
     contacts and colours are the bits of the index-order frames -- eager frames over two refreshes of the order with a camera
     that moves, a frame graph replayed over two refreshes, and the sub-tree sharing (budget 128) included."""
@@ -1311,7 +1311,7 @@ def test_block_start_order_changes_no_bit(group, monkeypatch):
         cams.append(as_capi_camera(cam))
     ctxs = [capi.Context(0), capi.Context(0)]
     try:
-        ctxs[1].set_block_order(False)
+        ctxs[1].set_frames_in_flight(2)
         scs = [capi.DeviceScene(c, packed_scene(name)) for c in ctxs]
         bvhs = [capi.DeviceBVH(c, s).build() for c, s in zip(ctxs, scs)]
         assert bvhs[1].block_order() is None
