@@ -818,8 +818,15 @@ __device__ __forceinline__ void leaf_test_masked(const TraceArgs& a, uint32_t le
 // ... of a primary ray, against the camera-relative record: the ray contributes its direction only
 __device__ __forceinline__ void leaf_test_camera(const TriCam* __restrict__ tricam, uint32_t leaf, RayState& r, bool reached)
 {
+#ifdef RTMI_EXP_NO_LEAF
+    return;                      // EXPERIMENT (wrong contacts): what the walk costs without its triangle tests
+#endif
     const float4* p = reinterpret_cast<const float4*>(tricam + leaf);
     const float4 w0 = ld_const4(p), w1 = ld_const4(p + 1), w2 = ld_const4(p + 2), w3 = ld_const4(p + 3);
+#ifdef RTMI_EXP_LEAF_LOAD_ONLY
+    asm volatile("" :: "s"(w0.x), "s"(w1.x), "s"(w2.x), "s"(w3.x));      // EXPERIMENT (wrong contacts): the record arrives, nothing is computed
+    return;
+#endif
     const f3 edge1 = f3{ w0.x, w0.y, w0.z }, edge2 = f3{ w0.w, w1.x, w1.y }, tvec = f3{ w1.z, w1.w, w2.x }, qvec = f3{ w2.y, w2.z, w2.w };
     const uint32_t pos = __float_as_uint(w3.y);
     f3 pvec = f3_cross(r.d, edge2);
@@ -1129,7 +1136,10 @@ __device__ __forceinline__ const TraceArgs& rare_args()
 }
 
 template <int PRIMARY, int CAL, int SHARE, int OCT, int FUSE>
-__global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
+#ifndef P4_MIN_WAVES
+#define P4_MIN_WAVES 8
+#endif
+__global__ __launch_bounds__(TRACE_BLOCK, P4_MIN_WAVES) void k_trace_packet4(TraceArgs a)
 {
     __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
     __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
@@ -1347,6 +1357,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, 8) void k_trace_packet4(TraceArgs a)
             P4_KEEP("s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]));
             P4_STAMP(T2);
             // leaves are tested on the spot by the lanes that reached them (an unused slot counts as a leaf nobody reaches)
+            // (round 3, measured with the tight search tree, where a frame lasts as long as its heaviest block: without the triangle tests
+            //  ManFigure's walk takes 0.056 instead of 0.092 ms and Tenryuu's 0.089 instead of 0.175 (-DRTMI_EXP_NO_LEAF); with the records
+            //  fetched but nothing computed 0.067 / 0.126 (-DRTMI_EXP_LEAF_LOAD_ONLY): the tests' arithmetic is 27-28 % of the critical
+            //  path, their scalar-load round trips 12-21 %.  Tried: the record of a reached leaf fetched by LDS-DMA (global_load_lds_dwordx4,
+            //  lanes 0-3, checked alone in tools/micro/glds_leaf.hip) and its test run one step later, behind the issue of the next record's
+            //  loads -- a leaf's result decides nothing about the walk.  Bit-exact, but no faster (Tenryuu 0.140 vs 0.140, ManFigure 0.106
+            //  vs 0.106): the compiler waits for the first of the four record loads before it issues the rest once the deferred tests sit
+            //  between the loads and their use.  Not kept.)
             // (round 3: ONE branch around the whole section -- leaf masks by select, the slots' masks cleared by select -- instead of these
             //  four mostly not-taken ones: ManFigure 0.270 -> 0.361 ms, Gardenlight 0.063 -> 0.071: the sixteen scalar selects every step
             //  pays cost more than the branches it skips; this kernel's time follows its scalar instruction count)

@@ -262,3 +262,57 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def build_hybrid(llo, lhi, cut=32, top='sah'):
+    """the radix tree's sub-trees of at most `cut` leaves kept, the hierarchy above them rebuilt (top-down binned SAH or PLOC over the
+    sub-trees' boxes)"""
+    base = build_lbvh(llo, lhi)
+    n = len(llo)
+    # leaves below every inner node
+    cnt = np.zeros(base.count, np.int64)
+    for i in range(base.count - 1, -1, -1):          # children have larger indices (pre-order numbering of rec)
+        c = 0
+        for ch in (base.left[i], base.right[i]):
+            c += 1 if ch < 0 else cnt[ch]
+        cnt[i] = c
+    roots = []                                       # sub-tree roots at the cut (child ids: >= 0 inner, < 0 leaf)
+    stack = [0]
+    while stack:
+        i = stack.pop()
+        for ch in (base.left[i], base.right[i]):
+            if ch >= 0 and cnt[ch] > cut:
+                stack.append(int(ch))
+            else:
+                roots.append(int(ch))
+    rlo = np.array([llo[~r] if r < 0 else base.lo[r] for r in roots]); rhi = np.array([lhi[~r] if r < 0 else base.hi[r] for r in roots])
+    topt = (build_sah if top == 'sah' else build_ploc)(rlo, rhi)
+    # splice: new tree = top nodes (ids 0..k-1) + kept base nodes (renumbered behind them)
+    k = topt.count
+    t = Tree(n)
+    t.count = 0
+    remap = {}
+    def copy_sub(r):                                  # base sub-tree -> t, returns child id
+        if r < 0:
+            return r
+        me = k + len(remap); remap[r] = me
+        return me
+    # first assign ids to all kept base inner nodes
+    keep = []
+    for r in roots:
+        if r >= 0:
+            st = [r]
+            while st:
+                i = st.pop(); keep.append(i)
+                for ch in (base.left[i], base.right[i]):
+                    if ch >= 0:
+                        st.append(int(ch))
+    ids = {b: k + j for j, b in enumerate(keep)}
+    conv = lambda ch: ch if ch < 0 else ids[int(ch)]
+    for b, me in ids.items():
+        t.left[me], t.right[me], t.lo[me], t.hi[me] = conv(base.left[b]), conv(base.right[b]), base.lo[b], base.hi[b]
+    convtop = lambda ch: ch if ch >= 0 else (roots[~ch] if roots[~ch] < 0 else ids[roots[~ch]])
+    for i in range(k):
+        t.left[i], t.right[i], t.lo[i], t.hi[i] = convtop(topt.left[i]), convtop(topt.right[i]), topt.lo[i], topt.hi[i]
+    t.count = k + len(keep)
+    return t, len(roots)
