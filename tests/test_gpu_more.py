@@ -1356,3 +1356,46 @@ def test_block_start_order_changes_no_bit(group, monkeypatch):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['man', 'tenryuu', 'clumsydragon', 'cube'])
+def test_search_tree_nests_tightly_over_the_reference_leaves(name, monkeypatch):
+    """What DESIGN.md section 2 asks of the search tree and nothing more: the SAME n leaf boxes as the reference tree (bit for bit),
+    every leaf below the root exactly once, every inner box the plain union of its children's boxes (rt_bvh_read_search_nodes) -- in
+    particular no maximum pulled up to FLT_MIN as in the reference's own refit (BVH.h:309-310), which the reference tree keeps --
+    and, with RTMI_SEARCH_TREE_BOXES=reference, round 2's clamped boxes, the same contacts either way."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    osc, ob = oracle_bvh(name)
+    n = ob.n
+    cam = as_capi_camera(osc.demo_camera(320, 200))
+    frames = {}
+    for boxes in ('tight', 'reference'):
+        monkeypatch.setenv('RTMI_SEARCH_TREE_BOXES', boxes)
+        ctx = capi.Context(0)
+        try:
+            sc = capi.DeviceScene(ctx, packed_scene(name))
+            gb = capi.DeviceBVH(ctx, sc).build()
+            ref, sn = gb.read_nodes(), gb.read_search_nodes()
+            for f in ('boundsMin', 'boundsMax'):                                            # the reference's leaves (their parents differ, of course)
+                assert ref[f][:n].tobytes() == sn[f][:n].tobytes()
+            assert np.array_equal(ref['data'][:n, 1:], sn['data'][:n, 1:])
+            assert ref.tobytes() == ob.nodes.tobytes()                                    # ... and the reference tree is still the oracle's
+            lo, hi = sn['boundsMin'][:, :3].copy(), sn['boundsMax'][:, :3].copy()
+            a, b = sn['data'][n:, 1].astype(np.int64), sn['data'][n:, 2].astype(np.int64)
+            seen = np.bincount(np.concatenate([a, b]), minlength=2 * n - 1)
+            assert (seen[:n] == 1).all() and seen[n] == 0 and (seen[n + 1:] == 1).all()   # a tree: every node but the root has one parent
+            want_lo, want_hi = np.minimum(lo[a], lo[b]), np.maximum(hi[a], hi[b])
+            if boxes == 'tight':
+                assert np.array_equal(lo[n:], want_lo) and np.array_equal(hi[n:], want_hi)
+                if name != 'cube':
+                    assert (hi[n:] < 0).any()                                             # boxes of the negative half end where their triangles do
+            else:
+                fmin = np.float32(np.finfo(np.float32).tiny)
+                assert np.array_equal(lo[n:], want_lo) and np.array_equal(hi[n:], np.maximum(want_hi, fmin))
+            frames[boxes] = gb.generate_contacts_primary(cam).tobytes()
+            gb.close(); sc.close()
+        finally:
+            ctx.close()
+    assert frames['tight'] == frames['reference'] == ob.trace_primary(osc.demo_camera(320, 200))[0].tobytes()
