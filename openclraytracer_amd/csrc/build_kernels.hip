@@ -719,3 +719,13 @@ void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t*
 {
     if (sc.n_tris) hipLaunchKernelGGL(k_pack_triangles, dim3((sc.n_tris + 255) / 256), dim3(256), 0, s, sc, pos, out);
 }
+
+// rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
+// frame of a process otherwise pays for it -- the traversal kernels' object alone takes ~2 ms)
+bool rt_preload_build()
+{
+    hipFuncAttributes attr;
+    const bool ok = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_gather_triangles)) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}

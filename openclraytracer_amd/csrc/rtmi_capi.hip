@@ -139,6 +139,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         return RT_ERROR;
     }
     ctx->stream = ctx->own_stream;
+    // (failures are not fatal: the object is then loaded where it is first used)
+    (void)rt_preload_trace(); (void)rt_preload_build(); (void)rt_preload_sort_scan(); (void)rt_preload_shade(); (void)rt_preload_tlg(); (void)rt_preload_secondary();
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_LONG_LIST_MAX")) ctx->long_list_limit = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_POISON")) ctx->poison = (int)std::strtol(env, nullptr, 10);

@@ -355,6 +355,7 @@ void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, 
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);   // t.prepare_parts
 void launch_device_clock(hipStream_t s, unsigned long long* d_out);      // the clock the calibration deadlines are on (s_memrealtime)
 bool launch_block_order(hipStream_t s, const uint32_t* cost, uint32_t* order, uint32_t blocks, uint32_t group_log, bool identity);
+bool rt_preload_trace(); bool rt_preload_build(); bool rt_preload_secondary(); bool rt_preload_shade(); bool rt_preload_sort_scan(); bool rt_preload_tlg();
 size_t trace_ctrl_bytes();
 size_t trace_task_bytes(uint32_t cap_per_shard);
 size_t trace_ctrl_error_offset();

@@ -58,3 +58,13 @@ void launch_secondary_emit(hipStream_t s, const rt_camera* cam, const rt_ray* ra
     hipLaunchKernelGGL(k_secondary_emit, dim3((count + 255) / 256), dim3(256), 0, s, c, cam ? 1 : 0, rays_in, contacts, count, scan,
                        kind, target[0], target[1], target[2], eps, out);
 }
+
+// rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
+// frame of a process otherwise pays for it -- the traversal kernels' object alone takes ~2 ms)
+bool rt_preload_secondary()
+{
+    hipFuncAttributes attr;
+    const bool ok = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_secondary_flags)) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}

@@ -139,3 +139,13 @@ void launch_untile_rgba(hipStream_t s, const rt_camera& cam, uint32_t nranks, co
     hipLaunchKernelGGL(k_untile_rgba, dim3((n + 255) / 256), dim3(256), 0, s, cam, nranks, gathered, slots_per_rank,
                        frame);
 }
+
+// rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
+// frame of a process otherwise pays for it -- the traversal kernels' object alone takes ~2 ms)
+bool rt_preload_shade()
+{
+    hipFuncAttributes attr;
+    const bool ok = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_shade)) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}

@@ -217,3 +217,13 @@ int launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint
     hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(SCAN_THREADS), 0, s, in, out, n, (const uint32_t*)totals);
     return 0;
 }
+
+// rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
+// frame of a process otherwise pays for it -- the traversal kernels' object alone takes ~2 ms)
+bool rt_preload_sort_scan()
+{
+    hipFuncAttributes attr;
+    const bool ok = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_bitonic_lds_sort)) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}

@@ -651,3 +651,13 @@ void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays
     a.rays = rays; a.total_work = count; a.out = out;
     if (count) hipLaunchKernelGGL(k_tlg_trace<0>, blocks_for(count), dim3(TLG_BLOCK), 0, s, a);
 }
+
+// rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
+// frame of a process otherwise pays for it -- the traversal kernels' object alone takes ~2 ms)
+bool rt_preload_tlg()
+{
+    hipFuncAttributes attr;
+    const bool ok = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_tlg_count_top)) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}

@@ -2068,3 +2068,13 @@ void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, 
     // arbitrary rays may use the search tree too, each under its own guard (ray_root)
     launch<0>(s, t, a);
 }
+
+// rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
+// frame of a process otherwise pays for it -- the traversal kernels' object alone takes ~2 ms)
+bool rt_preload_trace()
+{
+    hipFuncAttributes attr;
+    const bool ok = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_device_clock)) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
