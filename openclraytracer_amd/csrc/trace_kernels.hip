@@ -220,16 +220,7 @@ __device__ __forceinline__ bool child_valid(float lox, float loy, float loz, flo
 // near_k <= far_k (lo <= hi, monotone rounding) is max3(near) <= min3(far); tmin is max3(near).  Signed zeros compare equal.
 // This form is pure VALU -- v_min / v_max / v_max3 / v_min3, no compare-into-SGPR + select round trips between the vector
 // and the scalar unit, which is what a wave step of the packet kernel waited for.
-__device__ __forceinline__ bool child_valid_nonan(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayState& r,
-                                                  bool inside_marked)
-{
-    const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
-    const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
-    const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
-    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    return ((tnear <= tfar) & (tnear > 0.0f)) | inside_marked;
-}
+// (the per-lane kernels evaluate it with the planes selected by sign: child_valid_signed below)
 
 // ... and on the camera-relative records of primary rays (k_prepare_camera): d* = plane - origin, subtracted once per camera
 __device__ __forceinline__ bool child_valid_delta(float dlox, float dloy, float dloz, float dhix, float dhiy, float dhiz, const RayState& r,
@@ -240,6 +231,35 @@ __device__ __forceinline__ bool child_valid_delta(float dlox, float dloy, float 
     const float az = dloz * r.inv.z, bz = dhiz * r.inv.z;
     const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return (tnear <= tfar) & (tnear > threshold);
+}
+
+// The same two tests with the near / far planes SELECTED by the direction's sign instead of min / max of the two products (the same
+// values whenever neither product is NaN, and the same number of vector instructions), for the lane-per-ray and wave-per-ray kernels
+// on search-tree records: a 0 * inf on the x axis then stays a NaN, which v_max_f32 / v_min_f32 ignore -- the extended-real form of the
+// test that DESIGN.md section 2 ("the first axis") shows to be the reference's for such rays, and the form the four-wide kernel's
+// per-octant records evaluate (child_mask_octant).  min / max of the products would turn that NaN into the wrong infinity.  So since
+// round 3 a ray of these kernels leaves the search tree only for a possible 0 * inf on y or z (ray_root with the x bit cleared):
+// ClumsyDragon's 1 080 centre-column rays (camera x = 0 is a plane of that model, direction.x = 0) no longer walk the reference tree,
+// whose boxes of the model's whole negative half reach up to the plane x = 0 (FLT_MIN) and all contain such a ray's x.
+__device__ __forceinline__ bool child_valid_signed(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayState& r,
+                                                   bool sx, bool sy, bool sz, bool inside_marked)
+{
+    const float nx = ((sx ? hix : lox) - r.o.x) * r.inv.x, fx = ((sx ? lox : hix) - r.o.x) * r.inv.x;
+    const float ny = ((sy ? hiy : loy) - r.o.y) * r.inv.y, fy = ((sy ? loy : hiy) - r.o.y) * r.inv.y;
+    const float nz = ((sz ? hiz : loz) - r.o.z) * r.inv.z, fz = ((sz ? loz : hiz) - r.o.z) * r.inv.z;
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+    const float tfar = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    return ((tnear <= tfar) & (tnear > 0.0f)) | inside_marked;
+}
+__device__ __forceinline__ bool child_valid_delta_signed(float dlox, float dloy, float dloz, float dhix, float dhiy, float dhiz, const RayState& r,
+                                                         bool sx, bool sy, bool sz, float threshold)
+{
+    const float nx = (sx ? dhix : dlox) * r.inv.x, fx = (sx ? dlox : dhix) * r.inv.x;
+    const float ny = (sy ? dhiy : dloy) * r.inv.y, fy = (sy ? dloy : dhiy) * r.inv.y;
+    const float nz = (sz ? dhiz : dloz) * r.inv.z, fz = (sz ? dloz : dhiz) * r.inv.z;
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+    const float tfar = __builtin_fminf(__builtin_fminf(fx, fy), fz);
     return (tnear <= tfar) & (tnear > threshold);
 }
 
@@ -267,8 +287,8 @@ __device__ __forceinline__ uint64_t child_mask_octant(float nx, float ny, float 
     return __builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tnear > threshold);
 }
 
-// a child of a BINARY record: the pure-VALU form on search-tree records (no NaN possible there, see above), the reference's
-// staged form on reference-tree records (where rays with a possible 0 * inf walk)
+// a child of a BINARY record: the pure-VALU, sign-selected form on search-tree records (a NaN only on x there, and ignored: see above),
+// the reference's staged form on reference-tree records (where rays with a possible 0 * inf on y or z walk)
 template <int PRIMARY>
 __device__ __forceinline__ bool child_valid_on(bool search_tree_record, float lox, float loy, float loz, float hix, float hiy, float hiz,
                                                const RayState& r, bool sx, bool sy, bool sz, bool inside_marked)
@@ -276,7 +296,7 @@ __device__ __forceinline__ bool child_valid_on(bool search_tree_record, float lo
     if (search_tree_record) {
         const bool inside = PRIMARY ? inside_marked
                                     : ((lox <= r.o.x) & (r.o.x <= hix) & (loy <= r.o.y) & (r.o.y <= hiy) & (loz <= r.o.z) & (r.o.z <= hiz));
-        return child_valid_nonan(lox, loy, loz, hix, hiy, hiz, r, inside);
+        return child_valid_signed(lox, loy, loz, hix, hiy, hiz, r, sx, sy, sz, inside);
     }
     return child_valid<PRIMARY>(lox, loy, loz, hix, hiy, hiz, r, sx, sy, sz, inside_marked);
 }
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
     const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
     gu32* long_count = (gu32*)&a.ctrl->long_count;
     gu32* error_word = (gu32*)&a.ctrl->error;
-    const uint32_t plane_bits = PRIMARY ? camera_plane_bits(a) : 0u;
+    const uint32_t plane_bits = PRIMARY ? camera_plane_bits(a) & ~1u : 0u;       // (x: child_valid_signed)
 
     RayState r;
     r.o = f3{ 0, 0, 0 }; r.d = f3{ 0, 0, 1 }; r.inv = f3{ 0, 0, 1 };
@@ -611,12 +631,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                     const float4* p = reinterpret_cast<const float4*>(a.quad + cur);
                     const float4 g0 = p[0], g1 = p[1], g2 = p[2], g3 = p[3], g4 = p[4], g5 = p[5], g6 = p[6], g7 = p[7];
                     const uint32_t i0 = __float_as_uint(g0.w), i1 = __float_as_uint(g1.w), i2 = __float_as_uint(g2.w), i3 = __float_as_uint(g3.w);
-                    // (rays on search-tree records cannot produce NaN slab products, ray_root: the pure-VALU form of the test;
-                    //  primary rays read the camera-relative copy of the records)
+                    // (rays on search-tree records can produce a NaN slab product on x only, ray_root: the sign-selected pure-VALU form
+                    //  of the test; primary rays read the camera-relative copy of the records)
                     auto slot_valid = [&](const float4& lo, const float4& hi, float threshold) {
-                        if (PRIMARY) return child_valid_delta(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, threshold);
+                        if (PRIMARY) return child_valid_delta_signed(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, sx, sy, sz, threshold);
                         const bool inside = (lo.x <= r.o.x) & (r.o.x <= hi.x) & (lo.y <= r.o.y) & (r.o.y <= hi.y) & (lo.z <= r.o.z) & (r.o.z <= hi.z);
-                        return child_valid_nonan(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, inside);
+                        return child_valid_signed(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, sx, sy, sz, inside);
                     };
                     uint32_t c0 = slot_valid(g0, g1, g4.w) ? i0 : RT_SENTINEL;
                     uint32_t c1 = slot_valid(g2, g3, g5.w) ? i1 : RT_SENTINEL;
