@@ -5,7 +5,7 @@ tree of librtmi.so (openclraytracer_amd/csrc/build_kernels.hip, section 6) inste
     python tests/golden/make_golden_search.py
 
 The search tree is restated here with the oracle's own building blocks: keys as k_search_tree_keys computes them (fp32),
-the reference's bitonic network, radix-tree and refit restatements (oracle/rt_oracle.c), then the oracle's traversal with
+the reference's bitonic network and radix-tree restatements (oracle/rt_oracle.c), inner boxes as plain unions (what k_refit<TIGHT> computes), then the oracle's traversal with
 its visit counters.  The leaf-test count and the contacts are those of the reference tree (asserted below: same reached
 leaves); only `inner_visits` differs.  bench.py uses the numbers for the `walked` fields of its roofline object.
 """
@@ -51,7 +51,20 @@ def search_tree(orc, b):
     nodes = np.zeros(2 * n - 1, dtype=orc.NODE)
     nodes[:n] = b.nodes[:n]
     L.orc_radix_tree(nodes.ctypes.data, pairs.ctypes.data, n, 0)
-    L.orc_refit(nodes.ctypes.data, n, 0)
+    L.orc_refit(nodes.ctypes.data, n, 0)                                 # parents, depth; boxes as the REFERENCE refit makes them ...
+    # ... and since round 3 the search tree's inner boxes are the plain unions of their children's (k_refit<TIGHT>, build_kernels.hip:
+    # no maximum pulled up to FLT_MIN).  Bottom-up over the finished tree: a node's children are done before it in a post-order walk.
+    data = nodes['data']
+    order, stack = [], [n]
+    while stack:
+        i = stack.pop()
+        if i >= n:
+            order.append(i)
+            stack.append(int(data[i, 1])); stack.append(int(data[i, 2]))
+    for i in reversed(order):
+        a, c = int(data[i, 1]), int(data[i, 2])
+        nodes['lo'][i, :3] = np.minimum(nodes['lo'][a, :3], nodes['lo'][c, :3])
+        nodes['hi'][i, :3] = np.maximum(nodes['hi'][a, :3], nodes['hi'][c, :3])
     d = C.c_uint32(0)
     L.orc_check_hierarchy(nodes.ctypes.data, n, C.byref(d))
     return nodes, d.value
