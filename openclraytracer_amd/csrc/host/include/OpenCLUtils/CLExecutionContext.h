@@ -29,6 +29,9 @@ public:
     CLExecutionContext& operator=(const CLExecutionContext&) = delete;
     Common::Result flushQueue(Common::Errata& err) const;      // CLExecutionContext.h:436
     Common::Result finishQueue(Common::Errata& err) const;     // CLExecutionContext.h:445
+    /** beyond the reference's interface: how many frames the application keeps in flight on this device (rt_ctx_set_frames_in_flight,
+     *  include/rtmi.h): 1 = the Demo's RTFrame loop (latency policy, the default), > 1 = throughput policy.  Same contacts either way. */
+    Common::Result setFramesInFlight(unsigned n, Common::Errata& err) const;
     rt_ctx* handle() const { return _ctx; }
     /** turns a failed C-ABI call into the reference's (Result, Errata) pair */
     Common::Result check(int rc, Common::Errata& err, const char* file, const char* func, int line) const;

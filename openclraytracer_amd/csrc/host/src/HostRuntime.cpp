@@ -37,6 +37,7 @@ Result CLExecutionContext::check(int rc, Errata& err, const char* file, const ch
 }
 Result CLExecutionContext::flushQueue(Errata&) const { return Success; }     // HIP submits eagerly
 Result CLExecutionContext::finishQueue(Errata& err) const { return check(rt_ctx_synchronize(_ctx), err, __FILE__, __func__, __LINE__); }
+Result CLExecutionContext::setFramesInFlight(unsigned n, Errata& err) const { return check(rt_ctx_set_frames_in_flight(_ctx, n), err, __FILE__, __func__, __LINE__); }
 
 // ------------------------------------------------------------------ CLBuffer (CLBuffer.cpp:40-121)
 CLBuffer::CLBuffer(const CLExecutionContext& context, size_t size, CLBufferFlags::CLBufferAccess access)
