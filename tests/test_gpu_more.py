@@ -460,7 +460,9 @@ def test_search_tree_is_an_implementation_detail(monkeypatch):
 def test_camera_on_a_box_plane_falls_back_to_the_reference_tree(gpu_ctx, name):
     """camera x == 0 == a plane of leaf boxes of these models, and the middle pixel column has direction.x == 0: the slab
     test multiplies 0 by inf there (NaN), the one case the search-tree argument excludes.  The device notices the plane
-    and starts exactly those rays at the reference tree's root; contacts are the oracle's either way."""
+    (used_by_last_camera == 2); on a y or z plane exactly those rays start at the reference tree's root, on an x plane -- this
+    test -- they stay on the search tree since the end of round 3 in every kernel (the NaN on the first axis is absorbed:
+    DESIGN.md section 2, child_valid_signed / child_mask_octant); contacts are the oracle's either way."""
     osc, ob = oracle_bvh(name)
     _, gb = gpu_bvh(gpu_ctx, name)
     cam = osc.demo_camera(160, 120).copy()
@@ -486,9 +488,9 @@ def test_camera_on_a_box_plane_falls_back_to_the_reference_tree(gpu_ctx, name):
 @pytest.mark.parametrize('name', ['man', 'clumsydragon'])
 def test_camera_on_a_box_plane_with_every_kernel(name, packet, budget, monkeypatch):
     """the same camera (x on a plane of leaf boxes, a pixel column with direction.x == 0) under every forced strategy: the
-    four-wide records skip the boxes of inner children, which is sound on the search tree only, so the lane-per-ray kernel
-    walks such rays with binary steps on the reference tree (and the four-wide packet kernel hands them to the wave-per-ray
-    kernel when the plane is a y or z plane: test_cameras_on_planes_of_every_axis)."""
+    four-wide records skip the boxes of inner children, which is sound on the search tree only; on an x plane every kernel keeps
+    such rays on the search tree (sign-selected planes, NaN ignored), on a y or z plane they walk the reference tree with binary
+    steps (the four-wide packet kernel hands them to the wave-per-ray kernel: test_cameras_on_planes_of_every_axis)."""
     from openclraytracer_amd import capi
     from conftest import packed_scene
     monkeypatch.setenv('RTMI_PACKET', packet)
