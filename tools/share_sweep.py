@@ -9,11 +9,13 @@ import bench
 from openclraytracer_amd import capi
 
 SETTINGS = [('packet4 whole blocks', '4', 1 << 20), ('packet4 share 1024', '4', 1024), ('packet4 share 256', '4', 256), ('packet4 share 128', '4', 128),
-            ('packet4 share 64', '4', 64), ('packet4 share 32', '4', 32), ('lane-per-ray 16', '0', 16), ('lane-per-ray 64', '0', 64)]
+            ('packet4 share 64', '4', 64), ('packet4 share 32', '4', 32), ('packet4 share 16', '4', 16), ('packet4 share 8', '4', 8), ('lane-per-ray 16', '0', 16), ('lane-per-ray 64', '0', 64)]
 
 
 def main():
     global SETTINGS
+    if os.environ.get('SWEEP') == 'small':
+        SETTINGS = [x for x in SETTINGS if x[0] in ('packet4 share 64', 'packet4 share 32', 'packet4 share 16', 'packet4 share 8')]
     if os.environ.get('SWEEP') == 'quick':
         SETTINGS = [x for x in SETTINGS if x[0] in ('packet4 whole blocks', 'packet4 share 128')]
     names = sys.argv[1:] or ['man']
