@@ -339,8 +339,8 @@ int  rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t 
  *   n <= 1 (the Demo's RTFrame loop: a frame has the device to itself, its LATENCY counts): the four-wide kernel starts the blocks
  *          that cost the most steps in earlier frames of the same shape first, so a frame does not end on a few long blocks
  *          (environment RTMI_BLOCK_ORDER=0 switches that off), and the first-frame calibration takes sub-tree sharing at face value;
- *   n  > 1 (a server rendering many views: THROUGHPUT counts, other frames' waves fill a frame's end anyway): blocks in index order
- *          (the bookkeeping costs the five-frame step 2-5 %), and a sharing strategy must beat whole blocks by 1.6 x to be chosen
+ *   n  > 1 (a server rendering many views: THROUGHPUT counts, other frames' waves fill a frame's end anyway): blocks in index order,
+ *          workgroups of one wave (placed wherever a wave slot frees up: +6 % on five bundled scenes in flight), and a sharing strategy must beat whole blocks by 1.6 x to be chosen
  *          (its helper waves and queues cost the other frames more than they gain: five bundled scenes in flight 0.284 ms per step
  *          with whole blocks, 0.316 with Tenryuu's sub-trees shared, which alone is 0.15 against 0.19 ms).
  * Read at each eager trace and at rt_frame_graph_create / rt_multi_frame_create; part of the calibration key, so a BVH keeps one

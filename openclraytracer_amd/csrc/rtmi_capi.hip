@@ -155,6 +155,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
     if (const char* env = std::getenv("RTMI_FUSED_FRAMES")) ctx->no_fused_frames = env[0] == '0';
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER")) ctx->no_block_order = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_TRACE_WORKGROUP")) { const uint32_t v = (uint32_t)std::strtoul(env, nullptr, 10); if (v == 64u || v == 128u || v == 256u) ctx->trace_workgroup_waves = v / 64u; }
     if (const char* env = std::getenv("RTMI_SEARCH_TREE_BOXES")) ctx->search_tree_reference_boxes = std::strcmp(env, "reference") == 0;
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER_GROUP")) { const uint32_t g = (uint32_t)std::strtoul(env, nullptr, 10); if (g && g <= 64u && !(g & (g - 1u))) { ctx->block_order_group_log = 0; while ((1u << ctx->block_order_group_log) < g) ctx->block_order_group_log++; } }
     if (const char* env = std::getenv("RTMI_SHARE_MIN_BUDGET")) ctx->share_min_budget = (uint32_t)std::strtoul(env, nullptr, 10);
@@ -687,6 +688,7 @@ struct FrameMode {
     uint32_t parts_drop = 0;               // RT_PREP_* this frame's kernels do not read although their strategy normally does
     // a captured frame keeps the strategy it was captured with (the BVH remembers one calibration, for the last resolution / tiling traced)
     bool fixed_strategy = false, packet = false, quad = false;
+    uint32_t waves_per_block = 0;           // with fixed_strategy: the workgroup size the graph was captured with
     uint32_t budget = 0;
     BlockOrder* block_order = nullptr;     // a captured frame's own start-order buffers (null: the BVH's)
 };
@@ -699,6 +701,8 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32
     t.defer_budget = b->ctx->defer_budget;
     t.packet = false; t.packet4 = false; t.tag = b->ctx->profiling_tag; t.diagnostics = b->ctx->trace_diagnostics;
     t.quad = b->d_quad; t.quad_cam = b->d_quad_cam; t.quad_cam_variants = b->quad_cam_variants; t.no_unsafe_rays = b->capture_no_unsafe_rays;
+    t.waves_per_block = (mode && mode->fixed_strategy) ? mode->waves_per_block
+                        : b->ctx->trace_workgroup_waves ? b->ctx->trace_workgroup_waves : (b->ctx->frames_in_flight > 1u ? 1u : 0u);
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
     t.task_shards = b->ctx->d_task_list; t.task_cap = b->ctx->task_cap; t.task_helper_blocks = b->ctx->task_helper_blocks;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
@@ -1242,6 +1246,7 @@ struct rt_frame_graph {
     bool no_unsafe = false;                  // captured without the wave-per-ray launch (and, unless switched off, with fused shading)
     bool eager = false;                      // the current camera cannot be served by the captured sequence: launch issues the frame eagerly
     uint32_t plane_bits_known = 0;
+    uint32_t waves_per_block = 0;            // workgroup size of the first-phase kernel, as captured
     BlockOrder bo;                           // this frame's start order of the blocks (its buffers' addresses are arguments of the captured kernel)
     bool bo_sorted = false;
     int last_launch = -1;                    // 0 steady state, 1 with the preparation, 2 eager
@@ -1324,7 +1329,7 @@ static FrameMode graph_mode(rt_frame_graph* g, int which, bool update)
     m.plane_bits_known = g->plane_bits_known;
     // without the wave-per-ray kernel nothing reads the marks of the binary records, and the plane bits come by value
     m.parts_drop = (g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u;
-    m.fixed_strategy = true; m.packet = g->packet; m.quad = g->quad; m.budget = g->budget;
+    m.fixed_strategy = true; m.packet = g->packet; m.quad = g->quad; m.budget = g->budget; m.waves_per_block = g->waves_per_block;
     m.block_order = &g->bo;
     return m;
 }
@@ -1393,6 +1398,7 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     bool packet = false, quad = false;
     current_strategy(b, packet, quad);
     g->packet = packet; g->quad = quad;
+    g->waves_per_block = ctx->trace_workgroup_waves ? ctx->trace_workgroup_waves : (ctx->frames_in_flight > 1u ? 1u : 0u);
     g->budget = (ctx->defer_budget == 0 && b->tuned) ? b->tuned_budget : ctx->defer_budget;
     g->four_wide = packet && quad;
     g->octant_records = g->four_wide && b->quad_cam_variants == 9u;

@@ -112,6 +112,7 @@ struct rt_ctx {
     unsigned long long* d_clock = nullptr;  // one word: the device clock sample of a calibration
     bool search_tree_reference_boxes = false;   // knob RTMI_SEARCH_TREE_BOXES=reference: the search tree's boxes clamped like the reference's (round 2's)
     bool no_block_order = false;            // knob RTMI_BLOCK_ORDER=0: waves walk the blocks in index order
+    uint32_t trace_workgroup_waves = 0;     // knob RTMI_TRACE_WORKGROUP=64/128/256: waves per workgroup of the first-phase kernels (0: by policy)
     uint32_t frames_in_flight = 1;          // rt_ctx_set_frames_in_flight: > 1 = throughput policy (index order, sharing handicapped)
     uint32_t block_order_group_log = 4;     // knob RTMI_BLOCK_ORDER_GROUP=1..64: consecutive blocks that stay together (a power of two)
 };
@@ -283,16 +284,16 @@ struct GraphNodes {
     bool failed = false;          // a node was missing, appeared twice, or the runtime refused the new arguments
 };
 template <typename K, typename A>
-inline void rt_launch_node(GraphNodes* record, GraphNodes* update, int kind, K kernel, dim3 grid, dim3 block, hipStream_t s, A& args)
+inline void rt_launch_node(GraphNodes* record, GraphNodes* update, int kind, K kernel, dim3 grid, dim3 block, hipStream_t s, A& args, uint32_t lds_bytes = 0)
 {
     if (update) {
         hipKernelNodeParams p{};
         void* params[1] = { (void*)&args };
-        p.func = (void*)kernel; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = params; p.extra = nullptr;
+        p.func = (void*)kernel; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = lds_bytes; p.kernelParams = params; p.extra = nullptr;
         if (!update->node[kind] || hipGraphExecKernelNodeSetParams(update->exec, update->node[kind], &p) != hipSuccess) update->failed = true;
         return;
     }
-    hipLaunchKernelGGL(kernel, grid, block, 0, s, args);
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, s, args);
     if (record) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         const hipGraphNode_t* deps = nullptr; size_t n_deps = 0;
@@ -308,6 +309,7 @@ struct TraceLaunch {
     uint32_t octant_mask;         // primary rays, four-wide kernel on per-octant records: the octant copies that are valid
     uint32_t plane_bits_known;    // 0x80000000 | bits: the host knows the camera-on-a-plane bits (else the kernels read tree_select)
     const uint32_t* block_order;  // four-wide kernel: wave -> block permutation (null: identity)
+    uint32_t waves_per_block;     // first-phase kernels: waves per workgroup (0: the default of four)
     uint32_t* block_cost;         // ... and where it counts this frame's steps per block (null: not counted)
     unsigned long long cal_deadline;   // calibration launches (tag 1): device clock value after which the kernels stop walking, 0 = none
     const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)

@@ -577,11 +577,11 @@ __device__ __forceinline__ void store_colour(const TraceArgs& a, uint32_t out_in
 template <int PRIMARY, int CAL>
 __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
 {
-    __shared__ uint32_t s_stack[TRACE_WAVES][LDS_STACK][64];
+    extern __shared__ uint32_t s_dynamic[];              // LDS_STACK x 64 words per wave of the workgroup (launch_tagged sizes it)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t (*stack)[64] = s_stack[wave];
-    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
+    uint32_t (*stack)[64] = reinterpret_cast<uint32_t (*)[64]>(s_dynamic + wave * (LDS_STACK * 64u));
+    const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave;     // (workgroups of one to TRACE_WAVES waves: launch_tagged)
     gu32* long_count = (gu32*)&a.ctrl->long_count;
     gu32* error_word = (gu32*)&a.ctrl->error;
     const uint32_t plane_bits = PRIMARY ? camera_plane_bits(a) & ~1u : 0u;       // (x: child_valid_signed)
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
     __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
+    const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave;
     uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
     // deep stacks spill to a global area (3 words per entry), taken on the first overflow
     uint32_t* spill = nullptr;
@@ -1163,13 +1163,11 @@ template <int PRIMARY, int CAL, int SHARE, int OCT, int FUSE>
 #endif
 __global__ __launch_bounds__(TRACE_BLOCK, P4_MIN_WAVES) void k_trace_packet4(TraceArgs a)
 {
-    __shared__ uint32_t s_node[TRACE_WAVES][PACKET_STACK];
-    __shared__ uint32_t s_mlo[TRACE_WAVES][PACKET_STACK];
-    __shared__ uint32_t s_mhi[TRACE_WAVES][PACKET_STACK];
+    extern __shared__ uint32_t s_dynamic[];              // three stacks of PACKET_STACK words per wave of the workgroup (launch_tagged sizes it)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t wave_gid = blockIdx.x * TRACE_WAVES + wave;
-    uint32_t* st_node = s_node[wave]; uint32_t* st_lo = s_mlo[wave]; uint32_t* st_hi = s_mhi[wave];
+    const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave;
+    uint32_t* st_node = s_dynamic + wave * (3u * PACKET_STACK); uint32_t* st_lo = st_node + PACKET_STACK; uint32_t* st_hi = st_lo + PACKET_STACK;
     uint32_t* spill = nullptr;                           // taken on the first overflow of the LDS stack
     uint32_t spill_slot = 0xFFFFFFFFu;
     // The first PACKET_VSTACK entries of the (node, lane mask) stack live in LANES of three vector registers: entry i = lane i.
@@ -1571,7 +1569,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, P4_MIN_WAVES) void k_trace_packet4(Tra
         // everything has finished: the shared blocks' contacts come out of the key buffer
         uint32_t n_split = __hip_atomic_load((gu32*)&A.ctrl->split_tiles, RLX_AGENT);
         if (n_split > A.long_cap) n_split = A.long_cap;
-        const uint32_t n_helpers = gridDim.x * TRACE_WAVES - n_block_waves;
+        const uint32_t n_helpers = gridDim.x * (blockDim.x >> 6) - n_block_waves;
         const uint32_t plane_bits = PRIMARY ? (OCT ? camera_plane_bits(A) & ~1u : camera_plane_bits(A)) : 0u;     // as where the blocks start
         for (uint32_t i = wave_gid - n_block_waves; i < n_split; i += n_helpers) {
             const uint32_t w = __hip_atomic_load((gu32*)(A.split_list + i), RLX_AGENT) + lane;
@@ -1875,7 +1873,12 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     // First-phase kernels: one wave per 64-ray block and the hardware dispatcher as the work queue.  (A persistent grid --
     // resident waves pulling blocks from sharded counters, idle lanes refilled -- measured 25-50 % slower on every bundled
     // scene: Cube 0.157 -> 0.106 ms, ManFigure lane-per-ray 1.25 -> 0.81 ms)
-    const uint32_t grid = ((a.total_work + 63u) / 64u + TRACE_WAVES - 1u) / TRACE_WAVES;
+    // Workgroups of the first-phase kernels: TRACE_WAVES waves (neighbouring blocks of a frame on one CU: they walk the same records),
+    // or ONE wave when several frames are in flight (rt_ctx_set_frames_in_flight): the dispatcher then places single waves wherever a
+    // slot frees up instead of waiting for four on one CU -- five bundled scenes in flight 0.282 -> 0.260 ms per step, an isolated
+    // ManFigure frame 0.105 -> 0.110 (the LDS arrays stay sized for TRACE_WAVES: 4.6 KB per workgroup, 32 of them fit a CU)
+    const uint32_t wpb = (t.waves_per_block >= 1u && t.waves_per_block <= TRACE_WAVES) ? t.waves_per_block : TRACE_WAVES;
+    const uint32_t grid = ((a.total_work + 63u) / 64u + wpb - 1u) / wpb;
     // The wave-per-ray kernel does not know its work on the host: resident waves pull batches of deferred rays.  Resident
     // blocks per CU are a property of the code object, asked once (the query costs microseconds of host time).
     static int b1 = 0;
@@ -1896,7 +1899,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
             // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
             if (!upd) (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
-            const uint32_t helpers = t.task_helper_blocks ? t.task_helper_blocks : 256u;      // x TRACE_WAVES waves = one per SIMD: far fewer than wave slots
+            const uint32_t helpers = (t.task_helper_blocks ? t.task_helper_blocks : 256u) * TRACE_WAVES / wpb;      // 256 x TRACE_WAVES waves = one per SIMD: far fewer than wave slots
 #if RTMI_P4_VARIANT == 3
             static unsigned long long* dbg = nullptr; static size_t dbg_n = 0;
             const size_t want = (size_t)(grid + helpers) * TRACE_WAVES * P4_DBG_JOBS * 3u;
@@ -1906,9 +1909,10 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
                 a.dbg = dbg;
             }
 #endif
-            const dim3 g(grid + helpers), blk(TRACE_BLOCK);
-            if (a.quad_octant_records) { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 1, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 1, 0>, g, blk, s, a); }
-            else { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 0, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 0, 0>, g, blk, s, a); }
+            const dim3 g(grid + helpers), blk(wpb * 64u);
+            const uint32_t lds = wpb * 3u * PACKET_STACK * 4u;
+            if (a.quad_octant_records) { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 1, 1>, g, blk, s, a, lds); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 1, 0>, g, blk, s, a, lds); }
+            else { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 0, 1>, g, blk, s, a, lds); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 1, 0, 0>, g, blk, s, a, lds); }
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 std::vector<unsigned long long> h(want);
@@ -1918,9 +1922,10 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
             }
 #endif
         } else {
-            const dim3 g(grid), blk(TRACE_BLOCK);
-            if (a.quad_octant_records) { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 1, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 1, 0>, g, blk, s, a); }
-            else { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 0, 1>, g, blk, s, a); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 0, 0>, g, blk, s, a); }
+            const dim3 g(grid), blk(wpb * 64u);
+            const uint32_t lds = wpb * 3u * PACKET_STACK * 4u;
+            if (a.quad_octant_records) { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 1, 1>, g, blk, s, a, lds); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 1, 0>, g, blk, s, a, lds); }
+            else { if (a.fused_rgba) rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 0, 1>, g, blk, s, a, lds); else rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet4<1, CAL, 0, 0, 0>, g, blk, s, a, lds); }
 #if RTMI_P4_VARIANT == 3
             if (const char* path = getenv("RTMI_P4_WAVES")) {
                 const size_t n = (size_t)grid * TRACE_WAVES * 3u;
@@ -1940,7 +1945,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     }
     if (PRIMARY && t.packet) {
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
-        rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet<PRIMARY, CAL>, dim3(grid), dim3(TRACE_BLOCK), s, a);
+        rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace_packet<PRIMARY, CAL>, dim3((a.total_work + TRACE_BLOCK - 1u) / TRACE_BLOCK), dim3(TRACE_BLOCK), s, a);     // (always TRACE_WAVES waves)
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // without a budget the packet kernel hands nothing over: the wave-per-ray and resolve kernels would find empty lists
         if (a.defer_budget < (1u << 20)) {
@@ -1951,7 +1956,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         return;
     }
     if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
-    rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace<PRIMARY, CAL>, dim3(grid), dim3(TRACE_BLOCK), s, a);
+    rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace<PRIMARY, CAL>, dim3(grid), dim3(wpb * 64u), s, a, wpb * LDS_STACK * 64u * 4u);
     if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
     // wave-per-ray phase: the number of deferred rays lives on the device; a fixed grid pulls from the list
     rt_launch_node(rec, upd, RT_NODE_LONG, k_trace_long<PRIMARY, CAL>, dim3(grid1), dim3(TRACE_BLOCK), s, a);
