@@ -850,7 +850,8 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             // several frames in flight (rt_ctx_set_frames_in_flight): the helper waves and queues of a sharing launch cost the OTHER frames
             // more than its own shorter tail gains (the bundled five: 0.284 ms per step with whole blocks, 0.316 with Tenryuu shared
             // after 64 steps, which alone is 0.15 against 0.19 ms) -- sharing must then win by far, as it does where whole blocks crawl
-            if (ctx->frames_in_flight > 1u) h *= 1.6f;
+            static const float in_flight = [] { const char* e = std::getenv("RTMI_IN_FLIGHT_SHARE_HANDICAP"); const float v = e ? (float)std::atof(e) : 0.f; return v >= 1.0f ? v : 1.6f; }();
+            if (ctx->frames_in_flight > 1u) h *= in_flight;
             return h;
         };
         auto usable = [&](int ci) {
