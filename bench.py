@@ -388,8 +388,8 @@ def main():
             first_frame_ms[it['name']] = ((time.perf_counter() - t1) * 1e3, it['bvh'].calibration_launches(), it['bvh'].calibration_gpu_ms())
     use_graphs = not tiled and not args.no_graphs and os.environ.get('RTMI_BENCH_GRAPHS', '1') != '0'
     if use_graphs:
-        # a step keeps the five scenes' frames in flight together, and says so (rt_ctx_set_frames_in_flight, include/rtmi.h: blocks in
-        # index order, sub-tree sharing only where it wins by far -- both measured here).  The isolated pass, the first frames and
+        # a step keeps the five scenes' frames in flight together, and says so (rt_ctx_set_frames_in_flight, include/rtmi.h: workgroups
+        # of one wave, sub-tree sharing only where it wins by far -- both measured here).  The isolated pass, the first frames and
         # the 4K leg run one frame at a time, with the library's default policy.
         for it in work:
             it['ctx'].set_frames_in_flight(len(SCENES))

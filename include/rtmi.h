@@ -336,13 +336,14 @@ int  rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t 
 /* ---- one frame at a time, or several in flight ------------------------------------------- */
 /* How many frames the application keeps in flight on this device (streams of different contexts); default 1.  Two speed policies
  * follow it -- results are the same bits either way:
- *   n <= 1 (the Demo's RTFrame loop: a frame has the device to itself, its LATENCY counts): the four-wide kernel starts the blocks
- *          that cost the most steps in earlier frames of the same shape first, so a frame does not end on a few long blocks
- *          (environment RTMI_BLOCK_ORDER=0 switches that off), and the first-frame calibration takes sub-tree sharing at face value;
- *   n  > 1 (a server rendering many views: THROUGHPUT counts, other frames' waves fill a frame's end anyway): blocks in index order,
- *          workgroups of one wave (placed wherever a wave slot frees up: +6 % on five bundled scenes in flight), and a sharing strategy must beat whole blocks by 1.6 x to be chosen
- *          (its helper waves and queues cost the other frames more than they gain: five bundled scenes in flight 0.284 ms per step
- *          with whole blocks, 0.316 with Tenryuu's sub-trees shared, which alone is 0.15 against 0.19 ms).
+ *   n <= 1 (the Demo's RTFrame loop: a frame has the device to itself, its LATENCY counts): first-phase kernels in workgroups of
+ *          four waves (neighbouring 8x8 blocks on one CU), and the first-frame calibration takes sub-tree sharing at face value;
+ *   n  > 1 (a server rendering many views: THROUGHPUT counts): workgroups of one wave (placed wherever a wave slot frees up: +6 %
+ *          on five bundled scenes in flight), and a sharing strategy must beat whole blocks by 1.6 x to be chosen (its helper
+ *          waves and queues cost the other frames more than they gain: five bundled scenes in flight 0.262 ms per step with whole
+ *          blocks, 0.289 with Tenryuu's sub-trees shared, which alone is 0.13 against 0.17 ms).
+ * Under both the four-wide kernel starts the blocks that cost the most steps in earlier frames of the same shape first, so a frame
+ * does not end on a few long blocks (RTMI_BLOCK_ORDER=0 switches that off; RTMI_BLOCK_ORDER_IN_FLIGHT=0 for n > 1 only).
  * Read at each eager trace and at rt_frame_graph_create / rt_multi_frame_create; part of the calibration key, so a BVH keeps one
  * strategy per policy.                                                                                                            */
 int  rt_ctx_set_frames_in_flight(rt_ctx* ctx, uint32_t n);

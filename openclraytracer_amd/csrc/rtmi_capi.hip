@@ -155,6 +155,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_TASK_CAP")) { ctx->task_cap = (uint32_t)std::strtoul(env, nullptr, 10); ctx->task_cap_auto = false; }   // 0: no sharing
     if (const char* env = std::getenv("RTMI_FUSED_FRAMES")) ctx->no_fused_frames = env[0] == '0';
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER")) ctx->no_block_order = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_BLOCK_ORDER_IN_FLIGHT")) ctx->order_in_flight = env[0] != '0';
     if (const char* env = std::getenv("RTMI_TRACE_WORKGROUP")) { const uint32_t v = (uint32_t)std::strtoul(env, nullptr, 10); if (v == 64u || v == 128u || v == 256u) ctx->trace_workgroup_waves = v / 64u; }
     if (const char* env = std::getenv("RTMI_SEARCH_TREE_BOXES")) ctx->search_tree_reference_boxes = std::strcmp(env, "reference") == 0;
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER_GROUP")) { const uint32_t g = (uint32_t)std::strtoul(env, nullptr, 10); if (g && g <= 64u && !(g & (g - 1u))) { ctx->block_order_group_log = 0; while ((1u << ctx->block_order_group_log) < g) ctx->block_order_group_log++; } }
@@ -749,7 +750,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     // start order of the blocks (four-wide kernel): the buffers of this frame shape
     BlockOrder* const bo = (mode && mode->block_order) ? mode->block_order : &b->block_order;
     const bool captured = mode && (mode->record || mode->update);
-    const bool order_ok = !ctx->no_block_order && ctx->frames_in_flight <= 1u && b->d_quad && b->have_search_tree &&
+    const bool order_ok = !ctx->no_block_order && (ctx->frames_in_flight <= 1u || ctx->order_in_flight) && b->d_quad && b->have_search_tree &&
                           (captured ? bo->count != 0 : block_order_fit(ctx, *bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u));
     const uint64_t key = ((uint64_t)cam->resX << 40) ^ ((uint64_t)cam->resY << 16) ^ ((uint64_t)nranks << 8) ^ rank ^ (compact ? 1ull << 63 : 0) ^
                          (ctx->frames_in_flight > 1u ? 1ull << 62 : 0);      // (one strategy per policy, rt_ctx_set_frames_in_flight)
@@ -1068,7 +1069,7 @@ int rt_bvh_block_order(rt_bvh* b, uint32_t* h_order, uint32_t* h_cost, uint32_t 
     if (!b || !blocks) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
     rt_ctx* ctx = b->ctx;
     const BlockOrder& o = b->block_order;
-    *blocks = (o.valid && !ctx->no_block_order && ctx->frames_in_flight <= 1u) ? o.count : 0u;
+    *blocks = (o.valid && !ctx->no_block_order && (ctx->frames_in_flight <= 1u || ctx->order_in_flight)) ? o.count : 0u;
     if (*blocks == 0) return RT_SUCCESS;
     if (*blocks > capacity) return RT_FAIL(ctx, "rt_bvh_block_order: capacity too small");
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1415,7 +1416,7 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     g->plane_bits_known = 0x80000000u | (plane_bits & 7u);
     g->no_unsafe = g->four_wide && (plane_bits & (g->octant_records ? 6u : 7u)) == 0u;
     g->parts = strategy_parts(b, cam, packet, quad) & ~((g->four_wide && g->no_unsafe) ? RT_PREP_MARKS : 0u);
-    if (g->four_wide && !ctx->no_block_order && ctx->frames_in_flight <= 1u && block_order_fit(ctx, g->bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u)) {
+    if (g->four_wide && !ctx->no_block_order && (ctx->frames_in_flight <= 1u || ctx->order_in_flight) && block_order_fit(ctx, g->bo, (rt_tiles_owned_pixels(cam, rank, nranks) + 63u) / 64u)) {
         // the captured kernel reads its start order from this graph's own buffer: index order until the first launches have been counted
         g->bo.valid = launch_block_order(ctx->stream, g->bo.d_cost, g->bo.d_order, g->bo.count, ctx->block_order_group_log, true);
         if (!g->bo.valid) block_order_free(g->bo);

@@ -113,6 +113,7 @@ struct rt_ctx {
     bool search_tree_reference_boxes = false;   // knob RTMI_SEARCH_TREE_BOXES=reference: the search tree's boxes clamped like the reference's (round 2's)
     bool no_block_order = false;            // knob RTMI_BLOCK_ORDER=0: waves walk the blocks in index order
     uint32_t trace_workgroup_waves = 0;     // knob RTMI_TRACE_WORKGROUP=64/128/256: waves per workgroup of the first-phase kernels (0: by policy)
+    bool order_in_flight = true;            // knob RTMI_BLOCK_ORDER_IN_FLIGHT=0: index order under the throughput policy (what paid on round 2's tree)
     uint32_t frames_in_flight = 1;          // rt_ctx_set_frames_in_flight: > 1 = throughput policy (index order, sharing handicapped)
     uint32_t block_order_group_log = 4;     // knob RTMI_BLOCK_ORDER_GROUP=1..64: consecutive blocks that stay together (a power of two)
 };

@@ -1303,6 +1303,7 @@ def test_block_start_order_changes_no_bit(group, monkeypatch):
     monkeypatch.setenv('RTMI_PACKET', '4')
     monkeypatch.setenv('RTMI_DEFER_BUDGET', '128')
     monkeypatch.setenv('RTMI_BLOCK_ORDER_GROUP', group)
+    monkeypatch.setenv('RTMI_BLOCK_ORDER_IN_FLIGHT', '0')     # the second context below (frames in flight) walks in index order
     name, res = 'man', (448, 320)
     npx = res[0] * res[1]
     osc, ob = oracle_bvh(name)
