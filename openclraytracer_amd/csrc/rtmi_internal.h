@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -283,10 +284,19 @@ struct GraphNodes {
     hipGraphExec_t exec = nullptr;
     hipGraphNode_t node[RT_NODE_KINDS] = {};
     bool failed = false;          // a node was missing, appeared twice, or the runtime refused the new arguments
+    // the same launches as plain data (kernel, geometry, a copy of the argument block): a captured sequence that consists of kernels
+    // only can be issued as ordinary launches, which follow each other on a stream with a shorter gap than graph launches do
+    struct Direct { const void* func = nullptr; dim3 grid, block; uint32_t lds = 0; uint32_t bytes = 0; alignas(16) unsigned char args[768]; } direct[RT_NODE_KINDS];
 };
 template <typename K, typename A>
 inline void rt_launch_node(GraphNodes* record, GraphNodes* update, int kind, K kernel, dim3 grid, dim3 block, hipStream_t s, A& args, uint32_t lds_bytes = 0)
 {
+    static_assert(sizeof(A) <= sizeof(GraphNodes::Direct::args), "argument block larger than GraphNodes::Direct::args");
+    if (GraphNodes* n = update ? update : record) {
+        GraphNodes::Direct& d = n->direct[kind];
+        d.func = (const void*)kernel; d.grid = grid; d.block = block; d.lds = lds_bytes; d.bytes = (uint32_t)sizeof(A);
+        std::memcpy(d.args, &args, sizeof(A));
+    }
     if (update) {
         hipKernelNodeParams p{};
         void* params[1] = { (void*)&args };
