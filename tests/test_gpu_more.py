@@ -1402,3 +1402,41 @@ def test_search_tree_nests_tightly_over_the_reference_leaves(name, monkeypatch):
         finally:
             ctx.close()
     assert frames['tight'] == frames['reference'] == ob.trace_primary(osc.demo_camera(320, 200))[0].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('knobs', [dict(), dict(RTMI_PACKET='4', RTMI_DEFER_BUDGET='32'), dict(RTMI_PACKET='0', RTMI_DEFER_BUDGET='16')],
+                         ids=['calibrated', 'packet4-share32', 'lane16'])
+def test_throughput_policy_changes_no_bit(knobs, monkeypatch):
+    """rt_ctx_set_frames_in_flight(n > 1): workgroups of one wave for the first-phase kernels (their LDS stacks sized per launch), the
+    sharing handicap in the calibration, a calibration of its own -- and the contacts and colours of the default policy, eager and
+    through a frame graph (which, holding kernels only, is issued as plain launches), byte for byte."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    res = (416, 296)
+    npx = res[0] * res[1]
+    for name in ('tenryuu', 'clumsydragon'):
+        osc, ob = oracle_bvh(name)
+        cam = as_capi_camera(osc.demo_camera(*res))
+        want = ob.trace_primary(osc.demo_camera(*res))[0].tobytes()
+        frames = []
+        for n_in_flight in (1, 3):
+            ctx = capi.Context(0)
+            try:
+                ctx.set_frames_in_flight(n_in_flight)
+                sc = capi.DeviceScene(ctx, packed_scene(name))
+                gb = capi.DeviceBVH(ctx, sc).build()
+                eager = gb.generate_contacts_primary(cam).tobytes()
+                d_c, d_o = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+                fg = capi.FrameGraph(gb, sc, cam, d_c, d_o)
+                for _ in range(3):
+                    fg.launch()
+                ctx.synchronize()
+                frames.append((eager, ctx.download(d_c, npx * 32, np.uint8).tobytes(), ctx.download(d_o, npx * 16, np.uint8).tobytes()))
+                fg.close(); ctx.free(d_c); ctx.free(d_o); gb.close(); sc.close()
+            finally:
+                ctx.close()
+        assert frames[0] == frames[1]
+        assert frames[0][0] == want and frames[0][1] == want
