@@ -1310,7 +1310,8 @@ static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, u
     FusedShade fused{ d_out, layout == RT_FRAME_TILED_PACKED ? slots_per_rank : 0u, false };
     FrameMode plain;
     FrameMode* m = mode ? mode : &plain;
-    m->fused = b->capture_no_unsafe_rays && !ctx->no_fused_frames ? &fused : nullptr;
+    // (... and a captured frame of the lane-per-ray strategy lets its two kernels shade what they store)
+    m->fused = (b->capture_no_unsafe_rays || (m->fixed_strategy && !m->packet)) && !ctx->no_fused_frames ? &fused : nullptr;
     const bool update = m->update != nullptr;
     if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts, m)) return RT_ERROR;
     if (fused.done) { if (!update) RT_HIP(ctx, hipGetLastError()); return RT_SUCCESS; }

@@ -611,6 +611,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                 float4* o = reinterpret_cast<float4*>(a.out + slot);
                 o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (a.fused_rgba != nullptr) store_colour(a, slot, 0u, 0.0f, NO_LEAF);
             }
         }
     }
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
             // ---- retire finished rays ----
             if (active && cur == RT_SENTINEL && pending == NO_LEAF) {
                 store_contact(a, r.out_index, r.pixel, r.best_t, r.best_leaf);
+                if (PRIMARY && a.fused_rgba != nullptr) store_colour(a, r.out_index, r.pixel, r.best_t, r.best_leaf);   // fused frame of the lane-per-ray strategy: launch_tagged
                 active = false;
             }
             if (__ballot(active) == 0ull) break;
@@ -1813,6 +1815,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
                     const uint32_t leaf = key != KEY_NONE ? a.pairs[(uint32_t)key].y : NO_LEAF;
                     const float t = key != KEY_NONE ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
                     store_contact(a, __float_as_uint(ray[lane][3].x), __float_as_uint(ray[lane][3].y), t, leaf);
+                    if (PRIMARY && a.fused_rgba != nullptr) store_colour(a, __float_as_uint(ray[lane][3].x), __float_as_uint(ray[lane][3].y), t, leaf);
                 }
             }
         }
@@ -1954,6 +1957,14 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         }
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
+    }
+    if constexpr (PRIMARY == 1) if (t.fused_rgba) {
+        // lane-per-ray + wave-per-ray: between them the two kernels store every contact of the frame exactly once (a ray finishes in
+        // the first or is handed, whole, to the second), so in a fused frame each shades what it stores and k_shade is not launched
+        a.fused_rgba = (float4*)t.fused_rgba; a.fused_plane_stride = t.fused_plane_stride;
+        a.fused_scene.scene = t.scene->bytes; a.fused_scene.n_lights = t.scene->n_lights; a.fused_scene.n_spheres = t.scene->n_spheres;
+        a.fused_scene.n_materials = t.scene->n_materials;
+        if (t.fused_done) *t.fused_done = true;
     }
     if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
     rt_launch_node(rec, upd, RT_NODE_TRACE, k_trace<PRIMARY, CAL>, dim3(grid), dim3(wpb * 64u), s, a, wpb * LDS_STACK * 64u * 4u);
