@@ -31,6 +31,7 @@ static void free_ctx_buffers(rt_ctx* ctx)
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
     if (ctx->d_split_list) (void)hipFree(ctx->d_split_list);
     if (ctx->d_clock) (void)hipFree(ctx->d_clock);
+    for (uint32_t i = 0; i < ctx->n_tile_tables; i++) if (ctx->tile_tables[i].d) (void)hipFree(ctx->tile_tables[i].d);
     if (ctx->d_task_list) (void)hipFree(ctx->d_task_list);
     ctx->d_task_list = nullptr;
     ctx->d_trace_ctrl = nullptr; ctx->d_long_list = nullptr; ctx->long_cap = 0;
@@ -744,6 +745,25 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32
 // moderately long rays: no deferral), and every budget produces the same contacts.  The first frame of a
 // (BVH, resolution, tiling) combination therefore runs once per candidate, timed with HIP events on the stream,
 // and later frames use the fastest.  RTMI_DEFER_BUDGET fixes the budget and switches the calibration off.
+// the table work_to_pixel_block reads: (x0, y0) of tile `ordinal` of this rank for (resolution, rank, tiling); null when the context
+// already holds RT_TILE_TABLES shapes or the allocation fails (the kernels then compute it per lane)
+static const uint2* tile_table(rt_ctx* ctx, const rt_camera* cam, uint32_t rank, uint32_t nranks)
+{
+    const uint64_t key = ((uint64_t)cam->resX << 44) ^ ((uint64_t)cam->resY << 24) ^ ((uint64_t)nranks << 8) ^ rank ^ (1ull << 63);
+    for (uint32_t i = 0; i < ctx->n_tile_tables; i++) if (ctx->tile_tables[i].key == key) return ctx->tile_tables[i].d;
+    if (ctx->n_tile_tables >= rt_ctx::RT_TILE_TABLES) return nullptr;
+    const uint32_t tiles_x = rt_tiles_x(cam->resX), owned = rt_owned_tiles(tiles_x * rt_tiles_y(cam->resY), rank, nranks);
+    if (owned == 0) return nullptr;
+    std::vector<uint2> h(owned);
+    for (uint32_t o = 0; o < owned; o++) { const uint32_t tile = rt_tile_of(rank, o, nranks); h[o] = make_uint2((tile % tiles_x) * RT_TILE, (tile / tiles_x) * RT_TILE); }
+    uint2* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)owned * sizeof(uint2)) != hipSuccess || hipMemcpy(d, h.data(), (size_t)owned * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError(); if (d) (void)hipFree(d); return nullptr;
+    }
+    ctx->tile_tables[ctx->n_tile_tables].key = key; ctx->tile_tables[ctx->n_tile_tables].d = d; ctx->n_tile_tables++;
+    return d;
+}
+
 static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out, const FrameMode* mode = nullptr)
 {
     rt_ctx* ctx = b->ctx;
@@ -821,6 +841,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             }
             ms = 0.f;
             (void)hipEventRecord(e0, ctx->stream);
+            t.tile_xy = tile_table(ctx, cam, rank, nranks);
             launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
             (void)hipEventRecord(e1, ctx->stream);
             launches++;
@@ -966,6 +987,7 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     if (mode && mode->fused) { t.fused_rgba = mode->fused->rgba; t.fused_plane_stride = mode->fused->plane_stride; t.fused_done = &mode->fused->done; }
     const bool ordered = packet && quad && order_ok;
     if (ordered) { t.block_cost = bo->d_cost; t.block_order = (bo->valid || captured) ? bo->d_order : nullptr; }
+    t.tile_xy = tile_table(ctx, cam, rank, nranks);
     launch_trace_primary(ctx->stream, t, *cam, rank, nranks, compact, out);
     if (mode && mode->update) return mode->update->failed ? RT_FAIL(ctx, "frame graph: a kernel node could not be updated") : RT_SUCCESS;
     // every few frames the order follows the costs the frame just enqueued will have counted (a captured frame: rt_frame_graph_launch)

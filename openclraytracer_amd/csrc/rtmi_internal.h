@@ -111,6 +111,12 @@ struct rt_ctx {
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
     std::vector<hipEvent_t> trace_events;   // triples, one per trace launch since the last query
     unsigned long long* d_clock = nullptr;  // one word: the device clock sample of a calibration
+    // where a rank's owned tiles lie, per frame shape (trace_kernels.hip, work_to_pixel_block): small device tables kept for the context's
+    // life (captured kernels hold their addresses); beyond RT_TILE_TABLES shapes the kernels compute the place per lane as before
+    struct TileTable { uint64_t key = 0; uint2* d = nullptr; };
+    enum { RT_TILE_TABLES = 16 };
+    TileTable tile_tables[RT_TILE_TABLES];
+    uint32_t n_tile_tables = 0;
     bool search_tree_reference_boxes = false;   // knob RTMI_SEARCH_TREE_BOXES=reference: the search tree's boxes clamped like the reference's (round 2's)
     bool no_block_order = false;            // knob RTMI_BLOCK_ORDER=0: waves walk the blocks in index order
     uint32_t trace_workgroup_waves = 0;     // knob RTMI_TRACE_WORKGROUP=64/128/256: waves per workgroup of the first-phase kernels (0: by policy)
@@ -321,6 +327,7 @@ struct TraceLaunch {
     uint32_t plane_bits_known;    // 0x80000000 | bits: the host knows the camera-on-a-plane bits (else the kernels read tree_select)
     const uint32_t* block_order;  // four-wide kernel: wave -> block permutation (null: identity)
     uint32_t waves_per_block;     // first-phase kernels: waves per workgroup (0: the default of four)
+    const uint2* tile_xy;         // primary frames: pixel origin of this rank's tile `ordinal` for this (resolution, rank, tiling), or null
     uint32_t* block_cost;         // ... and where it counts this frame's steps per block (null: not counted)
     unsigned long long cal_deadline;   // calibration launches (tag 1): device clock value after which the kernels stop walking, 0 = none
     const TravNode* trav;         // reference tree records [0, n-1), then (optionally) the search tree's [n-1, 2n-2)

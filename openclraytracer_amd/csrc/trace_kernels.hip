@@ -173,6 +173,7 @@ struct TraceArgs {
     // primary rays
     rt_camera cam;
     uint32_t rank, nranks, tiles_x;
+    const uint2* __restrict__ tile_xy;          // primary frames: pixel origin (x0, y0) of this rank's tile `ordinal` (null: computed per lane)
     uint32_t compact;
     // ray buffer
     const rt_ray* __restrict__ rays;
@@ -461,14 +462,30 @@ __device__ __forceinline__ bool work_to_pixel(const TraceArgs& a, uint32_t w, ui
     slot = (ordinal << 12) + ly * RT_TILE + lx;
     return x < a.cam.resX && y < a.cam.resY;
 }
+// ... for a wave whose 64 lanes hold the 64 consecutive work items of ONE 8x8 block (every first-phase kernel): the tile is the same
+// for all of them, and where it lies comes out of a table of this frame shape (one scalar load) instead of three integer divisions per
+// lane (~80 vector instructions of the ~165 a wave spends outside its steps)
+__device__ __forceinline__ bool work_to_pixel_block(const TraceArgs& a, uint32_t w, uint32_t& x, uint32_t& y, uint32_t& slot)
+{
+    if (a.tile_xy == nullptr) return work_to_pixel(a, w, x, y, slot);
+    const uint32_t ordinal = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 12));
+    const uint2 t0 = a.tile_xy[ordinal];
+    const uint32_t within = w & 4095u;
+    const uint32_t blk = within >> 6, lp = within & 63u;
+    const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3);
+    const uint32_t lx = ((blk & 7u) << 3) + (lp & 7u);
+    x = t0.x + lx; y = t0.y + ly;
+    slot = (ordinal << 12) + ly * RT_TILE + lx;
+    return x < a.cam.resX && y < a.cam.resY;
+}
 
 // loads the ray of work item w; false when the item is a slot outside the frame
-template <int PRIMARY>
+template <int PRIMARY, bool BLOCK = true>            // BLOCK: the wave's lanes hold one 8x8 block's work items (work_to_pixel_block)
 __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayState& r, bool& sx, bool& sy, bool& sz)
 {
     if (PRIMARY) {
         uint32_t x, y, slot;
-        if (!work_to_pixel(a, w, x, y, slot)) return false;
+        if (!(BLOCK ? work_to_pixel_block(a, w, x, y, slot) : work_to_pixel(a, w, x, y, slot))) return false;
         generate_ray_xy(a.cam, x, y, r.o, r.d);
         r.pixel = y * a.cam.resX + x;
         r.out_index = a.compact ? slot : r.pixel;
@@ -607,7 +624,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
             } else if (PRIMARY && a.compact) {
                 // slot of a border tile that lies outside the frame: defined as "no contact"
                 uint32_t x, y, slot;
-                work_to_pixel(a, w, x, y, slot);
+                work_to_pixel_block(a, w, x, y, slot);
                 float4* o = reinterpret_cast<float4*>(a.out + slot);
                 o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1220,7 +1237,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, P4_MIN_WAVES) void k_trace_packet4(Tra
             if (!SHARE || !is_task) {
                 if (PRIMARY && A.compact && !ok && w < A.total_work) {
                     uint32_t x, y, slot;
-                    work_to_pixel(A, w, x, y, slot);
+                    work_to_pixel_block(A, w, x, y, slot);
                     float4* o = reinterpret_cast<float4*>(A.out + slot);
                     o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1658,7 +1675,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
             }
             RayState r;
             bool sx, sy, sz;
-            load_ray<PRIMARY>(a, live ? work : 0u, r, sx, sy, sz);
+            load_ray<PRIMARY, false>(a, live ? work : 0u, r, sx, sy, sz);          // (each lane another record's ray)
             const uint32_t signs = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
             const uint32_t flags = (live ? LONG_LIVE : 0u) | (live && rec[LR_PARTIAL] != 0u ? LONG_PARTIAL : 0u);
             ray[lane][0] = make_float4(r.o.x, r.o.y, r.o.z, __uint_as_float(signs));
@@ -2008,6 +2025,7 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.cam = cam;
     a.rank = rank; a.nranks = nranks;
     a.tiles_x = rt_tiles_x(cam.resX);
+    a.tile_xy = t.tile_xy;
     uint32_t total_tiles = a.tiles_x * rt_tiles_y(cam.resY);
     a.compact = compact ? 1u : 0u;
     a.total_work = rt_owned_tiles(total_tiles, rank, nranks) * RT_TILE * RT_TILE;
