@@ -1180,7 +1180,13 @@ template <int PRIMARY, int CAL, int SHARE, int OCT, int FUSE>
 #ifndef P4_MIN_WAVES
 #define P4_MIN_WAVES 8
 #endif
-__global__ __launch_bounds__(TRACE_BLOCK, P4_MIN_WAVES) void k_trace_packet4(TraceArgs a)
+// (the instances without sharing: same bound.  "6" / "7" were measured when the fused instance still spilled 48 scalar registers per
+//  wave: 106 / 94 scalar registers, bench +1.5 %, the 4K frame 0.38 -> 0.42 / 0.395 ms; the spills are gone since the fused frame's
+//  shading arguments are read where they are used)
+#ifndef P4_MIN_WAVES_WHOLE
+#define P4_MIN_WAVES_WHOLE 8
+#endif
+__global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? P4_MIN_WAVES : P4_MIN_WAVES_WHOLE)) void k_trace_packet4(TraceArgs a)
 {
     extern __shared__ uint32_t s_dynamic[];              // three stacks of PACKET_STACK words per wave of the workgroup (launch_tagged sizes it)
     const uint32_t lane = threadIdx.x & 63u;
@@ -1474,7 +1480,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, P4_MIN_WAVES) void k_trace_packet4(Tra
             cost_steps++;
         }
         }                                                // next octant group
-        const TraceArgs& A = SHARE ? rare_args<4>() : a;
+        // (a fused frame's shading arguments -- scene pointers, counts, the whole camera -- would otherwise live in scalar registers
+        //  through the walk and be spilled into vector lanes at the top of every wave: they are read here, where they are used)
+        const TraceArgs& A = (SHARE || FUSE) ? rare_args<4>() : a;
         // what this block cost, for the start order of later frames (launch_block_order): its own steps; a block that shared sub-trees
         // ranks before every block that did not
         if (A.block_cost != nullptr && lane == 0 && !(SHARE && is_task)) A.block_cost[job_w0 >> 6] = cost_steps + (split ? 0x10000u : 0u);
