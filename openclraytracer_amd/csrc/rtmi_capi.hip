@@ -506,7 +506,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             return RT_FAIL(ctx, std::string("initializeFrame: device allocation failed: ") + hipGetErrorString(e));
         }
         b->n = n; b->N = N;
-        b->build_generation++;
+        b->build_generation++; b->eager_frames = 0; b->eager_frames = 0;
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -745,6 +745,12 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32
 // moderately long rays: no deferral), and every budget produces the same contacts.  The first frame of a
 // (BVH, resolution, tiling) combination therefore runs once per candidate, timed with HIP events on the stream,
 // and later frames use the fastest.  RTMI_DEFER_BUDGET fixes the budget and switches the calibration off.
+static int ensure_host_planes(rt_bvh* b);
+static uint32_t host_plane_bits(const rt_bvh* b, const float origin[3]);
+// eager four-wide frames on one build before the host reads the leaf boxes' planes back (once per build: a synchronisation, a copy
+// of the leaves and three sorts -- milliseconds, which a scene that is rebuilt every frame never pays)
+#define RT_EAGER_PLANES_AFTER 8u
+
 // the table work_to_pixel_block reads: (x0, y0) of tile `ordinal` of this rank for (resolution, rank, tiling); null when the context
 // already holds RT_TILE_TABLES shapes or the allocation fails (the kernels then compute it per lane)
 static const uint2* tile_table(rt_ctx* ctx, const rt_camera* cam, uint32_t rank, uint32_t nranks)
@@ -982,7 +988,23 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
     if (ctx->defer_budget == 0 && b->tuned) { budget = b->tuned_budget; packet = b->tuned_packet; quad = b->tuned_quad; }
     if (ctx->defer_budget != 0 && ctx->force_packet) { packet = true; quad = ctx->force_packet4 && b->d_quad; }
     if (mode && mode->fixed_strategy) { packet = mode->packet; quad = mode->quad; budget = mode->budget; }
-    TraceLaunch t = make_launch(b, cam, strategy_parts(b, cam, packet, quad) & ~(mode ? mode->parts_drop : 0u), mode);
+    uint32_t parts = strategy_parts(b, cam, packet, quad) & ~(mode ? mode->parts_drop : 0u);
+    // Eager frames of the four-wide kernel end with a launch of the wave-per-ray kernel that finds nothing to do unless the camera
+    // sits on a box plane (~6.5 us of a 0.05-0.1 ms frame; a captured frame leaves it out, rt_frame_graph_create).  Once a build has
+    // served a few frames the host knows the planes (ensure_host_planes: what rt_frame_graph_set_camera uses) and looks the camera up
+    // itself: off every plane that matters, the launch and the per-camera marks are left out here as well.  Error bit 6 guards it.
+    uint32_t eager_bits = 0; bool eager_no_unsafe = false;
+    if (!captured && packet && quad && b->have_search_tree && b->d_quad && b->d_tricam) {
+        if (b->eager_frames < RT_EAGER_PLANES_AFTER) b->eager_frames++;
+        else if (ensure_host_planes(b) == RT_SUCCESS) {
+            const float origin[3] = { cam->viewTransform[3], cam->viewTransform[7], cam->viewTransform[11] };
+            const uint32_t bits = host_plane_bits(b, origin);
+            eager_bits = 0x80000000u | bits;
+            if ((bits & (b->quad_cam_variants == 9u ? 6u : 7u)) == 0u) { eager_no_unsafe = true; parts &= ~RT_PREP_MARKS; }
+        }
+    }
+    TraceLaunch t = make_launch(b, cam, parts, mode);
+    if (eager_bits) { t.plane_bits_known = eager_bits; t.no_unsafe_rays = eager_no_unsafe; }
     t.defer_budget = budget; t.packet = packet; t.packet4 = quad;
     if (mode && mode->fused) { t.fused_rgba = mode->fused->rgba; t.fused_plane_stride = mode->fused->plane_stride; t.fused_done = &mode->fused->done; }
     const bool ordered = packet && quad && order_ok;

@@ -198,6 +198,7 @@ struct rt_bvh {
     uint32_t calibration_launches = 0;      // full-size launches the last calibration took (diagnostic)
     float calibration_gpu_ms = 0.f;         // ... and their device time
     uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)
+    uint32_t eager_frames = 0;              // eager four-wide frames traced on this build (from RT_EAGER_PLANES_AFTER on the host looks the plane bits up)
     bool frame_initialised = false;
     bool built = false;
 };

@@ -1440,3 +1440,40 @@ def test_throughput_policy_changes_no_bit(knobs, monkeypatch):
                 ctx.close()
         assert frames[0] == frames[1]
         assert frames[0][0] == want and frames[0][1] == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['man', 'clumsydragon'])
+def test_eager_frames_after_the_host_knows_the_planes(name, monkeypatch):
+    """From the ninth eager four-wide frame on a build the host looks the camera up in the planes of the leaf boxes itself
+    (ensure_host_planes) and leaves the wave-per-ray launch and the per-camera marks out when the camera sits on no plane that
+    matters.  Cameras off every plane, on an x plane (stays on the search tree), on a y and on a z plane (rays with a zero
+    direction component there are handed over: the launch must be there), twelve frames each and interleaved: every frame is the
+    oracle's, and a rebuild starts the count again."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    import plane_rays as pr
+    monkeypatch.setenv('RTMI_PACKET', '4')
+    monkeypatch.setenv('RTMI_DEFER_BUDGET', '1048576')
+    osc, ob = oracle_bvh(name)
+    res = (160, 120)
+    n = ob.n
+    cams = [osc.demo_camera(*res)]
+    cx = osc.demo_camera(*res).copy(); cx['m'][0][3] = 0.0; cams.append(cx)                       # x on a plane of these models
+    cams.append(pr.plane_camera(osc, res, 1, ob.nodes['hi'][23 % n, 1]))                          # y on a plane, a pixel row with direction.y == 0
+    cams.append(pr.plane_camera(osc, res, 2, ob.nodes['lo'][17 % n, 2]))                          # z on a plane, every ray with direction.z == 0
+    want = [ob.trace_primary(c)[0].tobytes() for c in cams]
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        for round_ in range(2):
+            for k, c in enumerate(cams):
+                for _ in range(12):
+                    assert gb.generate_contacts_primary(as_capi_camera(c)).tobytes() == want[k], (round_, k)
+            for i in range(16):                                                                    # interleaved
+                k = (i * 7 + 3) % len(cams)
+                assert gb.generate_contacts_primary(as_capi_camera(cams[k])).tobytes() == want[k], (round_, 'mixed', k)
+            gb.build()                                                                             # the count starts again
+    finally:
+        ctx.close()
