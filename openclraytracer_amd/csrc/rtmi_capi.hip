@@ -755,8 +755,10 @@ static uint32_t host_plane_bits(const rt_bvh* b, const float origin[3]);
 // already holds RT_TILE_TABLES shapes or the allocation fails (the kernels then compute it per lane)
 static const uint2* tile_table(rt_ctx* ctx, const rt_camera* cam, uint32_t rank, uint32_t nranks)
 {
-    const uint64_t key = ((uint64_t)cam->resX << 44) ^ ((uint64_t)cam->resY << 24) ^ ((uint64_t)nranks << 8) ^ rank ^ (1ull << 63);
-    for (uint32_t i = 0; i < ctx->n_tile_tables; i++) if (ctx->tile_tables[i].key == key) return ctx->tile_tables[i].d;
+    for (uint32_t i = 0; i < ctx->n_tile_tables; i++) {
+        const rt_ctx::TileTable& e = ctx->tile_tables[i];
+        if (e.resX == cam->resX && e.resY == cam->resY && e.rank == rank && e.nranks == nranks) return e.d;      // (the whole tuple: no hashed key)
+    }
     if (ctx->n_tile_tables >= rt_ctx::RT_TILE_TABLES) return nullptr;
     const uint32_t tiles_x = rt_tiles_x(cam->resX), owned = rt_owned_tiles(tiles_x * rt_tiles_y(cam->resY), rank, nranks);
     if (owned == 0) return nullptr;
@@ -766,7 +768,8 @@ static const uint2* tile_table(rt_ctx* ctx, const rt_camera* cam, uint32_t rank,
     if (hipMalloc((void**)&d, (size_t)owned * sizeof(uint2)) != hipSuccess || hipMemcpy(d, h.data(), (size_t)owned * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError(); if (d) (void)hipFree(d); return nullptr;
     }
-    ctx->tile_tables[ctx->n_tile_tables].key = key; ctx->tile_tables[ctx->n_tile_tables].d = d; ctx->n_tile_tables++;
+    rt_ctx::TileTable& slot = ctx->tile_tables[ctx->n_tile_tables++];
+    slot.resX = cam->resX; slot.resY = cam->resY; slot.rank = rank; slot.nranks = nranks; slot.d = d;
     return d;
 }
 

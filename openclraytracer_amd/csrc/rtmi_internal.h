@@ -113,7 +113,7 @@ struct rt_ctx {
     unsigned long long* d_clock = nullptr;  // one word: the device clock sample of a calibration
     // where a rank's owned tiles lie, per frame shape (trace_kernels.hip, work_to_pixel_block): small device tables kept for the context's
     // life (captured kernels hold their addresses); beyond RT_TILE_TABLES shapes the kernels compute the place per lane as before
-    struct TileTable { uint64_t key = 0; uint2* d = nullptr; };
+    struct TileTable { uint32_t resX = 0, resY = 0, rank = 0, nranks = 0; uint2* d = nullptr; };
     enum { RT_TILE_TABLES = 16 };
     TileTable tile_tables[RT_TILE_TABLES];
     uint32_t n_tile_tables = 0;

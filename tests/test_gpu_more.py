@@ -1477,3 +1477,39 @@ def test_eager_frames_after_the_host_knows_the_planes(name, monkeypatch):
             gb.build()                                                                             # the count starts again
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_tile_tables_of_many_frame_shapes_in_one_context():
+    """The first-phase kernels read where a rank's tile lies from a per-shape table (work_to_pixel_block / tile_table): a context keeps
+    up to 16 of them, keyed by the whole (resolution, rank, tiling) tuple -- among the shapes here a pair that a hashed key of shifted
+    fields would confuse (resY 120 with 0 extra tiles against resY 121 with 1) -- and computes the place per lane beyond that.  Every
+    rank's compact contacts, put back in place, are the untiled frame's."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    osc, ob = oracle_bvh('gardenlight')
+    shapes = [((200, 120), 3, 0), ((200, 121), 3, 1), ((200, 121), 3, 0), ((200, 120), 3, 1), ((333, 200), 2, 2), ((130, 70), 4, 0),
+              ((130, 70), 4, 1), ((64, 64), 2, 0), ((65, 64), 2, 0), ((640, 360), 8, 1)]
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene('gardenlight'))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        for round_ in range(2):                                   # second round: every table exists (or never will)
+            for res, n_ranks, extra in shapes:
+                cam = as_capi_camera(osc.demo_camera(*res))
+                til = capi.tiling(n_ranks, extra)
+                full = gb.generate_contacts_primary(cam)
+                if round_ == 0:
+                    assert full.tobytes() == ob.trace_primary(osc.demo_camera(*res))[0].tobytes()
+                rank_of, slot_of = capi.tile_slot_map(res[0], res[1], til)
+                for r in range(n_ranks):
+                    slots = capi.tiles_owned_pixels(cam, r, til)
+                    d = ctx.alloc(max(slots, 1) * 32)
+                    ctx.fill_u32(d, 0xDEADBEEF, max(slots, 1) * 8)
+                    gb.generate_contacts_primary_tiled_d(cam, r, til, d)
+                    compact = ctx.download(d, slots, capi.CONTACT)
+                    ctx.free(d)
+                    mine = rank_of == r
+                    assert compact[slot_of[mine]].tobytes() == full[mine].tobytes(), (res, n_ranks, extra, r)
+    finally:
+        ctx.close()
