@@ -944,6 +944,12 @@ static int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, u
             // the neighbours of the best lane-per-ray budget, two candidates away on either side (the list is ~sqrt(2) apart)
             sample(first - 2 >= LANE_8 ? first - 2 : LANE_8);
             sample(first + 2 < LANE_NONE ? first + 2 : LANE_NONE - 1);
+            // ... then the direct neighbours of whichever is best now (ClumsyDragon: 8 / 16 / 32 steps make 16 the best, 12 is 5 % better)
+            const int mid = best_of(-1);
+            if (mid >= LANE_8 && mid < LANE_NONE) {
+                if (mid - 1 >= LANE_8 && cand_n[mid - 1] == 0) sample(mid - 1);
+                if (mid + 1 < LANE_NONE && cand_n[mid + 1] == 0) sample(mid + 1);
+            }
         };
         if (calibrate_all) {
             for (int ci = 0; ci < N_CAND; ci++) { sample(ci); sample(ci); }

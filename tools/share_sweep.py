@@ -14,6 +14,8 @@ SETTINGS = [('packet4 whole blocks', '4', 1 << 20), ('packet4 share 1024', '4', 
 
 def main():
     global SETTINGS
+    if os.environ.get('SWEEP') == 'lane':
+        SETTINGS = [('lane-per-ray %d' % b, '0', b) for b in (6, 8, 12, 16, 24, 32, 48)]
     if os.environ.get('SWEEP') == 'small':
         SETTINGS = [x for x in SETTINGS if x[0] in ('packet4 share 64', 'packet4 share 32', 'packet4 share 16', 'packet4 share 8')]
     if os.environ.get('SWEEP') == 'quick':
