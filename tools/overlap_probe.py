@@ -50,3 +50,4 @@ else:
     out['all again'] = run(names)
 for k, v in out.items():
     print('%-24s %.4f ms per step' % (k, v), flush=True)
+print(json.dumps(dict(what='frame graphs of the bundled scenes at 1920x1080, one per scene on its own stream, launched back to back; ms per step for subsets of the scenes', policy='latency' if order else 'throughput (rt_ctx_set_frames_in_flight(5))', strategies={n: items[n]['strategy'] for n in names}, ms_per_step={k: round(v, 4) for k, v in out.items()})))
