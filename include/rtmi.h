@@ -135,6 +135,9 @@ int  rt_bvh_trace_strategy(const rt_bvh* bvh, int* packet_kernel, uint32_t* budg
 /* full-size launches the last calibration took (about a dozen: a coarse pass over few candidates, the neighbours of the best, the two
  * fastest once more; env RTMI_CALIBRATE_ALL=1: the exhaustive pass over all 25 candidates); 0 = not calibrated                  */
 uint32_t rt_bvh_calibration_launches(const rt_bvh* bvh);
+/* test / inspection: how often the host read the leaf boxes back to know their planes (once per build that serves more than a few
+ * eager four-wide frames or a moving frame graph; never for a scene that is rebuilt every frame) */
+uint32_t rt_bvh_host_plane_reads(const rt_bvh* bvh);
 float    rt_bvh_calibration_gpu_ms(const rt_bvh* bvh);        /* device time of those launches (HIP events on the stream) */
 /* Primary rays (all with the camera position as origin) walk a second hierarchy over the same leaf boxes, ordered by
  * properly normalised Morton codes (depth ~25-50 instead of the reference tree's 94-10 835).  A leaf whose box passes the

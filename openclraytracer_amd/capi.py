@@ -37,7 +37,7 @@ SYMBOLS = [
     'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_upload_indexed', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_read_nodes',
-    'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
+    'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_host_plane_reads', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
     'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_frames_in_flight', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
@@ -356,6 +356,11 @@ class DeviceBVH:
         self.ctx.lib.rt_bvh_block_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         self.ctx.check(self.ctx.lib.rt_bvh_block_order(self.h, order.ctypes.data, cost.ctypes.data, capacity, C.byref(n)))
         return (order[:n.value].copy(), cost[:n.value].copy()) if n.value else None
+
+    def host_plane_reads(self) -> int:
+        self.ctx.lib.rt_bvh_host_plane_reads.argtypes = [C.c_void_p]
+        self.ctx.lib.rt_bvh_host_plane_reads.restype = C.c_uint32
+        return int(self.ctx.lib.rt_bvh_host_plane_reads(self.h))
 
     def calibration_gpu_ms(self) -> float:
         self.ctx.lib.rt_bvh_calibration_gpu_ms.argtypes = [C.c_void_p]

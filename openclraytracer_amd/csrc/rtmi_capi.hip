@@ -506,7 +506,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             return RT_FAIL(ctx, std::string("initializeFrame: device allocation failed: ") + hipGetErrorString(e));
         }
         b->n = n; b->N = N;
-        b->build_generation++; b->eager_frames = 0; b->eager_frames = 0;
+        b->build_generation++; b->eager_frames = 0;
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
@@ -594,7 +594,7 @@ int rt_bvh_construct(rt_bvh* b)
     b->frame_initialised = false;
     b->built = true;
     b->marked_valid = false;
-    b->build_generation++;
+    b->build_generation++; b->eager_frames = 0;            // (the host's copy of the planes is this build's only after a few frames on it)
     // Dynamic scenes rebuild every frame (OpenCLRayTracerDemo.cpp:230-234).  The calibrated strategy is a property of how the
     // model fills the frame, not of one build: it is kept while the triangle count stays (the key holds resolution and tiling),
     // and every strategy produces the same contacts anyway.  RTMI_RECALIBRATE=1 restores a calibration per construct().
@@ -1132,6 +1132,7 @@ int rt_bvh_block_order(rt_bvh* b, uint32_t* h_order, uint32_t* h_cost, uint32_t 
 }
 
 uint32_t rt_bvh_calibration_launches(const rt_bvh* b) { return b ? b->calibration_launches : 0u; }
+uint32_t rt_bvh_host_plane_reads(const rt_bvh* b) { return b ? b->h_planes_reads : 0u; }
 float rt_bvh_calibration_gpu_ms(const rt_bvh* b) { return b ? b->calibration_gpu_ms : 0.f; }
 
 int rt_bvh_search_tree(const rt_bvh* b, uint32_t* depth, int* used_by_last_camera)
@@ -1343,6 +1344,7 @@ static int ensure_host_planes(rt_bvh* b)
         v.erase(std::unique(v.begin(), v.end()), v.end());
     }
     b->h_planes_generation = b->build_generation;
+    b->h_planes_reads++;
     return RT_SUCCESS;
 }
 static uint32_t host_plane_bits(const rt_bvh* b, const float origin[3])

@@ -183,6 +183,7 @@ struct rt_bvh {
     // plane" without asking the device -- read back on first use per build (movable frame graphs, rt_frame_graph_set_camera)
     std::vector<float> h_planes[3];
     uint64_t h_planes_generation = 0;
+    uint32_t h_planes_reads = 0;            // how often the leaves were read back for them (rt_bvh_host_plane_reads: tests)
     bool tuned = false;                     // deferral budget calibrated for tuned_key
     uint64_t tuned_key = 0;
     uint32_t tuned_n = 0;                   // triangle count the strategy was calibrated for (kept across rebuilds of the same size)

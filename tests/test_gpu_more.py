@@ -1474,7 +1474,14 @@ def test_eager_frames_after_the_host_knows_the_planes(name, monkeypatch):
             for i in range(16):                                                                    # interleaved
                 k = (i * 7 + 3) % len(cams)
                 assert gb.generate_contacts_primary(as_capi_camera(cams[k])).tobytes() == want[k], (round_, 'mixed', k)
+            assert gb.host_plane_reads() == round_ + 1                                              # once per build, from its ninth frame on
             gb.build()                                                                             # the count starts again
+        # a scene that is rebuilt every frame never pays for the read-back
+        reads = gb.host_plane_reads()
+        for _ in range(12):
+            gb.build()
+            assert gb.generate_contacts_primary(as_capi_camera(cams[0])).tobytes() == want[0]
+        assert gb.host_plane_reads() == reads
     finally:
         ctx.close()
 
