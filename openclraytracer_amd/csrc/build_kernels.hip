@@ -729,3 +729,25 @@ bool rt_preload_build()
     if (!ok) (void)hipGetLastError();
     return ok;
 }
+
+// ----------------------------------------------------------------------------------------
+// 9. the planes of the leaf boxes, sorted, for the host (rtmi_capi.hip, ensure_host_planes): per axis the 2n corner coordinates as
+//    sortable keys (a float's bits, sign handled; NaN and the padding sort last), ordered by the library's bitonic network -- the
+//    host copies the result back instead of sorting 2n floats three times itself (20 ms at 70 000 leaves, 80 ms at 260 000)
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plane_keys(const rt_bvh_node* __restrict__ nodes, uint32_t n, uint32_t axis, uint2* __restrict__ pairs, uint32_t n_pow2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    uint32_t key = 0xFFFFFFFFu;
+    if (i < 2u * n) {
+        const float v = (i & 1u) ? nodes[i >> 1].boundsMax[axis] : nodes[i >> 1].boundsMin[axis];
+        if (v == v) { const uint32_t b = __float_as_uint(v); key = (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+    }
+    pairs[i] = make_uint2(key, i);
+}
+void launch_plane_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint32_t axis, uint2* pairs, uint32_t n_pow2)
+{
+    hipLaunchKernelGGL(k_plane_keys, dim3((n_pow2 + 255) / 256), dim3(256), 0, s, leaves, n, axis, pairs, n_pow2);
+    launch_bitonic_sort(s, pairs, n_pow2);
+}

@@ -747,9 +747,12 @@ static TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32
 // and later frames use the fastest.  RTMI_DEFER_BUDGET fixes the budget and switches the calibration off.
 static int ensure_host_planes(rt_bvh* b);
 static uint32_t host_plane_bits(const rt_bvh* b, const float origin[3]);
-// eager four-wide frames on one build before the host reads the leaf boxes' planes back (once per build: a synchronisation, a copy
-// of the leaves and three sorts -- milliseconds, which a scene that is rebuilt every frame never pays)
-#define RT_EAGER_PLANES_AFTER 8u
+// eager four-wide frames on one build before the host reads the leaf boxes' planes back (once per build: a synchronisation, three
+// sorts on the device and their copies -- 11 ms at 70 000 leaves, which a scene that is rebuilt every frame or lives for a few
+// frames never pays; it pays back 2-6 us per frame and the marks of a moved camera)
+#ifndef RT_EAGER_PLANES_AFTER
+#define RT_EAGER_PLANES_AFTER 32u
+#endif
 
 // the table work_to_pixel_block reads: (x0, y0) of tile `ordinal` of this rank for (resolution, rank, tiling); null when the context
 // already holds RT_TILE_TABLES shapes or the allocation fails (the kernels then compute it per lane)
@@ -1328,21 +1331,31 @@ static int ensure_host_planes(rt_bvh* b)
 {
     rt_ctx* ctx = b->ctx;
     if (b->h_planes_generation == b->build_generation && !b->h_planes[0].empty()) return RT_SUCCESS;
-    std::vector<rt_bvh_node> leaves(b->n);
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_HIP(ctx, hipMemcpy(leaves.data(), b->d_nodes, (size_t)b->n * sizeof(rt_bvh_node), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 3; k++) {
+    // sorted on the device (launch_plane_keys), copied back per axis; FLT_MIN joins them here (BVH.h:310)
+    static const bool dbg_t = [] { const char* e = std::getenv("RTMI_GRAPH_DEBUG"); return e && e[0] == '1'; }();
+    const double t_begin = dbg_t ? now_us() : 0.0;
+    uint32_t p2 = 1; while (p2 < 2u * b->n) p2 <<= 1;
+    uint2* d_tmp = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&d_tmp, (size_t)p2 * sizeof(uint2)));
+    std::vector<uint2> h(p2);
+    for (uint32_t k = 0; k < 3; k++) {
+        launch_plane_keys(ctx->stream, b->d_nodes, b->n, k, d_tmp, p2);
+        hipError_t e = hipMemcpyAsync(h.data(), d_tmp, (size_t)p2 * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(d_tmp); return RT_FAIL(ctx, std::string("leaf planes: ") + hipGetErrorString(e)); }
         std::vector<float>& v = b->h_planes[k];
         v.clear(); v.reserve(2 * (size_t)b->n + 1);
-        for (uint32_t i = 0; i < b->n; i++) {
-            const float lo = leaves[i].boundsMin[k], hi = leaves[i].boundsMax[k];
-            if (lo == lo) v.push_back(lo);
-            if (hi == hi) v.push_back(hi);
+        bool fmin_in = false;
+        for (uint32_t i = 0; i < p2 && h[i].x != 0xFFFFFFFFu; i++) {
+            const uint32_t key = h[i].x, bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+            float f; std::memcpy(&f, &bits, 4);
+            if (!fmin_in && f > FLT_MIN) { if (v.empty() || v.back() != FLT_MIN) v.push_back(FLT_MIN); fmin_in = true; }
+            if (v.empty() || v.back() != f) v.push_back(f);               // ascending: duplicates are neighbours (-0 == +0)
         }
-        v.push_back(FLT_MIN);
-        std::sort(v.begin(), v.end());
-        v.erase(std::unique(v.begin(), v.end()), v.end());
+        if (!fmin_in && (v.empty() || v.back() != FLT_MIN)) v.push_back(FLT_MIN);
     }
+    (void)hipFree(d_tmp);
+    if (dbg_t) std::fprintf(stderr, "rtmi: leaf planes of %u leaves on the host in %.0f us\n", b->n, now_us() - t_begin);
     b->h_planes_generation = b->build_generation;
     b->h_planes_reads++;
     return RT_SUCCESS;

@@ -274,6 +274,7 @@ void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t*
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
+void launch_plane_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint32_t axis, uint2* pairs, uint32_t n_pow2);   // sorted (key, .) of the 2n corner coordinates of one axis
 int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch);
 size_t scan_scratch_words(uint32_t n);
 // trace_kernels.hip

@@ -1967,6 +1967,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
         // rays the four-wide records may not be used for (see the kernel) wait on the deferred list: normally none, and the
         // wave-per-ray kernel returns at once (left out where the caller knows that there are none: frame graphs)
+        // (a smaller grid for this usually empty launch was measured: the 6.4 us are the launch, not its size)
         if (!t.no_unsafe_rays) rt_launch_node(rec, upd, RT_NODE_LONG, k_trace_long<PRIMARY, CAL>, dim3(grid1), dim3(TRACE_BLOCK), s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;

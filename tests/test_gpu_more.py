@@ -1445,10 +1445,10 @@ def test_throughput_policy_changes_no_bit(knobs, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['man', 'clumsydragon'])
 def test_eager_frames_after_the_host_knows_the_planes(name, monkeypatch):
-    """From the ninth eager four-wide frame on a build the host looks the camera up in the planes of the leaf boxes itself
+    """From the 33rd eager four-wide frame on a build the host looks the camera up in the planes of the leaf boxes itself
     (ensure_host_planes) and leaves the wave-per-ray launch and the per-camera marks out when the camera sits on no plane that
     matters.  Cameras off every plane, on an x plane (stays on the search tree), on a y and on a z plane (rays with a zero
-    direction component there are handed over: the launch must be there), twelve frames each and interleaved: every frame is the
+    direction component there are handed over: the launch must be there), forty frames each and interleaved: every frame is the
     oracle's, and a rebuild starts the count again."""
     from openclraytracer_amd import capi
     from conftest import packed_scene
@@ -1469,12 +1469,12 @@ def test_eager_frames_after_the_host_knows_the_planes(name, monkeypatch):
         gb = capi.DeviceBVH(ctx, sc).build()
         for round_ in range(2):
             for k, c in enumerate(cams):
-                for _ in range(12):
+                for _ in range(40):
                     assert gb.generate_contacts_primary(as_capi_camera(c)).tobytes() == want[k], (round_, k)
             for i in range(16):                                                                    # interleaved
                 k = (i * 7 + 3) % len(cams)
                 assert gb.generate_contacts_primary(as_capi_camera(cams[k])).tobytes() == want[k], (round_, 'mixed', k)
-            assert gb.host_plane_reads() == round_ + 1                                              # once per build, from its ninth frame on
+            assert gb.host_plane_reads() == round_ + 1                                              # once per build, from its 33rd frame on
             gb.build()                                                                             # the count starts again
         # a scene that is rebuilt every frame never pays for the read-back
         reads = gb.host_plane_reads()
