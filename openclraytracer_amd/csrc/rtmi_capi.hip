@@ -1309,6 +1309,7 @@ struct rt_frame_graph {
     bool direct[2] = { false, false };       // the sequence holds kernel nodes only and is issued as plain launches (RTMI_GRAPH_DIRECT=1)
     BlockOrder bo;                           // this frame's start order of the blocks (its buffers' addresses are arguments of the captured kernel)
     bool bo_sorted = false;
+    uint32_t bo_interval = RT_BLOCK_ORDER_REFRESH;   // frames until the next sort of this graph's order
     int last_launch = -1;                    // 0 steady state, 1 with the preparation, 2 eager
     double host_update_us = 0.0, host_launch_us = 0.0, host_set_camera_us = 0.0;   // RTMI_GRAPH_DEBUG=1: host time per stage
     uint64_t host_updates = 0, host_launches = 0, host_set_cameras = 0;
@@ -1527,6 +1528,7 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
     for (int a = 0; a < 2; a++) for (int k = 0; k < 2; k++) g->dirty[a][k] = true;
     g->eager = !g->nodes_known;
     g->moved = true;
+    g->bo_interval = RT_BLOCK_ORDER_REFRESH;
     if (g->four_wide) {
         if (ensure_host_planes(b)) return RT_ERROR;
         const uint32_t bits = host_plane_bits(b, g->origin);
@@ -1604,7 +1606,12 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     g->launched[which][k] = true;
     g->slot[which] = k;
     // the blocks' start order follows the costs the kernel counts: sorted behind the first replay, then every few frames
-    if (g->bo.count && g->four_wide && (!g->bo_sorted || ++g->bo.age >= RT_BLOCK_ORDER_REFRESH)) { block_order_refresh(ctx, g->bo); g->bo_sorted = true; }
+    // (a camera that stands still keeps its order: the interval doubles up to 1 024 frames and starts again when the camera moves)
+    if (g->bo.count && g->four_wide && (!g->bo_sorted || ++g->bo.age >= g->bo_interval)) {
+        block_order_refresh(ctx, g->bo);
+        if (g->bo_sorted && g->bo_interval < 1024u) g->bo_interval <<= 1;
+        g->bo_sorted = true;
+    }
     if (which == 1) {
         std::memcpy(b->marked_origin, g->origin, sizeof g->origin);
         b->marked_parts = same ? (b->marked_parts | g->parts) : g->parts;
