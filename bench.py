@@ -260,6 +260,125 @@ def note(msg):
         print('bench [%6.1f s] %s' % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# in-run verification: the buffers the timed region wrote are compared with the CPU oracle's committed digests
+# (tests/golden/bench_frames.json, made by tests/golden/make_golden_bench.py) -- contacts bit for bit (SHA-256), shaded RGBA within 1e-5
+# relative (per-channel sums in float64 and every sample_stride-th pixel; alpha exact).  A mismatch fails the run.
+# ---------------------------------------------------------------------------------------------------------------------------
+RGB_TOL = 1e-5
+_BENCH_FIXTURE = None
+
+
+def bench_fixture():
+    global _BENCH_FIXTURE
+    if _BENCH_FIXTURE is None:
+        _BENCH_FIXTURE = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_frames.json')))
+    return _BENCH_FIXTURE
+
+
+def sha256_hex(a):
+    import hashlib
+    return hashlib.sha256(memoryview(np.ascontiguousarray(a)).cast('B')).hexdigest()
+
+
+def camera_from_bits(bits):
+    from openclraytracer_amd import capi
+    return np.array(bits, dtype=np.uint32).view(capi.CAMERA).copy()
+
+
+def rgba_mismatch(rgba, rec, stride):
+    """rgba: float32 [npx, 4] as rendered; rec: fixture record.  -> None or a description of the first difference"""
+    got_sum = rgba.astype(np.float64).sum(axis=0)
+    want_sum = np.array(rec['rgba_sum'], dtype=np.float64)
+    rel = np.abs(got_sum - want_sum) / np.maximum(np.abs(want_sum), 1.0)           # (a channel no material has sums to 0)
+    if float(np.where(got_sum == want_sum, 0.0, rel).max()) > RGB_TOL:
+        return 'rgba channel sums %s differ from the oracle\'s %s by more than %g relative' % (got_sum.tolist(), want_sum.tolist(), RGB_TOL)
+    want = np.array(rec['rgba_samples_bits'], dtype=np.uint32).view(np.float32)
+    got = rgba[::stride]
+    if got.shape != want.shape:
+        return 'rgba sample count %s != %s' % (got.shape, want.shape)
+    if not np.array_equal(got[:, 3], want[:, 3]):
+        return 'alpha of the sampled pixels differs from the oracle\'s'
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want.astype(np.float64)), 1e-30)
+    err = np.where(got == want, 0.0, err)
+    if float(err.max()) > RGB_TOL:
+        k = int(np.argmax(err.max(axis=1)))
+        return 'sampled pixel %d: %s vs the oracle\'s %s' % (k * stride, got[k].tolist(), want[k].tolist())
+    return None
+
+
+def verify_frame(ctx, d_contacts, d_rgba, npx, rec, stride, what):
+    """downloads one rendered frame (contacts and / or RGBA device buffers) and compares it with a fixture record"""
+    if d_contacts is not None:
+        got = sha256_hex(ctx.download(d_contacts, npx * 32, np.uint8))
+        if got != rec['contacts_sha256']:
+            raise SystemExit('VERIFICATION FAILED (%s): contacts sha256 %s, the oracle\'s %s' % (what, got, rec['contacts_sha256']))
+    if d_rgba is not None:
+        msg = rgba_mismatch(ctx.download(d_rgba, npx * 4, np.float32).reshape(npx, 4), rec, stride)
+        if msg:
+            raise SystemExit('VERIFICATION FAILED (%s): %s' % (what, msg))
+
+
+def ray_buffer_leg(ctx, bvh, cam, fx, frames=8):
+    """The second entry point of the manager, generateContacts(CLBuffer& rays, CLBuffer& contacts, n) (BVHManager.cpp:292-329, kernel
+    generateContacts2 BVHKernels.cl:103-117): (i) the camera's own rays handed over as Ray[], (ii) the reflection bounce and (iii) the
+    shadow rays towards the scene's light, both generated on the device from the contacts of (i) (rt_generate_secondary_rays; the use
+    the reference plans, KNOWN_ISSUES_AND_TODO.txt:27-30).  Per leg: HIP-event time of `frames` calls, Mrays/s, and the rays and the
+    contacts compared with the oracle's digests (fx = fixture entry 'ray_buffer')."""
+    from openclraytracer_amd import capi
+    npx = int(cam['resX'][0]) * int(cam['resY'][0])
+    d_rays0, d_rays1, d_c0, d_c1 = ctx.alloc(npx * 48), ctx.alloc(npx * 48), ctx.alloc(npx * 32), ctx.alloc(npx * 32)
+    light, eps = bench_fixture()['light'], bench_fixture()['eps']
+    out = {}
+    tm = capi.Timer(ctx)
+    try:
+        capi.generate_primary_rays_d(ctx, cam, d_rays0)
+        bvh.generate_contacts_rays_d(d_rays0, npx, d_c0)
+        ctx.synchronize()
+        for leg in ('primary', 'reflect', 'shadow'):
+            if leg == 'primary':
+                d_rays, n, d_c = d_rays0, npx, d_c0
+            else:
+                n = capi.generate_secondary_rays_d(ctx, d_c0, npx, capi_kind(leg), d_rays1, light, eps, d_rays_in=d_rays0)
+                d_rays, d_c = d_rays1, d_c1
+            want = fx[leg]
+            if n != want['rays']:
+                raise SystemExit('VERIFICATION FAILED (ray buffer, %s): %d rays generated, the oracle\'s %d' % (leg, n, want['rays']))
+            got = sha256_hex(ctx.download(d_rays, n * 48, np.uint8))
+            if got != want['rays_sha256']:
+                raise SystemExit('VERIFICATION FAILED (ray buffer, %s): generated rays differ from the oracle\'s' % leg)
+            for _ in range(2):
+                bvh.generate_contacts_rays_d(d_rays, n, d_c)
+            ctx.synchronize()
+            tm.start()
+            for _ in range(frames):
+                bvh.generate_contacts_rays_d(d_rays, n, d_c)
+            tm.stop()
+            ms = tm.elapsed_ms() / frames
+            got = sha256_hex(ctx.download(d_c, n * 32, np.uint8))
+            if got != want['contacts_sha256']:
+                raise SystemExit('VERIFICATION FAILED (ray buffer, %s): contacts sha256 %s, the oracle\'s %s' % (leg, got, want['contacts_sha256']))
+            out[leg] = dict(rays=n, ms=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 1), hits=want['hits'], verified=True,
+                            reference_inner_visits_per_ray=round(want['inner_visits'] / max(n, 1), 1))
+    finally:
+        tm.close()
+        for d in (d_rays0, d_rays1, d_c0, d_c1):
+            ctx.free(d)
+    return out
+
+
+def q_slots(work, name):
+    for it in work:
+        if it['name'] == name:
+            return it['slots']
+    return 0
+
+
+def capi_kind(leg):
+    from openclraytracer_amd import capi
+    return {'shadow': 0, 'reflect': 1}[leg]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -271,6 +390,7 @@ def main():
     ap.add_argument('--no-graphs', action='store_true', help='N = 1: issue every frame eagerly instead of replaying a HIP graph per frame')
     ap.add_argument('--check-frames', action='store_true',
                     help='tiled: rank 0 also traces every frame untiled and compares it with the assembled one')
+    ap.add_argument('--no-verify', action='store_true', help='skip the in-run comparison of the rendered frames with the oracle digests')
     ap.add_argument('--keep-pmc', default=None, help='directory that receives the raw counter rows of this run')
     ap.add_argument('--pmc-child', default=None, metavar='DIR', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -443,14 +563,44 @@ def main():
             print('frame check ok (%s): %d assembled frames equal the untiled ones' % (when, checked), file=sys.stderr)
         fence()
 
+    bfx = None if args.no_verify else bench_fixture()
+
+    def verify_timed(when):
+        # N = 1: every scene's contact and colour buffers as the last frame left them; tiled: the assembled colour frame on the rank that
+        # assembles it (contacts stay on the ranks that traced them).  -> frames verified over all ranks
+        done = 0
+        for it in work:
+            rec = bfx['scenes'][it['name']][key]['default']
+            if [int(x) for x in np.asarray(it['cam']).view(np.uint32).ravel()] != rec['camera_bits']:
+                raise SystemExit('VERIFICATION FAILED (%s): the camera differs from the fixture\'s' % it['name'])
+            if tiled:
+                root_frame = it['frames'][it['root']] if group_ranks else (it['frames'][0] if rank == it['root'] else None)
+                if root_frame is None:
+                    continue
+                root_frame.wait()
+                msg = rgba_mismatch(root_frame.download_frame(), rec, bfx['sample_stride'])
+                if msg:
+                    raise SystemExit('VERIFICATION FAILED (%s, assembled frame, %s): %s' % (it['name'], when, msg))
+            else:
+                verify_frame(it['ctx'], it['contacts'], it['rgba'], npx, rec, bfx['sample_stride'], '%s, %s' % (it['name'], when))
+            done += 1
+        if dist is not None:
+            box = [None] * world
+            dist.all_gather_object(box, done)
+            done = sum(box)
+        return done
+
     note('warm-up and timed steps')
     for _ in range(args.warmup):
         step()
     fence()
-    if args.check_frames and tiled:
+    if tiled and (args.check_frames or not args.no_verify):
         if args.warmup == 0:
             step(); fence()
-        check_frames('after the warm-up')
+        if not args.no_verify:          # by default: the first assembled frame of every scene against the oracle's digest, before timing
+            note('verified before timing: %d assembled frames' % verify_timed('after the warm-up'))
+        if args.check_frames:
+            check_frames('after the warm-up')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -460,6 +610,12 @@ def main():
     check_errors()                               # an invalid frame anywhere in the timed region fails the run
     if args.check_frames and tiled:
         check_frames('after the timed steps')     # the frames of the last, fully overlapped steps
+    # ---- what the timed region wrote, against the oracle's digests (outside the timed region; a mismatch ends the run non-zero) ----
+    verified = None
+    if not args.no_verify:
+        verified = dict(against='tests/golden/bench_frames.json (CPU oracle): contacts SHA-256, RGBA sums and samples within %g relative' % RGB_TOL,
+                        frames=verify_timed('the last step of the timed region'))
+        note('verified: %d frames of the timed region equal the oracle\'s' % verified['frames'])
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -569,6 +725,10 @@ def main():
             sctx.synchronize()
             ps['rebuild_plus_trace_ms'] = round((time.perf_counter() - tw) * 1e3 / K, 4)
             ps['strategy_after_rebuilds'] = it['bvh'].trace_strategy()
+            if verified is not None:            # the frame of the BVH rebuilt K + 2 times
+                verify_frame(sctx, it['contacts'], it['rgba'], npx, bfx['scenes'][it['name']][key]['default'], bfx['sample_stride'],
+                             '%s, rebuild-per-frame leg' % it['name'])
+                verified['rebuilt_frames'] = verified.get('rebuilt_frames', 0) + 1
         tm.close()
         if tiled:
             sctx.free(dc)
@@ -579,8 +739,18 @@ def main():
     if not tiled and use_graphs and not args.no_extra_legs:
         M, R = 32, 4
         note('moving-camera leg')
+        pose_bits_replaced = 0
         for it in work:
             it['poses'] = moving_cameras(it['bytes'], RES[0], RES[1], M)
+            if verified is not None:
+                # the poses that get verified are the fixture's cameras, bit for bit (this host's sin / cos may round another way)
+                for kname, rec in bfx['scenes'][it['name']][key].items():
+                    if kname.startswith('pose'):
+                        k = int(kname[4:])
+                        fc = camera_from_bits(rec['camera_bits'])
+                        if it['poses'][k:k + 1].tobytes() != fc.tobytes():
+                            pose_bits_replaced += 1
+                        it['poses'][k] = fc[0]
             it['graph'].close()                             # the rebuild-per-frame leg above has rebuilt the BVH: a graph of its own
             it['ctx'].set_frames_in_flight(len(SCENES))     # five frames in flight, as in the timed region
             it['graph'] = capi.FrameGraph(it['bvh'], it['scene'], it['cam'], it['contacts'], it['rgba'])
@@ -660,6 +830,23 @@ def main():
         fence()
         eager_step = (time.perf_counter() - t1) * 1e3 / K
         check_errors()
+        moved_verified = 0
+        if verified is not None:
+            # frames of a camera that moved, rendered through the graph path (set_camera + launch) and through the eager calls,
+            # against the oracle's frames of exactly these cameras (pose 0 = the default camera)
+            for it in work:
+                recs = {0: bfx['scenes'][it['name']][key]['default']}
+                recs.update({int(kn[4:]): r for kn, r in bfx['scenes'][it['name']][key].items() if kn.startswith('pose')})
+                for k, rec in sorted(recs.items()):
+                    it['graph'].set_camera(pose(it, k)); it['graph'].launch(); it['ctx'].synchronize()
+                    verify_frame(it['ctx'], it['contacts'], it['rgba'], npx, rec, bfx['sample_stride'], '%s, moving camera pose %d (graph)' % (it['name'], k))
+                    it['bvh'].generate_contacts_primary_d(pose(it, k), it['contacts'])
+                    capi.shade_blinn_phong_frame_d(it['ctx'], it['scene'], pose(it, k), it['contacts'], it['rgba'])
+                    it['ctx'].synchronize()
+                    verify_frame(it['ctx'], it['contacts'], it['rgba'], npx, rec, bfx['sample_stride'], '%s, moving camera pose %d (eager)' % (it['name'], k))
+                    moved_verified += 2
+            verified['moving_camera_frames'] = moved_verified
+            verified['moving_camera_poses_taken_from_fixture_bits'] = pose_bits_replaced
         for it in work:
             it['graph'].set_camera(it['cam'])
         moving = dict(what='every frame a new camera position and orientation (%d poses around the default camera, pose 0 = the default camera); '
@@ -671,6 +858,7 @@ def main():
 
     # ---- config 5 (BASELINE.json configs[4]): the Sponza-class stand-in at 3840x2160, BVH, the frame tiled over the ranks --------
     config5 = None
+    fx5 = None
     if atrium_bytes is not None:
         note('config 5 leg')
         cam5 = demo_camera(atrium_bytes, *RES5)
@@ -709,6 +897,22 @@ def main():
             t = torch.tensor([e5], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e5 = float(t.item())
+        if verified is not None:
+            if sha256_hex(np.frombuffer(atrium_bytes, dtype=np.uint8)) != bfx['atrium']['scene_sha256']:
+                verified['config5'] = 'NOT verified: this host generated other bytes for the procedural stand-in scene than the fixture\'s host'
+            else:
+                fx5 = bfx['atrium']
+                rec5 = fx5['%dx%d' % RES5]['default']
+                if tiled:
+                    root5 = f5[0] if (group_ranks or rank == 0) else None
+                    if root5 is not None:
+                        root5.wait()
+                        msg = rgba_mismatch(root5.download_frame(), rec5, bfx['sample_stride'])
+                        if msg:
+                            raise SystemExit('VERIFICATION FAILED (config 5, assembled frame): %s' % msg)
+                else:
+                    verify_frame(c5[0], d5c, d5o, RES5[0] * RES5[1], rec5, bfx['sample_stride'], 'config 5, 3840x2160')
+                verified['config5'] = 'frame equals the oracle\'s'
         config5 = dict(workload='Sponza-class stand-in (assets/synth, %d triangles) x 3840x2160 primary rays, BVH trace + shade, frame tiled over %d rank(s), '
                                 'one RCCL gather per frame' % (s5[0].n_tris, nranks), frames=K5, ms_per_frame=round(e5 / K5 * 1e3, 3),
                        mrays_per_s=round(RES5[0] * RES5[1] * K5 / e5 / 1e6, 1), build_ms=round(build5, 2), reference_tree_depth=b5[0].info()['max_depth'],
@@ -719,6 +923,23 @@ def main():
             config5['calibration_gpu_ms'] = round(b5[0].calibration_gpu_ms(), 2)
             config5['calibration_gpu_over_steady_frame'] = round(b5[0].calibration_gpu_ms() / max(e5 / K5 * 1e3, 1e-6), 1)
             config5['first_frame_over_steady_frame'] = round(first5 / max(e5 / K5 * 1e3, 1e-6), 1)
+
+    # ---- the ray-buffer entry point: generateContacts(CLBuffer& rays, CLBuffer& contacts, n), BVHManager.cpp:292-329 -----------------
+    ray_buffer = None
+    if not tiled and not args.no_extra_legs and not args.no_verify:
+        note('ray-buffer leg')
+        ray_buffer = dict(what='rt_bvh_generate_contacts_rays at 1920x1080: the camera\'s rays handed over as Ray[] (primary), the reflection bounce and '
+                               'the shadow rays towards the light, generated on the device from the primary contacts; rays and contacts equal the oracle\'s',
+                          per_scene={})
+        for it in work:
+            ray_buffer['per_scene'][it['name']] = ray_buffer_leg(it['ctx'], it['bvh'], it['cam'], bfx['scenes'][it['name']][key]['ray_buffer'])
+            note('  ray buffer, %s: %s' % (it['name'], {k: v['mrays_per_s'] for k, v in ray_buffer['per_scene'][it['name']].items()}))
+        if atrium_bytes is not None and fx5 is not None:
+            ray_buffer['per_scene']['atrium'] = ray_buffer_leg(c5[0], b5[0], demo_camera(atrium_bytes, *RES), fx5[key]['ray_buffer'])
+            note('  ray buffer, atrium: %s' % {k: v['mrays_per_s'] for k, v in ray_buffer['per_scene']['atrium'].items()})
+        for leg in ('primary', 'reflect', 'shadow'):
+            ray_buffer['min_mrays_per_s_' + leg] = min(v[leg]['mrays_per_s'] for v in ray_buffer['per_scene'].values())
+        verified['ray_buffer_legs'] = 3 * len(ray_buffer['per_scene'])
 
     if rank != 0:
         if dist is not None:
@@ -776,6 +997,29 @@ def main():
                     binds='not HBM: the records are L2 / scalar-cache resident and a packet fetches a record once for up to 64 rays, so the '
                           'reference algorithm\'s bytes per second (reference_algorithm_gbps) exceed the HBM peak and are no fraction of it; '
                           'see roofline_valu_issue')
+
+    # the roof that does bound the path: what a step MUST move through HBM whatever the algorithm -- one 32-byte Contact and one 16-byte
+    # RGBA per ray (the records are cache resident; SURVEY.md 8(d)'s 56 I + 40 L bytes are no HBM traffic, see `binds`)
+    compulsory_step = 48.0 * rays_per_step
+    floor_step_ms = compulsory_step / (HBM_PEAK_GBPS * 1e9) * 1e3
+    roofline['compulsory_bytes_per_step'] = int(compulsory_step)
+    roofline['output_floor_ms_per_step'] = round(floor_step_ms, 5)
+    roofline['frac_of_output_floor'] = round(floor_step_ms / (elapsed / args.steps * 1e3), 4)
+    roofline['frac_of_output_floor_is'] = ('(48 B per ray x rays per step / 8 TB/s) / ms_per_step of the timed region: 1.0 = the step takes exactly as long '
+                                           'as writing its contacts and colours at the HBM peak; no algorithm can exceed it')
+    bound_per_scene = {}
+    for n in SCENES:
+        q = per_scene[n]
+        floor_ms = 32.0 * q_slots(work, n) / (HBM_PEAK_GBPS * 1e9) * 1e3          # an isolated traversal launch writes the contacts only
+        f_floor = floor_ms / max(q['trace_ms'], 1e-9)
+        f_hbm = (q['hbm_bytes_per_launch'] / (q['trace_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if 'hbm_bytes_per_launch' in q else None
+        f_valu = q.get('valu_issue_frac')
+        cands = [('hbm (output writes)', f_hbm if f_hbm is not None else f_floor), ('valu_issue', f_valu or 0.0)]
+        top = max(cands, key=lambda c: c[1])
+        bound_per_scene[n] = dict(frac_of_output_floor=round(f_floor, 4), hbm_frac_measured=(round(f_hbm, 4) if f_hbm is not None else None),
+                                  valu_issue_frac=f_valu,
+                                  binds=(top[0] if top[1] >= 0.3 else 'latency of a wave step x steps of the heaviest 8x8 block (no roof above 30 %%; nearest: %s %.2f)' % top))
+    roofline['per_scene'] = bound_per_scene
 
     cpu_baseline = None
     if world == 1 and not tiled and not args.no_cpu_baseline:
@@ -836,7 +1080,8 @@ def main():
                            policy='timed region and moving-camera leg: rt_ctx_set_frames_in_flight(5); isolated frames, first frames, config5: the default (one frame at a time)'),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
-               roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, config5=config5, per_rank=per_rank, per_scene=per_scene)
+               verified=verified, roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, ray_buffer=ray_buffer, config5=config5,
+               per_rank=per_rank, per_scene=per_scene)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -218,6 +218,11 @@ enum { RT_RAYS_SHADOW = 0, RT_RAYS_REFLECT = 1 };
 int  rt_generate_secondary_rays(rt_ctx* ctx, const rt_camera* cam, const void* d_rays_in, const void* d_contacts, uint32_t count,
                                 int kind, const float target[3], float eps, void* d_rays_out, uint32_t* out_count);
 
+/* The camera's own rays as a ray buffer: generateRay (CLStructs.h:95-106) for every pixel p in [0, resX*resY), Ray.idx = p --
+ * the buffer a host uploads when it sends the FIRST bounce through generateContacts(CLBuffer& rays, ..) too
+ * (BVHManager.cpp:292-329).  Asynchronous on the context's stream.                                                        */
+int  rt_generate_primary_rays(rt_ctx* ctx, const rt_camera* cam, void* d_rays_out);
+
 /* ---- framebuffer tiling for multi-GPU frames (new functionality) ---------
  * The frame is cut into tile x tile pixel squares (tile = 64), numbered row-major; rank r of
  * `nranks` owns tiles r, r+nranks, ...  The compact per-rank buffers are ordered by

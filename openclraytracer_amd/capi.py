@@ -46,7 +46,7 @@ SYMBOLS = [
     'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
     'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl', 'rt_comm_rccl_ranks', 'rt_multi_frame_create_rooted', 'rt_multi_frame_root', 'rt_multi_frame_set_camera', 'rt_multi_frame_set_timing', 'rt_multi_frame_times',
     'rt_multi_frame_create', 'rt_multi_frame_render', 'rt_multi_frame_wait', 'rt_multi_frame_pixels', 'rt_multi_frame_layout', 'rt_multi_frame_destroy',
-    'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays',
+    'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays', 'rt_generate_primary_rays',
 ]
 
 
@@ -151,6 +151,7 @@ def load_library() -> C.CDLL:
     L.rt_tlg_read.argtypes = [vp, i32, vp, u64]
     L.rt_tlg_pow_third.argtypes = [C.c_float]; L.rt_tlg_pow_third.restype = C.c_float
     L.rt_generate_secondary_rays.argtypes = [vp, vp, vp, vp, u32, i32, C.POINTER(C.c_float), C.c_float, vp, C.POINTER(u32)]
+    L.rt_generate_primary_rays.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -529,6 +530,21 @@ def generate_secondary_rays(ctx: Context, contacts: np.ndarray, kind: int, targe
         ctx.free(dc); ctx.free(dr)
         if di:
             ctx.free(di)
+
+
+def generate_primary_rays_d(ctx: Context, cam: np.ndarray, d_rays: int):
+    """rt_generate_primary_rays: resX*resY rays of `cam` into a device buffer of 48 bytes per ray"""
+    ctx.check(ctx.lib.rt_generate_primary_rays(ctx.h, _p(cam), C.c_void_p(d_rays)))
+
+
+def generate_secondary_rays_d(ctx: Context, d_contacts: int, count: int, kind: int, d_rays_out: int, target=(0.0, 0.0, 0.0),
+                              eps: float = 1e-3, cam: np.ndarray | None = None, d_rays_in: int | None = None) -> int:
+    """rt_generate_secondary_rays on device buffers; -> number of rays written (synchronises)"""
+    tgt = (C.c_float * 3)(*[float(x) for x in target])
+    cnt = C.c_uint32(0)
+    ctx.check(ctx.lib.rt_generate_secondary_rays(ctx.h, _p(cam) if cam is not None else None, C.c_void_p(d_rays_in) if d_rays_in else None,
+                                                 C.c_void_p(d_contacts), count, kind, tgt, eps, C.c_void_p(d_rays_out), C.byref(cnt)))
+    return int(cnt.value)
 
 
 def tiles_owned_pixels(cam: np.ndarray, rank: int, nranks: int) -> int:

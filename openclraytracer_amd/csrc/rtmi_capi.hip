@@ -1702,6 +1702,17 @@ int rt_generate_secondary_rays(rt_ctx* ctx, const rt_camera* cam, const void* d_
     return RT_SUCCESS;
 }
 
+int rt_generate_primary_rays(rt_ctx* ctx, const rt_camera* cam, void* d_rays_out)
+{
+    if (!ctx) return RT_FAIL(nullptr, "ctx is null");
+    if (!cam || !d_rays_out) return RT_FAIL(ctx, "null argument");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    RT_ENTER(ctx);
+    launch_primary_rays(ctx->stream, cam, (rt_ray*)d_rays_out);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
 // ---------------------------------------------------------------------------------------
 // per-kernel timing of the trace launches (HIP events on the stream the kernels run on)
 // ---------------------------------------------------------------------------------------

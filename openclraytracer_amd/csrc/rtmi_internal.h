@@ -413,6 +413,7 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
 void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 // secondary_kernels.hip
 void launch_secondary_flags(hipStream_t s, const rt_contact* contacts, uint32_t count, uint32_t* flags);
+void launch_primary_rays(hipStream_t s, const rt_camera* cam, rt_ray* out);
 void launch_secondary_emit(hipStream_t s, const rt_camera* cam, const rt_ray* rays_in, const rt_contact* contacts, uint32_t count,
                            const uint32_t* scan, int kind, const float target[3], float eps, rt_ray* out);
 // shade_kernels.hip

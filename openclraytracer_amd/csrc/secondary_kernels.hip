@@ -45,6 +45,27 @@ __global__ __launch_bounds__(256) void k_secondary_emit(rt_camera cam, int use_c
     op[2] = make_float4(D.x, D.y, D.z, 0.0f);
 }
 
+// the camera's own rays as a ray buffer (generateRay, CLStructs.h:95-106, one per pixel; Ray.idx = pixel): what a host hands to
+// generateContacts(CLBuffer& rays, ..) (BVHManager.cpp:292-329) when it wants the first bounce through the ray-buffer entry
+__global__ __launch_bounds__(256) void k_primary_rays(rt_camera cam, uint32_t count, rt_ray* __restrict__ out)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    f3 o, d;
+    generate_ray(cam, k, o, d);
+    float4* op = reinterpret_cast<float4*>(out + k);
+    const uint4 h = make_uint4(k, 0u, 0u, 0u);
+    op[0] = *reinterpret_cast<const float4*>(&h);
+    op[1] = make_float4(o.x, o.y, o.z, 0.0f);
+    op[2] = make_float4(d.x, d.y, d.z, 0.0f);
+}
+
+void launch_primary_rays(hipStream_t s, const rt_camera* cam, rt_ray* out)
+{
+    const uint32_t count = cam->resX * cam->resY;
+    hipLaunchKernelGGL(k_primary_rays, dim3((count + 255) / 256), dim3(256), 0, s, *cam, count, out);
+}
+
 void launch_secondary_flags(hipStream_t s, const rt_contact* contacts, uint32_t count, uint32_t* flags)
 {
     hipLaunchKernelGGL(k_secondary_flags, dim3((count + 255) / 256), dim3(256), 0, s, contacts, count, flags);

@@ -74,6 +74,7 @@ def lib():
         L.orc_sizeof.argtypes = [C.c_char_p]
         L.orc_demo_camera.argtypes = [vp, u32, u32, vp]
         L.orc_generate_ray.argtypes = [vp, u32, vp]
+        L.orc_generate_rays.argtypes = [vp, u32, u32, vp]
         L.orc_scene_triangle_count.restype = C.c_uint64
         L.orc_scene_triangle_count.argtypes = [vp]
         L.orc_scene_triangle.argtypes = [vp, u32, vp, vp, vp]
@@ -246,9 +247,7 @@ def generate_rays(cam: np.ndarray, first: int = 0, count: int | None = None) -> 
     if count is None:
         count = npx - first
     rays = np.zeros(count, dtype=RAY)
-    L = lib()
-    for k in range(count):
-        L.orc_generate_ray(_p(cam), first + k, C.c_void_p(rays.ctypes.data + 48 * k))
+    lib().orc_generate_rays(_p(cam), first, count, _p(rays))
     return rays
 
 

@@ -255,6 +255,13 @@ void orc_generate_ray(const orc_camera* cam, uint32_t pixelIndex, orc_ray* ray)
     ray->idx = pixelIndex;
 }
 
+/* the whole primary ray buffer of a camera, pixels [first, first + count): what a host that feeds generateContacts(CLBuffer& rays, ..)
+ * (BVHManager.cpp:292-329) with the camera's own rays would upload */
+void orc_generate_rays(const orc_camera* cam, uint32_t first, uint32_t count, orc_ray* rays)
+{
+    for (uint32_t k = 0; k < count; k++) orc_generate_ray(cam, first + k, rays + k);
+}
+
 /* ------------------------------------------------------------------ */
 /* ray / box, ray / triangle                                           */
 /* ------------------------------------------------------------------ */

@@ -76,6 +76,7 @@ void     orc_demo_camera(const void* scene, uint32_t resX, uint32_t resY, orc_ca
 
 /* ---- ray generation (CLStructs.h:95-106) */
 void     orc_generate_ray(const orc_camera* cam, uint32_t pixelIndex, orc_ray* out);
+void     orc_generate_rays(const orc_camera* cam, uint32_t first, uint32_t count, orc_ray* rays);   /* pixels [first, first + count) */
 
 /* ---- primitives */
 float    orc_aabb_intersect(const orc_aabb* box, orc_f4 ro, orc_f4 rd);      /* AABB.h:126-142 */

@@ -400,3 +400,44 @@ def test_host_cpu_shade_blinn_phong_equals_the_oracle():
             c = contacts[i:i + 1].copy()
             fn(cam.ctypes.data, c.ctypes.data, scene.ctypes.data, out.ctypes.data)
             assert out.tobytes() == want[c['pixelIndex'][0]].tobytes(), (name, int(i))
+
+
+def test_bench_verification_fixture_and_comparator():
+    """tests/golden/bench_frames.json (what bench.py verifies its timed frames against): the default-camera records agree with
+    frames.json, the oracle reproduces one of its moving-camera poses and one ray-buffer leg at a small cost, and bench.rgba_mismatch
+    accepts the oracle's own colours, tolerates 1e-5 relative and rejects a wrong pixel, a wrong alpha and a shifted sum."""
+    import bench
+    import oracle as orc
+    fx = bench.bench_fixture()
+    frames = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'frames.json')))
+    for name in MODELS:
+        e = fx['scenes'][name]['1920x1080']
+        assert e['default']['contacts_sha256'] == frames[name]['1920x1080']['contacts_sha256']
+        assert e['default']['camera_bits'] == frames[name]['1920x1080']['camera_bits']
+        assert e['ray_buffer']['primary']['contacts_sha256'] == e['default']['contacts_sha256']      # generateContacts2 on the camera's rays
+        assert set(e) >= {'default', 'pose5', 'pose17', 'ray_buffer', 'scene_sha256'}
+    assert fx['atrium']['3840x2160']['default']['rays'] == 3840 * 2160
+    # one pose and the reflection leg of the cube, recomputed
+    osc, ob = oracle_bvh('cube')
+    e = fx['scenes']['cube']['1920x1080']
+    cam = np.array(e['pose5']['camera_bits'], dtype=np.uint32).view(orc.CAMERA)
+    c, st = ob.trace_primary(cam)
+    assert hashlib.sha256(c.tobytes()).hexdigest() == e['pose5']['contacts_sha256'] and int(st.hits) == e['pose5']['hits']
+    rgba = orc.shade_frame(osc, cam, c)
+    assert bench.rgba_mismatch(rgba, e['pose5'], fx['sample_stride']) is None
+    near = rgba * np.float32(1.0 + 4e-6)
+    near[:, 3] = rgba[:, 3]
+    assert bench.rgba_mismatch(near, e['pose5'], fx['sample_stride']) is None
+    hit = int(np.nonzero(rgba[::fx['sample_stride'], 3] > 0)[0][0])
+    bad = rgba.copy(); bad[fx['sample_stride'] * hit, 0] *= np.float32(0.99)
+    assert 'sampled pixel' in bench.rgba_mismatch(bad, e['pose5'], fx['sample_stride'])
+    bad = rgba.copy(); bad[fx['sample_stride'] * 5, 3] = 1.0 - bad[fx['sample_stride'] * 5, 3]
+    assert bench.rgba_mismatch(bad, e['pose5'], fx['sample_stride']) is not None
+    bad = rgba.copy(); bad[1::2, 0] *= np.float32(1.001)
+    assert 'sums' in bench.rgba_mismatch(bad, e['pose5'], fx['sample_stride'])
+    cam0 = osc.demo_camera(1920, 1080)
+    c0, _ = ob.trace_primary(cam0)
+    rays = orc.generate_secondary_rays(c0, 1, eps=fx['eps'], rays_in=orc.generate_rays(cam0))
+    assert len(rays) == e['ray_buffer']['reflect']['rays'] and hashlib.sha256(rays.tobytes()).hexdigest() == e['ray_buffer']['reflect']['rays_sha256']
+    cr, _ = ob.trace_rays(rays)
+    assert hashlib.sha256(cr.tobytes()).hexdigest() == e['ray_buffer']['reflect']['contacts_sha256']

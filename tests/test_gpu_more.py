@@ -30,6 +30,29 @@ def test_ray_buffer_entry_equals_primary(gpu_ctx, name, res):
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize('name,res', [('cube', (64, 48)), ('man', (333, 77))])
+def test_primary_rays_as_a_ray_buffer(gpu_ctx, name, res):
+    """rt_generate_primary_rays: the camera's rays as Ray[] (generateRay, CLStructs.h:95-106), bit for bit the oracle's, and the
+    ray-buffer entry on them gives the primary frame's contacts."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, ob = oracle_bvh(name)
+    _, gb = gpu_bvh(gpu_ctx, name)
+    cam = osc.demo_camera(*res)
+    npx = res[0] * res[1]
+    d_rays, d_c = gpu_ctx.alloc(npx * 48), gpu_ctx.alloc(npx * 32)
+    try:
+        gpu_ctx.fill_u32(d_rays, 0xDEADBEEF, npx * 12)
+        capi.generate_primary_rays_d(gpu_ctx, as_capi_camera(cam), d_rays)
+        got = gpu_ctx.download(d_rays, npx, capi.RAY)
+        assert got.tobytes() == orc.generate_rays(cam).tobytes()
+        gb.generate_contacts_rays_d(d_rays, npx, d_c)
+        want, _ = ob.trace_primary(cam)
+        assert gpu_ctx.download(d_c, npx, capi.CONTACT).tobytes() == want.tobytes()
+    finally:
+        gpu_ctx.free(d_rays); gpu_ctx.free(d_c)
+
+
 def test_ray_buffer_ragged_random_and_degenerate(gpu_ctx):
     """seeded incoherent rays, a count that is not a multiple of 64, axis-parallel / zero / NaN directions."""
     import oracle as orc
