@@ -1,0 +1,272 @@
+// rtmi_bvh.hip -- C ABI, the BVH manager's build side: rt_bvh_create / initialize_frame / construct / destroy and the parity
+// read-backs (BVHManager.cpp:57-228).  Host-side orchestration only; the kernels are in build_kernels.hip / sort_scan_kernels.hip.
+#include "rtmi_internal.h"
+#include "rtmi_host.h"
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <sstream>
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------
+// BVH manager
+// ---------------------------------------------------------------------------------------
+static uint32_t morton_buffer_items(uint32_t n)     // BVHManager.cpp:128-131
+{
+    uint32_t p = 1;
+    while ((uint64_t)p * 2 <= n) p *= 2;
+    if (p < n) p *= 2;
+    return p;
+}
+
+int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** out)
+{
+    if (!ctx || !scene || !out) return RT_FAIL(ctx, "null argument");
+    *out = nullptr;
+    if (scene->ctx != ctx) return RT_FAIL(ctx, "scene belongs to another context");
+    if (parity_mode != RT_MODE_FIXED && parity_mode != RT_MODE_LITERAL_ZERO) return RT_FAIL(ctx, "unknown parity mode");
+    rt_bvh* b = new (std::nothrow) rt_bvh();
+    if (!b) return RT_FAIL(ctx, "out of host memory");
+    b->ctx = ctx; b->scene = scene; b->mode = parity_mode;
+    *out = b;
+    return RT_SUCCESS;
+}
+
+
+static void free_build_buffers(rt_bvh* b)
+{
+    if (b->d_nodes) (void)hipFree(b->d_nodes);
+    if (b->d_pairs) (void)hipFree(b->d_pairs);
+    if (b->d_counters) (void)hipFree(b->d_counters);
+    if (b->d_trav) (void)hipFree(b->d_trav);
+    if (b->d_quad) (void)hipFree(b->d_quad);
+    if (b->d_quad_cam) (void)hipFree(b->d_quad_cam);
+    b->d_quad = nullptr; b->d_quad_cam = nullptr;
+    if (b->d_depth) (void)hipFree(b->d_depth);
+    if (b->d_pos) (void)hipFree(b->d_pos);
+    if (b->d_trirec) (void)hipFree(b->d_trirec);
+    b->d_trirec = nullptr;
+    if (b->d_tricam) (void)hipFree(b->d_tricam);
+    b->d_tricam = nullptr;
+    if (b->d_packet_spill) (void)hipFree(b->d_packet_spill);
+    b->d_packet_spill = nullptr; b->packet_spill_entries = 0;
+    if (b->d_tree_select) (void)hipFree(b->d_tree_select);
+    b->d_tree_select = nullptr; b->have_search_tree = false;
+    if (b->s_nodes) (void)hipFree(b->s_nodes);
+    if (b->s_pairs) (void)hipFree(b->s_pairs);
+    if (b->s_counters) (void)hipFree(b->s_counters);
+    if (b->s_pos) (void)hipFree(b->s_pos);
+    if (b->d_spans) (void)hipFree(b->d_spans);
+    if (b->d_rq_scratch) (void)hipFree(b->d_rq_scratch);
+    b->d_spans = nullptr; b->d_rq_scratch = nullptr;
+    b->s_nodes = nullptr; b->s_pairs = nullptr; b->s_counters = nullptr; b->s_pos = nullptr;
+    b->d_nodes = nullptr; b->d_pairs = nullptr; b->d_counters = nullptr; b->d_trav = nullptr;
+    b->d_depth = nullptr; b->d_pos = nullptr;
+}
+
+void rt_bvh_destroy(rt_bvh* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    free_build_buffers(b);
+    block_order_free(b->block_order);
+    delete b;
+}
+
+// Large scenes refit by range queries instead of climbing parent links (build_kernels.hip 4a): the climb is serial in the depth of
+// the reference tree, which duplicate Morton codes turn into chains of thousands of levels.  Same node bytes either way; below
+// the threshold the single climbing launch is faster than the dozen small launches of the query structure.
+// env RTMI_REFIT=rq / climb forces one (tests run both on every fixture).
+static bool refit_by_range_queries(const rt_ctx* ctx, uint32_t n, int mode)
+{
+    if (mode != RT_MODE_FIXED || n < 256u) return false;
+    if (ctx->refit_choice) return ctx->refit_choice == 1;
+    return n >= (1u << 17);
+}
+
+int rt_bvh_initialize_frame(rt_bvh* b)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    RT_ENTER(ctx);
+    uint32_t n = b->scene->d.n_tris;
+    if (n < 2) return RT_FAIL(ctx, "a BVH needs at least two triangles");
+    uint32_t N = morton_buffer_items(n);
+    if (n != b->n) {                                  // grow-only in the reference (CLBuffer::resize); exact here
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        free_build_buffers(b);
+        b->n = 0; b->N = 0;                           // stays 0 unless every allocation below succeeds
+        // LITERAL_ZERO: no search tree (its boxes are not nested: the spine above the never-built node keeps the init boxes)
+        const bool want_search = !ctx->no_search_tree && b->mode == RT_MODE_FIXED;
+        const size_t trees = want_search ? 2u : 1u;
+        hipError_t e = hipMalloc((void**)&b->d_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_pairs, (size_t)N * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_counters, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_trav, (size_t)(n - 1) * sizeof(TravNode) * trees);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_depth, 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_pos, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_trirec, (size_t)n * sizeof(TriRec));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_tree_select, 256);
+        if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_quad, (size_t)(n - 1) * sizeof(QuadNode) * trees);
+        if (e == hipSuccess && !ctx->no_packet4) {
+            // the camera-relative copy, and eight more with the near / far planes already in place for one direction octant
+            // each (memory for vector instructions: 6 of the 16 per box test), unless that would be several GB
+            const size_t one = (size_t)(n - 1) * sizeof(QuadNode) * trees;
+            b->quad_cam_variants = (one * 9 <= ((size_t)4 << 30) && !std::getenv("RTMI_NO_OCTANT_RECORDS")) ? 9u : 1u;
+            e = hipMalloc((void**)&b->d_quad_cam, one * b->quad_cam_variants);
+        }
+        if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_tricam, (size_t)n * sizeof(TriCam));
+        if (e == hipSuccess && want_search) {   // working set of the search-tree build, kept between builds (an allocation costs ~0.1 ms)
+            e = hipMalloc((void**)&b->s_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
+            if (e == hipSuccess) e = hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc((void**)&b->s_counters, (size_t)n * sizeof(uint32_t) + 256);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->s_pos, (size_t)n * sizeof(uint32_t));
+        }
+        if (e == hipSuccess && refit_by_range_queries(ctx, n, b->mode)) {
+            e = hipMalloc((void**)&b->d_spans, (size_t)(n - 1) * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc(&b->d_rq_scratch, refit_rq_scratch_bytes(n));
+        }
+        if (e != hipSuccess) {
+            free_build_buffers(b);
+            (void)hipGetLastError();
+            return RT_FAIL(ctx, std::string("initializeFrame: device allocation failed: ") + hipGetErrorString(e));
+        }
+        b->n = n; b->N = N;
+        b->build_generation++; b->eager_frames = 0;
+    }
+    // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
+    // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
+    RT_HIP(ctx, hipMemsetAsync(b->d_pairs, 0xFF, (size_t)N * sizeof(uint2), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), ctx->stream));
+    b->frame_initialised = true;
+    b->built = false;
+    return RT_SUCCESS;
+}
+
+int rt_bvh_construct(rt_bvh* b)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!b->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
+    RT_ENTER(ctx);
+    hipStream_t s = ctx->stream;
+    const DeviceScene& sc = b->scene->d;
+    launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
+    launch_bitonic_sort(s, b->d_pairs, b->N);                     // 2. :195
+    const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
+    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
+    if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
+    else if (b->d_spans) {
+        // 4. by range queries; NaN boxes (not associative) send it back to the climb
+        launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_rq_scratch, b->d_depth, b->d_depth + 1);
+        uint32_t nan_boxes = 0;
+        RT_HIP(ctx, hipMemcpyAsync(&nan_boxes, b->d_depth + 1, 4, hipMemcpyDeviceToHost, s));
+        RT_HIP(ctx, hipStreamSynchronize(s));
+        if (nan_boxes) launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
+    }
+    else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
+    launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n);  // traversal records, DFS ranks
+    launch_pack_triangles(s, sc, b->d_pos, b->d_trirec);
+    RT_HIP(ctx, hipGetLastError());
+    uint32_t depth = 0;
+    RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
+    // search tree for primary rays: same leaves, better order
+    uint32_t search_depth = 0;
+    b->have_search_tree = false;
+    const bool want_search = !ctx->no_search_tree && !literal;
+    if (want_search) {
+        const uint32_t n = b->n, N = b->N;
+        rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
+        RT_HIP(ctx, hipMemsetAsync(s_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
+        RT_HIP(ctx, hipMemcpyAsync(s_nodes, b->d_nodes, (size_t)n * sizeof(rt_bvh_node), hipMemcpyDeviceToDevice, s));   // the leaves
+        RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));
+        RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
+        launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
+        launch_bitonic_sort(s, s_pairs, N);
+        launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u);
+        uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
+        launch_refit(s, s_nodes, s_counters, n, s_depth, !ctx->search_tree_reference_boxes);
+        launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
+        RT_HIP(ctx, hipGetLastError());
+        RT_HIP(ctx, hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s));
+    }
+    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (want_search ? 2u : 1u));
+    RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
+    b->max_depth = depth;
+    b->search_depth = search_depth;
+    // (a degenerate model -- thousands of coincident box centres -- makes this tree as deep as the reference's: no gain then,
+    // but the four-wide records may only be used on the search tree, so it is used whenever it exists)
+    b->have_search_tree = want_search && search_depth != 0;
+    {   // packet kernel: (node, lane mask) stack entries beyond the LDS part live in a per-wave global area
+        // the four-wide packet kernel pushes up to three entries per two levels
+        // (the packet kernels walk the search tree by default, whose depth is independent of the reference tree's)
+        const uint32_t deeper = depth > search_depth ? depth : search_depth;
+        const uint32_t deepest = b->d_quad ? 2u * deeper + 16u : deeper + 8u;
+        uint32_t need = deepest > trace_packet_stack_entries() ? deepest - trace_packet_stack_entries() : 0u;
+        if (need != b->packet_spill_entries) {
+            if (b->d_packet_spill) { (void)hipFree(b->d_packet_spill); b->d_packet_spill = nullptr; }
+            b->packet_spill_entries = need;
+            // one area per wave the device can hold at once (a wave takes one only when its LDS stack overflows)
+            b->packet_spill_slots = ((uint32_t)ctx->prop.multiProcessorCount * (uint32_t)(ctx->prop.maxThreadsPerMultiProcessor / 64) + 31u) & ~31u;
+            if (need) {
+                const size_t bytes = ((size_t)(b->packet_spill_slots >> 5) + (size_t)b->packet_spill_slots * need * 3u) * sizeof(uint32_t);
+                RT_HIP(ctx, hipMalloc((void**)&b->d_packet_spill, bytes));
+                RT_HIP(ctx, hipMemsetAsync(b->d_packet_spill, 0, (size_t)(b->packet_spill_slots >> 5) * sizeof(uint32_t), s));   // all areas free
+                RT_HIP(ctx, hipStreamSynchronize(s));
+            }
+        }
+    }
+    b->frame_initialised = false;
+    b->built = true;
+    b->marked_valid = false;
+    b->build_generation++; b->eager_frames = 0;            // (the host's copy of the planes is this build's only after a few frames on it)
+    // Dynamic scenes rebuild every frame (OpenCLRayTracerDemo.cpp:230-234).  The calibrated strategy is a property of how the
+    // model fills the frame, not of one build: it is kept while the triangle count stays (the key holds resolution and tiling),
+    // and every strategy produces the same contacts anyway.  RTMI_RECALIBRATE=1 restores a calibration per construct().
+    if (b->tuned_n != b->n || ctx->recalibrate) { b->tuned = false; for (auto& e : b->tuned_cache) e.valid = false; }
+    b->tuned_n = b->n;
+    return RT_SUCCESS;
+}
+
+int rt_bvh_read_nodes(const rt_bvh* b, void* h_nodes)
+{
+    if (!b || !h_nodes) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
+    if (!b->built) return RT_FAIL(b->ctx, "BVH not built");
+    return rt_buf_download(b->ctx, h_nodes, b->d_nodes, (uint64_t)(2 * b->n - 1) * sizeof(rt_bvh_node));
+}
+
+int rt_bvh_read_search_nodes(const rt_bvh* b, void* h_nodes)
+{
+    if (!b || !h_nodes) return RT_FAIL(b ? b->ctx : nullptr, "null argument");
+    if (!b->built) return RT_FAIL(b->ctx, "BVH not built");
+    if (!b->have_search_tree || !b->s_nodes) return RT_FAIL(b->ctx, "this BVH has no search tree");
+    return rt_buf_download(b->ctx, h_nodes, b->s_nodes, (uint64_t)(2 * b->n - 1) * sizeof(rt_bvh_node));
+}
+
+int rt_bvh_read_morton_pairs(const rt_bvh* b, void* h_pairs, uint32_t* n_pow2)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    if (!b->built) return RT_FAIL(b->ctx, "BVH not built");
+    if (n_pow2) *n_pow2 = b->N;
+    if (!h_pairs) return RT_SUCCESS;
+    return rt_buf_download(b->ctx, h_pairs, b->d_pairs, (uint64_t)b->N * sizeof(uint2));
+}
+
+int rt_bvh_info(const rt_bvh* b, uint32_t* leaves, uint32_t* morton_items, uint32_t* max_depth)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    if (leaves) *leaves = b->n;
+    if (morton_items) *morton_items = b->N;
+    if (max_depth) *max_depth = b->max_depth;
+    return RT_SUCCESS;
+}
+
+}  // extern "C"

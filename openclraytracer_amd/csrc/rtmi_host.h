@@ -1,0 +1,42 @@
+// rtmi_host.h -- declarations shared by the host-side translation units of librtmi.so (rtmi_capi.hip, rtmi_bvh.hip,
+// rtmi_trace_policy.hip, rtmi_frame_graph.hip, rtmi_rays.hip).  Not part of the ABI: hidden symbols.
+#pragma once
+#include "rtmi_internal.h"
+#include <chrono>
+
+#define RT_HIDDEN __attribute__((visibility("hidden")))
+#define RT_BLOCK_ORDER_REFRESH 32u          // frames between two sorts of a frame shape's block order (one launch of one workgroup, k_block_order)
+
+// Per-launch options of a primary frame beyond the strategy: a captured / updated frame graph, a fused colour buffer
+struct FusedShade { void* rgba; uint32_t plane_stride; bool done; };
+struct FrameMode {
+    FusedShade* fused = nullptr;
+    GraphNodes* record = nullptr;          // the launches are being captured: note the kernel nodes
+    GraphNodes* update = nullptr;          // nothing is enqueued: set the arguments of captured nodes
+    bool force_prepare = false;            // (re)compute the per-camera records whatever the BVH's marks say (the graph with the preparation in it)
+    uint32_t plane_bits_known = 0;         // 0x80000000 | bits: the host knows the camera-on-a-plane bits
+    uint32_t parts_drop = 0;               // RT_PREP_* this frame's kernels do not read although their strategy normally does
+    // a captured frame keeps the strategy it was captured with (the BVH remembers one calibration, for the last resolution / tiling traced)
+    bool fixed_strategy = false, packet = false, quad = false;
+    uint32_t waves_per_block = 0;           // with fixed_strategy: the workgroup size the graph was captured with
+    uint32_t budget = 0;
+    BlockOrder* block_order = nullptr;     // a captured frame's own start-order buffers (null: the BVH's)
+};
+
+extern "C" {
+// rtmi_capi.hip
+RT_HIDDEN int ensure_long_list(rt_ctx* ctx, uint64_t work_items);        // deferred-ray / split / key / task buffers for a launch of so many work items
+RT_HIDDEN int check_trace_error(rt_ctx* ctx);                            // the trace kernels' sticky error word, once per launch batch
+// rtmi_trace_policy.hip
+RT_HIDDEN uint32_t strategy_parts(const rt_bvh* b, const rt_camera* cam, bool packet, bool quad);
+RT_HIDDEN void block_order_free(BlockOrder& o);
+RT_HIDDEN bool block_order_fit(rt_ctx* ctx, BlockOrder& o, uint32_t blocks);
+RT_HIDDEN void block_order_refresh(rt_ctx* ctx, BlockOrder& o);
+RT_HIDDEN TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam = nullptr, uint32_t parts = 0, const FrameMode* mode = nullptr);
+RT_HIDDEN int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out, const FrameMode* mode = nullptr);
+RT_HIDDEN void current_strategy(const rt_bvh* b, bool& packet, bool& quad);
+RT_HIDDEN int ensure_host_planes(rt_bvh* b);
+RT_HIDDEN uint32_t host_plane_bits(const rt_bvh* b, const float origin[3]);
+RT_HIDDEN const uint2* tile_table(rt_ctx* ctx, const rt_camera* cam, uint32_t rank, uint32_t nranks);
+}
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
