@@ -359,7 +359,7 @@ def ray_buffer_leg(ctx, bvh, cam, fx, frames=8):
             if got != want['contacts_sha256']:
                 raise SystemExit('VERIFICATION FAILED (ray buffer, %s): contacts sha256 %s, the oracle\'s %s' % (leg, got, want['contacts_sha256']))
             out[leg] = dict(rays=n, ms=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 1), hits=want['hits'], verified=True,
-                            reference_inner_visits_per_ray=round(want['inner_visits'] / max(n, 1), 1))
+                            reference_inner_visits_per_ray=round(want['inner_visits'] / max(n, 1), 1), strategy=bvh.rays_strategy())
     finally:
         tm.close()
         for d in (d_rays0, d_rays1, d_c0, d_c1):

@@ -118,6 +118,13 @@ int  rt_bvh_construct(rt_bvh* bvh);          /* construct(), BVHManager.cpp:156-
 int  rt_bvh_generate_contacts_primary(rt_bvh* bvh, const rt_camera* cam, void* d_contacts);
 /* generateContacts(CLBuffer& rays, CLBuffer& contacts, n), BVHManager.cpp:292-329 + generateContacts2, BVHKernels.cl:103-117 */
 int  rt_bvh_generate_contacts_rays(rt_bvh* bvh, const void* d_rays, uint32_t ray_count, void* d_contacts);
+/* How ray buffers of this BVH are traced: *packet_kernel = 0 lane-per-ray kernel (budget = steps after which a ray still walking is
+ * handed to the wave-per-ray kernel), 2 four-wide packets of 64 consecutive rays (budget = steps after which a wave shares its waiting
+ * sub-trees with other waves, 2^20 = never); budget 0 = not calibrated yet (buffers below 32 768 rays are then traced lane-per-ray,
+ * 64 steps).  Calibrated per size class (power of two) of the buffers, on the first buffer of a class with at least 32 768 rays (a
+ * handful of timed launches on it, reported here for the last calibration); reported: the strategy of the last such buffer traced.
+ * Kept across rebuilds of the same triangle count; env RTMI_RAYS=lane:<steps> | p4 | p4s:<steps> fixes it.  A speed knob only.   */
+int  rt_bvh_rays_strategy(const rt_bvh* bvh, int* packet_kernel, uint32_t* budget, uint32_t* calibration_launches, float* calibration_gpu_ms);
 /* parity/debug read-backs in the reference's own layouts (blocking) */
 int  rt_bvh_read_nodes(const rt_bvh* bvh, void* h_nodes /* (2n-1) * 48 B */);
 int  rt_bvh_read_morton_pairs(const rt_bvh* bvh, void* h_pairs /* N * 8 B */, uint32_t* n_pow2);

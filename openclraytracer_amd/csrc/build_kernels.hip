@@ -680,7 +680,9 @@ __global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restric
             }
         }
     }
-    for (; n < 4; n++) { for (int k = 0; k < 3; k++) { lo[n][k] = FLT_MAX; hi[n][k] = -FLT_MAX; } id[n] = RT_SENTINEL; }
+    // an unused slot: id = RT_SENTINEL and a box of NaN planes, which no ray enters under any of the kernels' tests (every compare with
+    // a NaN is false; the camera-relative copies get an empty box of their own, k_prepare_camera)
+    for (; n < 4; n++) { for (int k = 0; k < 3; k++) { lo[n][k] = __builtin_nanf(""); hi[n][k] = __builtin_nanf(""); } id[n] = RT_SENTINEL; }
     QuadNode q;
     q.q[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], __uint_as_float(id[0]));
     q.q[1] = make_float4(hi[0][0], hi[0][1], hi[0][2], __uint_as_float(id[1]));

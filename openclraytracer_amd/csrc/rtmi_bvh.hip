@@ -233,6 +233,8 @@ int rt_bvh_construct(rt_bvh* b)
     // and every strategy produces the same contacts anyway.  RTMI_RECALIBRATE=1 restores a calibration per construct().
     if (b->tuned_n != b->n || ctx->recalibrate) { b->tuned = false; for (auto& e : b->tuned_cache) e.valid = false; }
     b->tuned_n = b->n;
+    if (b->rays_tuned_n != b->n || ctx->recalibrate) { for (auto& e : b->rays_tuned) e.valid = false; b->rays_last = -1; }     // (the ray-buffer entry's strategies likewise)
+    b->rays_tuned_n = b->n;
     return RT_SUCCESS;
 }
 

@@ -39,4 +39,21 @@ RT_HIDDEN int ensure_host_planes(rt_bvh* b);
 RT_HIDDEN uint32_t host_plane_bits(const rt_bvh* b, const float origin[3]);
 RT_HIDDEN const uint2* tile_table(rt_ctx* ctx, const rt_camera* cam, uint32_t rank, uint32_t nranks);
 }
+// Deadlines of calibration launches on the device's own clock (trace_kernels.hip, cal_expired): a sample of that clock next to a host
+// time stamp maps "now + limit" onto it.  The sample's kernel ran before the read-back returned, so mapped deadlines come a few
+// tens of microseconds early: a slack is added.  A launch that was cut off says so in TraceCtrl::expired (candidate_state).
+struct CalClock {
+    unsigned long long clock0 = 0; double ticks_per_ms = 0.0; std::chrono::steady_clock::time_point host0;
+    void sample(rt_ctx* ctx);                                     // behind whatever is enqueued on the context's stream; synchronises
+    unsigned long long deadline(float limit_ms) const             // 0 = no deadline
+    {
+        if (!(ticks_per_ms > 0.0) || !(limit_ms > 0.f)) return 0ull;
+        const double now_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count();
+        return clock0 + (unsigned long long)((now_ms + (double)limit_ms + 0.1) * ticks_per_ms);
+    }
+};
+// after a calibration launch has finished: its error word (cleared again when set: a discarded candidate must not fail the frame) and
+// whether a wave stopped at the deadline; false = a runtime call failed
+RT_HIDDEN bool candidate_state(rt_ctx* ctx, uint32_t& error_bits, bool& expired);
+
 static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

@@ -198,6 +198,15 @@ struct rt_bvh {
     BlockOrder block_order;                 // eager frames
     uint32_t calibration_launches = 0;      // full-size launches the last calibration took (diagnostic)
     float calibration_gpu_ms = 0.f;         // ... and their device time
+    // the ray-buffer entry (rtmi_rays.hip): kernel and budget calibrated on the first large buffer traced through this BVH
+    // ... one entry per size class (power of two) of the buffers: the buffers of one bounce of a frame loop keep their size class and their
+    // character from frame to frame (a camera's 2 M rays, the 0.8 M reflections of their hits, ...), different bounces seldom share one
+    struct RaysTuned { uint32_t size_class = 0, budget = 0; bool packet = false, valid = false; };
+    enum { RT_RAYS_TUNED = 6 };
+    RaysTuned rays_tuned[RT_RAYS_TUNED];
+    uint32_t rays_tuned_next = 0, rays_tuned_n = 0;
+    int rays_last = -1;                      // entry the last large buffer was traced with (rt_bvh_rays_strategy)
+    uint32_t rays_calibration_launches = 0; float rays_calibration_gpu_ms = 0.f;     // of the last calibration
     uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)
     uint32_t eager_frames = 0;              // eager four-wide frames traced on this build (from RT_EAGER_PLANES_AFTER on the host looks the plane bits up)
     bool frame_initialised = false;
@@ -382,6 +391,7 @@ bool rt_preload_trace(); bool rt_preload_build(); bool rt_preload_secondary(); b
 size_t trace_ctrl_bytes();
 size_t trace_task_bytes(uint32_t cap_per_shard);
 size_t trace_ctrl_error_offset();
+size_t trace_ctrl_expired_offset();
 void trace_ctrl_counter_offsets(size_t out[RT_TRACE_COUNTERS]);
 size_t trace_long_record_bytes();
 uint32_t trace_packet_stack_entries();

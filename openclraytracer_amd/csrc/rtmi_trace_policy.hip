@@ -13,6 +13,36 @@
 #include <new>
 #include <sstream>
 
+void CalClock::sample(rt_ctx* ctx)
+{
+    static const bool off = [] { const char* e = std::getenv("RTMI_CALIBRATION_DEADLINE"); return e && e[0] == '0'; }();
+    ticks_per_ms = 0.0;
+    if (off) return;
+    if (!ctx->d_clock && hipMalloc((void**)&ctx->d_clock, 8) != hipSuccess) { (void)hipGetLastError(); ctx->d_clock = nullptr; return; }
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); return; }
+    launch_device_clock(ctx->stream, ctx->d_clock);
+    unsigned long long v = 0;
+    if (hipMemcpyAsync(&v, ctx->d_clock, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    host0 = std::chrono::steady_clock::now();
+    clock0 = v; ticks_per_ms = (double)khz;
+}
+
+bool candidate_state(rt_ctx* ctx, uint32_t& error_bits, bool& expired)
+{
+    // `expired` and the error word stand on neighbouring 128-byte lines of the control block: one copy
+    const size_t lo = trace_ctrl_expired_offset(), hi = trace_ctrl_error_offset();
+    uint32_t words[64] = { 0 };
+    const size_t bytes = hi + 4 - lo;
+    if (hi < lo || bytes > sizeof words) return false;
+    if (hipMemcpyAsync(words, (const char*)ctx->d_trace_ctrl + lo, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    expired = words[0] != 0u;
+    error_bits = words[(hi - lo) / 4];
+    if (error_bits && (hipMemsetAsync((char*)ctx->d_trace_ctrl + hi, 0, 4, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) return false;
+    return true;
+}
+
 extern "C" {
 
 // Direction octants (bit k: 1 / direction negative on axis k) the rays of a camera can have: every component of the un-normalised
@@ -215,36 +245,18 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
         uint32_t launches = 0;
         float gpu_ms = 0.f;               // device time of all calibration launches (events on the stream)
         const uint32_t cal_parts = calibration_parts(b, cam);
-        // Deadlines of the candidates on the device's own clock (trace_kernels.hip, cal_expired): a sample of that clock next to a
-        // host time stamp maps "now + limit" onto it.  The sample is taken behind the warm-up launch; its kernel ran before the
-        // read-back returned, so the mapped deadlines come a few tens of microseconds early: a slack is added.
-        unsigned long long clock0 = 0; double clock_rate = 0.0;        // ticks per millisecond
-        std::chrono::steady_clock::time_point host0;
+        CalClock cal_clock;                                            // deadlines of the candidates on the device's own clock
         float limit_ms = 0.f;                                          // 0 = the next launch has no deadline
-        auto sample_clock = [&]() {
-            static const bool off = [] { const char* e = std::getenv("RTMI_CALIBRATION_DEADLINE"); return e && e[0] == '0'; }();
-            if (off) return;
-            if (!ctx->d_clock && hipMalloc((void**)&ctx->d_clock, 8) != hipSuccess) { (void)hipGetLastError(); ctx->d_clock = nullptr; return; }
-            int khz = 0;
-            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); return; }
-            launch_device_clock(ctx->stream, ctx->d_clock);
-            unsigned long long v = 0;
-            if (hipMemcpyAsync(&v, ctx->d_clock, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return; }
-            host0 = std::chrono::steady_clock::now();
-            clock0 = v; clock_rate = (double)khz;
-        };
         // one launch of one candidate; false = runtime failure
-        auto run_once = [&](int ci, float& ms, bool& valid) -> bool {
+        // (cut_off: a wave stopped at the deadline, so the elapsed time is not the strategy's time)
+        auto run_once = [&](int ci, float& ms, bool& valid, bool& cut_off) -> bool {
             const auto& cand = candidates[ci];
             TraceLaunch t = make_launch(b, cam, cal_parts);              // (the camera is prepared by the first of them)
             t.packet = cand.packet; t.packet4 = cand.quad;
             t.defer_budget = cand.budget;
             t.tag = 1;
             if (cand.packet && cand.quad && order_ok) { t.block_cost = bo->d_cost; t.block_order = bo->valid ? bo->d_order : nullptr; }
-            if (clock_rate > 0.0 && limit_ms > 0.f) {
-                const double now_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count();
-                t.cal_deadline = clock0 + (unsigned long long)((now_ms + (double)limit_ms + 0.1) * clock_rate);
-            }
+            t.cal_deadline = cal_clock.deadline(limit_ms);
             ms = 0.f;
             (void)hipEventRecord(e0, ctx->stream);
             t.tile_xy = tile_table(ctx, cam, rank, nranks);
@@ -254,15 +266,13 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
             gpu_ms += ms;
             uint32_t cand_err = 0;
-            if (hipMemcpyAsync(&cand_err, (const char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+            if (!candidate_state(ctx, cand_err, cut_off)) return false;
             valid = cand_err == 0;                                       // e.g. a list too small for this strategy: not a candidate
-            if (cand_err && (hipMemsetAsync((char*)ctx->d_trace_ctrl + trace_ctrl_error_offset(), 0, 4, ctx->stream) != hipSuccess ||
-                             hipStreamSynchronize(ctx->stream) != hipSuccess)) return false;   // the word is sticky: a discarded candidate must not fail the frame
             last_failed = !valid;
             if (ctx->calibration_log)
-                std::fprintf(stderr, "rtmi calibration: n=%u %ux%u %s budget %u: %.4f ms%s\n", b->n, cam->resX, cam->resY,
-                             cand.packet ? (cand.quad ? "packet4" : "packet") : "lane-per-ray", cand.budget, ms, valid ? "" : " (error word set, discarded)");
+                std::fprintf(stderr, "rtmi calibration: n=%u %ux%u %s budget %u: %.4f ms%s%s\n", b->n, cam->resX, cam->resY,
+                             cand.packet ? (cand.quad ? "packet4" : "packet") : "lane-per-ray", cand.budget, ms, valid ? "" : " (error word set, discarded)",
+                             cut_off ? " (stopped at its deadline: no sample)" : "");
             return true;
         };
         // The candidates are timed with the device to themselves.  Sharing sub-trees between waves fills a launch's idle tail --
@@ -301,9 +311,12 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
                 for (int k = 0; k < N_CAND; k++) if (cand_n[k] > 0 && (best == 0.f || cand_ms[k] < best)) best = cand_ms[k];
                 limit_ms = best > 0.f ? 1.6f * best + 0.02f : 0.f;
             }
-            float m = 0.f; bool valid = false;
-            if (!run_once(ci, m, valid)) { broken = true; return; }
+            float m = 0.f; bool valid = false, cut_off = false;
+            if (!run_once(ci, m, valid, cut_off)) { broken = true; return; }
             if (!valid) { cand_n[ci] = -1; return; }
+            // a launch that was cut off lost against the limit it was given; its elapsed time says nothing else (in particular it is
+            // not a fast sample when the deadline was mapped too early): a candidate with earlier samples keeps them
+            if (cut_off) { if (cand_n[ci] == 0) cand_n[ci] = -1; return; }
             m *= handicap(ci);
             cand_ms[ci] = cand_n[ci] == 0 ? m : (m < cand_ms[ci] ? m : cand_ms[ci]);
             cand_n[ci]++;
@@ -332,10 +345,10 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
         {
             int warm = first_cand;
             for (int ci = 0; ci < N_CAND && warm < 0; ci++) if (cand_n[ci] == 0) warm = ci;
-            if (warm >= 0) { float m; bool v = false; if (!run_once(warm, m, v)) broken = true; }
+            if (warm >= 0) { float m; bool v = false, c = false; if (!run_once(warm, m, v, c)) broken = true; }
             // the warm-up ran to its end: its block costs give the candidates the start order the frames will have
             if (!broken && warm >= 0 && candidates[warm].packet && candidates[warm].quad && order_ok) block_order_refresh(ctx, *bo);
-            if (!broken) sample_clock();
+            if (!broken) cal_clock.sample(ctx);
         }
         auto refine_lane = [&](int first) {
             // the neighbours of the best lane-per-ray budget, two candidates away on either side (the list is ~sqrt(2) apart)

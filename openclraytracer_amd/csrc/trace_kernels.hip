@@ -82,7 +82,7 @@ struct TraceCtrl {
     uint32_t split_count; uint32_t p3[31];   // rays whose sub-trees were handed to phase 1 by the packet kernel
     uint32_t spill_taken; uint32_t p4[31];   // packet kernels: overflow areas taken in this launch (diagnostic)
     uint32_t long_steps;  uint32_t long_steps_max; uint32_t long_nodes; uint32_t p5[29];   // wave-per-ray kernel: pool steps, all records / longest record (diagnostic)
-    uint32_t split_tiles; uint32_t shared_tasks; uint32_t p9[30];   // k_trace_packet4 with shared tasks: blocks whose contacts come out of the key buffer (entries of
+    uint32_t split_tiles; uint32_t shared_tasks; uint32_t expired; uint32_t p9[29];   // k_trace_packet4 with shared tasks: blocks whose contacts come out of the key buffer (entries of
                                              // split_list); tasks published (diagnostic, written by the helper waves at the end)
     uint32_t error;       uint32_t p2[31];   // bit 1: long-ray list full on a forced deferral, 2: phase-1 pool overflow, 3: packet stack
                                              // beyond its spill area, 4: bad deferred record, 5: no free spill area, 6: a ray was handed over
@@ -94,6 +94,7 @@ static_assert(offsetof(TraceCtrl, error) == (WORK_SHARDS + 5) * 128, "the error 
 #define TRACE_FAIL(word, code) __hip_atomic_fetch_or((word), 1u << (code), RLX_AGENT)
 size_t trace_ctrl_bytes() { return sizeof(TraceCtrl); }
 size_t trace_ctrl_error_offset() { return offsetof(TraceCtrl, error); }
+size_t trace_ctrl_expired_offset() { return offsetof(TraceCtrl, expired); }      // calibration launches: a wave stopped at the deadline
 void trace_ctrl_counter_offsets(size_t out[RT_TRACE_COUNTERS]) { out[6] = offsetof(TraceCtrl, split_tiles); out[7] = offsetof(TraceCtrl, shared_tasks);
                                                   out[0] = offsetof(TraceCtrl, long_count); out[1] = offsetof(TraceCtrl, split_count); out[2] = offsetof(TraceCtrl, spill_taken);
                                                   out[3] = offsetof(TraceCtrl, long_steps); out[4] = offsetof(TraceCtrl, long_steps_max); out[5] = offsetof(TraceCtrl, long_nodes); }
@@ -266,6 +267,20 @@ __device__ __forceinline__ bool child_valid_delta_signed(float dlox, float dloy,
     return (tnear <= tfar) & (tnear > threshold);
 }
 
+// A ray of a RAY BUFFER on search-tree records (ray_root<0>: finite origin of moderate size, every 1 / direction finite and at least
+// ~1 in magnitude -- no NaN, no product that underflows to zero): "origin inside the box" is then tnear <= 0 <= tfar, and the
+// reference's (flag && tmin > 0) || inside is tnear <= tfar && tfar >= 0 (derivation at child_mask_general).
+__device__ __forceinline__ bool child_valid_general_signed(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayState& r,
+                                                           bool sx, bool sy, bool sz)
+{
+    const float nx = ((sx ? hix : lox) - r.o.x) * r.inv.x, fx = ((sx ? lox : hix) - r.o.x) * r.inv.x;
+    const float ny = ((sy ? hiy : loy) - r.o.y) * r.inv.y, fy = ((sy ? loy : hiy) - r.o.y) * r.inv.y;
+    const float nz = ((sz ? hiz : loz) - r.o.z) * r.inv.z, fz = ((sz ? loz : hiz) - r.o.z) * r.inv.z;
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+    const float tfar = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    return (tnear <= tfar) & (tfar >= 0.0f);
+}
+
 // ... as the mask of the wave's lanes that enter the box.  The two compares write their lane masks straight into scalar
 // registers and the rest is scalar arithmetic on 64-bit masks; as a per-lane bool the compiler turns every `__ballot` of it into
 // a select and a compare of its own (two vector instructions per slot and step).
@@ -278,6 +293,26 @@ __device__ __forceinline__ uint64_t child_mask_delta(float dlox, float dloy, flo
     const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
     return __builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tnear > threshold);
+}
+
+// ... and for the rays of a RAY BUFFER walked as a packet (k_trace_packet4<0, ..>): every lane has an origin of its own, so the
+// subtraction stays per lane, and so does "origin inside the box" (isPointInside, AABB.h:178-184) -- which the slab values already
+// hold.  Only rays that ray_root lets onto the search tree come here: finite origins of moderate size, every 1 / direction finite and
+// at least ~1 in magnitude.  For such a ray no slab product is NaN, and none underflows to zero: the sign of an fp32 difference of
+// finite numbers is exact, and a non-zero difference times a factor of magnitude >= 0.99 rounds to a non-zero number.  Hence
+//     origin inside (lo <= o <= hi on every axis)  <=>  every near product <= 0 and every far product >= 0  <=>  tnear <= 0 <= tfar,
+// and the reference's decision  (flag && tmin > 0) || inside  (BVH.h:366-369) is
+//     tnear <= tfar  &&  (tnear > 0 || (tnear <= 0 && tfar >= 0))   ==   tnear <= tfar && tfar >= 0
+// -- the textbook test, here derived from the reference's.  (The equivalence needs lo <= hi; an unused slot's box is NaN on every
+// plane, k_relayout_quad: all its products are NaN, v_min / v_max return NaN for two NaN operands, and both compares are false.)
+__device__ __forceinline__ uint64_t child_mask_general(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayState& r)
+{
+    const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
+    const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
+    const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return __builtin_amdgcn_ballot_w64(tnear <= tfar) & __builtin_amdgcn_ballot_w64(tfar >= 0.0f);
 }
 
 // ... and on a per-octant copy of those records, for a wave whose rays all have the copy's direction octant: the near planes
@@ -297,9 +332,8 @@ __device__ __forceinline__ bool child_valid_on(bool search_tree_record, float lo
                                                const RayState& r, bool sx, bool sy, bool sz, bool inside_marked)
 {
     if (search_tree_record) {
-        const bool inside = PRIMARY ? inside_marked
-                                    : ((lox <= r.o.x) & (r.o.x <= hix) & (loy <= r.o.y) & (r.o.y <= hiy) & (loz <= r.o.z) & (r.o.z <= hiz));
-        return child_valid_signed(lox, loy, loz, hix, hiy, hiz, r, sx, sy, sz, inside);
+        if (!PRIMARY) return child_valid_general_signed(lox, loy, loz, hix, hiy, hiz, r, sx, sy, sz);
+        return child_valid_signed(lox, loy, loz, hix, hiy, hiz, r, sx, sy, sz, inside_marked);
     }
     return child_valid<PRIMARY>(lox, loy, loz, hix, hiy, hiz, r, sx, sy, sz, inside_marked);
 }
@@ -508,11 +542,16 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint32_t w, RayStat
 // candidate strategy that has fallen clearly behind the best one so far stops walking -- its frame is thrown away anyway -- so that
 // the first frame on a BVH costs a bounded multiple of a steady one whatever the hopeless candidates would have taken
 // (round 2: up to 55 ms for one of them against 0.1-7.5 ms frames).  Compiled out of every other instance.
+// A wave that stops here says so (TraceCtrl::expired, cleared per launch): the host must not take the elapsed time of a launch that
+// was cut off for the time the strategy needs -- a deadline mapped too early (the host thread descheduled between its time stamp
+// and the launch) would otherwise make a truncated candidate the fastest one.
 template <int CAL>
-__device__ __forceinline__ bool cal_expired(unsigned long long deadline)
+__device__ __forceinline__ bool cal_expired(const TraceArgs& a)
 {
     if (CAL != 1) return false;
-    return deadline != 0ull && __builtin_amdgcn_s_memrealtime() > deadline;
+    const bool expired = a.cal_deadline != 0ull && __builtin_amdgcn_s_memrealtime() > a.cal_deadline;       // (wave-uniform: scalar)
+    if (expired && (threadIdx.x & 63u) == 0u) __hip_atomic_store((gu32*)&a.ctrl->expired, 1u, RLX_AGENT);
+    return expired;
 }
 __global__ void k_device_clock(unsigned long long* out) { *out = __builtin_amdgcn_s_memrealtime(); }
 void launch_device_clock(hipStream_t s, unsigned long long* d_out) { hipLaunchKernelGGL(k_device_clock, dim3(1), dim3(1), 0, s, d_out); }
@@ -535,7 +574,10 @@ __device__ __forceinline__ uint32_t ray_root(const TraceArgs& a, const RayState&
         // its slab products can be 0 * inf or underflow -- every 1/d finite and not smaller than ~1 in magnitude, which
         // normalised directions without a zero component satisfy
         const float ax = fabsf(r.inv.x), ay = fabsf(r.inv.y), az = fabsf(r.inv.z);
-        const bool safe = (ax <= FLT_MAX) && (ay <= FLT_MAX) && (az <= FLT_MAX) && (ax >= 0.99f) && (ay >= 0.99f) && (az >= 0.99f);
+        // ... and a finite origin of moderate size: a NaN origin coordinate on y or z makes the reference's staged test forget its
+        // earlier axes ("the first axis"), and (plane - origin) must not overflow
+        const bool safe = (ax <= FLT_MAX) && (ay <= FLT_MAX) && (az <= FLT_MAX) && (ax >= 0.99f) && (ay >= 0.99f) && (az >= 0.99f) &&
+                          (fabsf(r.o.x) <= 1e30f) && (fabsf(r.o.y) <= 1e30f) && (fabsf(r.o.z) <= 1e30f);
         return safe ? a.search_root : 0u;
     }
     const bool risky = ((plane_bits & 1u) && !(fabsf(r.inv.x) <= FLT_MAX)) || ((plane_bits & 2u) && !(fabsf(r.inv.y) <= FLT_MAX)) ||
@@ -632,12 +674,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
             }
         }
     }
-    if (cal_expired<CAL>(a.cal_deadline)) return;
+    if (cal_expired<CAL>(a)) return;
     uint32_t cal_tick = 0;
     if (__ballot(active) != 0ull) {
         // ---------------- traversal steps until every ray of the block has finished or moved on ----------------
         for (;;) {
-            if (CAL == 1 && (++cal_tick & 15u) == 0u && cal_expired<CAL>(a.cal_deadline)) break;
+            if (CAL == 1 && (++cal_tick & 15u) == 0u && cal_expired<CAL>(a)) break;
             uint32_t extra = RT_SENTINEL;     // child that did not fit on the stack (forces a deferral)
             if (active) {
                 iters++;
@@ -655,8 +697,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 5) void k_trace(TraceArgs a)
                     //  of the test; primary rays read the camera-relative copy of the records)
                     auto slot_valid = [&](const float4& lo, const float4& hi, float threshold) {
                         if (PRIMARY) return child_valid_delta_signed(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, sx, sy, sz, threshold);
-                        const bool inside = (lo.x <= r.o.x) & (r.o.x <= hi.x) & (lo.y <= r.o.y) & (r.o.y <= hi.y) & (lo.z <= r.o.z) & (r.o.z <= hi.z);
-                        return child_valid_signed(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, sx, sy, sz, inside);
+                        return child_valid_general_signed(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, sx, sy, sz);
                     };
                     uint32_t c0 = slot_valid(g0, g1, g4.w) ? i0 : RT_SENTINEL;
                     uint32_t c1 = slot_valid(g2, g3, g5.w) ? i1 : RT_SENTINEL;
@@ -828,10 +869,10 @@ __device__ __forceinline__ void leaf_test_uniform(const TraceArgs& a, uint32_t l
 
 // the same for the lanes of `reached` only, without divergent control flow: every lane computes, the update is a select; the
 // tie on t (the rule of the depth-first rank) is rare and sits behind a wave-uniform test
-__device__ __forceinline__ void leaf_test_masked(const TraceArgs& a, uint32_t leaf, RayState& r, bool reached)
+__device__ __forceinline__ void leaf_test_record(const TriRec* __restrict__ trirec, uint32_t leaf, RayState& r, bool reached)
 {
     // the packed record through the scalar path: one address, twelve dwords
-    const float4* p = reinterpret_cast<const float4*>(a.trirec + leaf);
+    const float4* p = reinterpret_cast<const float4*>(trirec + leaf);
     const float4 w0 = ld_const4(p), w1 = ld_const4(p + 1), w2 = ld_const4(p + 2);
     const f3 vert0 = f3{ w0.x, w0.y, w0.z }, edge1 = f3{ w0.w, w1.x, w1.y }, edge2 = f3{ w1.z, w1.w, w2.x };
     const uint32_t pos = __float_as_uint(w2.y);
@@ -970,9 +1011,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(TraceArgs a)
         uint32_t steps = 0;                              // nodes this block has walked
         bool walking = __ballot(in) != 0ull;
         NodeRec cur = ld_record(a.trav, node);           // record of `node`, kept in registers across steps
-        if (cal_expired<CAL>(a.cal_deadline)) walking = false;
+        if (cal_expired<CAL>(a)) walking = false;
         while (walking) {
-            if (CAL == 1 && (steps & 15u) == 15u && cal_expired<CAL>(a.cal_deadline)) break;
+            if (CAL == 1 && (steps & 15u) == 15u && cal_expired<CAL>(a)) break;
             // A block that keeps walking with a handful of lanes wastes the wave, and a block that walks thousands of
             // nodes sets the frame time.  After PACKET_LOW_RUN low-occupancy steps the current node -- after `defer_budget`
             // steps everything the block has left (current node and every stack entry) -- is handed, per taking-part lane,
@@ -1186,7 +1227,8 @@ template <int PRIMARY, int CAL, int SHARE, int OCT, int FUSE>
 #ifndef P4_MIN_WAVES_WHOLE
 #define P4_MIN_WAVES_WHOLE 8
 #endif
-__global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? P4_MIN_WAVES : P4_MIN_WAVES_WHOLE)) void k_trace_packet4(TraceArgs a)
+// (the sharing instance for ray buffers carries six more subtractions per box and the rays' own origins: 63 registers and spills at eight waves)
+__global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? (PRIMARY ? P4_MIN_WAVES : 6) : P4_MIN_WAVES_WHOLE)) void k_trace_packet4(TraceArgs a)
 {
     extern __shared__ uint32_t s_dynamic[];              // three stacks of PACKET_STACK words per wave of the workgroup (launch_tagged sizes it)
     const uint32_t lane = threadIdx.x & 63u;
@@ -1208,6 +1250,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? P4_MIN_WAVES : P4_MIN_WAVES_W
     const QuadNode* const quad_general = a.quad;
     const uint32_t octant_records = a.quad_octant_records;
     const TriCam* const tricam = a.tricam;
+    const TriRec* const trirec = a.trirec;               // ray buffers (PRIMARY = 0): the triangles as they are, every lane its own origin
     const uint32_t budget = a.defer_budget;
     const uint32_t n_block_waves = (a.total_work + 63u) >> 6;
     const bool helper = wave_gid >= n_block_waves;       // SHARE only: the grid ends with waves that have no block of their own
@@ -1299,7 +1342,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? P4_MIN_WAVES : P4_MIN_WAVES_W
         // OCT: the lanes walk in groups of one direction octant each, on that octant's copy of the records (near / far planes in
         // place, child_mask_octant).  All but the blocks on the image's centre lines are one group; a task's lanes come out
         // of one group and are one again.  Without the copies: one group on the general records.
-        if (cal_expired<CAL>(a.cal_deadline)) todo = 0ull;          // (the wave still goes through its exit: counters of the sharing protocol)
+        if (cal_expired<CAL>(a)) todo = 0ull;          // (the wave still goes through its exit: counters of the sharing protocol)
         uint32_t cal_tick = 0;
         while (todo != 0ull) {
         uint64_t in = todo;                              // the lanes that walk the current node
@@ -1318,7 +1361,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? P4_MIN_WAVES : P4_MIN_WAVES_W
         bool walking = true;
         while (walking) {
             P4_STAMP(T0);
-            if (CAL == 1 && (++cal_tick & 31u) == 0u && cal_expired<CAL>(a.cal_deadline)) { todo = 0ull; break; }
+            if (CAL == 1 && (++cal_tick & 31u) == 0u && cal_expired<CAL>(a)) { todo = 0ull; break; }
             if (SHARE && ++steps > share_after) {
                 steps = 0;
                 share_after = share_after >> 1 > SHARE_MIN_STEPS ? share_after >> 1 : SHARE_MIN_STEPS;
@@ -1392,11 +1435,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? P4_MIN_WAVES : P4_MIN_WAVES_W
                 m[1] = in & child_mask_octant(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, q5.w);
                 m[2] = in & child_mask_octant(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w);
                 m[3] = in & child_mask_octant(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, q7.w);
-            } else {
+            } else if (PRIMARY) {
                 m[0] = in & child_mask_delta(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r, q4.w);
                 m[1] = in & child_mask_delta(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r, q5.w);
                 m[2] = in & child_mask_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w);
                 m[3] = in & child_mask_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, q7.w);
+            } else {
+                // a ray buffer's packet on the records as built (k_relayout_quad): origins differ from lane to lane
+                m[0] = in & child_mask_general(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r);
+                m[1] = in & child_mask_general(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r);
+                m[2] = in & child_mask_general(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r);
+                m[3] = in & child_mask_general(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r);
             }
             const uint32_t ids[4] = { id0, id1, id2, id3 };
             P4_KEEP("s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]));
@@ -1413,10 +1462,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? P4_MIN_WAVES : P4_MIN_WAVES_W
             // (round 3: ONE branch around the whole section -- leaf masks by select, the slots' masks cleared by select -- instead of these
             //  four mostly not-taken ones: ManFigure 0.270 -> 0.361 ms, Gardenlight 0.063 -> 0.071: the sixteen scalar selects every step
             //  pays cost more than the branches it skips; this kernel's time follows its scalar instruction count)
-            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull) leaf_test_camera(tricam, id0 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[0])); m[0] = 0ull; }
-            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull) leaf_test_camera(tricam, id1 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[1])); m[1] = 0ull; }
-            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull) leaf_test_camera(tricam, id2 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[2])); m[2] = 0ull; }
-            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull) leaf_test_camera(tricam, id3 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[3])); m[3] = 0ull; }
+            if ((id0 & RT_LEAF_FLAG) != 0u) { if (m[0] != 0ull) { if (PRIMARY) leaf_test_camera(tricam, id0 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[0])); else leaf_test_record(trirec, id0 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[0])); } m[0] = 0ull; }
+            if ((id1 & RT_LEAF_FLAG) != 0u) { if (m[1] != 0ull) { if (PRIMARY) leaf_test_camera(tricam, id1 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[1])); else leaf_test_record(trirec, id1 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[1])); } m[1] = 0ull; }
+            if ((id2 & RT_LEAF_FLAG) != 0u) { if (m[2] != 0ull) { if (PRIMARY) leaf_test_camera(tricam, id2 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[2])); else leaf_test_record(trirec, id2 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[2])); } m[2] = 0ull; }
+            if ((id3 & RT_LEAF_FLAG) != 0u) { if (m[3] != 0ull) { if (PRIMARY) leaf_test_camera(tricam, id3 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[3])); else leaf_test_record(trirec, id3 & ~RT_LEAF_FLAG, r, __builtin_amdgcn_inverse_ballot_w64(m[3])); } m[3] = 0ull; }
             P4_KEEP("v"(r.best_t), "v"(r.best_leaf), "v"(r.best_pos));
             P4_STAMP(T3);
             // the LAST wanted inner child is walked next, the ones before it wait on the stack with their lanes: a slot that is
@@ -1661,7 +1710,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
     uint32_t shard = wave_gid % WORK_SHARDS, shards_tried = 0;
     for (;;) {
         if (bi >= n_batches) break;
-        if (cal_expired<CAL>(a.cal_deadline)) break;
+        if (cal_expired<CAL>(a)) break;
         // ---------------- set the batch up: lane s < batch prepares slot s ----------------
         if (lane < batch) {
             const uint32_t i = bi * batch + lane;
@@ -1719,7 +1768,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_long(TraceArgs a)
         uint32_t pool_steps = 0, pool_nodes = 0;
         while (n_inner != 0u || n_leaf != 0u) {
             pool_steps++;
-            if (CAL == 1 && (pool_steps & 15u) == 0u && cal_expired<CAL>(a.cal_deadline)) break;
+            if (CAL == 1 && (pool_steps & 15u) == 0u && cal_expired<CAL>(a)) break;
             // ---- leaves, 64 at a time, when the pool is filling up or nothing else is left ----
             if (n_leaf >= POOL_LEAF - 128u || n_inner == 0u) {
                 uint32_t k = n_leaf < 64u ? n_leaf : 64u;
@@ -1969,6 +2018,24 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         // wave-per-ray kernel returns at once (left out where the caller knows that there are none: frame graphs)
         // (a smaller grid for this usually empty launch was measured: the 6.4 us are the launch, not its size)
         if (!t.no_unsafe_rays) rt_launch_node(rec, upd, RT_NODE_LONG, k_trace_long<PRIMARY, CAL>, dim3(grid1), dim3(TRACE_BLOCK), s, a);
+        if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
+        return;
+    }
+    if constexpr (PRIMARY == 0) if (t.packet && t.packet4 && t.quad && t.trirec && t.search_root) {
+        // A ray buffer walked as packets: 64 consecutive rays per wave on the four-wide records as built (every lane its own origin,
+        // child_mask_general), sub-trees shared between waves under a step budget as for primary frames.  Rays that may not use the
+        // search tree (ray_root) are handed, whole, to the wave-per-ray kernel.
+        if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
+        const uint32_t lds = wpb * 3u * PACKET_STACK * 4u;
+        if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
+            (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
+            const uint32_t helpers = (t.task_helper_blocks ? t.task_helper_blocks : 256u) * TRACE_WAVES / wpb;
+            hipLaunchKernelGGL((k_trace_packet4<0, CAL, 1, 0, 0>), dim3(grid + helpers), dim3(wpb * 64u), lds, s, a);
+        } else {
+            hipLaunchKernelGGL((k_trace_packet4<0, CAL, 0, 0, 0>), dim3(grid), dim3(wpb * 64u), lds, s, a);
+        }
+        if (t.ev[1]) (void)hipEventRecord(t.ev[1], s);
+        hipLaunchKernelGGL((k_trace_long<0, CAL>), dim3(grid1), dim3(TRACE_BLOCK), 0, s, a);
         if (t.ev[2]) (void)hipEventRecord(t.ev[2], s);
         return;
     }
