@@ -72,7 +72,13 @@ enum { RT_SUCCESS = 0, RT_ERROR = 1 };
  * beyond the last leaf clamped to it, BVHKernels.cl:67), parent links outside the node array end a walk -- the visible
  * artefact of the shipped reference (the spine above the lost node keeps its inverted init boxes and is never entered),
  * made deterministic.  Node bytes and contacts equal the oracle's LITERAL_ZERO mode; no search tree in this mode.      */
-enum { RT_MODE_FIXED = 0, RT_MODE_LITERAL_ZERO = 1 };
+/* FAST (for scenes rebuilt every frame, OpenCLRayTracerDemo.cpp:230-234): as FIXED, but the Morton pairs of the reference tree are ordered
+ * by a stable radix sort instead of the reference's bitonic network.  Leaves with DIFFERENT codes stand where FIXED puts them; leaves
+ * with EQUAL codes stand in index order instead of the network's order, so the radix tree differs inside runs of duplicate codes and so
+ * do depth-first ranks there.  Contacts: hit / miss and t are FIXED's bit for bit; normal and materialIndex can differ only where two
+ * triangles are hit at exactly the same t (the tie goes to the lower rank) -- and for rays whose slab test meets 0 * inf on y or z,
+ * whose reached set depends on the hierarchy itself.                                                     */
+enum { RT_MODE_FIXED = 0, RT_MODE_LITERAL_ZERO = 1, RT_MODE_FAST = 2 };
 
 /* ---- context: replaces CLExecutionContext creation (CLExecutionContext.cpp:270-300) ------ */
 int         rt_abi_version(void);
@@ -345,6 +351,10 @@ void rt_frame_graph_destroy(rt_frame_graph* g);
 /* BitonicSort::sort (Include/Algorithms/Sorting.h:77, BitonicSort.cpp:118-189): uint2 pairs, key = .x,
  * same comparator network => same permutation of equal keys.  n_pow2 must be a power of two.     */
 int  rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2);
+/* The same interface with the algorithm named (SURVEY.md 8(b) `rt_sort_kv_u32`): RT_SORT_BITONIC = the reference's network (n a power
+ * of two); RT_SORT_RADIX = LSD radix sort, 8 bits x 4 passes, LDS-staged, STABLE (equal keys keep their input order), any n.      */
+enum { RT_SORT_BITONIC = 0, RT_SORT_RADIX = 1 };
+int  rt_sort_pairs(rt_ctx* ctx, void* d_pairs, uint32_t n, int algorithm);
 /* PrefixSum::computePrefixSum (Include/Algorithms/PrefixSum.h:68): inclusive uint scan          */
 int  rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n);
 

@@ -39,7 +39,7 @@ SYMBOLS = [
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_rays_strategy', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_host_plane_reads', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
-    'rt_sort_pairs_bitonic', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_frames_in_flight', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
+    'rt_sort_pairs_bitonic', 'rt_sort_pairs', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_frames_in_flight', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
@@ -117,6 +117,7 @@ def load_library() -> C.CDLL:
     L.rt_untile_rgba_packed.argtypes = [vp, vp, u32, vp, u32, u64, vp]
     L.rt_sort_pairs_bitonic.argtypes = [vp, vp, u32]
     L.rt_scan_inclusive_u32.argtypes = [vp, vp, vp, u32]
+    L.rt_sort_pairs.argtypes = [vp, vp, u32, i32]
     L.rt_ctx_set_profiling.argtypes = [vp, i32]
     L.rt_ctx_set_frames_in_flight.argtypes = [vp, u32]
     L.rt_ctx_trace_kernel_times.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -252,6 +253,16 @@ class Context:
         try:
             self.upload(d, pairs)
             self.check(self.lib.rt_sort_pairs_bitonic(self.h, C.c_void_p(d), len(pairs)))
+            return self.download(d, len(pairs), PAIR)
+        finally:
+            self.free(d)
+
+    def sort_pairs(self, pairs: np.ndarray, algorithm: int = 1) -> np.ndarray:
+        """rt_sort_pairs: 0 the reference's bitonic network (power-of-two counts), 1 the stable radix sort (any count)"""
+        d = self.alloc(max(pairs.nbytes, 8))
+        try:
+            self.upload(d, pairs)
+            self.check(self.lib.rt_sort_pairs(self.h, C.c_void_p(d), len(pairs), algorithm))
             return self.download(d, len(pairs), PAIR)
         finally:
             self.free(d)

@@ -30,10 +30,11 @@ int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** 
     if (!ctx || !scene || !out) return RT_FAIL(ctx, "null argument");
     *out = nullptr;
     if (scene->ctx != ctx) return RT_FAIL(ctx, "scene belongs to another context");
-    if (parity_mode != RT_MODE_FIXED && parity_mode != RT_MODE_LITERAL_ZERO) return RT_FAIL(ctx, "unknown parity mode");
+    if (parity_mode != RT_MODE_FIXED && parity_mode != RT_MODE_LITERAL_ZERO && parity_mode != RT_MODE_FAST) return RT_FAIL(ctx, "unknown parity mode");
     rt_bvh* b = new (std::nothrow) rt_bvh();
     if (!b) return RT_FAIL(ctx, "out of host memory");
     b->ctx = ctx; b->scene = scene; b->mode = parity_mode;
+    if (const char* e = std::getenv("RTMI_SEARCH_SORT")) b->search_sort_bitonic = std::strcmp(e, "bitonic") == 0;
     *out = b;
     return RT_SUCCESS;
 }
@@ -62,6 +63,9 @@ static void free_build_buffers(rt_bvh* b)
     if (b->s_pairs) (void)hipFree(b->s_pairs);
     if (b->s_counters) (void)hipFree(b->s_counters);
     if (b->s_pos) (void)hipFree(b->s_pos);
+    if (b->d_sort_tmp) (void)hipFree(b->d_sort_tmp);
+    if (b->d_sort_scratch) (void)hipFree(b->d_sort_scratch);
+    b->d_sort_tmp = nullptr; b->d_sort_scratch = nullptr;
     if (b->d_spans) (void)hipFree(b->d_spans);
     if (b->d_rq_scratch) (void)hipFree(b->d_rq_scratch);
     b->d_spans = nullptr; b->d_rq_scratch = nullptr;
@@ -86,7 +90,7 @@ void rt_bvh_destroy(rt_bvh* b)
 // env RTMI_REFIT=rq / climb forces one (tests run both on every fixture).
 static bool refit_by_range_queries(const rt_ctx* ctx, uint32_t n, int mode)
 {
-    if (mode != RT_MODE_FIXED || n < 256u) return false;
+    if (mode == RT_MODE_LITERAL_ZERO || n < 256u) return false;
     if (ctx->refit_choice) return ctx->refit_choice == 1;
     return n >= (1u << 17);
 }
@@ -104,7 +108,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         free_build_buffers(b);
         b->n = 0; b->N = 0;                           // stays 0 unless every allocation below succeeds
         // LITERAL_ZERO: no search tree (its boxes are not nested: the spine above the never-built node keeps the init boxes)
-        const bool want_search = !ctx->no_search_tree && b->mode == RT_MODE_FIXED;
+        const bool want_search = !ctx->no_search_tree && b->mode != RT_MODE_LITERAL_ZERO;
         const size_t trees = want_search ? 2u : 1u;
         hipError_t e = hipMalloc((void**)&b->d_nodes, (size_t)(2 * n - 1) * sizeof(rt_bvh_node));
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_pairs, (size_t)N * sizeof(uint2));
@@ -128,6 +132,10 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_pairs, (size_t)N * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_counters, (size_t)n * sizeof(uint32_t) + 256);
             if (e == hipSuccess) e = hipMalloc((void**)&b->s_pos, (size_t)n * sizeof(uint32_t));
+        }
+        if (e == hipSuccess && (want_search || b->mode == RT_MODE_FAST)) {      // the radix sort's second buffer and histograms
+            e = hipMalloc((void**)&b->d_sort_tmp, (size_t)n * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc((void**)&b->d_sort_scratch, radix_sort_scratch_words(n) * sizeof(uint32_t));
         }
         if (e == hipSuccess && refit_by_range_queries(ctx, n, b->mode)) {
             e = hipMalloc((void**)&b->d_spans, (size_t)(n - 1) * sizeof(uint2));
@@ -160,7 +168,11 @@ int rt_bvh_construct(rt_bvh* b)
     hipStream_t s = ctx->stream;
     const DeviceScene& sc = b->scene->d;
     launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
-    launch_bitonic_sort(s, b->d_pairs, b->N);                     // 2. :195
+    // 2. :195 -- the reference's network (the order of equal Morton codes is part of its result: it decides the radix tree's topology and
+    // the depth-first ranks that break ties between equal t).  RT_MODE_FAST: a stable radix sort instead (30-bit codes: four passes over
+    // n pairs instead of ~log^2 N / 2 network levels over N) -- the same tree wherever codes differ, leaves with EQUAL codes in index order
+    if (b->mode == RT_MODE_FAST) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp, b->n, 30u, b->d_sort_scratch);
+    else launch_bitonic_sort(s, b->d_pairs, b->N);
     const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
     launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
     if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
@@ -190,7 +202,10 @@ int rt_bvh_construct(rt_bvh* b)
         RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));
         RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
         launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
-        launch_bitonic_sort(s, s_pairs, N);
+        // the search tree's order is the library's own (any nested hierarchy over the reference's leaves gives the reference's contacts,
+        // ties between equal t are broken by the REFERENCE rank, d_pos): a stable radix sort
+        if (b->search_sort_bitonic || !b->d_sort_tmp) launch_bitonic_sort(s, s_pairs, N);
+        else launch_radix_sort(s, s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
         launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u);
         uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
         launch_refit(s, s_nodes, s_counters, n, s_depth, !ctx->search_tree_reference_boxes);

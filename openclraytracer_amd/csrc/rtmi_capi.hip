@@ -510,6 +510,24 @@ int rt_sort_pairs_bitonic(rt_ctx* ctx, void* d_pairs, uint32_t n_pow2)
     return RT_SUCCESS;
 }
 
+int rt_sort_pairs(rt_ctx* ctx, void* d_pairs, uint32_t n, int algorithm)
+{
+    if (algorithm == RT_SORT_BITONIC) return rt_sort_pairs_bitonic(ctx, d_pairs, n);
+    if (!ctx || (n && !d_pairs)) return RT_FAIL(ctx, "null argument");
+    if (algorithm != RT_SORT_RADIX) return RT_FAIL(ctx, "unknown sort algorithm");
+    if (n < 2) return RT_SUCCESS;
+    RT_ENTER(ctx);
+    void* tmp = nullptr;
+    const size_t pair_bytes = ((size_t)n * sizeof(uint2) + 255u) & ~(size_t)255u;
+    RT_HIP(ctx, hipMalloc(&tmp, pair_bytes + radix_sort_scratch_words(n) * sizeof(uint32_t)));
+    launch_radix_sort(ctx->stream, (uint2*)d_pairs, (uint2*)tmp, n, 32u, (uint32_t*)((char*)tmp + pair_bytes));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the scratch is freed below
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return RT_FAIL(ctx, std::string("radix sort failed: ") + hipGetErrorString(e));
+    return RT_SUCCESS;
+}
+
 int rt_scan_inclusive_u32(rt_ctx* ctx, const void* d_in, void* d_out, uint32_t n)
 {
     if (!ctx) return RT_FAIL(nullptr, "ctx is null");

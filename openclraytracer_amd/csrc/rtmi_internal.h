@@ -170,6 +170,9 @@ struct rt_bvh {
     uint2* s_pairs = nullptr;
     uint32_t* s_counters = nullptr;
     uint32_t* s_pos = nullptr;
+    uint2* d_sort_tmp = nullptr;       // radix sort: n pairs to ping-pong with, then its histograms (launch_radix_sort)
+    uint32_t* d_sort_scratch = nullptr;
+    bool search_sort_bitonic = false;  // knob RTMI_SEARCH_SORT=bitonic: the search tree's keys through the bitonic network, as in rounds 1-3
     uint2* d_spans = nullptr;          // range-query refit: [first, last] of every inner node + its scratch (large scenes only)
     void* d_rq_scratch = nullptr;
     uint32_t* d_packet_spill = nullptr;   // packet kernels: bitmap + stack overflow areas, sized from the tree depth
@@ -283,6 +286,8 @@ void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t*
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
+size_t radix_sort_scratch_words(uint32_t n);
+void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint32_t key_bits, uint32_t* scratch);   // stable LSD radix sort by the low key_bits of .x
 void launch_plane_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint32_t axis, uint2* pairs, uint32_t n_pow2);   // sorted (key, .) of the 2n corner coordinates of one axis
 int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch);
 size_t scan_scratch_words(uint32_t n);

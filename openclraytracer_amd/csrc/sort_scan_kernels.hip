@@ -218,6 +218,209 @@ int launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint
     return 0;
 }
 
+// ----------------------------------------------------------------------------------------
+// LSD radix sort of uint2 (key = .x), 8 bits per pass, STABLE: equal keys keep their input order (the bitonic network above
+// permutes them the way the reference's network does, which is part of the reference's result; this sort is for orders that are
+// the library's own -- the search tree's keys, ray bins -- and for the FAST build mode).  HBM-bound integer work: per pass the keys
+// are read twice and the pairs written once (n x 24 B), nothing is reshaped into anything else.
+//   k_radix_hist     one block per tile of RDX_TILE elements: 256-bin digit histogram (LDS atomics) -> hist[digit][tile]
+//   k_radix_rows     one block per digit: exclusive scan of its row of tile counts (coalesced), row total -> totals[digit]
+//   k_radix_scatter  one block per tile: every wave ranks its 1 024 consecutive elements digit by digit -- lanes with the same digit
+//                    find each other with eight ballots, the lowest of them bumps the wave's counter of that digit in LDS, a lane's
+//                    rank is the old count plus the equal-digit lanes below it -- then the counts of the four waves, the tile's
+//                    digit starts and the global starts (row prefix + scan of the totals) are combined, the pairs are staged in LDS
+//                    in sorted order and written out in runs of consecutive addresses per digit
+//   k_radix_small    n <= RDX_TILE: all passes in one block, in LDS
+// ----------------------------------------------------------------------------------------
+#define RDX_BINS 256u
+#define RDX_THREADS 256u
+#define RDX_WAVES (RDX_THREADS / 64u)
+#define RDX_TILE 4096u
+#define RDX_ROUNDS (RDX_TILE / RDX_THREADS)            // elements per thread: a wave's 1 024 consecutive elements in 16 rounds of 64
+
+__device__ __forceinline__ uint32_t rdx_lanes_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// block-wide exclusive scan of one value per thread (256 threads); *total = the sum
+__device__ __forceinline__ uint32_t rdx_block_exclusive(uint32_t v, uint32_t* wave_sums /* RDX_WAVES words of LDS */, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= (uint32_t)off) inc += o; }
+    if (lane == 63u) wave_sums[wave] = inc;
+    __syncthreads();
+    uint32_t prefix = 0, sum = 0;
+    for (uint32_t w = 0; w < RDX_WAVES; w++) { const uint32_t ws = wave_sums[w]; if (w < wave) prefix += ws; sum += ws; }
+    __syncthreads();
+    *total = sum;
+    return inc - v + prefix;
+}
+
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const uint2* __restrict__ in, uint32_t n, uint32_t shift, uint32_t tiles, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t cnt[RDX_BINS];
+    cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RDX_TILE;
+#pragma unroll 4
+    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+        const uint32_t i = base + k * RDX_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(in[i].x >> shift) & (RDX_BINS - 1u)], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * tiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_rows(uint32_t* __restrict__ hist, uint32_t tiles, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t wave_sums[RDX_WAVES];
+    uint32_t* row = hist + (size_t)blockIdx.x * tiles;
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < tiles; t0 += RDX_THREADS) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < tiles ? row[t] : 0u;
+        uint32_t total;
+        const uint32_t ex = rdx_block_exclusive(v, wave_sums, &total);
+        if (t < tiles) row[t] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// ranks of a wave's elements among the wave's elements with the same digit seen so far; cnt = this wave's 256 counters in LDS
+__device__ __forceinline__ uint32_t rdx_rank(uint32_t digit, bool live, uint32_t* cnt)
+{
+    uint64_t m = __ballot(live);
+#pragma unroll
+    for (uint32_t b = 0; b < 8u; b++) {
+        const bool bit = (digit >> b) & 1u;
+        const uint64_t bal = __ballot(live && bit);
+        m &= bit ? bal : ~bal;
+    }
+    // (a lane that is not live holds garbage in m: it neither counts nor is counted)
+    const uint32_t below = rdx_lanes_below(m);
+    uint32_t old = 0;
+    if (live && below == 0u) { old = cnt[digit]; cnt[digit] = old + (uint32_t)__popcll(m); }
+    const int leader = live ? (int)__builtin_ctzll(m) : 0;
+    old = (uint32_t)__shfl((int)old, leader, 64);
+    return old + below;
+}
+
+// one pass over the block's RDX_TILE elements held in registers (element k of a thread: index wave * 1024 + k * 64 + lane):
+// ranks them, stages them in `stage` in sorted order, leaves the tile's digit starts in dig_start.  count = live elements.
+__device__ __forceinline__ void rdx_tile_pass(const uint2 (&e)[RDX_ROUNDS], uint32_t count, uint32_t shift, uint32_t (*cnt)[RDX_BINS],
+                                              uint32_t* dig_start, uint32_t* wave_sums, uint2* stage)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t w = 0; w < RDX_WAVES; w++) cnt[w][threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t rank[RDX_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+        rank[k] = rdx_rank((e[k].x >> shift) & (RDX_BINS - 1u), idx < count, cnt[wave]);
+    }
+    __syncthreads();
+    {   // thread d: digit d's counts of the four waves -> their exclusive prefix; the tile's digit starts
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < RDX_WAVES; w++) { const uint32_t c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
+        uint32_t total;
+        dig_start[threadIdx.x] = rdx_block_exclusive(run, wave_sums, &total);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+        if (idx < count) {
+            const uint32_t d = (e[k].x >> shift) & (RDX_BINS - 1u);
+            stage[dig_start[d] + cnt[wave][d] + rank[k]] = e[k];
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __restrict__ in, uint2* __restrict__ out, uint32_t n, uint32_t shift,
+                                                               uint32_t tiles, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t cnt[RDX_WAVES][RDX_BINS];
+    __shared__ uint32_t dig_start[RDX_BINS];
+    __shared__ uint32_t gbase[RDX_BINS];
+    __shared__ uint32_t wave_sums[RDX_WAVES];
+    __shared__ uint2 stage[RDX_TILE];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * RDX_TILE;
+    const uint32_t count = n - base < RDX_TILE ? n - base : RDX_TILE;
+    uint2 e[RDX_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+        e[k] = idx < count ? in[base + idx] : make_uint2(0u, 0u);
+    }
+    {   // where this tile's run of digit d starts in the output: elements with smaller digits anywhere + this digit in earlier tiles
+        uint32_t total;
+        const uint32_t before = rdx_block_exclusive(totals[threadIdx.x], wave_sums, &total);
+        gbase[threadIdx.x] = before + hist[threadIdx.x * tiles + blockIdx.x];
+    }
+    rdx_tile_pass(e, count, shift, cnt, dig_start, wave_sums, stage);
+    for (uint32_t i = threadIdx.x; i < count; i += RDX_THREADS) {
+        const uint2 v = stage[i];
+        const uint32_t d = (v.x >> shift) & (RDX_BINS - 1u);
+        out[gbase[d] + (i - dig_start[d])] = v;
+    }
+}
+
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_small(uint2* __restrict__ data, uint32_t n, uint32_t passes)
+{
+    __shared__ uint32_t cnt[RDX_WAVES][RDX_BINS];
+    __shared__ uint32_t dig_start[RDX_BINS];
+    __shared__ uint32_t wave_sums[RDX_WAVES];
+    __shared__ uint2 stage[RDX_TILE];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 e[RDX_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+        e[k] = idx < n ? data[idx] : make_uint2(0u, 0u);
+    }
+    for (uint32_t p = 0; p < passes; p++) {
+        rdx_tile_pass(e, n, p * 8u, cnt, dig_start, wave_sums, stage);
+#pragma unroll
+        for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+            const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+            if (idx < n) e[k] = stage[idx];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+        if (idx < n) data[idx] = e[k];
+    }
+}
+
+// scratch words a sort of n pairs needs behind its n-pair ping-pong buffer: hist[256][tiles] + totals[256]
+size_t radix_sort_scratch_words(uint32_t n) { return (size_t)RDX_BINS * ((n + RDX_TILE - 1u) / RDX_TILE) + RDX_BINS; }
+
+// sorts pairs[0, n) by the low key_bits bits of .x (the bits above must be equal on all keys, e.g. zero), stable; tmp holds n pairs,
+// scratch radix_sort_scratch_words(n) words.  The result is in `pairs`.
+void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint32_t key_bits, uint32_t* scratch)
+{
+    if (n < 2) return;
+    const uint32_t passes = key_bits == 0 ? 1u : (key_bits + 7u) / 8u;
+    if (n <= RDX_TILE) { hipLaunchKernelGGL(k_radix_small, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes); return; }
+    const uint32_t tiles = (n + RDX_TILE - 1u) / RDX_TILE;
+    uint32_t* hist = scratch; uint32_t* totals = scratch + (size_t)RDX_BINS * tiles;
+    uint2* src = pairs; uint2* dst = tmp;
+    for (uint32_t p = 0; p < passes; p++) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist);
+        hipLaunchKernelGGL(k_radix_rows, dim3(RDX_BINS), dim3(RDX_THREADS), 0, s, hist, tiles, totals);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals);
+        uint2* t = src; src = dst; dst = t;
+    }
+    if (src != pairs) (void)hipMemcpyAsync(pairs, src, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, s);
+}
+
 // rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
 // frame of a process otherwise pays for it -- the traversal kernels' object alone takes ~2 ms)
 bool rt_preload_sort_scan()

@@ -210,6 +210,110 @@ def test_sort_and_scan_primitives(gpu_ctx):
     assert len(gpu_ctx.scan_inclusive(np.zeros(0, dtype=np.uint32))) == 0
 
 
+def test_radix_sort_is_a_stable_sort(gpu_ctx):
+    """rt_sort_pairs(.., RT_SORT_RADIX): the pairs in ascending key order, equal keys in input order (numpy's stable argsort), for counts
+    around every boundary of the implementation (one LDS tile of 4 096, partial last tiles, one wave's 1 024, thousands of tiles), keys
+    with few distinct values (every digit run long), full-range keys, keys that differ in one byte only, and already sorted / reversed
+    input; RT_SORT_BITONIC through the same entry is the network."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    rng = np.random.default_rng(20261005)
+
+    def check(pairs):
+        got = gpu_ctx.sort_pairs(pairs, 1)
+        order = np.argsort(pairs['key'], kind='stable')
+        assert got.tobytes() == pairs[order].tobytes(), len(pairs)
+
+    for n in [0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12289, 65536, 100003, (1 << 20) + 17, 3000001]:
+        pairs = np.zeros(n, dtype=capi.PAIR)
+        pairs['value'] = np.arange(n, dtype=np.uint32)
+        pairs['key'] = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+        check(pairs)
+        pairs['key'] = rng.integers(0, 5, size=n, dtype=np.uint32)                     # long runs of equal keys: stability
+        check(pairs)
+        pairs['key'] = rng.integers(0, 256, size=n, dtype=np.uint32) << 16             # one byte differs
+        check(pairs)
+    n = 50000
+    pairs = np.zeros(n, dtype=capi.PAIR)
+    pairs['value'] = rng.permutation(n).astype(np.uint32)
+    pairs['key'] = np.arange(n, dtype=np.uint32) * 85899                               # sorted
+    check(pairs)
+    pairs['key'] = pairs['key'][::-1].copy()                                            # reversed
+    check(pairs)
+    pairs['key'] = 0xFFFFFFFF                                                           # all equal, all bits set
+    check(pairs)
+    p2 = np.zeros(4096, dtype=capi.PAIR)
+    p2['key'] = rng.integers(0, 16, size=4096, dtype=np.uint32); p2['value'] = np.arange(4096, dtype=np.uint32)
+    assert gpu_ctx.sort_pairs(p2, 0).tobytes() == orc.bitonic_sort(p2.view(orc.PAIR)).tobytes()
+    with pytest.raises(capi.RtError, match='unknown sort algorithm'):
+        gpu_ctx.sort_pairs(p2, 5)
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_fast_mode_keeps_hits_and_distances(gpu_ctx, name):
+    """RT_MODE_FAST (the reference tree's Morton pairs through the stable radix sort instead of the reference's network): sorted by code
+    like FIXED's pairs, equal codes in leaf order; every node still holds the union of its leaves; contacts: hit mask and t bit for bit
+    FIXED's (= the oracle's), normal / material different only where another triangle is hit at exactly the same t."""
+    from openclraytracer_amd import capi
+    osc, ob = oracle_bvh(name)
+    sc, fixed = gpu_bvh(gpu_ctx, name)
+    fast = capi.DeviceBVH(gpu_ctx, sc, mode=2).build()
+    try:
+        pf, px = fast.read_morton_pairs()[:ob.n], fixed.read_morton_pairs()[:ob.n]
+        assert np.array_equal(pf['key'], px['key'])                                              # the same codes in the same places
+        order = np.lexsort((pf['value'], pf['key']))
+        assert np.array_equal(order, np.arange(ob.n))                                            # ... equal codes by leaf index (stable)
+        assert sorted(pf['value'].tolist()) == list(range(ob.n))
+        for res in [(320, 240), (1920, 1080)]:
+            cam = as_capi_camera(osc.demo_camera(*res))
+            a, b = fast.generate_contacts_primary(cam), fixed.generate_contacts_primary(cam)
+            assert a['pixelIndex'].tobytes() == b['pixelIndex'].tobytes()
+            assert a['normalAndDistance'][:, 3].tobytes() == b['normalAndDistance'][:, 3].tobytes()   # hit mask and t
+            differ = np.nonzero((a['materialIndex'] != b['materialIndex']) | (a['normalAndDistance'][:, :3] != b['normalAndDistance'][:, :3]).any(axis=1))[0]
+            assert len(differ) < 0.002 * len(a) + 8, (name, res, len(differ))
+            if len(differ):
+                # such a pixel's ray hits two triangles at exactly the same t: the oracle's brute-force list of hits says so
+                rays = __import__('oracle').generate_rays(osc.demo_camera(*res))[differ[:16]]
+                v, _, _ = osc.triangles() if ob.n <= 20000 else (None, None, None)
+                if v is not None:
+                    for k, r in enumerate(rays):
+                        ts = _all_hit_distances(v, r)
+                        t = a['normalAndDistance'][differ[k], 3]
+                        assert (ts == t).sum() >= 2, (name, int(differ[k]))
+        rays = __import__('oracle').generate_secondary_rays(fixed.generate_contacts_primary(as_capi_camera(osc.demo_camera(200, 150))).view(__import__('oracle').CONTACT), 1,
+                                                           eps=1e-3, cam=osc.demo_camera(200, 150))
+        if len(rays):
+            a, b = fast.generate_contacts_rays(_rays_capi(rays)), fixed.generate_contacts_rays(_rays_capi(rays))
+            assert a['normalAndDistance'][:, 3].tobytes() == b['normalAndDistance'][:, 3].tobytes()
+    finally:
+        fast.close()
+
+
+def _all_hit_distances(verts, ray):
+    """triangleIntersect (Triangle.h:66-107) of one ray against every triangle, in numpy fp32 with the reference's operation order; -> t"""
+    f = np.float32
+    o, d = ray['origin'][:3].astype(f), ray['direction'][:3].astype(f)
+    v0, v1, v2 = verts[:, 0, :3], verts[:, 1, :3], verts[:, 2, :3]
+    e1, e2 = v1 - v0, v2 - v0
+
+    def cross(a, b):
+        return np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1], a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2], a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], axis=-1)
+
+    def dot(a, b):
+        return a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1] + a[..., 2] * b[..., 2]
+    with np.errstate(all='ignore'):
+        pvec = cross(np.broadcast_to(d, e2.shape), e2)
+        det = dot(e1, pvec)
+        inv = f(1.0) / det
+        tvec = o - v0
+        u = dot(tvec, pvec) * inv
+        qvec = cross(tvec, e1)
+        v = dot(np.broadcast_to(d, qvec.shape), qvec) * inv
+        t = dot(e2, qvec) * inv
+        ok = (np.abs(det) >= np.finfo(f).eps) & (u < 1) & (u >= 0) & (u + v <= 1) & (v >= 0) & (t > 0)
+    return t[ok]
+
+
 def test_error_behaviour(gpu_ctx):
     """0/1 results with a message, nothing thrown across the boundary (Errata convention)."""
     from openclraytracer_amd import capi
@@ -221,7 +325,7 @@ def test_error_behaviour(gpu_ctx):
         capi.DeviceScene(gpu_ctx, bytes(bad))
     sc = capi.DeviceScene(gpu_ctx, packed)
     with pytest.raises(capi.RtError, match='unknown parity mode'):
-        capi.DeviceBVH(gpu_ctx, sc, mode=2)
+        capi.DeviceBVH(gpu_ctx, sc, mode=7)
     b = capi.DeviceBVH(gpu_ctx, sc)
     with pytest.raises(capi.RtError, match='initializeFrame must precede construct'):
         b.construct()
