@@ -157,9 +157,18 @@ __device__ KeySpan inner_node_span(const uint2* __restrict__ keys, uint32_t i, u
     if (i == 0u) return KeySpan{ 0u, n - 1u };
     const uint32_t mine = keys[i].x, before = keys[i - 1u].x, after = keys[i + 1u].x;
     if (before == mine && after == mine) {
-        uint32_t e = i + 1u;                                        // the rest of the run of equal keys
-        while (e + 1u < n && keys[e + 1u].x == mine) e++;
-        return KeySpan{ i, e };
+        // the rest of the run of equal keys: the keys are sorted, so "keys[i + steps] == mine" holds up to the run's end and never after --
+        // doubling, then bisection (a step-by-step scan made this kernel quadratic in the run length: 684 us per tree on the Sponza-class
+        // stand-in, whose longest run has ~10 800 keys, 63 % of its construct())
+        const uint32_t room = n - 1u - i;
+        auto same = [&](uint32_t steps) { return steps <= room && keys[i + steps].x == mine; };
+        uint32_t yes = 1u, no = 2u;                                  // same(1) holds: after == mine
+        while (same(no)) { yes = no; no <<= 1; }
+        while (no - yes > 1u) {
+            const uint32_t mid = yes + ((no - yes) >> 1);
+            if (same(mid)) yes = mid; else no = mid;
+        }
+        return KeySpan{ i, i + yes };
     }
     const int with_before = shared_top_bits(mine, before), with_after = shared_top_bits(mine, after);
     const bool backwards = with_before > with_after;
@@ -251,6 +260,25 @@ __device__ __forceinline__ void refit_merge(float4 alo, float4 ahi, float4 blo, 
 }
 
 #define REFIT_RUN 8
+// One 16-byte access at device scope (sc1: performed at the level every XCD's L2 and every CU's L1 agree on).  The hand-shake at a node
+// with two inner children needs the first arriver's box to be visible to the second -- and nothing else: an agent-scope release /
+// acquire FENCE pair gives that by writing back and invalidating the caches of the whole CU / XCD for every walker that passes such a
+// node, which is what a refit cost (ClumsyDragon, 50 032 leaves: 230 us for either tree, whatever its depth -- 58 % of construct()).
+// With the boxes that another walker reads written by sc1 stores, the walker's wait for its own stores (vmcnt) before the counter's
+// atomic, and the second arriver's sc1 loads behind the atomic's return, no cache-wide operation is left (the same protocol as the
+// sub-tree sharing of k_trace_packet4, trace_kernels.hip).
+typedef float v4f_dev __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_sc1(float* p, float4 v)
+{
+    v4f_dev x = { v.x, v.y, v.z, v.w };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ float4 load16_sc1(const float* p)
+{
+    v4f_dev x;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+    return make_float4(x.x, x.y, x.z, x.w);
+}
 // One walker per pair of sibling leaves climbs towards the root and carries the box it has just computed in registers.
 //   * a node whose other child is a LEAF is merged on the spot: a leaf's box is final, no hand-shake is needed -- this is
 //     every step along a chain of duplicate Morton codes (node i = leaf + node i+1), the deep part of the reference tree;
@@ -276,8 +304,8 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
     // with two inner children the first arriver leaves its height in the upper bits of the arrival counter.
     uint32_t height = 1;
     for (;;) {
-        *reinterpret_cast<float4*>(nodes[current].boundsMin) = lo;
-        *reinterpret_cast<float4*>(nodes[current].boundsMax) = hi;
+        store16_sc1(nodes[current].boundsMin, lo);          // (the sibling's walker may be the one that reads it: see store16_sc1)
+        store16_sc1(nodes[current].boundsMax, hi);
         // Along a chain of duplicate Morton codes node i is (leaf, node i + 1): the nodes above `current` are current - 1,
         // current - 2, ...  Eight levels are taken per round trip: their records and their leaves' boxes are fetched together,
         // the chain shape is checked, and the eight merges run in registers in the same order as one by one.
@@ -318,19 +346,21 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
         const bool i_am_a = ca == current;
         const uint32_t sibling = i_am_a ? cb : ca;
         uint32_t sibling_height = 0;
+        float4 slo, shi;
         if (sibling >= n) {
-            // inner sibling: whoever comes second merges
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // inner sibling: whoever comes second merges.  My box stands in memory (sc1 stores) once my stores are acknowledged ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t old = atomicAdd(&counters[parent - n], 1u + (height << 2));     // two bits of arrivals, 30 of height
+            const uint32_t old = __hip_atomic_fetch_add(&counters[parent - n], 1u + (height << 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // two bits of arrivals, 30 of height
             if (old == 0) break;                           // first arriver leaves; its box is in memory, its height in the counter
             sibling_height = old >> 2;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... and the first arriver's was there before its atomic was: read where it was written
+            slo = load16_sc1(nodes[sibling].boundsMin);
+            shi = load16_sc1(nodes[sibling].boundsMax);
+        } else {
+            slo = *reinterpret_cast<const float4*>(nodes[sibling].boundsMin);       // a leaf's box: written by an earlier kernel
+            shi = *reinterpret_cast<const float4*>(nodes[sibling].boundsMax);
         }
         height = (height > sibling_height ? height : sibling_height) + 1u;
-        const float4 slo = *reinterpret_cast<const float4*>(nodes[sibling].boundsMin);
-        const float4 shi = *reinterpret_cast<const float4*>(nodes[sibling].boundsMax);
         float4 rlo, rhi;
         if (i_am_a) refit_merge<TIGHT>(lo, hi, slo, shi, rlo, rhi);
         else refit_merge<TIGHT>(slo, shi, lo, hi, rlo, rhi);
@@ -500,16 +530,17 @@ void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, cons
 __device__ __forceinline__ void literal_merge(rt_bvh_node* nodes, uint32_t cur)
 {
     const uint32_t a = nodes[cur].data[1], b = nodes[cur].data[2];
-    const float4 alo = *reinterpret_cast<const float4*>(nodes[a].boundsMin), ahi = *reinterpret_cast<const float4*>(nodes[a].boundsMax);
-    const float4 blo = *reinterpret_cast<const float4*>(nodes[b].boundsMin), bhi = *reinterpret_cast<const float4*>(nodes[b].boundsMax);
-    const float4 slo = *reinterpret_cast<const float4*>(nodes[cur].boundsMin), shi = *reinterpret_cast<const float4*>(nodes[cur].boundsMax);
+    // (the children's boxes may have been written by other walkers of this launch: device-scope loads, see store16_sc1)
+    const float4 alo = load16_sc1(nodes[a].boundsMin), ahi = load16_sc1(nodes[a].boundsMax);
+    const float4 blo = load16_sc1(nodes[b].boundsMin), bhi = load16_sc1(nodes[b].boundsMax);
+    const float4 slo = load16_sc1(nodes[cur].boundsMin), shi = load16_sc1(nodes[cur].boundsMax);
     float4 t, lo, hi;                                  // merge3 (AABB.h:107-113) on all four lanes: (A, B), then the node's own box
     t.x = RMIN(alo.x, blo.x); t.y = RMIN(alo.y, blo.y); t.z = RMIN(alo.z, blo.z); t.w = RMIN(alo.w, blo.w);
     lo.x = RMIN(t.x, slo.x); lo.y = RMIN(t.y, slo.y); lo.z = RMIN(t.z, slo.z); lo.w = RMIN(t.w, slo.w);
     t.x = RMAX(ahi.x, bhi.x); t.y = RMAX(ahi.y, bhi.y); t.z = RMAX(ahi.z, bhi.z); t.w = RMAX(ahi.w, bhi.w);
     hi.x = RMAX(t.x, shi.x); hi.y = RMAX(t.y, shi.y); hi.z = RMAX(t.z, shi.z); hi.w = RMAX(t.w, shi.w);
-    *reinterpret_cast<float4*>(nodes[cur].boundsMin) = lo;
-    *reinterpret_cast<float4*>(nodes[cur].boundsMax) = hi;
+    store16_sc1(nodes[cur].boundsMin, lo);
+    store16_sc1(nodes[cur].boundsMax, hi);
 }
 
 __global__ __launch_bounds__(256) void k_refit_literal(rt_bvh_node* nodes, uint32_t* counters, uint32_t n)
@@ -519,15 +550,14 @@ __global__ __launch_bounds__(256) void k_refit_literal(rt_bvh_node* nodes, uint3
     uint32_t current = nodes[leaf].data[0];
     while (current != UINT_MAX) {
         if (current < n || current >= 2u * n - 1u) break;
-        // (as in k_refit: the write-back of the release and the invalidate of the acquire complete asynchronously, MI355X_MICROARCH.md;
-        //  without the waits a second arriver read a child box of before the first arriver's merge once in some thousand builds --
-        //  round 3, test_literal_zero_mode_on_the_device[clumsydragon]: three nodes with boxes too small)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // As in k_refit: the box this walker merged last stands in memory (sc1 stores, acknowledged: vmcnt) before its arrival is counted,
+        // and the second arriver reads the children's boxes with device-scope loads behind the atomic's return.  (Round 3 had agent-scope
+        // fences here, whose cache write-back / invalidate completes asynchronously: once in some thousand builds a second arriver read a
+        // child box of before the first arriver's merge -- three nodes with boxes too small.  The loads were plain loads then, which a
+        // non-coherent L1 / L2 may serve; now no access of the hand-shake goes through a cache that another walker's write can miss.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t old = atomicAdd(&counters[current - n], 1u);
+        const uint32_t old = __hip_atomic_fetch_add(&counters[current - n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == 0u) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         literal_merge(nodes, current);
         current = nodes[current].data[0];
     }

@@ -197,14 +197,16 @@ int rt_bvh_construct(rt_bvh* b)
     if (want_search) {
         const uint32_t n = b->n, N = b->N;
         rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
-        RT_HIP(ctx, hipMemsetAsync(s_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
+        // (the inner nodes need no clearing: k_radix_tree writes every field of all n - 1 of them -- the parent link of a node comes from
+        //  its parent, the root's is set -- and the search tree is never read back as "the reference on zeroed buffers")
         RT_HIP(ctx, hipMemcpyAsync(s_nodes, b->d_nodes, (size_t)n * sizeof(rt_bvh_node), hipMemcpyDeviceToDevice, s));   // the leaves
-        RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));
+        const bool search_bitonic = b->search_sort_bitonic || !b->d_sort_tmp;
+        if (search_bitonic) RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));          // the network's padding
         RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
         launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
         // the search tree's order is the library's own (any nested hierarchy over the reference's leaves gives the reference's contacts,
         // ties between equal t are broken by the REFERENCE rank, d_pos): a stable radix sort
-        if (b->search_sort_bitonic || !b->d_sort_tmp) launch_bitonic_sort(s, s_pairs, N);
+        if (search_bitonic) launch_bitonic_sort(s, s_pairs, N);
         else launch_radix_sort(s, s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
         launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u);
         uint32_t* s_depth = s_counters + n;                     // spare words behind the counters

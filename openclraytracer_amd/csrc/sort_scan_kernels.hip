@@ -235,8 +235,11 @@ int launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint
 #define RDX_BINS 256u
 #define RDX_THREADS 256u
 #define RDX_WAVES (RDX_THREADS / 64u)
-#define RDX_TILE 4096u
-#define RDX_ROUNDS (RDX_TILE / RDX_THREADS)            // elements per thread: a wave's 1 024 consecutive elements in 16 rounds of 64
+// elements per thread R (template argument): a tile is R x 256 elements, a wave's share R x 64 consecutive ones in R rounds of 64.
+// R = 16 (tiles of 4 096: 32 KB of staging, long runs per digit in the scatter) for large inputs; R = 4 (tiles of 1 024) below
+// RDX_SMALL_TILES_BELOW elements, where 4 096-element tiles would leave most of the 256 CUs idle and every block's 16 dependent rounds
+// are the pass's latency (50 032 pairs: 13 blocks, 10.8 us per scatter pass)
+#define RDX_SMALL_TILES_BELOW (1u << 19)
 
 __device__ __forceinline__ uint32_t rdx_lanes_below(uint64_t m)
 {
@@ -257,14 +260,15 @@ __device__ __forceinline__ uint32_t rdx_block_exclusive(uint32_t v, uint32_t* wa
     return inc - v + prefix;
 }
 
+template <uint32_t R>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const uint2* __restrict__ in, uint32_t n, uint32_t shift, uint32_t tiles, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t cnt[RDX_BINS];
     cnt[threadIdx.x] = 0u;
     __syncthreads();
-    const uint32_t base = blockIdx.x * RDX_TILE;
-#pragma unroll 4
-    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
+    const uint32_t base = blockIdx.x * (R * RDX_THREADS);
+#pragma unroll
+    for (uint32_t k = 0; k < R; k++) {
         const uint32_t i = base + k * RDX_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&cnt[(in[i].x >> shift) & (RDX_BINS - 1u)], 1u);
     }
@@ -307,18 +311,19 @@ __device__ __forceinline__ uint32_t rdx_rank(uint32_t digit, bool live, uint32_t
     return old + below;
 }
 
-// one pass over the block's RDX_TILE elements held in registers (element k of a thread: index wave * 1024 + k * 64 + lane):
+// one pass over the block's R x 256 elements held in registers (element k of a thread: index wave * R * 64 + k * 64 + lane):
 // ranks them, stages them in `stage` in sorted order, leaves the tile's digit starts in dig_start.  count = live elements.
-__device__ __forceinline__ void rdx_tile_pass(const uint2 (&e)[RDX_ROUNDS], uint32_t count, uint32_t shift, uint32_t (*cnt)[RDX_BINS],
+template <uint32_t R>
+__device__ __forceinline__ void rdx_tile_pass(const uint2 (&e)[R], uint32_t count, uint32_t shift, uint32_t (*cnt)[RDX_BINS],
                                               uint32_t* dig_start, uint32_t* wave_sums, uint2* stage)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t w = 0; w < RDX_WAVES; w++) cnt[w][threadIdx.x] = 0u;
     __syncthreads();
-    uint32_t rank[RDX_ROUNDS];
+    uint32_t rank[R];
 #pragma unroll
-    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
-        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+    for (uint32_t k = 0; k < R; k++) {
+        const uint32_t idx = wave * (R * 64u) + k * 64u + lane;
         rank[k] = rdx_rank((e[k].x >> shift) & (RDX_BINS - 1u), idx < count, cnt[wave]);
     }
     __syncthreads();
@@ -330,8 +335,8 @@ __device__ __forceinline__ void rdx_tile_pass(const uint2 (&e)[RDX_ROUNDS], uint
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
-        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+    for (uint32_t k = 0; k < R; k++) {
+        const uint32_t idx = wave * (R * 64u) + k * 64u + lane;
         if (idx < count) {
             const uint32_t d = (e[k].x >> shift) & (RDX_BINS - 1u);
             stage[dig_start[d] + cnt[wave][d] + rank[k]] = e[k];
@@ -340,6 +345,7 @@ __device__ __forceinline__ void rdx_tile_pass(const uint2 (&e)[RDX_ROUNDS], uint
     __syncthreads();
 }
 
+template <uint32_t R>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __restrict__ in, uint2* __restrict__ out, uint32_t n, uint32_t shift,
                                                                uint32_t tiles, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals)
 {
@@ -347,14 +353,14 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __re
     __shared__ uint32_t dig_start[RDX_BINS];
     __shared__ uint32_t gbase[RDX_BINS];
     __shared__ uint32_t wave_sums[RDX_WAVES];
-    __shared__ uint2 stage[RDX_TILE];
+    __shared__ uint2 stage[R * RDX_THREADS];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * RDX_TILE;
-    const uint32_t count = n - base < RDX_TILE ? n - base : RDX_TILE;
-    uint2 e[RDX_ROUNDS];
+    const uint32_t base = blockIdx.x * (R * RDX_THREADS);
+    const uint32_t count = n - base < R * RDX_THREADS ? n - base : R * RDX_THREADS;
+    uint2 e[R];
 #pragma unroll
-    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
-        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+    for (uint32_t k = 0; k < R; k++) {
+        const uint32_t idx = wave * (R * 64u) + k * 64u + lane;
         e[k] = idx < count ? in[base + idx] : make_uint2(0u, 0u);
     }
     {   // where this tile's run of digit d starts in the output: elements with smaller digits anywhere + this digit in earlier tiles
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __re
         const uint32_t before = rdx_block_exclusive(totals[threadIdx.x], wave_sums, &total);
         gbase[threadIdx.x] = before + hist[threadIdx.x * tiles + blockIdx.x];
     }
-    rdx_tile_pass(e, count, shift, cnt, dig_start, wave_sums, stage);
+    rdx_tile_pass<R>(e, count, shift, cnt, dig_start, wave_sums, stage);
     for (uint32_t i = threadIdx.x; i < count; i += RDX_THREADS) {
         const uint2 v = stage[i];
         const uint32_t d = (v.x >> shift) & (RDX_BINS - 1u);
@@ -370,37 +376,40 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __re
     }
 }
 
+#define RDX_ONE_BLOCK 4096u       // up to here: all passes in one block, in LDS (R = 16)
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_small(uint2* __restrict__ data, uint32_t n, uint32_t passes)
 {
+    constexpr uint32_t R = RDX_ONE_BLOCK / RDX_THREADS;
     __shared__ uint32_t cnt[RDX_WAVES][RDX_BINS];
     __shared__ uint32_t dig_start[RDX_BINS];
     __shared__ uint32_t wave_sums[RDX_WAVES];
-    __shared__ uint2 stage[RDX_TILE];
+    __shared__ uint2 stage[RDX_ONE_BLOCK];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 e[RDX_ROUNDS];
+    uint2 e[R];
 #pragma unroll
-    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
-        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+    for (uint32_t k = 0; k < R; k++) {
+        const uint32_t idx = wave * (R * 64u) + k * 64u + lane;
         e[k] = idx < n ? data[idx] : make_uint2(0u, 0u);
     }
     for (uint32_t p = 0; p < passes; p++) {
-        rdx_tile_pass(e, n, p * 8u, cnt, dig_start, wave_sums, stage);
+        rdx_tile_pass<R>(e, n, p * 8u, cnt, dig_start, wave_sums, stage);
 #pragma unroll
-        for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
-            const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+        for (uint32_t k = 0; k < R; k++) {
+            const uint32_t idx = wave * (R * 64u) + k * 64u + lane;
             if (idx < n) e[k] = stage[idx];
         }
         __syncthreads();
     }
 #pragma unroll
-    for (uint32_t k = 0; k < RDX_ROUNDS; k++) {
-        const uint32_t idx = wave * (RDX_TILE / RDX_WAVES) + k * 64u + lane;
+    for (uint32_t k = 0; k < R; k++) {
+        const uint32_t idx = wave * (R * 64u) + k * 64u + lane;
         if (idx < n) data[idx] = e[k];
     }
 }
 
+static uint32_t radix_tile(uint32_t n) { return (n < RDX_SMALL_TILES_BELOW ? 4u : 16u) * RDX_THREADS; }
 // scratch words a sort of n pairs needs behind its n-pair ping-pong buffer: hist[256][tiles] + totals[256]
-size_t radix_sort_scratch_words(uint32_t n) { return (size_t)RDX_BINS * ((n + RDX_TILE - 1u) / RDX_TILE) + RDX_BINS; }
+size_t radix_sort_scratch_words(uint32_t n) { return (size_t)RDX_BINS * ((n + 1023u) / 1024u) + RDX_BINS; }
 
 // sorts pairs[0, n) by the low key_bits bits of .x (the bits above must be equal on all keys, e.g. zero), stable; tmp holds n pairs,
 // scratch radix_sort_scratch_words(n) words.  The result is in `pairs`.
@@ -408,14 +417,16 @@ void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint
 {
     if (n < 2) return;
     const uint32_t passes = key_bits == 0 ? 1u : (key_bits + 7u) / 8u;
-    if (n <= RDX_TILE) { hipLaunchKernelGGL(k_radix_small, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes); return; }
-    const uint32_t tiles = (n + RDX_TILE - 1u) / RDX_TILE;
+    if (n <= RDX_ONE_BLOCK) { hipLaunchKernelGGL(k_radix_small, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes); return; }
+    const uint32_t tile = radix_tile(n), tiles = (n + tile - 1u) / tile;
     uint32_t* hist = scratch; uint32_t* totals = scratch + (size_t)RDX_BINS * tiles;
     uint2* src = pairs; uint2* dst = tmp;
     for (uint32_t p = 0; p < passes; p++) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist);
+        if (tile == 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_hist<4u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist);
+        else hipLaunchKernelGGL(k_radix_hist<16u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist);
         hipLaunchKernelGGL(k_radix_rows, dim3(RDX_BINS), dim3(RDX_THREADS), 0, s, hist, tiles, totals);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals);
+        if (tile == 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_scatter<4u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals);
+        else hipLaunchKernelGGL(k_radix_scatter<16u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals);
         uint2* t = src; src = dst; dst = t;
     }
     if (src != pairs) (void)hipMemcpyAsync(pairs, src, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, s);
