@@ -28,7 +28,7 @@ using namespace CLRayTracer::AccelerationStructures;
 int main(int argc, char* argv[])
 {
     int window_width = 0, window_height = 0, frames = 1;
-    std::string scenePath, accStruct, headersPath, outPath, rawContacts, devices;
+    std::string scenePath, accStruct, headersPath, outPath, rawContacts, devices, arith = "host", build = "fixed";
     int gpus = 1;
     bool referenceFrame = false;
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -43,10 +43,12 @@ int main(int argc, char* argv[])
         else if (k == "--contacts") rawContacts = v;
         else if (k == "--gpus") gpus = std::atoi(v.c_str());          // frame tiled over N GPUs, one gather (BVH only)
         else if (k == "--reference-frame") referenceFrame = std::atoi(v.c_str()) != 0;   // RTFrame as the reference wrote it: contacts to the host, host shading loop
+        else if (k == "--arith") arith = v;                          // host (default) | device: dot() / cross() as the reference's device branch on this GPU (RT_MODE_DEVICE_ARITH)
+        else if (k == "--build") build = v;                          // fixed (default) | literal | fast: rt_bvh_create's parity mode
         else if (k == "--devices") devices = v;                        // e.g. 0,0,0: which HIP device each rank uses (default rank r -> device r)
     }
     if (window_width <= 0 || window_height <= 0 || scenePath.empty() || accStruct.empty()) {
-        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm|img.pfm] [--contacts raw.bin] [--reference-frame 1] [--gpus n [--devices d0,d1,..]]" << std::endl;
+        std::cout << "usage: rt_demo -winH h -winW w -accStruct BVH|GRID -headersPath dir -scene file.txt [--frames n] [--out img.ppm|img.pfm] [--contacts raw.bin] [--reference-frame 1] [--arith host|device] [--build fixed|literal|fast] [--gpus n [--devices d0,d1,..]]" << std::endl;
         return 0;
     }
     if (accStruct != "BVH" && accStruct != "GRID") {              // OpenCLRayTracerDemo.cpp:221-224
@@ -130,7 +132,12 @@ int main(int argc, char* argv[])
     Quaternion cameraOrientation = zeroRotation();
 
     std::unique_ptr<AccelerationStructureManager> accelerationStruct;
-    if (accStruct == "BVH") accelerationStruct.reset(new BVHManager(*context, scene));
+    if (accStruct == "BVH") {
+        BVHManager* m = new BVHManager(*context, scene);
+        if ((arith != "host" && arith != "device") || (build != "fixed" && build != "literal" && build != "fast")) { std::cout << "unknown --arith / --build value" << std::endl; return 1; }
+        m->setBuildMode((build == "literal" ? BVHManager::BuildLiteralZero : build == "fast" ? BVHManager::BuildFast : BVHManager::BuildFixed) | (arith == "device" ? BVHManager::BuildDeviceArithmetic : 0));
+        accelerationStruct.reset(m);
+    }
     else accelerationStruct.reset(new TwoLevelGridManager(*context, scene));
     CHECKED_CALL(accelerationStruct->initialize(err));
     CHECKED_CALL(accelerationStruct->initializeFrame(err));

@@ -79,6 +79,14 @@ enum { RT_SUCCESS = 0, RT_ERROR = 1 };
  * triangles are hit at exactly the same t (the tie goes to the lower rank) -- and for rays whose slab test meets 0 * inf on y or z,
  * whose reached set depends on the hierarchy itself.                                                     */
 enum { RT_MODE_FIXED = 0, RT_MODE_LITERAL_ZERO = 1, RT_MODE_FAST = 2 };
+/* Which of the reference's two arithmetic branches the traversal computes, OR-ed onto the mode.  The dual-target headers compute dot()
+ * and cross() with separate multiplies and adds in their HOST branch (CLPortability.h:266-278: the reference's CPU path, what the library
+ * restates by default, bit for bit) and leave them to the OpenCL C built-ins in their DEVICE branch (CLPortability.h:41-45), which ROCm's
+ * device library evaluates with fused multiply-adds.  With RT_MODE_DEVICE_ARITH the traversal kernels fuse them the same way: the ray-buffer
+ * entry then returns pixelIndex, materialIndex and every bit of t of the reference's own generateContacts2 kernel compiled by ROCm for this
+ * GPU and run on it (tests/test_gpu_reference_cl.py); normals stay the library's (exact normalize; the reference kernel's fast_normalize is a
+ * hardware approximation).  Shading is host code in the reference and keeps the host branch's arithmetic in both modes.            */
+#define RT_MODE_DEVICE_ARITH 0x100
 
 /* ---- context: replaces CLExecutionContext creation (CLExecutionContext.cpp:270-300) ------ */
 int         rt_abi_version(void);
@@ -119,6 +127,9 @@ int  rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh**
 void rt_bvh_destroy(rt_bvh* bvh);
 int  rt_bvh_initialize_frame(rt_bvh* bvh);   /* initializeFrame(), BVHManager.cpp:122-150: size + clear build buffers */
 int  rt_bvh_construct(rt_bvh* bvh);          /* construct(), BVHManager.cpp:156-228: morton -> sort -> radix tree -> refit (+ relayout) */
+/* test / inspection: construct() calls on this BVH that were served by replaying the captured build graph (the second build on an
+ * allocation captures the sequence, later ones replay it; env RTMI_BUILD_GRAPH=0: never)                                        */
+uint32_t rt_bvh_graph_builds(const rt_bvh* bvh);
 /* generateContacts(Camera&), BVHManager.cpp:234-284 + kernel generateContacts, BVHKernels.cl:84-98.
  * Writes resX*resY contacts, contacts[p].pixelIndex == p.                                         */
 int  rt_bvh_generate_contacts_primary(rt_bvh* bvh, const rt_camera* cam, void* d_contacts);

@@ -35,7 +35,7 @@ SYMBOLS = [
     'rt_abi_version', 'rt_ctx_create', 'rt_ctx_destroy', 'rt_last_error', 'rt_ctx_set_stream', 'rt_ctx_get_stream',
     'rt_ctx_synchronize', 'rt_device_synchronize', 'rt_ctx_device_info', 'rt_buf_alloc', 'rt_buf_free', 'rt_buf_upload', 'rt_buf_download',
     'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_upload_indexed', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
-    'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct',
+    'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct', 'rt_bvh_graph_builds',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_rays_strategy', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_host_plane_reads', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
@@ -346,6 +346,11 @@ class DeviceBVH:
         self.initialize_frame()
         self.construct()
         return self
+
+    def graph_builds(self) -> int:
+        self.ctx.lib.rt_bvh_graph_builds.argtypes = [C.c_void_p]
+        self.ctx.lib.rt_bvh_graph_builds.restype = C.c_uint32
+        return int(self.ctx.lib.rt_bvh_graph_builds(self.h))
 
     def info(self) -> dict:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()

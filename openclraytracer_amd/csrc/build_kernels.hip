@@ -287,9 +287,12 @@ __device__ __forceinline__ float4 load16_sc1(const float* p)
 //     behind an agent-scope release, the second reads it after an agent-scope acquire (per-CU L1 and per-XCD L2 are not
 //     coherent, MI355X_MICROARCH "inter-workgroup visibility").
 // Same merges in the same operand order as one walker per leaf with a counter at every node, hence the same bytes.
+// only_if != null: the launch does nothing unless *only_if is non-zero (the climb as the fall-back of the range-query refit, decided on the
+// device: no read-back in the middle of a build)
 template <bool TIGHT>
-__global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out)
+__global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, const uint32_t* only_if)
 {
+    if (only_if != nullptr && *only_if == 0u) return;
     const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
     uint32_t current = nodes[leaf].data[0];                // the leaf's parent
@@ -369,10 +372,10 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
     }
 }
 
-void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight)
+void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight, const uint32_t* only_if)
 {
-    if (tight) hipLaunchKernelGGL(k_refit<true>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
-    else hipLaunchKernelGGL(k_refit<false>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out);
+    if (tight) hipLaunchKernelGGL(k_refit<true>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out, only_if);
+    else hipLaunchKernelGGL(k_refit<false>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out, only_if);
 }
 
 // ----------------------------------------------------------------------------------------

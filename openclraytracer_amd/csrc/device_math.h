@@ -11,7 +11,7 @@
 // -ffp-contract=off), the same functions as plain inline C++ -- one statement of the arithmetic for both.
 #if defined(__HIP__) || defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define RT_FN __device__ __forceinline__
+#define RT_FN static __device__ __forceinline__      // (static: trace_kernels.hip is compiled twice with different bodies of dot / cross)
 #else
 #include <math.h>
 struct float4 { float x, y, z, w; };
@@ -30,7 +30,7 @@ RT_FN f3 f3_sub(f3 a, f3 b) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
 RT_FN f3 f3_add(f3 a, f3 b) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
 RT_FN f3 f3_scale(f3 a, float s) { return f3{ a.x * s, a.y * s, a.z * s }; }
 // cross / dot, CLPortability.h:266-278 (the HOST branch: separate multiplies and adds -- what the library computes).
-// -DRTMI_DEVICE_ARITH=1 (test twin librtmi_devarith.so only): the DEVICE branch leaves dot() / cross() to the OpenCL C library
+// -DRTMI_DEVICE_ARITH=1 (the second compilation of trace_kernels.hip, RT_MODE_DEVICE_ARITH): the DEVICE branch leaves dot() / cross() to the OpenCL C library
 // (CLPortability.h:41-45), and ROCm 7.2's (amdgcn/bitcode/opencl.bc, _Z3dotDv3_fS_ / _Z5crossDv3_fS_) fuses them as below; the
 // oracle restates the same behind orc_set_device_arith (oracle/rt_oracle.c).
 #if defined(RTMI_DEVICE_ARITH) && RTMI_DEVICE_ARITH

@@ -11,6 +11,8 @@ namespace CLRayTracer { namespace AccelerationStructures {
 
 class BVHManager : public AccelerationStructureManager {
 public:
+    /** rt_bvh_create's mode word, value for value (include/rtmi.h: RT_MODE_*) */
+    enum BuildMode { BuildFixed = 0, BuildLiteralZero = 1, BuildFast = 2, BuildDeviceArithmetic = 0x100 };
     BVHManager(const OpenCLUtils::CLExecutionContext& context, const Scene& scene);
     ~BVHManager() override;
     Common::Result initialize(Common::Errata& err) override;
@@ -22,11 +24,16 @@ public:
     const SharedPtr<OpenCLUtils::CLBuffer> getPrimaryContacts() const override { return _primaryContactsArray; }
     /** parity read-back of the hierarchy in the reference's 48-byte BVHNode layout (2n-1 nodes) */
     Common::Result readNodes(void* hostNodes, Common::Errata& err) const;
+    /** rt_bvh_create's mode word (include/rtmi.h: RT_MODE_FIXED, the default / RT_MODE_LITERAL_ZERO / RT_MODE_FAST, optionally
+     *  | RT_MODE_DEVICE_ARITH: dot() / cross() as the reference's DEVICE branch computes them on this GPU); before initialize() */
+    void setBuildMode(int mode) { _buildMode = mode; }
+    int buildMode() const { return _buildMode; }
     unsigned int leavesCount() const { return _bvhLeavesCount; }
     rt_bvh* deviceHandle() const { return _bvh; }                 // used by MultiGPUFrame of this library
 protected:
     unsigned int _bvhLeavesCount;
     rt_bvh* _bvh;
+    int _buildMode = 0;
     SharedPtr<OpenCLUtils::CLBuffer> _primaryContactsArray;
 };
 

@@ -18,6 +18,8 @@ using namespace CLRayTracer::Common;
 using namespace CLRayTracer::OpenCLUtils;
 using namespace CLRayTracer::AccelerationStructures;
 
+static_assert(BVHManager::BuildFixed == RT_MODE_FIXED && BVHManager::BuildLiteralZero == RT_MODE_LITERAL_ZERO && BVHManager::BuildFast == RT_MODE_FAST &&
+              BVHManager::BuildDeviceArithmetic == RT_MODE_DEVICE_ARITH, "BVHManager::BuildMode mirrors include/rtmi.h");
 static_assert(sizeof(Camera) == sizeof(rt_camera) && sizeof(Contact) == sizeof(rt_contact) && sizeof(Ray) == sizeof(rt_ray),
               "the reference PODs and the C-ABI PODs are the same bytes");
 
@@ -114,7 +116,7 @@ Result BVHManager::initialize(Errata& err)
     // the reference JIT-compiles its OpenCL kernels here; the HIP kernels are compiled offline
     if (_bvh) return Success;
     if (!_scene.deviceHandle()) { FILL_ERRATA(err, "Scene::loadToGPU must precede initialize"); return Error; }
-    RTMI_CHECK(_context, rt_bvh_create(_context.handle(), _scene.deviceHandle(), RT_MODE_FIXED, &_bvh), err);
+    RTMI_CHECK(_context, rt_bvh_create(_context.handle(), _scene.deviceHandle(), _buildMode, &_bvh), err);
     return Success;
 }
 Result BVHManager::initializeFrame(Errata& err)

@@ -30,18 +30,29 @@ int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** 
     if (!ctx || !scene || !out) return RT_FAIL(ctx, "null argument");
     *out = nullptr;
     if (scene->ctx != ctx) return RT_FAIL(ctx, "scene belongs to another context");
+    const bool device_arith = (parity_mode & RT_MODE_DEVICE_ARITH) != 0;
+    parity_mode &= ~RT_MODE_DEVICE_ARITH;
     if (parity_mode != RT_MODE_FIXED && parity_mode != RT_MODE_LITERAL_ZERO && parity_mode != RT_MODE_FAST) return RT_FAIL(ctx, "unknown parity mode");
+    if (device_arith) (void)rt_preload_trace_devarith();
     rt_bvh* b = new (std::nothrow) rt_bvh();
     if (!b) return RT_FAIL(ctx, "out of host memory");
-    b->ctx = ctx; b->scene = scene; b->mode = parity_mode;
+    b->ctx = ctx; b->scene = scene; b->mode = parity_mode; b->device_arith = device_arith;
     if (const char* e = std::getenv("RTMI_SEARCH_SORT")) b->search_sort_bitonic = std::strcmp(e, "bitonic") == 0;
     *out = b;
     return RT_SUCCESS;
 }
 
 
+static void drop_build_graph(rt_bvh* b)
+{
+    if (b->build_exec) (void)hipGraphExecDestroy(b->build_exec);
+    if (b->build_graph) (void)hipGraphDestroy(b->build_graph);
+    b->build_exec = nullptr; b->build_graph = nullptr; b->builds_on_allocation = 0;
+}
+
 static void free_build_buffers(rt_bvh* b)
 {
+    drop_build_graph(b);                   // it holds the addresses freed below
     if (b->d_nodes) (void)hipFree(b->d_nodes);
     if (b->d_pairs) (void)hipFree(b->d_pairs);
     if (b->d_counters) (void)hipFree(b->d_counters);
@@ -80,6 +91,7 @@ void rt_bvh_destroy(rt_bvh* b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     free_build_buffers(b);
+    if (b->h_depths) (void)hipHostFree(b->h_depths);
     block_order_free(b->block_order);
     delete b;
 }
@@ -151,22 +163,24 @@ int rt_bvh_initialize_frame(rt_bvh* b)
     }
     // BVHManager.cpp:134-147: morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.
     // The node buffer is zeroed as well: FIXED mode is defined on zero-initialised buffers.
-    RT_HIP(ctx, hipMemsetAsync(b->d_pairs, 0xFF, (size_t)N * sizeof(uint2), ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), ctx->stream));
+    // (enqueued at the head of construct(): one stream-ordered sequence, which a rebuild replays as one graph)
+    b->clears_pending = true;
+    if (!b->h_depths) RT_HIP(ctx, hipHostMalloc((void**)&b->h_depths, 64));
     b->frame_initialised = true;
     b->built = false;
     return RT_SUCCESS;
 }
 
-int rt_bvh_construct(rt_bvh* b)
+// everything a build enqueues, in stream order and nothing else (no allocation, no synchronisation: it is also what a capture records)
+static int enqueue_build(rt_bvh* b, hipStream_t s)
 {
-    if (!b) return RT_FAIL(nullptr, "bvh is null");
     rt_ctx* ctx = b->ctx;
-    if (!b->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
-    RT_ENTER(ctx);
-    hipStream_t s = ctx->stream;
     const DeviceScene& sc = b->scene->d;
+    const uint32_t n = b->n, N = b->N;
+    // BVHManager.cpp:134-147 (initializeFrame): morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0; the node buffer is zeroed as well
+    RT_HIP(ctx, hipMemsetAsync(b->d_pairs, 0xFF, (size_t)N * sizeof(uint2), s));
+    RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), s));
+    RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
     launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
     // 2. :195 -- the reference's network (the order of equal Morton codes is part of its result: it decides the radix tree's topology and
     // the depth-first ranks that break ties between equal t).  RT_MODE_FAST: a stable radix sort instead (30-bit codes: four passes over
@@ -177,25 +191,19 @@ int rt_bvh_construct(rt_bvh* b)
     launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
     if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
     else if (b->d_spans) {
-        // 4. by range queries; NaN boxes (not associative) send it back to the climb
+        // 4. by range queries; NaN boxes (not associative) send it back to the climb -- decided on the device: the climb is launched
+        // behind it and runs only if the query pass raised its flag
         launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_rq_scratch, b->d_depth, b->d_depth + 1);
-        uint32_t nan_boxes = 0;
-        RT_HIP(ctx, hipMemcpyAsync(&nan_boxes, b->d_depth + 1, 4, hipMemcpyDeviceToHost, s));
-        RT_HIP(ctx, hipStreamSynchronize(s));
-        if (nan_boxes) launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
+        launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth, false, b->d_depth + 1);
     }
     else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
     launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n);  // traversal records, DFS ranks
     launch_pack_triangles(s, sc, b->d_pos, b->d_trirec);
     RT_HIP(ctx, hipGetLastError());
-    uint32_t depth = 0;
-    RT_HIP(ctx, hipMemcpyAsync(&depth, b->d_depth, 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], b->d_depth, 4, hipMemcpyDeviceToHost, s));
     // search tree for primary rays: same leaves, better order
-    uint32_t search_depth = 0;
-    b->have_search_tree = false;
     const bool want_search = !ctx->no_search_tree && !literal;
     if (want_search) {
-        const uint32_t n = b->n, N = b->N;
         rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
         // (the inner nodes need no clearing: k_radix_tree writes every field of all n - 1 of them -- the parent link of a node comes from
         //  its parent, the root's is set -- and the search tree is never read back as "the reference on zeroed buffers")
@@ -213,10 +221,49 @@ int rt_bvh_construct(rt_bvh* b)
         launch_refit(s, s_nodes, s_counters, n, s_depth, !ctx->search_tree_reference_boxes);
         launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());
-        RT_HIP(ctx, hipMemcpyAsync(&search_depth, s_depth, 4, hipMemcpyDeviceToHost, s));
+        RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[1], s_depth, 4, hipMemcpyDeviceToHost, s));
     }
     if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (want_search ? 2u : 1u));
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
+int rt_bvh_construct(rt_bvh* b)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!b->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
+    RT_ENTER(ctx);
+    hipStream_t s = ctx->stream;
+    const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
+    const bool want_search = !ctx->no_search_tree && !literal;
+    b->have_search_tree = false;
+    b->h_depths[0] = 0u; b->h_depths[1] = 0u;
+    // A scene that moves is rebuilt every frame (OpenCLRayTracerDemo.cpp:230-234): the same ~40 launches, clears and copies on the same
+    // buffers.  The first build of an allocation is enqueued as it is, the second is captured into a graph, and from then on a build is
+    // one graph launch (12 triangles: 0.108 -> see DESIGN.md; the host issued the launches more slowly than the device ran them).
+    // RTMI_BUILD_GRAPH=0: always eager.
+    static const bool graphs = [] { const char* e = std::getenv("RTMI_BUILD_GRAPH"); return !(e && e[0] == '0'); }();
+    b->builds_on_allocation++;
+    bool launched = false;
+    if (graphs && b->builds_on_allocation >= 2u) {
+        if (!b->build_exec) {
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+            if (e == hipSuccess) {
+                const int rc = enqueue_build(b, s);
+                e = hipStreamEndCapture(s, &g);
+                if (rc == RT_SUCCESS && e == hipSuccess && g && hipGraphInstantiate(&b->build_exec, g, nullptr, nullptr, 0) == hipSuccess) b->build_graph = g;
+                else { if (g) (void)hipGraphDestroy(g); b->build_exec = nullptr; }
+            }
+            (void)hipGetLastError();                   // a runtime that cannot capture this sequence: the build stays eager
+        }
+        if (b->build_exec) { RT_HIP(ctx, hipGraphLaunch(b->build_exec, s)); launched = true; b->graph_builds++; }
+    }
+    if (!launched && enqueue_build(b, s)) return RT_ERROR;
+    b->clears_pending = false;
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
+    const uint32_t depth = b->h_depths[0], search_depth = want_search ? b->h_depths[1] : 0u;
     b->max_depth = depth;
     b->search_depth = search_depth;
     // (a degenerate model -- thousands of coincident box centres -- makes this tree as deep as the reference's: no gain then,
@@ -254,6 +301,8 @@ int rt_bvh_construct(rt_bvh* b)
     b->rays_tuned_n = b->n;
     return RT_SUCCESS;
 }
+
+uint32_t rt_bvh_graph_builds(const rt_bvh* b) { return b ? b->graph_builds : 0u; }
 
 int rt_bvh_read_nodes(const rt_bvh* b, void* h_nodes)
 {

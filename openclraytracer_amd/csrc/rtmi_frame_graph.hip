@@ -76,7 +76,8 @@ static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, u
     FrameMode plain;
     FrameMode* m = mode ? mode : &plain;
     // (... and a captured frame of the lane-per-ray strategy lets its two kernels shade what they store)
-    m->fused = (b->capture_no_unsafe_rays || (m->fixed_strategy && !m->packet)) && !ctx->no_fused_frames ? &fused : nullptr;
+    // (RT_MODE_DEVICE_ARITH: the trace kernels' dot() is the fused one; shading is host code in the reference and stays with k_shade)
+    m->fused = (b->capture_no_unsafe_rays || (m->fixed_strategy && !m->packet)) && !ctx->no_fused_frames && !b->device_arith ? &fused : nullptr;
     const bool update = m->update != nullptr;
     if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts, m)) return RT_ERROR;
     if (fused.done) { if (!update) RT_HIP(ctx, hipGetLastError()); return RT_SUCCESS; }

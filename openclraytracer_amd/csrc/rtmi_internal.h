@@ -148,7 +148,8 @@ struct rt_scene {
 struct rt_bvh {
     rt_ctx* ctx = nullptr;
     const rt_scene* scene = nullptr;
-    int mode = 0;
+    int mode = 0;              // RT_MODE_FIXED / LITERAL_ZERO / FAST
+    bool device_arith = false; // ... | RT_MODE_DEVICE_ARITH
     uint32_t n = 0;            // leaves
     uint32_t N = 0;            // morton buffer items (power of two)
     rt_bvh_node* d_nodes = nullptr;    // reference layout, 2n-1 entries
@@ -170,6 +171,13 @@ struct rt_bvh {
     uint2* s_pairs = nullptr;
     uint32_t* s_counters = nullptr;
     uint32_t* s_pos = nullptr;
+    // construct() as a HIP graph (rtmi_bvh.hip): the sequence of one build on this BVH's buffers, captured on the second build of an
+    // allocation and replayed by the later ones (a scene rebuilt every frame, OpenCLRayTracerDemo.cpp:230-234)
+    hipGraph_t build_graph = nullptr; hipGraphExec_t build_exec = nullptr;
+    uint32_t builds_on_allocation = 0;      // construct() calls since the buffers were (re)allocated
+    uint32_t* h_depths = nullptr;           // pinned: [0] reference tree depth, [1] search tree depth (read back at the end of a build)
+    bool clears_pending = false;            // initializeFrame's clears, enqueued with the build
+    uint32_t graph_builds = 0;              // construct() calls served by the graph (inspection)
     uint2* d_sort_tmp = nullptr;       // radix sort: n pairs to ping-pong with, then its histograms (launch_radix_sort)
     uint32_t* d_sort_scratch = nullptr;
     bool search_sort_bitonic = false;  // knob RTMI_SEARCH_SORT=bitonic: the search tree's keys through the bitonic network, as in rounds 1-3
@@ -278,7 +286,7 @@ size_t refit_rq_scratch_bytes(uint32_t n);
 void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
                      uint32_t* nan_flag_out);      // range-query refit (large scenes); *nan_flag_out != 0: NaN boxes, redo with launch_refit
 void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
-void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false);   // boxes + tree depth; tight: plain unions (search tree)
+void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false, const uint32_t* only_if = nullptr);   // boxes + tree depth; tight: plain unions (search tree); only_if: runs only when that device word is non-zero
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t id_offset = 0);
 void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records);
@@ -337,6 +345,7 @@ inline void rt_launch_node(GraphNodes* record, GraphNodes* update, int kind, K k
     }
 }
 struct TraceLaunch {
+    bool device_arith;            // the BVH was created with RT_MODE_DEVICE_ARITH: the launchers of the second compilation of trace_kernels.hip
     GraphNodes* graph_record;     // capture in progress: kernel nodes are noted here
     GraphNodes* graph_update;     // no launches: the arguments a launch would get are set on these nodes
     uint32_t prepare_parts;       // RT_PREP_* to (re)compute before the trace (0: nothing)
@@ -389,6 +398,11 @@ struct TraceLaunch {
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
                           bool compact, rt_contact* out);
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
+// the same three from the second compilation of trace_kernels.hip (RT_MODE_DEVICE_ARITH: dot / cross as ROCm's OpenCL C library fuses them)
+void launch_trace_primary_devarith(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out);
+void launch_trace_rays_devarith(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
+void launch_prepare_camera_devarith(hipStream_t s, const TraceLaunch& t, const float origin[3]);
+bool rt_preload_trace_devarith();
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);   // t.prepare_parts
 void launch_device_clock(hipStream_t s, unsigned long long* d_out);      // the clock the calibration deadlines are on (s_memrealtime)
 bool launch_block_order(hipStream_t s, const uint32_t* cost, uint32_t* order, uint32_t blocks, uint32_t group_log, bool identity);

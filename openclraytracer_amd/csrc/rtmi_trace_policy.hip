@@ -124,6 +124,7 @@ void block_order_refresh(rt_ctx* ctx, BlockOrder& o)
 TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam, uint32_t parts, const FrameMode* mode)
 {
     TraceLaunch t{};
+    t.device_arith = b->device_arith;
     t.trav = b->d_trav; t.search_root = b->have_search_tree ? b->n - 1 : 0u; t.tree_select = b->d_tree_select; t.scene = &b->scene->d; t.pos = b->d_pos; t.trirec = b->d_trirec; t.tricam = b->d_tricam; t.n_leaves = b->n;
     t.ctrl = b->ctx->d_trace_ctrl; t.long_list = b->ctx->d_long_list; t.long_cap = b->ctx->long_cap;
     t.defer_budget = b->ctx->defer_budget;

@@ -56,6 +56,39 @@
 #include <cstdio>
 #include <cstdlib>
 
+// This file is compiled TWICE into librtmi.so (csrc/Makefile): as it stands -- dot() / cross() of the reference's HOST branch, separate
+// multiplies and adds (CLPortability.h:266-278): the arithmetic of RT_MODE_FIXED / LITERAL_ZERO / FAST -- and with -DRTMI_DEVICE_ARITH=1 --
+// dot() / cross() as the OpenCL C built-ins the reference's DEVICE branch calls (CLPortability.h:41-45), which ROCm's device library fuses
+// (device_math.h) -- for BVHs created with RT_MODE_DEVICE_ARITH.  The second compilation renames every kernel and entry point below
+// (suffix _devarith); the first one's entry points hand a launch over when TraceLaunch::device_arith is set.
+#if defined(RTMI_DEVICE_ARITH) && RTMI_DEVICE_ARITH
+#define k_prepare_camera k_prepare_camera_devarith
+#define k_device_clock k_device_clock_devarith
+#define k_trace k_trace_devarith
+#define k_trace_packet k_trace_packet_devarith
+#define k_trace_packet4 k_trace_packet4_devarith
+#define k_trace_long k_trace_long_devarith
+#define k_resolve_split k_resolve_split_devarith
+#define k_block_order k_block_order_devarith
+#define launch_trace_primary launch_trace_primary_devarith
+#define launch_trace_rays launch_trace_rays_devarith
+#define launch_prepare_camera launch_prepare_camera_devarith
+#define launch_device_clock launch_device_clock_devarith
+#define launch_block_order launch_block_order_devarith
+#define rt_preload_trace rt_preload_trace_devarith
+#define trace_lds_stack_entries trace_lds_stack_entries_devarith
+#define trace_ctrl_bytes trace_ctrl_bytes_devarith
+#define trace_ctrl_error_offset trace_ctrl_error_offset_devarith
+#define trace_ctrl_expired_offset trace_ctrl_expired_offset_devarith
+#define trace_ctrl_counter_offsets trace_ctrl_counter_offsets_devarith
+#define trace_long_record_bytes trace_long_record_bytes_devarith
+#define trace_task_bytes trace_task_bytes_devarith
+#define trace_packet_stack_entries trace_packet_stack_entries_devarith
+#define RTMI_TRACE_HANDS_OVER 0
+#else
+#define RTMI_TRACE_HANDS_OVER 1
+#endif
+
 #ifndef TRACE_BLOCK
 #define TRACE_BLOCK 256u
 #endif
@@ -2096,6 +2129,9 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
                           bool compact, rt_contact* out)
 {
+#if RTMI_TRACE_HANDS_OVER
+    if (t.device_arith) { launch_trace_primary_devarith(s, t, cam, rank, nranks, compact, out); return; }
+#endif
     TraceArgs a{};
     fill_common(t, a);
     a.cam = cam;
@@ -2121,6 +2157,9 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
 // the per-camera records: t.prepare_parts says which (see k_prepare_camera)
 void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3])
 {
+#if RTMI_TRACE_HANDS_OVER
+    if (t.device_arith) { launch_prepare_camera_devarith(s, t, origin); return; }
+#endif
     if (t.n_leaves < 2 || t.prepare_parts == 0u) return;
     PrepareArgs a{};
     const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
@@ -2191,6 +2230,9 @@ bool launch_block_order(hipStream_t s, const uint32_t* cost, uint32_t* order, ui
 
 void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out)
 {
+#if RTMI_TRACE_HANDS_OVER
+    if (t.device_arith) { launch_trace_rays_devarith(s, t, rays, count, out); return; }
+#endif
     TraceArgs a{};
     fill_common(t, a);
     a.total_work = count;
@@ -2208,5 +2250,5 @@ bool rt_preload_trace()
     hipFuncAttributes attr;
     const bool ok = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_device_clock)) == hipSuccess;
     if (!ok) (void)hipGetLastError();
-    return ok;
+    return ok;           // (the RT_MODE_DEVICE_ARITH instances are loaded where a BVH of that mode is created: rt_bvh_create)
 }

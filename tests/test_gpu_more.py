@@ -344,6 +344,35 @@ def test_error_behaviour(gpu_ctx):
     b.close(); sc.close()
 
 
+@pytest.mark.parametrize('name,mode', [('cube', 0), ('tenryuu', 0), ('tenryuu', 2), ('gardenlight', 1)])
+def test_rebuilds_replay_a_build_graph(gpu_ctx, name, mode):
+    """A scene rebuilt every frame (OpenCLRayTracerDemo.cpp:230-234): the first build of an allocation is enqueued as it is, the second
+    is captured, later ones replay the graph -- every one of them leaves the oracle's node bytes (FIXED / LITERAL_ZERO) and the same
+    contacts, also with traces and another scene's builds in between."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    osc = orc.Scene(packed_scene(name))
+    ob = orc.BVH(osc, mode if mode != 2 else 0)
+    sc = capi.DeviceScene(gpu_ctx, packed_scene(name))
+    gb = capi.DeviceBVH(gpu_ctx, sc, mode=mode)
+    cam = as_capi_camera(osc.demo_camera(200, 150))
+    first = None
+    for k in range(6):
+        gb.build()
+        if mode != 2:
+            assert gb.read_nodes().tobytes() == ob.nodes.tobytes(), k
+            assert gb.read_morton_pairs().tobytes() == ob.pairs.tobytes(), k
+        frame = gb.generate_contacts_primary(cam).tobytes()
+        first = first or frame
+        assert frame == first, k
+        if k == 3:
+            _, other = gpu_bvh(gpu_ctx, 'man')
+            other.build()
+    assert gb.graph_builds() >= 4
+    gb.close(); sc.close()
+
+
 def test_rebuild_is_deterministic(gpu_ctx):
     """initializeFrame + construct can be repeated (per-frame rebuild, OpenCLRayTracerDemo.cpp:230-234)."""
     _, gb = gpu_bvh(gpu_ctx, 'man')

@@ -184,46 +184,38 @@ def test_reference_kernels_with_their_own_build_options(gpu_ctx, ref_default, na
         assert float((np.abs(tp - tr) / tr).max()) <= d['t_rel_max'] * 1.0001, kernel
 
 
-_DEVARITH_SCRIPT = r"""
-import sys, numpy as np
-sys.path.insert(0, %(root)r)
-from openclraytracer_amd import capi
-ctx = capi.Context(0)
-buf = open(sys.argv[1], 'rb').read()
-rays = np.load(sys.argv[2]).view(capi.RAY)
-sc = capi.DeviceScene(ctx, buf)
-bvh = capi.DeviceBVH(ctx, sc, mode=int(sys.argv[4])).build()
-np.save(sys.argv[3], bvh.generate_contacts_rays(rays).view(np.uint8))
-bvh.close(); sc.close(); ctx.close()
-"""
-
-
 @pytest.mark.parametrize('mode', [0, 1])
 @pytest.mark.parametrize('name', MODELS)
-def test_device_arith_twin_equals_the_reference_ray_kernel_bit_for_bit(ref, name, mode, tmp_path):
-    """librtmi_devarith.so = the library with dot() / cross() of its traversal kernels fused as ROCm's OpenCL C built-ins are
-    (csrc/device_math.h, RTMI_DEVICE_ARITH; csrc/Makefile).  Its ray-buffer entry -- lane-per-ray + wave-per-ray kernels, search
-    tree, four-wide steps and all -- gives the pixelIndex, materialIndex and every bit of t of the reference's own
-    generateContacts2 kernel run on this GPU, on the FIXED tree and on the LITERAL_ZERO tree: the product's machinery is exact,
-    what separates the shipped library from the reference's device branch is those two library functions alone."""
+def test_device_arith_mode_equals_the_reference_ray_kernel_bit_for_bit(gpu_ctx, ref, name, mode):
+    """RT_MODE_DEVICE_ARITH (rt_bvh_create's mode | 0x100; the shipped librtmi.so, in this process): dot() / cross() of the traversal
+    kernels fused as ROCm's OpenCL C built-ins are (csrc/device_math.h, the second compilation of trace_kernels.hip).  The ray-buffer entry
+    -- lane-per-ray + wave-per-ray kernels, four-wide packets, search tree and all, whatever the calibration picks -- gives the pixelIndex,
+    materialIndex and every bit of t of the reference's own generateContacts2 kernel run on this GPU, on the FIXED tree and on the
+    LITERAL_ZERO tree; the primary entry gives the same contacts as the ray-buffer entry on the camera's rays.  What separates the default
+    mode from the reference's device branch is those two library functions alone."""
     import oracle as orc
     from openclraytracer_amd import capi
     osc, _ = oracle_bvh(name)
     ob = orc.BVH(osc, mode)
-    rays = orc.generate_rays(osc.demo_camera(*RES))
+    cam = osc.demo_camera(*RES)
+    rays = orc.generate_rays(cam)
     got = ref.generate_contacts2(rays, ob.nodes, ob.n, packed_scene(name))
-    scene_path, rays_path, out_path = str(tmp_path / 's.bin'), str(tmp_path / 'r.npy'), str(tmp_path / 'c.npy')
-    open(scene_path, 'wb').write(packed_scene(name))
-    np.save(rays_path, rays.view(np.uint8))
-    env = dict(os.environ, RTMI_LIBRARY='librtmi_devarith.so')
-    r = subprocess.run([sys.executable, '-c', _DEVARITH_SCRIPT % dict(root=ROOT), scene_path, rays_path, out_path, str(mode)], env=env,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    prod = np.load(out_path).view(capi.CONTACT).reshape(-1)
-    assert (_key(got) == _key(prod, 'normalAndDistance')).all(), 'pixelIndex / materialIndex / t bits'
-    hit = got['normal_t'][:, 3] > 0
-    # (the normal: the twin keeps the library's precomputed one -- host-branch cross, exact normalize -- against fast_normalize of the fused cross)
-    assert hit.any() and np.abs(got['normal_t'][hit, :3] - prod['normalAndDistance'][hit, :3]).max() <= 3e-6
+    sc, _ = gpu_bvh(gpu_ctx, name)
+    bvh = capi.DeviceBVH(gpu_ctx, sc, mode=mode | 0x100).build()
+    try:
+        assert bvh.read_nodes().tobytes() == ob.nodes.tobytes()                     # the build is the same build
+        prod = bvh.generate_contacts_rays(rays.view(capi.RAY))
+        assert (_key(got) == _key(prod, 'normalAndDistance')).all(), 'pixelIndex / materialIndex / t bits'
+        hit = got['normal_t'][:, 3] > 0
+        # (the normal: the library's precomputed one -- host-branch cross, exact normalize -- against fast_normalize of the fused cross)
+        assert hit.any() and np.abs(got['normal_t'][hit, :3] - prod['normalAndDistance'][hit, :3]).max() <= 3e-6
+        prim = bvh.generate_contacts_primary(as_capi_camera(cam))
+        assert prim.tobytes() == prod.tobytes()
+        # ... and the default mode on the same BVH data differs from it only as tests/golden/reference_cl_distances.json says
+        rgba = capi.shade_blinn_phong(gpu_ctx, sc, as_capi_camera(cam), prim)
+        assert np.isfinite(rgba).all()
+    finally:
+        bvh.close()
 
 
 @pytest.mark.parametrize('name', MODELS)
