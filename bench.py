@@ -72,7 +72,7 @@ PMC_PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']),
 def pack_scene_file(scene_txt):
     """Packed scene buffer through the PRODUCT's loader: the C++ Scene::load packing (apps/bin/scene_pack_tool,
     openclraytracer_amd/csrc/host/src/SceneLoader.cpp)."""
-    tool = os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
+    tool = os.environ.get('RTMI_SCENE_PACK_TOOL') or os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
     if not os.path.exists(tool):
         raise SystemExit('apps/bin/scene_pack_tool is not built: run __graft_entry__.build()')
     with tempfile.NamedTemporaryFile(suffix='.bin') as tmp:
@@ -729,6 +729,64 @@ def main():
                 verify_frame(sctx, it['contacts'], it['rgba'], npx, bfx['scenes'][it['name']][key]['default'], bfx['sample_stride'],
                              '%s, rebuild-per-frame leg' % it['name'])
                 verified['rebuilt_frames'] = verified.get('rebuilt_frames', 0) + 1
+        # ---- the other modes of rt_bvh_create on this scene: RT_MODE_FAST (the build a scene that is rebuilt every frame would ask for) and
+        # RT_MODE_DEVICE_ARITH (dot / cross as the reference's device branch computes them on this GPU); each frame verified against what
+        # the mode promises (FAST: hit mask and t of FIXED; DEVICE_ARITH: pixelIndex, materialIndex and t of the oracle's device arithmetic)
+        if not tiled and not args.no_extra_legs:
+            K = 8
+            rec = bfx['scenes'][it['name']][key]['default'] if bfx is not None else None
+            fast = capi.DeviceBVH(sctx, it['scene'], mode=2)
+            for _ in range(3):
+                fast.build()
+
+            def dyn_fast():
+                fast.initialize_frame(); fast.construct()
+                fast.generate_contacts_primary_d(it['cam'], it['contacts'])
+                capi.shade_blinn_phong_frame_d(sctx, it['scene'], it['cam'], it['contacts'], it['rgba'])
+            dyn_fast(); dyn_fast(); sctx.synchronize()
+            tw = time.perf_counter()
+            for _ in range(K):
+                fast.build()
+            sctx.synchronize()
+            ps['fast_mode'] = dict(build_ms=round((time.perf_counter() - tw) * 1e3 / K, 4))
+            tw = time.perf_counter()
+            for _ in range(K):
+                dyn_fast()
+            sctx.synchronize()
+            ps['fast_mode']['rebuild_plus_trace_ms'] = round((time.perf_counter() - tw) * 1e3 / K, 4)
+            tw = time.perf_counter()
+            for _ in range(K):
+                it['bvh'].build()
+            sctx.synchronize()
+            ps['build_ms_rebuilt'] = round((time.perf_counter() - tw) * 1e3 / K, 4)       # FIXED, builds 2.. of an allocation (graph replays)
+            if rec is not None and 't_sha256' in rec:
+                dyn_fast(); sctx.synchronize()
+                got = sctx.download(it['contacts'], npx, capi.CONTACT)
+                if sha256_hex(np.ascontiguousarray(got['normalAndDistance'][:, 3])) != rec['t_sha256']:
+                    raise SystemExit('VERIFICATION FAILED (%s, RT_MODE_FAST): hit mask / t differ from FIXED\'s' % it['name'])
+                ps['fast_mode']['verified'] = 'hit mask and t equal FIXED\'s'
+                verified['fast_mode_frames'] = verified.get('fast_mode_frames', 0) + 1
+            fast.close()
+            da = capi.DeviceBVH(sctx, it['scene'], mode=0x100).build()
+            da.generate_contacts_primary_d(it['cam'], it['contacts']); sctx.synchronize()         # calibrates
+            tm2 = capi.Timer(sctx)
+            for _ in range(ISOLATED_FRAMES):
+                da.generate_contacts_primary_d(it['cam'], it['contacts'])
+            tm2.start()
+            for _ in range(ISOLATED_FRAMES):
+                da.generate_contacts_primary_d(it['cam'], it['contacts'])
+            tm2.stop()
+            ps['device_arith_mode'] = dict(trace_ms=round(tm2.elapsed_ms() / ISOLATED_FRAMES, 4), strategy=da.trace_strategy())
+            tm2.close()
+            if rec is not None and 'device_arith' in rec:
+                got = sctx.download(it['contacts'], npx, capi.CONTACT)
+                t_bits = np.ascontiguousarray(got['normalAndDistance'][:, 3]).view(np.uint32)
+                keyb = np.stack([got['pixelIndex'], got['materialIndex'], t_bits], axis=1).astype('<u4')
+                if sha256_hex(keyb) != rec['device_arith']['key_sha256']:
+                    raise SystemExit('VERIFICATION FAILED (%s, RT_MODE_DEVICE_ARITH): pixelIndex / materialIndex / t differ from the oracle\'s device arithmetic' % it['name'])
+                ps['device_arith_mode']['verified'] = 'pixelIndex, materialIndex, t equal the oracle with the device branch\'s dot / cross'
+                verified['device_arith_frames'] = verified.get('device_arith_frames', 0) + 1
+            da.close()
         tm.close()
         if tiled:
             sctx.free(dc)

@@ -18,8 +18,8 @@ using namespace CLRayTracer::Common;
 using namespace CLRayTracer::OpenCLUtils;
 using namespace CLRayTracer::AccelerationStructures;
 
-static_assert(BVHManager::BuildFixed == RT_MODE_FIXED && BVHManager::BuildLiteralZero == RT_MODE_LITERAL_ZERO && BVHManager::BuildFast == RT_MODE_FAST &&
-              BVHManager::BuildDeviceArithmetic == RT_MODE_DEVICE_ARITH, "BVHManager::BuildMode mirrors include/rtmi.h");
+static_assert((int)BVHManager::BuildFixed == (int)RT_MODE_FIXED && (int)BVHManager::BuildLiteralZero == (int)RT_MODE_LITERAL_ZERO && (int)BVHManager::BuildFast == (int)RT_MODE_FAST &&
+              (int)BVHManager::BuildDeviceArithmetic == (int)RT_MODE_DEVICE_ARITH, "BVHManager::BuildMode mirrors include/rtmi.h");
 static_assert(sizeof(Camera) == sizeof(rt_camera) && sizeof(Contact) == sizeof(rt_contact) && sizeof(Ray) == sizeof(rt_ray),
               "the reference PODs and the C-ABI PODs are the same bytes");
 

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, '_build', 'librt_oracle.so')
+LIB_PATH = os.environ.get('RTMI_ORACLE_LIB') or os.path.join(HERE, '_build', 'librt_oracle.so')      # (RTMI_ORACLE_LIB: the sanitizer build, tools/san)
 
 NODE = np.dtype([('data', '<u4', 4), ('lo', '<f4', 4), ('hi', '<f4', 4)])        # 48 B  BVHData.h:70-74
 CONTACT = np.dtype([('pixelIndex', '<u4'), ('materialIndex', '<u4'), ('pad', '<u4', 2),
@@ -54,6 +54,8 @@ class Stats(C.Structure):
 def build(force: bool = False) -> str:
     src = [os.path.join(HERE, f) for f in ('rt_oracle.c', 'tlg_oracle.c', 'rt_oracle.h', 'tlg_oracle.h') if
            os.path.exists(os.path.join(HERE, f))]
+    if os.environ.get('RTMI_ORACLE_LIB'):
+        return LIB_PATH
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if stale:

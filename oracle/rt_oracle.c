@@ -67,7 +67,6 @@ static uint16_t rd_u16(const char* p) { uint16_t v; memcpy(&v, p, 2); return v; 
 static uint64_t sh_lights(const char* s)    { return rd_u64(s + 16); }
 static uint64_t sh_spheres(const char* s)   { return rd_u64(s + 24); }
 static uint64_t sh_materials(const char* s) { return rd_u64(s + 32); }
-static uint64_t sh_models(const char* s)    { return rd_u64(s + 48); }
 static uint64_t sh_triangles(const char* s) { return rd_u64(s + 56); }
 static orc_aabb sh_bbox(const char* s)      { orc_aabb b; memcpy(&b, s + 64, 32); return b; }
 

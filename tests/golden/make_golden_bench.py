@@ -41,10 +41,28 @@ def sha(b):
     return hashlib.sha256(bytes(b)).hexdigest()
 
 
-def frame_record(osc, ob, cam):
+def key_bytes(c):
+    """what RT_MODE_DEVICE_ARITH pins bit for bit against the reference's own kernel: pixelIndex, materialIndex, t (the normal comes out of
+    another normalize there)"""
+    t = np.ascontiguousarray(c['normal_t'][:, 3]).view(np.uint32)
+    return np.stack([c['pixelIndex'], c['materialIndex'], t], axis=1).astype('<u4').tobytes()
+
+
+def frame_record(osc, ob, cam, modes=False):
     c, st = ob.trace_primary(cam)
     rgba = orc.shade_frame(osc, cam, c)
-    return c, dict(camera_bits=[int(x) for x in cam.view(np.uint32).ravel()], rays=len(c), hits=int(st.hits),
+    extra = {}
+    if modes:
+        # RT_MODE_FAST keeps hit mask and t (another tie order: normal / material may differ where two triangles tie on t)
+        extra['t_sha256'] = sha(np.ascontiguousarray(c['normal_t'][:, 3]).tobytes())
+        # RT_MODE_DEVICE_ARITH: dot / cross fused as ROCm's OpenCL C library fuses them (the oracle's switch, pinned on the reference kernels)
+        orc.set_device_arith(True)
+        try:
+            cd, std = ob.trace_primary(cam)
+        finally:
+            orc.set_device_arith(False)
+        extra['device_arith'] = dict(key_sha256=sha(key_bytes(cd)), hits=int(std.hits))
+    return c, dict(**extra, camera_bits=[int(x) for x in cam.view(np.uint32).ravel()], rays=len(c), hits=int(st.hits),
                    contacts_sha256=sha(c.tobytes()), rgba_sum=[float(x) for x in rgba.astype(np.float64).sum(axis=0)],
                    rgba_samples_bits=[[int(v) for v in px] for px in rgba[::SAMPLE_STRIDE].view(np.uint32)])
 
@@ -73,7 +91,7 @@ def main():
         ob = orc.BVH(osc, 0)
         cam = osc.demo_camera(*res)
         assert cam.tobytes() == bench.demo_camera(buf, *res).tobytes(), 'bench.demo_camera differs from the oracle camera'
-        c, rec = frame_record(osc, ob, cam)
+        c, rec = frame_record(osc, ob, cam, modes=True)
         entry = dict(scene_sha256=sha(buf), default=rec, ray_buffer=ray_buffer_record(ob, cam, c))
         poses = bench.moving_cameras(buf, res[0], res[1], 32)
         for k in POSES:

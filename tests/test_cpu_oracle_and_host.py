@@ -89,7 +89,7 @@ def test_scene_file_edge_cases(tmp_path):
 
 def _host_tools():
     import subprocess
-    tool = os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
+    tool = os.environ.get('RTMI_SCENE_PACK_TOOL') or os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')      # (the sanitizer build: tools/san)
     if not os.path.exists(tool):
         subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'openclraytracer_amd', 'csrc', 'host'),
                                os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')])
@@ -381,7 +381,7 @@ def test_host_cpu_shade_blinn_phong_equals_the_oracle():
     for bit on the oracle's contacts (same operations, same libm), on every bundled model.  No GPU involved."""
     import ctypes as C
     import oracle as orc
-    lib = C.CDLL(os.path.join(ROOT, 'openclraytracer_amd', 'librtmi_host.so'))
+    lib = C.CDLL(os.environ.get('RTMI_HOST_LIB') or os.path.join(ROOT, 'openclraytracer_amd', 'librtmi_host.so'))
     fn = getattr(lib, '_Z18cpuShadeBlinnPhongP6CameraP7ContactPcR10CL_FLOAT4_')
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     fn.restype = None
