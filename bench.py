@@ -72,6 +72,13 @@ PMC_PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']),
 def pack_scene_file(scene_txt):
     """Packed scene buffer through the PRODUCT's loader: the C++ Scene::load packing (apps/bin/scene_pack_tool,
     openclraytracer_amd/csrc/host/src/SceneLoader.cpp)."""
+    if os.environ.get('RTMI_PACKED') == '1':
+        # under rocprofv3 (tools/profile_round.sh) the scenes come packed and this process starts NO child: the profiler's library may
+        # have initialised the GPU before the program started, and a process in that state must not spawn
+        packed = '/tmp/_%s.bin' % os.path.splitext(os.path.basename(scene_txt))[0]
+        if not os.path.exists(packed):
+            raise SystemExit('RTMI_PACKED=1 but %s is missing: pack the scenes before the profiled pass (tools/profile_round.sh)' % packed)
+        return open(packed, 'rb').read()
     tool = os.environ.get('RTMI_SCENE_PACK_TOOL') or os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
     if not os.path.exists(tool):
         raise SystemExit('apps/bin/scene_pack_tool is not built: run __graft_entry__.build()')

@@ -4,6 +4,9 @@
 // processMaterials :129-167, mesh packing :380-441) and the behaviour of the OBJ/MTL parser the reference vendors
 // (Include/3rdParty/tiny_obj_loader.h v0.9.17: float grammar :266-383, index triples :421-452, face groups flushed
 // on usemtl / g / o with a per-flush vertex cache :516-585, fan triangulation, LoadMtl :587-813) with own code.
+// Third-party notice: fix_index and parse_triple below follow tinyobj's fixIndex / parseTriple (tiny_obj_loader.h v0.9.17 :408-449,
+// Copyright (c) 2012-2015 Syoyo Fujita, MIT licence) statement for statement -- twenty lines whose behaviour (atoi, which separators end a
+// field, what "1//3" and "-1" mean) IS the specification of the index grammar; everything else in this file is own code.
 // The byte layout is SceneBufferParser.h:55-160.  Bytes the reference leaves uninitialised (.w of CL_FLOAT3
 // temporaries) are 0.  tests/ compare the output with the oracle's packer and with the committed fixtures.
 #include "SceneLoader.h"

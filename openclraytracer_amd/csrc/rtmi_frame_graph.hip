@@ -183,11 +183,16 @@ int rt_frame_graph_create(rt_bvh* b, const rt_scene* scene, const rt_camera* cam
     g->four_wide = packet && quad;
     g->octant_records = g->four_wide && b->quad_cam_variants == 9u;
     // The four-wide packet kernel hands rays to the wave-per-ray kernel only when the camera sits on a box plane (ray_root; on its
-    // per-octant records: on a y or z plane): the eager frame above has computed those bits for this camera position, so a
+    // per-octant records: on a y or z plane): the eager frame above has computed those bits for this camera position on the device -- unless
+    // the host already knows the planes of this build and looked the position up itself (then the host's answer is taken here too) -- so a
     // captured frame of a camera on no such plane leaves the (then empty, ~7 us) wave-per-ray launch out.  When the camera
     // moves (rt_frame_graph_set_camera) the bits are looked up on the host.
     uint32_t plane_bits = 7u;
-    if (b->d_tree_select && b->have_search_tree) {
+    if (b->have_search_tree && b->h_planes_generation == b->build_generation && !b->h_planes[0].empty()) {
+        // the host knows this build's planes (eager frames beyond RT_EAGER_PLANES_AFTER, or a moved graph): the eager frame above may have
+        // left the per-camera marks out on the strength of them, in which case the device word belongs to an earlier camera position
+        plane_bits = host_plane_bits(b, g->origin);
+    } else if (b->d_tree_select && b->have_search_tree) {
         const hipError_t e = hipMemcpy(&plane_bits, b->d_tree_select, sizeof plane_bits, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { delete g; return RT_FAIL(ctx, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     }

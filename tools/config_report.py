@@ -12,7 +12,9 @@ import bench
 ONLY3 = sys.argv[1:] == ['config3']
 # pack the scenes with the product's loader BEFORE the GPU is touched (no child processes afterwards)
 for _name in ['synth_bunny'] + ([] if ONLY3 else ['synth_atrium']):
-    if os.environ.get('RTMI_PACKED') == '1' and os.path.exists('/tmp/_%s.bin' % _name):      # (under rocprofv3 --pmc: no child process)
+    if os.environ.get('RTMI_PACKED') == '1':      # under rocprofv3: the scenes come packed and NO child process is started
+        if not os.path.exists('/tmp/_%s.bin' % _name):
+            raise SystemExit('RTMI_PACKED=1 but /tmp/_%s.bin is missing: pack the scenes before the profiled pass (tools/profile_round.sh)' % _name)
         continue
     subprocess.check_call([os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool'), os.path.relpath(gen_scenes.ensure()[_name], ROOT),
                            '/tmp/_%s.bin' % _name], cwd=ROOT)

@@ -1,14 +1,20 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round (run on the GPU box through gpurun from the repo root):
-#   tools/profile_round.sh r02
+#   tools/profile_round.sh r04
 # 1) the bench line of the default command (it runs its own rocprofv3 counter passes: FETCH_SIZE, WRITE_SIZE, SQ_* + GRBM; raw rows kept),
-# 2) kernel trace + stats of the same bench command (without the nested counter passes), 3) config 4 and config 3 with their own stats,
-# 4) the host floor of the tiled path (four ranks in one process on this one GPU).
+# 2) kernel trace + stats of the same bench command (without the nested counter passes), 3) config 4 and config 3 with their own stats and
+# counter passes, 4) the ray-buffer entry (kernel stats + counters), 5) construct() per kernel, 6) the host floor of the tiled path.
+# Every profiled program stands directly behind `--` and starts no process of its own: the scenes are packed ONCE, up front
+# (RTMI_PACKED=1 makes the tools refuse to spawn the packer; a failed packing aborts the round).
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$R
 mkdir -p $OUT
+python3 assets/synth/gen_scenes.py > /dev/null || exit 1
+for s in synth_bunny synth_atrium; do apps/bin/scene_pack_tool assets/synth/$s.txt /tmp/_$s.bin || { echo "packing $s failed"; exit 1; }; done
+for s in cube gardenlight tenryuu man clumsydragon; do apps/bin/scene_pack_tool assets/scenes/$s.txt /tmp/_$s.bin || { echo "packing $s failed"; exit 1; }; done
+export RTMI_PACKED=1
 python3 bench.py --keep-pmc $OUT/pmc > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
 echo "bench line done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pmc > $OUT/bench_under_rocprof.log 2>&1 || exit 1
@@ -17,16 +23,20 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tlg_stats -- python
 echo "tlg done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config3_stats -- python3 tools/config_report.py config3 > $OUT/config3.log 2>&1 || echo "config3 stats pass failed"
 echo "config3 done"
-# counter passes of configs 3 and 4 (BASELINE configs[2] asks for the HBM-bandwidth run of the Bunny-class frame): the scenes are
-# packed beforehand, the profiled program (directly behind `--`) starts no process; one pass per counter group
-apps/bin/scene_pack_tool assets/synth/synth_bunny.txt /tmp/_synth_bunny.bin && apps/bin/scene_pack_tool assets/synth/synth_atrium.txt /tmp/_synth_atrium.bin
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raybuffer_stats -- python3 tools/rays_profile.py > $OUT/raybuffer.log 2>&1 || echo "ray-buffer stats pass failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/build_stats -- python3 tools/build_profile.py clumsydragon synth_atrium --k 20 > $OUT/build.log 2>&1 || echo "build stats pass failed"
+echo "ray buffer + build done"
+# counter passes (BASELINE configs[2] asks for the HBM-bandwidth run of the Bunny-class frame): one pass per counter group
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   set -- $pass; tag=$1; shift
-  RTMI_PACKED=1 timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/config3_pmc_$tag -- python3 tools/config_report.py config3 > $OUT/config3_pmc_$tag.log 2>&1 || echo "config3 counter pass $tag failed"
-  RTMI_PACKED=1 timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/tlg_pmc_$tag -- python3 tools/tlg_config4.py > $OUT/tlg_pmc_$tag.log 2>&1 || echo "config4 counter pass $tag failed"
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/config3_pmc_$tag -- python3 tools/config_report.py config3 > $OUT/config3_pmc_$tag.log 2>&1 || echo "config3 counter pass $tag failed"
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/tlg_pmc_$tag -- python3 tools/tlg_config4.py > $OUT/tlg_pmc_$tag.log 2>&1 || echo "config4 counter pass $tag failed"
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/raybuffer_pmc_$tag -- python3 tools/rays_profile.py > $OUT/raybuffer_pmc_$tag.log 2>&1 || echo "ray-buffer counter pass $tag failed"
 done
 echo "config counter passes done"
+unset RTMI_PACKED
 python3 tools/config_report.py > $OUT/config_report.json 2> $OUT/config_report.err || echo "config report failed"
+python3 tools/rays_sweep.py --out $OUT/raybuffer_sweep.json > $OUT/raybuffer_sweep.log 2>&1 || echo "ray-buffer sweep failed"
 RTMI_BENCH_GROUP=4 python3 bench.py --steps 100 --warmup 5 --no-extra-legs > $OUT/bench_group4.json 2> $OUT/bench_group4.err || echo "group run failed"
 echo "group done"
-find $OUT -name "*.csv" | head -30
+find $OUT -name "*.csv" | head -40

@@ -12,7 +12,10 @@ from openclraytracer_amd import capi
 name, res = 'synth_atrium', (1920, 1080)
 txt = gen_scenes.ensure()[name]
 tmp = '/tmp/_%s.bin' % name
-if not (os.environ.get('RTMI_PACKED') == '1' and os.path.exists(tmp)):      # (under rocprofv3 --pmc the scene comes packed: no child process)
+if os.environ.get('RTMI_PACKED') == '1':      # under rocprofv3 the scene comes packed and NO child process is started (a process whose GPU is initialised must not spawn)
+    if not os.path.exists(tmp):
+        raise SystemExit('RTMI_PACKED=1 but %s is missing: pack the scenes before the profiled pass (tools/profile_round.sh)' % tmp)
+else:
     subprocess.check_call([os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool'), os.path.relpath(txt, ROOT), tmp], cwd=ROOT)
 buf = open(tmp, 'rb').read()
 ctx = capi.Context(0)
