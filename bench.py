@@ -458,12 +458,53 @@ def main():
     npx = RES[0] * RES[1]
 
     # One context = one HIP stream per scene (and per rank of an in-process group): the five frames of a step are independent
-    comm_id = None
-    if world > 1:
+    def new_comm_id():
         box = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        comm_id = box[0]
+        return box[0]
+    # One RCCL communicator shared by the five scenes' frames (each on a stream of its own: rt_comm_share), or one communicator per
+    # scene (RTMI_BENCH_COMM=per_scene; also what the run falls back to, on every rank together, when the first frames on the shared
+    # communicator fail: see `tiled_warm_up`)
+    def make_frames(it):
+        for c in it['ctxs']:
+            c.set_frames_in_flight(len(SCENES))          # five scenes' frames are in flight per step (see use_graphs below)
+        it['frames'] = [capi.MultiFrame(c, b, s, it['cam'], root_extra, it['root']) for c, b, s in zip(it['comms'], it['bvhs'], it['scenes'])]
+        for c in it['ctxs']:
+            c.set_frames_in_flight(1)
+        it['slots'] = it['frames'][0].layout()['own_slots']
+    comm_mode = os.environ.get('RTMI_BENCH_COMM', 'shared')
+    comm_id = new_comm_id() if world > 1 else None
     main_comm = None
+    diag = dict(rank=rank, world=world, comm_mode=comm_mode, phase='setup', phase_since=time.perf_counter())      # what a failing or hanging rank reports about itself
+
+    def phase(name):
+        diag['phase'] = name; diag['phase_since'] = time.perf_counter()
+
+    def report(why):
+        # every rank, on stderr, whatever else happens: enough to tell a transport problem from a wrong frame
+        d = dict(diag, why=why, seconds_in_phase=round(time.perf_counter() - diag['phase_since'], 1))
+        d.pop('phase_since', None)
+        try:
+            if tiled and work and 'comms' in work[0]:
+                d['uses_rccl'] = [bool(it['comms'][0].uses_rccl()) for it in work if 'comms' in it]
+                d['rccl_ranks'] = [it['comms'][0].rccl_ranks() for it in work if 'comms' in it]
+                d['roots'] = [it.get('root') for it in work]
+                d['own_slots'] = [it.get('slots') for it in work]
+        except Exception as e:          # noqa: BLE001 (a diagnostic must not raise)
+            d['diag_error'] = repr(e)
+        print('BENCH_DIAG ' + json.dumps(d), file=sys.stderr, flush=True)
+
+    def watchdog():
+        # a rank that waits for a peer forever says where it stands and ends the process (a hung collective cannot be cancelled)
+        limit = float(os.environ.get('RTMI_BENCH_WATCHDOG_S', '300'))
+        while diag['phase'] != 'done':
+            time.sleep(2.0)
+            if time.perf_counter() - diag['phase_since'] > limit:
+                report('watchdog: no progress for %.0f s' % limit)
+                os._exit(3)
+    if tiled:
+        import threading
+        threading.Thread(target=watchdog, daemon=True).start()
     work, build_ms = [], {}
     for name in SCENES:
         buf = scene_bytes[name]
@@ -481,6 +522,9 @@ def main():
         if tiled:
             if group_ranks:
                 it['comms'] = capi.Comm.create_group(it['ctxs'])
+            elif comm_mode == 'per_scene':
+                it['comms'] = [capi.Comm.create(it['ctx'], comm_id if not work else new_comm_id(), rank, world)]      # collective: ncclCommInitRank
+                main_comm = main_comm or it['comms'][0]
             elif main_comm is None:
                 main_comm = capi.Comm.create(it['ctx'], comm_id, rank, world)      # collective: ncclCommInitRank
                 it['comms'] = [main_comm]
@@ -489,12 +533,7 @@ def main():
             # every scene's frame is assembled on another rank (scene i -> rank i mod N): what crosses the links into one GPU is one
             # frame's colour per step, not all five; RTMI_BENCH_ONE_ROOT=1 gathers everything into rank 0
             it['root'] = 0 if os.environ.get('RTMI_BENCH_ONE_ROOT') == '1' else len(work) % nranks
-            for c in it['ctxs']:
-                c.set_frames_in_flight(len(SCENES))          # five scenes' frames are in flight per step (see use_graphs below)
-            it['frames'] = [capi.MultiFrame(c, b, s, cam, root_extra, it['root']) for c, b, s in zip(it['comms'], it['bvhs'], it['scenes'])]
-            for c in it['ctxs']:
-                c.set_frames_in_flight(1)
-            it['slots'] = it['frames'][0].layout()['own_slots']
+            make_frames(it)
         else:
             it['slots'] = npx
             it['contacts'] = it['ctx'].alloc(npx * 32)
@@ -597,9 +636,49 @@ def main():
             done = sum(box)
         return done
 
+    def all_ranks_ok(ok):
+        if dist is None:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def tiled_warm_up():
+        # the first frames of a multi-rank run: a rank whose frames fail (an RCCL error surfaces in rt_multi_frame_render / _wait) says so,
+        # and all ranks decide together -- a rank that went on alone would wait in a gather nobody else issues
+        err = None
+        try:
+            for _ in range(max(args.warmup, 1)):
+                step()
+            for it in work:
+                for f in it['frames']:
+                    f.wait()
+        except capi.RtError as e:
+            err = str(e)
+        return all_ranks_ok(err is None), err
+
     note('warm-up and timed steps')
-    for _ in range(args.warmup):
-        step()
+    phase('warm-up')
+    if tiled:
+        ok, err = tiled_warm_up()
+        if not ok and world > 1 and comm_mode == 'shared':
+            # the five frames' streams share one RCCL communicator: if that combination does not work on this node, every rank takes a
+            # communicator per scene instead (collective: new ids over the control plane), and says so in the line
+            report('first frames failed on the shared communicator (%s): falling back to one communicator per scene' % (err or 'a peer failed'))
+            for it in work:
+                for f in it['frames']:
+                    f.close()
+            comm_mode = diag['comm_mode'] = 'per_scene (fall-back)'
+            for it in work:
+                it['comms'] = [capi.Comm.create(it['ctx'], new_comm_id(), rank, world)]
+                make_frames(it)
+            ok, err = tiled_warm_up()
+        if not ok:
+            report('the first frames failed: %s' % (err or 'on another rank'))
+            raise SystemExit(2)
+    else:
+        for _ in range(args.warmup):
+            step()
     fence()
     if tiled and (args.check_frames or not args.no_verify):
         if args.warmup == 0:
@@ -608,6 +687,7 @@ def main():
             note('verified before timing: %d assembled frames' % verify_timed('after the warm-up'))
         if args.check_frames:
             check_frames('after the warm-up')
+    phase('timed region')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -669,6 +749,7 @@ def main():
     # frame costs when it has the device to itself) -- the launches rocprofv3 lists as <1, 2>
     per_scene = {}
     tiling = capi.tiling(nranks, root_extra if nranks > 1 else 0)
+    phase('isolated pass')
     note('timed region done: %.4f ms per step; isolated pass per scene' % (elapsed / args.steps * 1e3))
     for it in work:
         sctx = it['ctx']
@@ -926,6 +1007,7 @@ def main():
     fx5 = None
     if atrium_bytes is not None:
         note('config 5 leg')
+        phase('config 5')
         cam5 = demo_camera(atrium_bytes, *RES5)
         ranks_here = range(nranks) if group_ranks else [rank]
         c5 = [capi.Context(local_rank) for _ in ranks_here]
@@ -1006,6 +1088,7 @@ def main():
             ray_buffer['min_mrays_per_s_' + leg] = min(v[leg]['mrays_per_s'] for v in ray_buffer['per_scene'].values())
         verified['ray_buffer_legs'] = 3 * len(ray_buffer['per_scene'])
 
+    phase('done')
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -1134,6 +1217,7 @@ def main():
                'frame (12 B per pixel, grouped RCCL send/recv issued by librtmi) into that rank: scene i is assembled on rank i mod N (roots %s), '
                'the five frames of a step on five HIP streams per rank'
                % (nranks, root_extra, nranks + root_extra, [it['root'] for it in work]))
+        par += '; RCCL communicator: %s' % comm_mode
         if group_ranks:
             par += '; REHEARSAL: all ranks in one process on one device, gather by device copies'
     out = dict(metric='Mrays/s (primary rays, BVH trace + shade, bundled TestModels, 1920x1080)', value=round(value, 1),

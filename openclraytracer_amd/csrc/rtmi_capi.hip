@@ -142,6 +142,18 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         return RT_ERROR;
     }
     ctx->stream = ctx->own_stream;
+    {
+        // Which HIP runtime serves the process: librtmi.so is built against the system's (HIP_VERSION at compile time); a process that
+        // imported torch first runs on the copy torch bundles, an older ROCm.  Measured in round 3 under that copy: an executable graph
+        // whose kernel-node arguments were re-set (hipGraphExecKernelNodeSetParams: a camera that moves) replays three times slower, and
+        // five streams of such graphs stall.  Frame graphs therefore never re-set node arguments there (rtmi_frame_graph.hip: sequences of
+        // kernels only are issued as plain launches with refreshed argument copies under every runtime; any other sequence falls back to the
+        // eager calls for a moved camera when the runtime is the older one).  RTMI_GRAPH_SETPARAMS=1 / 0 overrides the detection.
+        int rv = 0;
+        if (hipRuntimeGetVersion(&rv) != hipSuccess) { (void)hipGetLastError(); rv = 0; }
+        ctx->older_runtime = rv != 0 && rv < HIP_VERSION;
+        if (const char* env = std::getenv("RTMI_GRAPH_SETPARAMS")) ctx->older_runtime = env[0] == '0';
+    }
     // (failures are not fatal: the object is then loaded where it is first used)
     (void)rt_preload_trace(); (void)rt_preload_build(); (void)rt_preload_sort_scan(); (void)rt_preload_shade(); (void)rt_preload_tlg(); (void)rt_preload_secondary();
     if (const char* env = std::getenv("RTMI_DEFER_BUDGET")) ctx->defer_budget = (uint32_t)std::strtoul(env, nullptr, 10);

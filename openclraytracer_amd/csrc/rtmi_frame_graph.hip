@@ -229,6 +229,9 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
     g->origin[0] = cam->viewTransform[3]; g->origin[1] = cam->viewTransform[7]; g->origin[2] = cam->viewTransform[11];
     for (int a = 0; a < 2; a++) for (int k = 0; k < 2; k++) g->dirty[a][k] = true;
     g->eager = !g->nodes_known;
+    // a sequence with memset / copy nodes is replayed through hipGraphLaunch and would need its kernel nodes' arguments re-set: not under an
+    // older serving runtime (rt_ctx_create: three times slower replays, stalls) -- the eager calls render a moved camera there
+    if (ctx->older_runtime && !(g->direct[0] && g->direct[1])) g->eager = true;
     g->moved = true;
     g->bo_interval = RT_BLOCK_ORDER_REFRESH;
     if (g->four_wide) {
@@ -275,6 +278,22 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     // the instance to launch: the one launched last if its arguments are current, else the other one (its last launch is the older
     // one); its arguments are re-set only behind that launch
     int k = g->slot[which];
+    if (g->direct[which]) {
+        // kernels only: issued as plain launches from the recorded argument copies (a launch copies its arguments when it is enqueued, so
+        // refreshing the copies never touches a frame in flight: no second instance, no event, no hipGraphExecKernelNodeSetParams)
+        k = 0;
+        if (g->dirty[which][0] || g->dirty[which][1]) {
+            const double t0 = debug ? now_us() : 0.0;
+            FrameMode m = graph_mode(g, which, true);
+            g->nodes[which].failed = false;
+            g->nodes[which].args_only = true;
+            const int rc = graph_issue(g, &m);
+            g->nodes[which].args_only = false;
+            if (rc != RT_SUCCESS) return RT_ERROR;
+            g->dirty[which][0] = g->dirty[which][1] = false;
+            if (debug) { g->host_update_us += now_us() - t0; g->host_updates++; }
+        }
+    } else
     if (g->dirty[which][k]) {
         k ^= 1;
         if (g->dirty[which][k]) {
@@ -302,8 +321,8 @@ int rt_frame_graph_launch(rt_frame_graph* g)
         }
     } else
     RT_HIP(ctx, hipGraphLaunch(g->exec[which][k], ctx->stream));
-    g->has_event[which][k] = g->moved;
-    if (g->moved) RT_HIP(ctx, hipEventRecord(g->done[which][k], ctx->stream));
+    g->has_event[which][k] = g->moved && !g->direct[which];
+    if (g->has_event[which][k]) RT_HIP(ctx, hipEventRecord(g->done[which][k], ctx->stream));
     if (debug) { g->host_launch_us += now_us() - t1; g->host_launches++; }
     g->launched[which][k] = true;
     g->slot[which] = k;

@@ -121,6 +121,7 @@ struct rt_ctx {
     bool no_block_order = false;            // knob RTMI_BLOCK_ORDER=0: waves walk the blocks in index order
     uint32_t trace_workgroup_waves = 0;     // knob RTMI_TRACE_WORKGROUP=64/128/256: waves per workgroup of the first-phase kernels (0: by policy)
     bool order_in_flight = true;            // knob RTMI_BLOCK_ORDER_IN_FLIGHT=0: index order under the throughput policy (what paid on round 2's tree)
+    bool older_runtime = false;             // the HIP runtime serving this process is older than the one librtmi.so was built against (torch's bundled copy loaded first)
     uint32_t frames_in_flight = 1;          // rt_ctx_set_frames_in_flight: > 1 = throughput policy (index order, sharing handicapped)
     uint32_t block_order_group_log = 4;     // knob RTMI_BLOCK_ORDER_GROUP=1..64: consecutive blocks that stay together (a power of two)
 };
@@ -315,6 +316,7 @@ struct GraphNodes {
     hipGraphExec_t exec = nullptr;
     hipGraphNode_t node[RT_NODE_KINDS] = {};
     bool failed = false;          // a node was missing, appeared twice, or the runtime refused the new arguments
+    bool args_only = false;       // update mode: only the argument copies below are refreshed (the sequence is issued as plain launches: the executable graph is not touched)
     // the same launches as plain data (kernel, geometry, a copy of the argument block): a captured sequence that consists of kernels
     // only can be issued as ordinary launches, which follow each other on a stream with a shorter gap than graph launches do
     struct Direct { const void* func = nullptr; dim3 grid, block; uint32_t lds = 0; uint32_t bytes = 0; alignas(16) unsigned char args[768]; } direct[RT_NODE_KINDS];
@@ -328,6 +330,7 @@ inline void rt_launch_node(GraphNodes* record, GraphNodes* update, int kind, K k
         d.func = (const void*)kernel; d.grid = grid; d.block = block; d.lds = lds_bytes; d.bytes = (uint32_t)sizeof(A);
         std::memcpy(d.args, &args, sizeof(A));
     }
+    if (update && update->args_only) return;
     if (update) {
         hipKernelNodeParams p{};
         void* params[1] = { (void*)&args };
