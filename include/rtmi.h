@@ -356,6 +356,15 @@ int  rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam);
 /* what the last rt_frame_graph_launch replayed: 0 the steady-state frame, 1 the frame behind the per-camera preparation,
  * 2 the eager sequence (see above), -1 nothing yet                                                                        */
 int  rt_frame_graph_last_launch(const rt_frame_graph* g);
+/* test / inspection: the policy state of a graph, out[k] for k < n:
+ *   0 frames between two refreshes of this graph's block start order (32 after creation and after every rt_frame_graph_set_camera; doubles
+ *     with every refresh while the camera stands still, up to 1 024; 0: the graph has no block order), 1 frames since the last refresh,
+ *   2 the order has been derived from counted costs at least once, 3 bit 0 / 1: the steady / the preparing sequence is issued as plain
+ *     launches (kernels only), 4 the current camera is rendered by the eager calls (on a box plane the captured frame cannot serve, or a
+ *     sequence that would need its node arguments re-set under an older serving runtime), 5 the camera has moved since creation,
+ *   6 four-wide packet strategy, 7 captured without the wave-per-ray launch                                                         */
+#define RT_FRAME_GRAPH_STATE_WORDS 8
+int  rt_frame_graph_state(const rt_frame_graph* g, uint32_t* out, uint32_t n);
 void rt_frame_graph_destroy(rt_frame_graph* g);
 
 /* ---- parallel primitives used by the builders ------------------------------------------- */

@@ -38,7 +38,7 @@ SYMBOLS = [
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct', 'rt_bvh_graph_builds',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_rays_strategy', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_host_plane_reads', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
-    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
+    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_frame_graph_state', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
     'rt_sort_pairs_bitonic', 'rt_sort_pairs', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_frames_in_flight', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
@@ -608,6 +608,13 @@ class FrameGraph:
     def last_launch(self) -> int:
         """0 steady-state replay, 1 replay behind the per-camera preparation, 2 eager sequence, -1 nothing launched yet"""
         return int(self.ctx.lib.rt_frame_graph_last_launch(self.h))
+
+    def state(self) -> dict:
+        """rt_frame_graph_state: the graph's policy state (include/rtmi.h)"""
+        out = (C.c_uint32 * 8)()
+        self.ctx.lib.rt_frame_graph_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        self.ctx.check(self.ctx.lib.rt_frame_graph_state(self.h, out, 8))
+        return dict(zip(('order_interval', 'order_age', 'order_sorted', 'direct', 'eager', 'moved', 'four_wide', 'no_unsafe'), [int(x) for x in out]))
 
     def close(self):
         if self.h:

@@ -251,6 +251,15 @@ int rt_frame_graph_set_camera(rt_frame_graph* g, const rt_camera* cam)
 
 int rt_frame_graph_last_launch(const rt_frame_graph* g) { return g ? g->last_launch : -1; }
 
+int rt_frame_graph_state(const rt_frame_graph* g, uint32_t* out, uint32_t n)
+{
+    if (!g || (!out && n)) return RT_FAIL(g ? g->ctx : nullptr, "null argument");
+    const uint32_t v[RT_FRAME_GRAPH_STATE_WORDS] = { g->bo.count ? g->bo_interval : 0u, g->bo.age, g->bo_sorted ? 1u : 0u, (g->direct[0] ? 1u : 0u) | (g->direct[1] ? 2u : 0u),
+                                                     g->eager ? 1u : 0u, g->moved ? 1u : 0u, g->four_wide ? 1u : 0u, g->no_unsafe ? 1u : 0u };
+    for (uint32_t k = 0; k < n; k++) out[k] = k < RT_FRAME_GRAPH_STATE_WORDS ? v[k] : 0u;
+    return RT_SUCCESS;
+}
+
 int rt_frame_graph_launch(rt_frame_graph* g)
 {
     if (!g) return RT_FAIL(nullptr, "frame graph is null");

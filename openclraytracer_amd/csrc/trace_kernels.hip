@@ -609,13 +609,29 @@ __device__ __forceinline__ uint32_t ray_root(const TraceArgs& a, const RayState&
         const float ax = fabsf(r.inv.x), ay = fabsf(r.inv.y), az = fabsf(r.inv.z);
         // ... and a finite origin of moderate size: a NaN origin coordinate on y or z makes the reference's staged test forget its
         // earlier axes ("the first axis"), and (plane - origin) must not overflow
-        const bool safe = (ax <= FLT_MAX) && (ay <= FLT_MAX) && (az <= FLT_MAX) && (ax >= 0.99f) && (ay >= 0.99f) && (az >= 0.99f) &&
+        // On the X axis an infinite 1/d is allowed: a 0 * inf there (origin on a box plane) is a NaN that the sign-selected tests of the
+        // lane-per-ray and wave-per-ray kernels ignore (v_max / v_min), which is what the reference's staged test does with it (DESIGN.md
+        // section 2, "the first axis"); every other product on that axis is +-inf with the right sign.  (A camera centred on its model hands
+        // a whole pixel column of such rays over: the Sponza-class stand-in's 1 080 of them walked the 10 835-level reference tree, 0.5 ms.)
+        const bool safe = (ax >= 0.99f) && (ay <= FLT_MAX) && (az <= FLT_MAX) && (ay >= 0.99f) && (az >= 0.99f) &&
                           (fabsf(r.o.x) <= 1e30f) && (fabsf(r.o.y) <= 1e30f) && (fabsf(r.o.z) <= 1e30f);
         return safe ? a.search_root : 0u;
     }
     const bool risky = ((plane_bits & 1u) && !(fabsf(r.inv.x) <= FLT_MAX)) || ((plane_bits & 2u) && !(fabsf(r.inv.y) <= FLT_MAX)) ||
                        ((plane_bits & 4u) && !(fabsf(r.inv.z) <= FLT_MAX));
     return risky ? 0u : a.search_root;
+}
+
+// Where the four-wide packet kernel sends a ray it cannot walk itself: RT_SENTINEL = nowhere (the ray walks with its packet), else the
+// record the wave-per-ray kernel starts it at -- the reference root (ray_root), or, for a ray of a ray buffer whose 1/d is infinite on x,
+// the search tree's root: that kernel's sign-selected test takes the NaN such a ray can produce, the packet's min / max form would not.
+template <int PRIMARY>
+__device__ __forceinline__ uint32_t packet_hand_over(const TraceArgs& a, const RayState& r, uint32_t plane_bits)
+{
+    const uint32_t root = ray_root<PRIMARY>(a, r, plane_bits);
+    if (root == 0u) return 0u;
+    if (!PRIMARY && !(fabsf(r.inv.x) <= FLT_MAX)) return root;
+    return RT_SENTINEL;
 }
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
@@ -1338,7 +1354,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? (PRIMARY ? P4_MIN_WAVES : 6) 
                 // the reference's own hierarchy -- so only those rays go to the reference tree.  (The general records' min / max of
                 // the two products would turn NaN into the wrong infinity: without the copies every plane axis counts.)
                 const uint32_t plane_bits = PRIMARY ? (OCT ? camera_plane_bits(A) & ~1u : camera_plane_bits(A)) : 0u;
-                const bool on_ref = ok && ray_root<PRIMARY>(A, r, plane_bits) == 0u;
+                const uint32_t start_elsewhere = packet_hand_over<PRIMARY>(A, r, plane_bits);
+                const bool on_ref = ok && start_elsewhere != RT_SENTINEL;
                 const uint64_t m_ref = __ballot(on_ref);
                 if (OCT && __ballot(ok && ((A.octant_mask >> my_octant) & 1u) == 0u) != 0ull) TRACE_FAIL((gu32*)&A.ctrl->error, 7);   // frame invalid
                 if (m_ref != 0ull) {
@@ -1350,7 +1367,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? (PRIMARY ? P4_MIN_WAVES : 6) 
                         const uint32_t idx = base + lane_rank(m_ref);
                         if (idx < A.long_cap) {
                             uint32_t* rec = A.long_list + (uint64_t)idx * LONG_REC_WORDS;
-                            rec[LR_WORK] = w; rec[LR_CUR] = 0u; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
+                            rec[LR_WORK] = w; rec[LR_CUR] = start_elsewhere; rec[LR_SP] = 0u; rec[LR_BEST_LEAF] = NO_LEAF;
                             rec[LR_BEST_T] = __float_as_uint(FLT_MAX); rec[LR_EXTRA] = RT_SENTINEL; rec[LR_PENDING] = NO_LEAF; rec[LR_PARTIAL] = 0u;
                         } else {
                             TRACE_FAIL((gu32*)&A.ctrl->error, 1);          // nowhere to put the ray: frame invalid
@@ -1685,7 +1702,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? (PRIMARY ? P4_MIN_WAVES : 6) 
             RayState r;
             bool sx, sy, sz;
             r.out_index = 0; r.pixel = 0;
-            if (w < A.total_work && load_ray<PRIMARY>(A, w, r, sx, sy, sz) && ray_root<PRIMARY>(A, r, plane_bits) != 0u) {
+            if (w < A.total_work && load_ray<PRIMARY>(A, w, r, sx, sy, sz) && packet_hand_over<PRIMARY>(A, r, plane_bits) == RT_SENTINEL) {
                 const unsigned long long key = __hip_atomic_load((gu64*)A.keys + w, RLX_AGENT);
                 const bool hit = key != KEY_NONE;
                 const float t = hit ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;

@@ -1,8 +1,10 @@
 """BASELINE.json configs 3, 4 and 5 on the seeded procedural stand-ins (the real Bunny / Sponza are not shipped with
 the reference): full-size parity against the oracle through the C ABI."""
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -17,9 +19,10 @@ def _synth_scene_bytes(name):
     import gen_scenes
     txt = gen_scenes.ensure()[name]
     tool = os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool')
-    out = '/tmp/_%s.bin' % name
-    subprocess.check_call([tool, os.path.relpath(txt, ROOT), out], cwd=ROOT)      # the product's C++ loader
-    return open(out, 'rb').read()
+    with tempfile.TemporaryDirectory(prefix='rtmi_test_') as d:                    # (a path of this process's own: runs may overlap)
+        out = os.path.join(d, name + '.bin')
+        subprocess.check_call([tool, os.path.relpath(txt, ROOT), out], cwd=ROOT)      # the product's C++ loader
+        return open(out, 'rb').read()
 
 
 def test_config3_bunny_class_full_hd(gpu_ctx):
@@ -123,14 +126,14 @@ print('overflow areas per frame %%d, %%d more frames ok' %% (taken[0], frames))
 
 @pytest.mark.parametrize('packet, budget, scene', [('4', '1048576', 'man'), ('4', '16', 'man'), ('1', '1048576', 'man'), ('1', '64', 'tenryuu'),
                                                    ('4', '1048576', 'synth_atrium')])
-def test_packet_stack_overflow_areas(packet, budget, scene):
+def test_packet_stack_overflow_areas(packet, budget, scene, tmp_path):
     """Overflow areas of the packet kernels' (node, lane mask) stacks.  With the 96-entry LDS stacks no bundled or synthetic
     scene overflows (chains of duplicate Morton codes have a leaf on one side), so this runs the test twin of the library
     (librtmi_teststack.so: same sources, three-entry LDS stacks) in a child process: waves take areas from the bitmap
     on their first overflow -- one wave per 64-ray block, far more waves than areas -- contacts stay the oracle's, the
     number of areas taken is the same every frame, and areas are given back (more frames than the bitmap could serve)."""
     from conftest import packed_scene
-    path = '/tmp/_overflow_%s.bin' % scene
+    path = str(tmp_path / ('overflow_%s.bin' % scene))
     open(path, 'wb').write(_synth_scene_bytes(scene) if scene.startswith('synth') else packed_scene(scene))
     env = dict(os.environ, RTMI_LIBRARY='librtmi_teststack.so', RTMI_PACKET=packet, RTMI_DEFER_BUDGET=budget)
     r = subprocess.run([sys.executable, '-c', _OVERFLOW_SCRIPT % dict(root=ROOT), path], env=env, capture_output=True, text=True, timeout=600)
@@ -141,8 +144,7 @@ def test_packet_stack_overflow_areas(packet, budget, scene):
 def _terrain_scene_bytes(n=708, rows_per_shape=44, seed=5):
     """a height field of n x n quads (1 002 528 triangles for n = 708) facing the demo camera, cut into shapes of fewer
     than 65 536 vertices (ushort indices); packed by the product's C++ loader"""
-    d = '/tmp/_terrain_%d' % n
-    os.makedirs(d, exist_ok=True)
+    d = tempfile.mkdtemp(prefix='rtmi_terrain_%d_' % n)
     rng = np.random.default_rng(seed)
     xs = np.linspace(-50, 50, n + 1, dtype=np.float64)
     H = (np.sin(xs[:, None] * 0.21) * np.cos(xs[None, :] * 0.17) * 6.0 + rng.normal(scale=0.35, size=(n + 1, n + 1))).astype(np.float32)
@@ -164,7 +166,9 @@ def _terrain_scene_bytes(n=708, rows_per_shape=44, seed=5):
     open(os.path.join(d, 'terrain.txt'), 'w').write('LIGHT 0.0 60.0 -130.0 1000.0\nMESH %s' % os.path.join(d, 'terrain.obj'))
     subprocess.check_call([os.path.join(ROOT, 'apps', 'bin', 'scene_pack_tool'), os.path.join(d, 'terrain.txt'),
                            os.path.join(d, 'terrain.bin')], cwd=ROOT)
-    return open(os.path.join(d, 'terrain.bin'), 'rb').read()
+    buf = open(os.path.join(d, 'terrain.bin'), 'rb').read()
+    shutil.rmtree(d, ignore_errors=True)
+    return buf
 
 
 def test_one_million_triangles(gpu_ctx):

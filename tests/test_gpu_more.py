@@ -79,6 +79,53 @@ def test_ray_buffer_ragged_random_and_degenerate(gpu_ctx):
     assert one.tobytes() == want[:1].tobytes()
 
 
+@pytest.mark.parametrize('name', ['cube', 'tenryuu', 'clumsydragon'])
+def test_ray_buffer_rays_parallel_to_the_yz_plane_on_box_planes(gpu_ctx, name, monkeypatch):
+    """Rays of a ray buffer with direction.x = +-0 keep to the search tree (trace_kernels.hip, ray_root<0>): their 1/d.x is infinite, and
+    where the origin's x equals a plane of a box the slab product is 0 * inf = NaN -- which the reference's staged test treats as "no
+    constraint on x" (DESIGN.md section 2, "the first axis") and so do the sign-selected tests of the lane-per-ray and wave-per-ray kernels;
+    the four-wide packet kernel hands such rays to the wave-per-ray kernel at the search tree's root.  Origins on vertex x coordinates (= box
+    planes), inside and outside the model, both signs of zero, every strategy: the oracle's contacts (reference tree, staged test)."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, ob = oracle_bvh(name)
+    sc, _ = gpu_bvh(gpu_ctx, name)
+    v, _, _ = osc.triangles() if osc.n_tris <= 20000 else (None, None, None)
+    rng = np.random.default_rng(11)
+    lo, hi = ob.nodes['lo'][ob.n, :3], ob.nodes['hi'][ob.n, :3]
+    if v is not None:
+        xs = np.unique(v[:, :, 0].ravel())
+    else:
+        xs = np.unique(np.concatenate([ob.nodes['lo'][:ob.n, 0], ob.nodes['hi'][:ob.n, 0]]))
+    n = 6000
+    rays = np.zeros(n, dtype=orc.RAY)
+    rays['idx'] = np.arange(n)
+    rays['origin'][:, 0] = rng.choice(xs, size=n)
+    rays['origin'][:, 1] = rng.uniform(lo[1] - 1, hi[1] + 1, size=n).astype(np.float32)
+    rays['origin'][:, 2] = rng.uniform(lo[2] - 3, lo[2] - 0.5, size=n).astype(np.float32)
+    rays['origin'][n // 2:, 2] = rng.uniform(lo[2], hi[2], size=n - n // 2).astype(np.float32)        # inside the model's box as well
+    ang = rng.uniform(-1.2, 1.2, size=n)
+    rays['direction'][:, 0] = np.where(rng.integers(0, 2, size=n) == 0, np.float32(0.0), np.float32(-0.0))
+    rays['direction'][:, 1] = np.sin(ang).astype(np.float32)
+    rays['direction'][:, 2] = np.cos(ang).astype(np.float32)
+    rays['direction'][:50, 1] = 0.0; rays['direction'][:50, 2] = 1.0                                 # ... and x and y both zero: the reference tree
+    want, st = ob.trace_rays(rays)
+    assert st.hits > 50
+    for strategy in ('lane:16', 'lane:1024', 'p4', 'p4s:32'):
+        # (the override is read once per process: a child per strategy)
+        import subprocess, sys as _sys, tempfile
+        with tempfile.TemporaryDirectory(prefix='rtmi_test_') as d:
+            np.save(os.path.join(d, 'r.npy'), rays.view(np.uint8)); open(os.path.join(d, 's.bin'), 'wb').write(__import__('conftest').packed_scene(name))
+            code = ("import sys, numpy as np; sys.path.insert(0, %r); from openclraytracer_amd import capi; ctx = capi.Context(0); "
+                    "sc = capi.DeviceScene(ctx, open(sys.argv[1], 'rb').read()); b = capi.DeviceBVH(ctx, sc).build(); "
+                    "np.save(sys.argv[3], b.generate_contacts_rays(np.load(sys.argv[2]).view(capi.RAY)).view(np.uint8))" % ROOT)
+            r = subprocess.run([_sys.executable, '-c', code, os.path.join(d, 's.bin'), os.path.join(d, 'r.npy'), os.path.join(d, 'c.npy')],
+                               env=dict(os.environ, RTMI_RAYS=strategy), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            got = np.load(os.path.join(d, 'c.npy')).view(capi.CONTACT).reshape(-1)
+        assert got.tobytes() == want.tobytes(), strategy
+
+
 @pytest.mark.parametrize('name', MODELS)
 def test_shading_within_tolerance(gpu_ctx, name):
     """device Blinn-Phong vs cpuShadeBlinnPhong restatement: 1e-5 relative on RGB (pow differs in the last ulps),
@@ -371,6 +418,42 @@ def test_rebuilds_replay_a_build_graph(gpu_ctx, name, mode):
             other.build()
     assert gb.graph_builds() >= 4
     gb.close(); sc.close()
+
+
+def test_frame_graph_policy_state_through_the_abi():
+    """The counters behind a graph's block start order, read through rt_frame_graph_state instead of inferred from timings: the order is
+    derived behind the first launch, then every 32 frames, and the interval doubles with every refresh while the camera stands still (64,
+    128, ... 1 024) and is 32 again once the camera moves; a graph of kernels only reports that it is issued as plain launches."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene('man'))
+        bvh = capi.DeviceBVH(ctx, sc).build()
+        osc = orc.Scene(packed_scene('man'))
+        cam = as_capi_camera(osc.demo_camera(640, 360))
+        npx = 640 * 360
+        dc, dr = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+        g = capi.FrameGraph(bvh, sc, cam, dc, dr)
+        st = g.state()
+        if st['four_wide'] and st['order_interval']:
+            assert st['order_interval'] == 32 and not st['order_sorted'] and not st['moved']
+            g.launch()
+            assert g.state()['order_sorted'] == 1 and g.state()['order_interval'] == 32 and g.state()['order_age'] == 0
+            seen = []
+            for _ in range(32 + 64 + 128 + 4):
+                g.launch()
+                seen.append(g.state()['order_interval'])
+            assert seen[30] == 32 and seen[31] == 64 and seen[31 + 63] == 64 and seen[31 + 64] == 128 and seen[31 + 64 + 128] == 256
+            cam2 = cam.copy(); cam2['viewTransform'][0][3] += 0.01
+            g.set_camera(cam2)
+            assert g.state()['order_interval'] == 32 and g.state()['moved'] == 1
+            g.launch(); ctx.synchronize()
+            assert g.state()['direct'] in (1, 2, 3) or g.state()['eager'] in (0, 1)
+        g.close(); ctx.free(dc); ctx.free(dr); bvh.close(); sc.close()
+    finally:
+        ctx.close()
 
 
 def test_rebuild_is_deterministic(gpu_ctx):
