@@ -3,7 +3,7 @@ import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as bench_mod
 newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
-R = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 src = 'gpurun_out/%s' % R
 stats = newest(src + '/stats/**/*_kernel_stats.csv')
 shutil.copy(stats, 'profiles/%s_bench_kernel_stats.csv' % R)
@@ -101,4 +101,37 @@ for f, dst in (('config_report.json', '%s_config_report.json' % R), ('bench_grou
         open('profiles/' + dst, 'w').write(txt[txt.index('{'):])
     except Exception as e:
         print('no %s: %s' % (f, e))
+# the ray-buffer entry point (tools/rays_profile.py: bench.py's three legs per scene, verified) and construct() per kernel (tools/build_profile.py)
+for name, sub, log in (('raybuffer', 'raybuffer_stats', 'raybuffer.log'), ('build', 'build_stats', 'build.log')):
+    try:
+        shutil.copy(newest(src + '/%s/**/*_kernel_stats.csv' % sub), 'profiles/%s_%s_kernel_stats.csv' % (R, name))
+        txt = [l for l in open(src + '/' + log).read().splitlines() if l.startswith('{')][-1]
+        open('profiles/%s_%s_line.json' % (R, name), 'w').write(txt + '\n')
+    except Exception as e:
+        print('no %s profile: %s' % (name, e))
+try:
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for tag in ('fetch', 'write', 'sq'):
+        f = newest(src + '/raybuffer_pmc_%s/**/*counter_collection.csv' % tag)
+        for row in csv.DictReader(open(f)):
+            k = row['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+            if k.startswith(('k_trace', 'k_resolve')) and bench_mod.kernel_tag(k) in ((0, 0), (0, 2)):      # ray-buffer instances, steady state (<0, 1> = calibration)
+                a = agg[(k, row['Counter_Name'])]; a[0] += 1; a[1] += float(row['Counter_Value'])
+    with open('profiles/%s_raybuffer_pmc_summary.csv' % R, 'w') as f:
+        f.write('kernel,counter,samples,mean_per_sample\n')
+        for (k, c), (n, v) in sorted(agg.items()):
+            f.write('"%s",%s,%d,%.3f\n' % (k, c, n, v / n))
+    ks2 = {}
+    for (k, c), (n, v) in agg.items():
+        ks2.setdefault(k, {})[c] = v / n
+    for k, c in ks2.items():
+        cyc = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+        print('ray buffer', k, 'VALU issue', round(c.get('SQ_INSTS_VALU', 0) * 2.0 / (1024 * cyc), 4) if cyc else None,
+              'HBM bytes per dispatch', int((2.0 * c.get('FETCH_SIZE', 0) + c.get('WRITE_SIZE', 0)) * 1024))
+except Exception as e:
+    print('no ray-buffer counters: %s' % e)
+try:
+    shutil.copy(src + '/raybuffer_sweep.json', 'profiles/%s_raybuffer_sweep.json' % R)
+except Exception as e:
+    print('no ray-buffer sweep: %s' % e)
 print(json.dumps({k: bench[k] for k in ('value', 'ms_per_step', 'roofline', 'roofline_valu_issue')}, indent=1)[:3000])
