@@ -643,24 +643,29 @@ void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs
 //    DESIGN.md section 2 shows why primary rays may walk this tree instead of the reference's and still produce the
 //    reference's contacts bit for bit.
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_search_tree_keys(const rt_bvh_node* nodes, uint32_t n, uint2* pairs)
+// (normalised to the MODEL's box of the scene header -- the box the reference's own codes are scaled by, RTKernelUtils.h:63-69, here with the
+//  minimum subtracted -- passed by value: the keys need the leaves and nothing of the reference tree, so the two hierarchies can be built
+//  side by side.  Through round 3 the reference ROOT's box was read, i.e. the reference refit had to finish first.)
+struct KeyBox { float lo[3], hi[3]; };
+__global__ __launch_bounds__(256) void k_search_tree_keys(const rt_bvh_node* nodes, uint32_t n, uint2* pairs, KeyBox box)
 {
     uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
-    const rt_bvh_node* root = &nodes[n];                 // reference root: union of all leaf boxes
     float u[3];
     for (int k = 0; k < 3; k++) {
         float c = (nodes[leaf].boundsMin[k] + nodes[leaf].boundsMax[k]) * 0.5f;
-        float ext = root->boundsMax[k] - root->boundsMin[k];
-        float v = (c - root->boundsMin[k]) / ext;
+        float ext = box.hi[k] - box.lo[k];
+        float v = (c - box.lo[k]) / ext;
         u[k] = (v == v) ? v : 0.0f;                      // flat axis: 0/0
     }
     pairs[leaf] = make_uint2(morton3d(u[0], u[1], u[2]), leaf);
 }
 
-void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs)
+void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3])
 {
-    hipLaunchKernelGGL(k_search_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, ref_nodes, n, pairs);
+    KeyBox b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = box_lo[k]; b.hi[k] = box_hi[k]; }
+    hipLaunchKernelGGL(k_search_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, leaves, n, pairs, b);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -74,6 +74,9 @@ static void free_build_buffers(rt_bvh* b)
     if (b->s_pairs) (void)hipFree(b->s_pairs);
     if (b->s_counters) (void)hipFree(b->s_counters);
     if (b->s_pos) (void)hipFree(b->s_pos);
+    if (b->d_sort_tmp2) (void)hipFree(b->d_sort_tmp2);
+    if (b->d_sort_scratch2) (void)hipFree(b->d_sort_scratch2);
+    b->d_sort_tmp2 = nullptr; b->d_sort_scratch2 = nullptr;
     if (b->d_sort_tmp) (void)hipFree(b->d_sort_tmp);
     if (b->d_sort_scratch) (void)hipFree(b->d_sort_scratch);
     b->d_sort_tmp = nullptr; b->d_sort_scratch = nullptr;
@@ -92,6 +95,9 @@ void rt_bvh_destroy(rt_bvh* b)
     (void)hipStreamSynchronize(b->ctx->stream);
     free_build_buffers(b);
     if (b->h_depths) (void)hipHostFree(b->h_depths);
+    if (b->build_side_stream) (void)hipStreamDestroy(b->build_side_stream);
+    if (b->build_fork) (void)hipEventDestroy(b->build_fork);
+    if (b->build_join) (void)hipEventDestroy(b->build_join);
     block_order_free(b->block_order);
     delete b;
 }
@@ -149,6 +155,10 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             e = hipMalloc((void**)&b->d_sort_tmp, (size_t)n * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_sort_scratch, radix_sort_scratch_words(n) * sizeof(uint32_t));
         }
+        if (e == hipSuccess && want_search && b->mode == RT_MODE_FAST) {        // ... and the reference tree's own, so that the two sorts can overlap
+            e = hipMalloc((void**)&b->d_sort_tmp2, (size_t)n * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc((void**)&b->d_sort_scratch2, radix_sort_scratch_words(n) * sizeof(uint32_t));
+        }
         if (e == hipSuccess && refit_by_range_queries(ctx, n, b->mode)) {
             e = hipMalloc((void**)&b->d_spans, (size_t)(n - 1) * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc(&b->d_rq_scratch, refit_rq_scratch_bytes(n));
@@ -172,7 +182,11 @@ int rt_bvh_initialize_frame(rt_bvh* b)
 }
 
 // everything a build enqueues, in stream order and nothing else (no allocation, no synchronisation: it is also what a capture records)
-static int enqueue_build(rt_bvh* b, hipStream_t s)
+// side != null (only while the build is being captured): the search tree's chain -- keys, sort, tree, refit, records -- is enqueued on that
+// stream between a fork behind the leaves and a join before the four-wide records, so the replayed graph runs the two hierarchies side by
+// side (each is a chain of small dependent kernels that leaves most of the device idle).  Eagerly the same was measured in round 3 and not
+// kept (fork / join through the host's launch path cost what the overlap gained); inside a graph the dependencies are the graph's edges.
+static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
 {
     rt_ctx* ctx = b->ctx;
     const DeviceScene& sc = b->scene->d;
@@ -185,9 +199,14 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     // 2. :195 -- the reference's network (the order of equal Morton codes is part of its result: it decides the radix tree's topology and
     // the depth-first ranks that break ties between equal t).  RT_MODE_FAST: a stable radix sort instead (30-bit codes: four passes over
     // n pairs instead of ~log^2 N / 2 network levels over N) -- the same tree wherever codes differ, leaves with EQUAL codes in index order
-    if (b->mode == RT_MODE_FAST) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp, b->n, 30u, b->d_sort_scratch);
-    else launch_bitonic_sort(s, b->d_pairs, b->N);
     const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
+    const bool want_search = !ctx->no_search_tree && !literal;
+    if (side && want_search) {                                     // fork: the search tree needs the leaves and nothing else of this chain
+        RT_HIP(ctx, hipEventRecord(b->build_fork, s));
+        RT_HIP(ctx, hipStreamWaitEvent(side, b->build_fork, 0));
+    }
+    if (b->mode == RT_MODE_FAST) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2 ? b->d_sort_tmp2 : b->d_sort_tmp, b->n, 30u, b->d_sort_scratch2 ? b->d_sort_scratch2 : b->d_sort_scratch);
+    else launch_bitonic_sort(s, b->d_pairs, b->N);
     launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
     if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
     else if (b->d_spans) {
@@ -202,8 +221,9 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], b->d_depth, 4, hipMemcpyDeviceToHost, s));
     // search tree for primary rays: same leaves, better order
-    const bool want_search = !ctx->no_search_tree && !literal;
     if (want_search) {
+        hipStream_t s_main = s;
+        if (side) s = side;                                        // (this block's launches go to the side stream; joined below)
         rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
         // (the inner nodes need no clearing: k_radix_tree writes every field of all n - 1 of them -- the parent link of a node comes from
         //  its parent, the root's is set -- and the search tree is never read back as "the reference on zeroed buffers")
@@ -211,7 +231,7 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
         const bool search_bitonic = b->search_sort_bitonic || !b->d_sort_tmp;
         if (search_bitonic) RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));          // the network's padding
         RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
-        launch_search_tree_keys(s, b->d_nodes, n, s_pairs);
+        launch_search_tree_keys(s, s_nodes, n, s_pairs, sc.bb_lo, sc.bb_hi);
         // the search tree's order is the library's own (any nested hierarchy over the reference's leaves gives the reference's contacts,
         // ties between equal t are broken by the REFERENCE rank, d_pos): a stable radix sort
         if (search_bitonic) launch_bitonic_sort(s, s_pairs, N);
@@ -222,6 +242,11 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
         launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[1], s_depth, 4, hipMemcpyDeviceToHost, s));
+        if (side) {                                                // join: the four-wide records read both trees' binary records
+            RT_HIP(ctx, hipEventRecord(b->build_join, side));
+            s = s_main;
+            RT_HIP(ctx, hipStreamWaitEvent(s, b->build_join, 0));
+        }
     }
     if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (want_search ? 2u : 1u));
     RT_HIP(ctx, hipGetLastError());
@@ -249,9 +274,17 @@ int rt_bvh_construct(rt_bvh* b)
     if (graphs && b->builds_on_allocation >= 2u) {
         if (!b->build_exec) {
             hipGraph_t g = nullptr;
+            static const bool side_by_side = [] { const char* e = std::getenv("RTMI_BUILD_SIDE_BY_SIDE"); return !(e && e[0] == '0'); }();
+            // (a dozen triangles: the fork and the join cost more than two chains of 2 us kernels overlap -- Cube 0.088 -> 0.138 ms; from a few
+            //  thousand triangles on: ClumsyDragon 0.446 -> 0.357, FAST 0.298; atrium 0.75 -> 0.68 / 0.54)
+            const bool fork = side_by_side && want_search && b->n >= 4096u;
+            if (fork && !b->build_side_stream) {
+                if (hipStreamCreateWithFlags(&b->build_side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->build_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&b->build_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); if (b->build_side_stream) (void)hipStreamDestroy(b->build_side_stream); b->build_side_stream = nullptr; }
+            }
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
             if (e == hipSuccess) {
-                const int rc = enqueue_build(b, s);
+                const int rc = enqueue_build(b, s, fork ? b->build_side_stream : nullptr);
                 e = hipStreamEndCapture(s, &g);
                 if (rc == RT_SUCCESS && e == hipSuccess && g && hipGraphInstantiate(&b->build_exec, g, nullptr, nullptr, 0) == hipSuccess) b->build_graph = g;
                 else { if (g) (void)hipGraphDestroy(g); b->build_exec = nullptr; }

@@ -175,6 +175,8 @@ struct rt_bvh {
     // construct() as a HIP graph (rtmi_bvh.hip): the sequence of one build on this BVH's buffers, captured on the second build of an
     // allocation and replayed by the later ones (a scene rebuilt every frame, OpenCLRayTracerDemo.cpp:230-234)
     hipGraph_t build_graph = nullptr; hipGraphExec_t build_exec = nullptr;
+    hipStream_t build_side_stream = nullptr; hipEvent_t build_fork = nullptr, build_join = nullptr;   // the captured build runs its two trees side by side
+    uint2* d_sort_tmp2 = nullptr; uint32_t* d_sort_scratch2 = nullptr;      // RT_MODE_FAST: the reference tree's radix sort has its own scratch (both sorts may run at once)
     uint32_t builds_on_allocation = 0;      // construct() calls since the buffers were (re)allocated
     uint32_t* h_depths = nullptr;           // pinned: [0] reference tree depth, [1] search tree depth (read back at the end of a build)
     bool clears_pending = false;            // initializeFrame's clears, enqueued with the build
@@ -292,7 +294,7 @@ void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs
                      uint32_t n, uint32_t id_offset = 0);
 void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records);
 void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out);
-void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* ref_nodes, uint32_t n, uint2* pairs);
+void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3]);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
 size_t radix_sort_scratch_words(uint32_t n);
