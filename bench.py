@@ -98,6 +98,13 @@ def load_atrium_bytes():
     return pack_scene_file(gen_scenes.ensure()['synth_atrium'])
 
 
+def load_bunny_bytes():
+    """config 3's scene: the Stanford Bunny is not shipped with the reference; seeded procedural stand-in of the same size (assets/synth)"""
+    sys.path.insert(0, os.path.join(ROOT, 'assets', 'synth'))
+    import gen_scenes
+    return pack_scene_file(gen_scenes.ensure()['synth_bunny'])
+
+
 def demo_camera(scene_bytes, resx, resy):
     """The Demo's default camera (OpenCLRayTracerDemo.cpp:202-217) as host code of the benchmark."""
     from openclraytracer_amd import capi
@@ -422,6 +429,7 @@ def main():
     # ---- everything that needs child processes happens before this process touches the GPU ------------------------------
     scene_bytes = {name: load_scene_bytes(name) for name in SCENES}
     atrium_bytes = None if args.no_extra_legs else load_atrium_bytes()
+    bunny_bytes = None if args.no_extra_legs else load_bunny_bytes()
     pmc = None
     if rank == 0 and not tiled and not args.no_pmc:
         note('counter passes (rocprofv3 --pmc, child processes)')
@@ -1088,6 +1096,68 @@ def main():
             ray_buffer['min_mrays_per_s_' + leg] = min(v[leg]['mrays_per_s'] for v in ray_buffer['per_scene'].values())
         verified['ray_buffer_legs'] = 3 * len(ray_buffer['per_scene'])
 
+    # ---- BASELINE.json configs[2] and configs[3] on this GPU (N = 1): the Bunny-class stand-in through the BVH and the Sponza-class stand-in through
+    # the Two-Level Grid (build + trace + shade) at 1920x1080, each frame verified like the others
+    config3 = config4 = None
+    if not tiled and not args.no_extra_legs:
+        note('configs 3 and 4')
+        phase('configs 3 and 4')
+        xctx = capi.Context(local_rank)
+        tmx = capi.Timer(xctx)
+        d_c, d_o = xctx.alloc(npx * 32), xctx.alloc(npx * 16)
+        if bunny_bytes is not None:
+            cam3 = demo_camera(bunny_bytes, *RES)
+            s3 = capi.DeviceScene(xctx, bunny_bytes)
+            t1 = time.perf_counter()
+            b3 = capi.DeviceBVH(xctx, s3).build()
+            build3 = (time.perf_counter() - t1) * 1e3
+            b3.generate_contacts_primary_d(cam3, d_c); xctx.synchronize()
+            g3 = capi.FrameGraph(b3, s3, cam3, d_c, d_o)
+            for _ in range(5):
+                g3.launch()
+            tmx.start()
+            for _ in range(20):
+                g3.launch()
+            tmx.stop()
+            ms3 = tmx.elapsed_ms() / 20
+            config3 = dict(workload='Bunny-class stand-in (assets/synth, %d triangles) x 1920x1080 primary rays, BVH trace + shade' % s3.n_tris,
+                           ms_per_frame=round(ms3, 4), mrays_per_s=round(npx / ms3 / 1e3, 1), first_build_ms=round(build3, 3), reference_tree_depth=b3.info()['max_depth'],
+                           search_tree_depth=b3.search_tree()['depth'], strategy=b3.trace_strategy())
+            if verified is not None:
+                if sha256_hex(np.frombuffer(bunny_bytes, dtype=np.uint8)) != bfx.get('bunny', {}).get('scene_sha256'):
+                    verified['config3'] = 'NOT verified: no digest for the stand-in scene as generated on this host'
+                else:
+                    xctx.synchronize()
+                    verify_frame(xctx, d_c, d_o, npx, bfx['bunny'][key]['default'], bfx['sample_stride'], 'config 3, Bunny-class BVH frame')
+                    verified['config3'] = 'frame equals the oracle\'s'
+            g3.close(); b3.close(); s3.close()
+        if atrium_bytes is not None:
+            cam4 = demo_camera(atrium_bytes, *RES)
+            s4 = capi.DeviceScene(xctx, atrium_bytes)
+            g4 = capi.DeviceTLG(xctx, s4).build()
+            xctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                g4.build()
+            xctx.synchronize()
+            build4 = (time.perf_counter() - t1) * 1e3 / 3
+            g4.generate_contacts_primary_d(cam4, d_c); xctx.synchronize()
+            tmx.start()
+            for _ in range(5):
+                g4.generate_contacts_primary_d(cam4, d_c)
+                capi.shade_blinn_phong_frame_d(xctx, s4, cam4, d_c, d_o)
+            tmx.stop()
+            ms4 = tmx.elapsed_ms() / 5
+            config4 = dict(workload='Sponza-class stand-in (assets/synth, %d triangles) x 1920x1080 primary rays, Two-Level Grid (densities 2.0 / 2.0) build + trace + shade' % s4.n_tris,
+                           build_ms=round(build4, 3), trace_plus_shade_ms=round(ms4, 4), mrays_per_s_grid_kept=round(npx / ms4 / 1e3, 1),
+                           mrays_per_s_rebuilt_every_frame=round(npx / (ms4 + build4) / 1e3, 1), grid=g4.info())
+            if verified is not None and fx5 is not None and 'tlg' in fx5[key]:
+                xctx.synchronize()
+                verify_frame(xctx, d_c, d_o, npx, fx5[key]['tlg'], bfx['sample_stride'], 'config 4, Two-Level Grid frame')
+                verified['config4'] = 'frame equals the oracle\'s'
+            g4.close(); s4.close()
+        xctx.free(d_c); xctx.free(d_o); tmx.close(); xctx.close()
+
     phase('done')
     if rank != 0:
         if dist is not None:
@@ -1229,7 +1299,7 @@ def main():
                            policy='timed region and moving-camera leg: rt_ctx_set_frames_in_flight(5); isolated frames, first frames, config5: the default (one frame at a time)'),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
-               verified=verified, roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, ray_buffer=ray_buffer, config5=config5,
+               verified=verified, roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, ray_buffer=ray_buffer, config3=config3, config4=config4, config5=config5,
                per_rank=per_rank, per_scene=per_scene)
     print(json.dumps(out))
     if dist is not None:

@@ -110,7 +110,24 @@ def main():
     assert cam5.tobytes() == bench.demo_camera(buf, *bench.RES5).tobytes()
     _, rec5 = frame_record(osc, ob, cam5)
     atrium['%dx%d' % bench.RES5] = dict(default=rec5)
+    # BASELINE.json configs[3]: the Two-Level Grid (densities 2.0 / 2.0) over the same stand-in, 1920x1080
+    tg = orc.TLG(osc)
+    ct, stt = tg.trace_primary(cam)
+    rgba_t = orc.shade_frame(osc, cam, ct)
+    atrium[key]['tlg'] = dict(contacts_sha256=sha(ct.tobytes()), hits=int(stt['hits']), info={k: int(v) for k, v in tg.info.items()},
+                              rgba_sum=[float(x) for x in rgba_t.astype(np.float64).sum(axis=0)],
+                              rgba_samples_bits=[[int(v) for v in px] for px in rgba_t[::SAMPLE_STRIDE].view(np.uint32)])
+    print('atrium grid done  %.0f s' % (time.time() - t0), flush=True)
     fx['atrium'] = atrium
+    # BASELINE.json configs[2]: the Bunny-class stand-in (69 564 triangles), BVH, 1920x1080
+    buf = bench.load_bunny_bytes()
+    osc = orc.Scene(buf)
+    ob = orc.BVH(osc, 0)
+    cam = osc.demo_camera(*res)
+    assert cam.tobytes() == bench.demo_camera(buf, *res).tobytes()
+    _, recb = frame_record(osc, ob, cam)
+    fx['bunny'] = {'scene_sha256': sha(buf), 'triangles': osc.n_tris, key: dict(default=recb)}
+    print('bunny done  %.0f s' % (time.time() - t0), flush=True)
     json.dump(fx, open(OUT, 'w'), indent=None, separators=(',', ':'), sort_keys=True)
     print('wrote %s (%.1f KB) in %.0f s' % (OUT, os.path.getsize(OUT) / 1024.0, time.time() - t0))
 

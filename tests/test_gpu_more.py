@@ -456,6 +456,39 @@ def test_frame_graph_policy_state_through_the_abi():
         ctx.close()
 
 
+@pytest.mark.parametrize('name', ['tenryuu', 'clumsydragon'])
+def test_fused_frame_colours_at_full_hd(name):
+    """The colour path of bench.py's timed region -- a captured frame whose trace kernels shade what they store (four-wide kernel: Tenryuu;
+    lane-per-ray + wave-per-ray: ClumsyDragon) -- against the oracle's cpuShadeBlinnPhong restatement at 1920x1080, every pixel: RGB within
+    1e-5 relative, alpha and the cleared pixels exact, contacts bit for bit.  (Round 3 compared colours at 320x240 and the fused path only
+    through graph == eager.)"""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    osc, ob = oracle_bvh(name)
+    cam = osc.demo_camera(1920, 1080)
+    want_c, _ = ob.trace_primary(cam)
+    want = orc.shade_frame(osc, cam, want_c)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_frames_in_flight(5)
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        bvh = capi.DeviceBVH(ctx, sc).build()
+        npx = 1920 * 1080
+        dc, dr = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+        g = capi.FrameGraph(bvh, sc, as_capi_camera(cam), dc, dr)
+        ctx.fill_u32(dr, 0x7FC00000, npx * 4); ctx.fill_u32(dc, 0xDEADBEEF, npx * 8)
+        g.launch(); g.launch(); ctx.synchronize()
+        assert ctx.download(dc, npx, capi.CONTACT).tobytes() == want_c.tobytes()
+        got = ctx.download(dr, npx * 4, np.float32).reshape(npx, 4)
+        assert np.array_equal(got[:, 3], want[:, 3])
+        err = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want.astype(np.float64)), 1e-30)
+        assert float(np.where(got == want, 0.0, err).max()) <= 1e-5
+        g.close(); ctx.free(dc); ctx.free(dr); bvh.close(); sc.close()
+    finally:
+        ctx.close()
+
+
 def test_rebuild_is_deterministic(gpu_ctx):
     """initializeFrame + construct can be repeated (per-frame rebuild, OpenCLRayTracerDemo.cpp:230-234)."""
     _, gb = gpu_bvh(gpu_ctx, 'man')
