@@ -521,6 +521,145 @@ void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, cons
 }
 
 // ----------------------------------------------------------------------------------------
+// 4a'. refit by SPANS (round 4; every scene from 256 triangles on, both hierarchies).  The same fact as 4a -- a node's box is the ordered fold
+//      of the leaf boxes over its contiguous span of the sorted leaves, clamped once -- with a query structure that costs O(n) to build and is
+//      read without any walker waiting for another: a segment tree over the sorted leaf boxes (level k, entry m = the fold of positions
+//      [m 2^k, (m + 1) 2^k) that exist; levels 0-8 inside a block's LDS, the few entries above by one block), and per inner node the
+//      standard bottom-up decomposition of its span into O(log n) entries, left parts folded left to right, right parts right to left
+//      (RMIN / RMAX keep the RIGHT operand on ties: the order is part of the bytes).  The climb (4.) hands every box through the device's
+//      coherence point twice per level -- 65-80 us per tree at 50 032 leaves, serial in the depth; 4a's sparse table costs O(n log n) and
+//      300 us at 262 656 leaves.  NaN boxes (not associative) are detected while the leaves are gathered and send the build to the climb.
+// ----------------------------------------------------------------------------------------
+#define SEG_MAX_LEVELS 30
+struct SegLevels { uint32_t off[SEG_MAX_LEVELS]; uint32_t cnt[SEG_MAX_LEVELS]; uint32_t levels; };
+static SegLevels seg_levels(uint32_t n)
+{
+    SegLevels L{};
+    uint32_t cnt = n, off = 0, k = 0;
+    for (;;) {
+        L.off[k] = off; L.cnt[k] = cnt; k++;
+        if (cnt <= 1u || k == SEG_MAX_LEVELS) break;
+        off += cnt; cnt = (cnt + 1u) >> 1;
+    }
+    L.levels = k;
+    return L;
+}
+static size_t seg_entries(uint32_t n) { const SegLevels L = seg_levels(n); return (size_t)L.off[L.levels - 1] + L.cnt[L.levels - 1]; }
+
+__global__ __launch_bounds__(256) void k_seg_low(const rt_bvh_node* __restrict__ nodes, const uint2* __restrict__ pairs, uint32_t n, float4* __restrict__ lo,
+                                                 float4* __restrict__ hi, SegLevels L, uint32_t* __restrict__ nan_flag)
+{
+    __shared__ float4 s_lo[256], s_hi[256];
+    const uint32_t t = threadIdx.x, base = blockIdx.x * 256u, j = base + t;
+    uint32_t live = n - base < 256u ? n - base : 256u;                   // entries of this block at the current level
+    BoxPair me{};
+    if (t < live) {
+        const rt_bvh_node* lf = &nodes[pairs[j].y];
+        me.lo = make_float4(lf->boundsMin[0], lf->boundsMin[1], lf->boundsMin[2], 0.0f);
+        me.hi = make_float4(lf->boundsMax[0], lf->boundsMax[1], lf->boundsMax[2], 0.0f);
+        if (me.lo.x != me.lo.x || me.lo.y != me.lo.y || me.lo.z != me.lo.z || me.hi.x != me.hi.x || me.hi.y != me.hi.y || me.hi.z != me.hi.z) atomicOr(nan_flag, 1u);
+        lo[j] = me.lo; hi[j] = me.hi;                                     // level 0 (L.off[0] == 0)
+    }
+    s_lo[t] = me.lo; s_hi[t] = me.hi;
+    __syncthreads();
+    for (uint32_t k = 1; k <= 8u && k < L.levels; k++) {
+        const uint32_t below = live;
+        live = (live + 1u) >> 1;
+        BoxPair a{};
+        if (t < live) {
+            a.lo = s_lo[2u * t]; a.hi = s_hi[2u * t];
+            if (2u * t + 1u < below) { BoxPair b; b.lo = s_lo[2u * t + 1u]; b.hi = s_hi[2u * t + 1u]; a = rm_fold(a, b); }
+        }
+        __syncthreads();
+        if (t < live) {
+            s_lo[t] = a.lo; s_hi[t] = a.hi;
+            const size_t at = (size_t)L.off[k] + (base >> k) + t;
+            lo[at] = a.lo; hi[at] = a.hi;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_seg_top(float4* __restrict__ lo, float4* __restrict__ hi, SegLevels L)
+{
+    for (uint32_t k = 9; k < L.levels; k++) {
+        const float4* plo = lo + L.off[k - 1]; const float4* phi = hi + L.off[k - 1];
+        for (uint32_t m = threadIdx.x; m < L.cnt[k]; m += 1024u) {
+            BoxPair a; a.lo = plo[2u * m]; a.hi = phi[2u * m];
+            if (2u * m + 1u < L.cnt[k - 1]) { BoxPair b; b.lo = plo[2u * m + 1u]; b.hi = phi[2u * m + 1u]; a = rm_fold(a, b); }
+            lo[(size_t)L.off[k] + m] = a.lo; hi[(size_t)L.off[k] + m] = a.hi;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+template <bool TIGHT>
+__global__ __launch_bounds__(256) void k_seg_refit(rt_bvh_node* __restrict__ nodes, const uint2* __restrict__ spans, uint32_t n, const float4* __restrict__ lo,
+                                                   const float4* __restrict__ hi, SegLevels L, int32_t* __restrict__ marks)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1u) return;
+    const uint2 sp = spans[i];
+    uint32_t a = sp.x, b = sp.y, k = 0;
+    BoxPair left{}, right{};
+    bool have_left = false, have_right = false;
+    for (;;) {
+        if (a & 1u) {                                               // a right child: nothing to its left belongs to the span
+            BoxPair e; e.lo = lo[(size_t)L.off[k] + a]; e.hi = hi[(size_t)L.off[k] + a];
+            left = have_left ? rm_fold(left, e) : e; have_left = true;
+            a++;
+        }
+        if (!(b & 1u)) {                                            // a left child: nothing to its right belongs to the span
+            BoxPair e; e.lo = lo[(size_t)L.off[k] + b]; e.hi = hi[(size_t)L.off[k] + b];
+            right = have_right ? rm_fold(e, right) : e; have_right = true;
+            if (b == 0u) break;                                     // (a > b follows: a >= 1 here unless the span was [0, 0], which no inner node has)
+            b--;
+        }
+        if (a > b) break;
+        a >>= 1; b >>= 1; k++;
+    }
+    const BoxPair acc = (have_left && have_right) ? rm_fold(left, right) : (have_left ? left : right);
+    rt_bvh_node* nd = &nodes[n + i];
+    if (TIGHT) {
+        nd->boundsMin[0] = acc.lo.x; nd->boundsMin[1] = acc.lo.y; nd->boundsMin[2] = acc.lo.z; nd->boundsMin[3] = 0.0f;
+        nd->boundsMax[0] = acc.hi.x; nd->boundsMax[1] = acc.hi.y; nd->boundsMax[2] = acc.hi.z; nd->boundsMax[3] = 0.0f;
+    } else {
+        // the clamps of merge3 against the node's init box (FLT_MAX, FLT_MIN): value preserving, applied once (as in 4a)
+        nd->boundsMin[0] = RMIN(acc.lo.x, FLT_MAX); nd->boundsMin[1] = RMIN(acc.lo.y, FLT_MAX); nd->boundsMin[2] = RMIN(acc.lo.z, FLT_MAX); nd->boundsMin[3] = 0.0f;
+        nd->boundsMax[0] = RMAX(acc.hi.x, FLT_MIN); nd->boundsMax[1] = RMAX(acc.hi.y, FLT_MIN); nd->boundsMax[2] = RMAX(acc.hi.z, FLT_MIN); nd->boundsMax[3] = 0.0f;
+    }
+    atomicAdd(&marks[sp.x], 1);
+    atomicAdd(&marks[sp.y + 1u], -1);
+}
+
+size_t refit_span_scratch_bytes(uint32_t n)
+{
+    return seg_entries(n) * 2 * sizeof(float4) + ((size_t)n + 1) * 2 * sizeof(uint32_t) + scan_scratch_words(n + 1) * sizeof(uint32_t) + 256;
+}
+
+// boxes of all inner nodes + the tree depth; *nan_flag_out (device word, zeroed here) != 0 afterwards: NaN boxes, the climb must redo it
+void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
+                       uint32_t* nan_flag_out, bool tight)
+{
+    const SegLevels L = seg_levels(n);
+    const size_t entries = seg_entries(n);
+    float4* lo = (float4*)scratch; float4* hi = lo + entries;
+    int32_t* marks = (int32_t*)(hi + entries);
+    uint32_t* covered = (uint32_t*)marks + (n + 1);
+    uint32_t* scan_scratch = covered + (n + 1);
+    (void)hipMemsetAsync(marks, 0, ((size_t)n + 1) * sizeof(int32_t), s);
+    (void)hipMemsetAsync(nan_flag_out, 0, sizeof(uint32_t), s);
+    (void)hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_seg_low, dim3((n + 255) / 256), dim3(256), 0, s, nodes, pairs, n, lo, hi, L, nan_flag_out);
+    if (L.levels > 9u) hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, s, lo, hi, L);
+    if (tight) hipLaunchKernelGGL(k_seg_refit<true>, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, spans, n, (const float4*)lo, (const float4*)hi, L, marks);
+    else hipLaunchKernelGGL(k_seg_refit<false>, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, spans, n, (const float4*)lo, (const float4*)hi, L, marks);
+    launch_scan_inclusive(s, (const uint32_t*)marks, covered, n, scan_scratch);         // two's complement: the running sums are the cover counts
+    hipLaunchKernelGGL(k_rq_depth, dim3(256), dim3(256), 0, s, covered, n, depth_out);
+}
+
+// ----------------------------------------------------------------------------------------
 // 4b. LITERAL_ZERO refit (compatibility mode): computeBoundingBoxes as launched by
 //     BVHManager.cpp:214-217 on zero-initialised buffers, made deterministic: one walker per work item of the
 //     64-wide launch (items beyond the last leaf are clamped to it, BVHKernels.cl:67), every arrival counted, every

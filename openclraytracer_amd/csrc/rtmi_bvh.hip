@@ -80,6 +80,10 @@ static void free_build_buffers(rt_bvh* b)
     if (b->d_sort_tmp) (void)hipFree(b->d_sort_tmp);
     if (b->d_sort_scratch) (void)hipFree(b->d_sort_scratch);
     b->d_sort_tmp = nullptr; b->d_sort_scratch = nullptr;
+    if (b->s_spans) (void)hipFree(b->s_spans);
+    if (b->s_span_scratch) (void)hipFree(b->s_span_scratch);
+    if (b->d_span_scratch) (void)hipFree(b->d_span_scratch);
+    b->s_spans = nullptr; b->s_span_scratch = nullptr; b->d_span_scratch = nullptr;
     if (b->d_spans) (void)hipFree(b->d_spans);
     if (b->d_rq_scratch) (void)hipFree(b->d_rq_scratch);
     b->d_spans = nullptr; b->d_rq_scratch = nullptr;
@@ -106,11 +110,18 @@ void rt_bvh_destroy(rt_bvh* b)
 // the reference tree, which duplicate Morton codes turn into chains of thousands of levels.  Same node bytes either way; below
 // the threshold the single climbing launch is faster than the dozen small launches of the query structure.
 // env RTMI_REFIT=rq / climb forces one (tests run both on every fixture).
-static bool refit_by_range_queries(const rt_ctx* ctx, uint32_t n, int mode)
+static bool refit_by_range_queries(const rt_ctx* ctx, uint32_t n, int mode)       // round 2's sparse table: only on request since round 4
 {
     if (mode == RT_MODE_LITERAL_ZERO || n < 256u) return false;
-    if (ctx->refit_choice) return ctx->refit_choice == 1;
-    return n >= (1u << 17);
+    return ctx->refit_choice == 1;
+}
+// Refit by spans over a segment tree of the sorted leaf boxes (build_kernels.hip 4a'): no walker waits for another, O(n) to build -- every
+// scene from 256 triangles on, both hierarchies (below that a climb of a handful of levels is one launch).  RTMI_REFIT=climb / rq restore
+// the older paths (tests run all three on every fixture: same node bytes).
+static bool refit_by_spans(const rt_ctx* ctx, uint32_t n, int mode)
+{
+    if (mode == RT_MODE_LITERAL_ZERO || n < 256u) return false;
+    return ctx->refit_choice == 0 || ctx->refit_choice == 3;
 }
 
 int rt_bvh_initialize_frame(rt_bvh* b)
@@ -163,6 +174,12 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             e = hipMalloc((void**)&b->d_spans, (size_t)(n - 1) * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc(&b->d_rq_scratch, refit_rq_scratch_bytes(n));
         }
+        if (e == hipSuccess && refit_by_spans(ctx, n, b->mode)) {
+            e = hipMalloc((void**)&b->d_spans, (size_t)(n - 1) * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc(&b->d_span_scratch, refit_span_scratch_bytes(n));
+            if (e == hipSuccess && want_search) e = hipMalloc((void**)&b->s_spans, (size_t)(n - 1) * sizeof(uint2));
+            if (e == hipSuccess && want_search) e = hipMalloc(&b->s_span_scratch, refit_span_scratch_bytes(n));
+        }
         if (e != hipSuccess) {
             free_build_buffers(b);
             (void)hipGetLastError();
@@ -210,9 +227,10 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
     launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
     if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
     else if (b->d_spans) {
-        // 4. by range queries; NaN boxes (not associative) send it back to the climb -- decided on the device: the climb is launched
-        // behind it and runs only if the query pass raised its flag
-        launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_rq_scratch, b->d_depth, b->d_depth + 1);
+        // 4. by spans (or, on request, round 2's range queries); NaN boxes (not associative) send it back to the climb -- decided on the
+        // device: the climb is launched behind it and runs only if the pass raised its flag
+        if (b->d_span_scratch) launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_span_scratch, b->d_depth, b->d_depth + 1, false);
+        else launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_rq_scratch, b->d_depth, b->d_depth + 1);
         launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth, false, b->d_depth + 1);
     }
     else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
@@ -236,9 +254,13 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
         // ties between equal t are broken by the REFERENCE rank, d_pos): a stable radix sort
         if (search_bitonic) launch_bitonic_sort(s, s_pairs, N);
         else launch_radix_sort(s, s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
-        launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u);
-        uint32_t* s_depth = s_counters + n;                     // spare words behind the counters
-        launch_refit(s, s_nodes, s_counters, n, s_depth, !ctx->search_tree_reference_boxes);
+        launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u, b->s_spans);
+        uint32_t* s_depth = s_counters + n;                     // spare words behind the counters ([0] depth, [1] NaN flag of the span refit)
+        const bool tight = !ctx->search_tree_reference_boxes;
+        if (b->s_spans && b->s_span_scratch) {
+            launch_refit_span(s, s_nodes, s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight);
+            launch_refit(s, s_nodes, s_counters, n, s_depth, tight, s_depth + 1);
+        } else launch_refit(s, s_nodes, s_counters, n, s_depth, tight);
         launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[1], s_depth, 4, hipMemcpyDeviceToHost, s));

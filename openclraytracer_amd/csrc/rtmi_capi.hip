@@ -162,7 +162,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_TRACE_DIAG")) ctx->trace_diagnostics = env[0] == '1';
     if (const char* env = std::getenv("RTMI_CALIBRATION_LOG")) ctx->calibration_log = env[0] == '1';
     if (const char* env = std::getenv("RTMI_RECALIBRATE")) ctx->recalibrate = env[0] == '1';
-    if (const char* env = std::getenv("RTMI_REFIT")) ctx->refit_choice = env[0] == 'r' ? 1 : env[0] == 'c' ? 2 : 0;
+    if (const char* env = std::getenv("RTMI_REFIT")) ctx->refit_choice = env[0] == 'r' ? 1 : env[0] == 'c' ? 2 : env[0] == 's' ? 3 : 0;
     if (const char* env = std::getenv("RTMI_SEARCH_TREE")) ctx->no_search_tree = env[0] == '0';
     if (const char* env = std::getenv("RTMI_PACKET")) { ctx->force_packet = env[0] == '1' || env[0] == '4'; ctx->force_packet4 = env[0] == '4'; ctx->no_packet = env[0] == '0'; }
     if (const char* env = std::getenv("RTMI_PACKET4")) ctx->no_packet4 = env[0] == '0';

@@ -105,7 +105,7 @@ struct rt_ctx {
     int poison = 0;               // test knob (env RTMI_POISON=bits): new deferred-list (1) / split-list (2) / key (4) buffers are filled with 0xCD
     bool no_search_tree = false;  // knob (env RTMI_SEARCH_TREE=0): primary rays walk the reference tree
     bool trace_diagnostics = false; // knob (env RTMI_TRACE_DIAG=1)
-    int refit_choice = 0;         // knob (env RTMI_REFIT=rq / climb): 1 range-query refit, 2 climbing refit, 0 by triangle count
+    int refit_choice = 0;         // knob (env RTMI_REFIT=rq / climb / span): 1 range-query refit (round 2's sparse table), 2 climbing refit, 3 / 0 refit by spans (from 256 triangles on)
     bool recalibrate = false;     // knob (env RTMI_RECALIBRATE=1): every construct() forgets the calibrated trace strategy
     bool calibration_log = false; // knob (env RTMI_CALIBRATION_LOG=1): one stderr line per calibration candidate
     uint32_t long_list_limit = 0; // test knob (env RTMI_LONG_LIST_MAX): caps the deferred-ray list, 0 = RT_LONG_LIST_MAX
@@ -184,6 +184,9 @@ struct rt_bvh {
     uint2* d_sort_tmp = nullptr;       // radix sort: n pairs to ping-pong with, then its histograms (launch_radix_sort)
     uint32_t* d_sort_scratch = nullptr;
     bool search_sort_bitonic = false;  // knob RTMI_SEARCH_SORT=bitonic: the search tree's keys through the bitonic network, as in rounds 1-3
+    uint2* s_spans = nullptr;          // the search tree's spans + scratch of its refit by spans
+    void* s_span_scratch = nullptr;
+    void* d_span_scratch = nullptr;    // the reference tree's (refit by spans)
     uint2* d_spans = nullptr;          // range-query refit: [first, last] of every inner node + its scratch (large scenes only)
     void* d_rq_scratch = nullptr;
     uint32_t* d_packet_spill = nullptr;   // packet kernels: bitmap + stack overflow areas, sized from the tree depth
@@ -288,6 +291,9 @@ void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, ui
 size_t refit_rq_scratch_bytes(uint32_t n);
 void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
                      uint32_t* nan_flag_out);      // range-query refit (large scenes); *nan_flag_out != 0: NaN boxes, redo with launch_refit
+size_t refit_span_scratch_bytes(uint32_t n);
+void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
+                       uint32_t* nan_flag_out, bool tight);   // refit by spans over a segment tree of the sorted leaf boxes (every size); *nan_flag_out != 0: redo with launch_refit
 void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false, const uint32_t* only_if = nullptr);   // boxes + tree depth; tight: plain unions (search tree); only_if: runs only when that device word is non-zero
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,

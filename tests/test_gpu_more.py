@@ -1321,13 +1321,16 @@ def test_cpp_demo_tiles_the_frame_over_several_ranks(gpu_ctx, tmp_path):
 
 # ---- round 2: refit by range queries (no serial climb) --------------------------------------------------------------------
 
+@pytest.mark.parametrize('how', ['rq', 'climb', 'span'])
 @pytest.mark.parametrize('name', ['gardenlight', 'tenryuu', 'man', 'clumsydragon'])
-def test_range_query_refit_gives_the_same_node_bytes(name, monkeypatch):
+def test_range_query_refit_gives_the_same_node_bytes(name, how, monkeypatch):
     """RTMI_REFIT=rq: every inner box as the rightmost minimum / maximum over the node's span of sorted leaves (prefix / suffix
-    folds per 64-leaf block + a sparse table) instead of climbing parent links: same 48-byte nodes, same depth, same contacts."""
+    folds per 64-leaf block + a sparse table) instead of climbing parent links; span (round 4, the default): the same fold read out of a
+    segment tree over the sorted leaf boxes; climb: parent links.  Same 48-byte nodes, same depth, same contacts, whichever -- and the search
+    tree, refitted the same way, nests tightly (test_search_tree_nests_tightly_over_the_reference_leaves runs on the default)."""
     from openclraytracer_amd import capi
     from conftest import packed_scene
-    monkeypatch.setenv('RTMI_REFIT', 'rq')
+    monkeypatch.setenv('RTMI_REFIT', how)
     osc, ob = oracle_bvh(name)
     ctx = capi.Context(0)
     try:
@@ -1347,12 +1350,14 @@ def test_range_query_refit_gives_the_same_node_bytes(name, monkeypatch):
         ctx.close()
 
 
-def test_range_query_refit_falls_back_on_nan_boxes(monkeypatch):
-    """a NaN vertex makes min / max non-associative: the range-query refit detects it and the climbing refit runs instead"""
+@pytest.mark.parametrize('how', ['rq', 'span'])
+def test_range_query_refit_falls_back_on_nan_boxes(how, monkeypatch):
+    """a NaN vertex makes min / max non-associative: the range-query / span refit detects it and the climbing refit runs instead (launched
+    behind it, decided on the device)"""
     import oracle as orc
     from openclraytracer_amd import capi
     from conftest import packed_scene
-    monkeypatch.setenv('RTMI_REFIT', 'rq')
+    monkeypatch.setenv('RTMI_REFIT', how)
     buf = bytearray(packed_scene('gardenlight'))
     h = __import__('scene_pack').scene_header(bytes(buf))
     # first vertex of the first mesh: SceneHeader 96 + lights 16 each + spheres 16 + materials 96 each, ModelHeader 64, MeshHeader 48
