@@ -96,10 +96,12 @@ __device__ __forceinline__ float normalize_scale(float oldMin, float oldMax, flo
     return percentage * newLen + 0.0f;
 }
 
-__global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_node* nodes, uint2* pairs)
+// (threads beyond the last triangle write the pair buffer's padding, (UINT_MAX, UINT_MAX) up to the power of two N: BVHManager.cpp:134-140 clears
+//  the whole buffer to it before the kernel; every entry below n is overwritten here anyway, so the clearing pass is this kernel's tail)
+__global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded)
 {
     uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= sc.n_tris) return;
+    if (leaf >= sc.n_tris) { if (leaf < padded) pairs[leaf] = make_uint2(UINT_MAX, UINT_MAX); return; }
     float4 a = sc.v0[leaf], b = sc.v1[leaf], c = sc.v2[leaf];
     float lo[3] = { RMIN(RMIN(a.x, b.x), c.x), RMIN(RMIN(a.y, b.y), c.y), RMIN(RMIN(a.z, b.z), c.z) };
     float hi[3] = { RMAX(RMAX(a.x, b.x), c.x), RMAX(RMAX(a.y, b.y), c.y), RMAX(RMAX(a.z, b.z), c.z) };
@@ -126,9 +128,10 @@ __global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_no
     pairs[leaf] = make_uint2(morton3d(nx, ny, nz), leaf);
 }
 
-void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs)
+void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded)
 {
-    hipLaunchKernelGGL(k_morton_leaves, dim3((sc.n_tris + 255) / 256), dim3(256), 0, s, sc, nodes, pairs);
+    const uint32_t threads = padded > sc.n_tris ? padded : sc.n_tris;
+    hipLaunchKernelGGL(k_morton_leaves, dim3((threads + 255) / 256), dim3(256), 0, s, sc, nodes, pairs, padded);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -199,9 +202,11 @@ __device__ uint32_t span_split(const uint2* __restrict__ keys, KeySpan sp)
     return yes;
 }
 
-__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* __restrict__ keys, uint32_t n, uint32_t built, uint2* __restrict__ spans)
+// (clear2: two words the refit behind this kernel accumulates into -- tree depth, NaN flag -- cleared here instead of by two fill launches)
+__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* __restrict__ keys, uint32_t n, uint32_t built, uint2* __restrict__ spans, uint32_t* clear2)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0u && clear2 != nullptr) { clear2[0] = 0u; clear2[1] = 0u; }
     if (i >= built) return;
     const KeySpan sp = inner_node_span(keys, i, n);
     const uint32_t split = span_split(keys, sp);
@@ -222,10 +227,10 @@ __global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const ui
     nodes[child_b].data[0] = self;
 }
 
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans)
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans, uint32_t* clear2)
 {
     if (built == 0u) return;
-    hipLaunchKernelGGL(k_radix_tree, dim3((built + 255) / 256), dim3(256), 0, s, nodes, pairs, n, built, spans);
+    hipLaunchKernelGGL(k_radix_tree, dim3((built + 255) / 256), dim3(256), 0, s, nodes, pairs, n, built, spans, clear2);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -547,7 +552,7 @@ static SegLevels seg_levels(uint32_t n)
 static size_t seg_entries(uint32_t n) { const SegLevels L = seg_levels(n); return (size_t)L.off[L.levels - 1] + L.cnt[L.levels - 1]; }
 
 __global__ __launch_bounds__(256) void k_seg_low(const rt_bvh_node* __restrict__ nodes, const uint2* __restrict__ pairs, uint32_t n, float4* __restrict__ lo,
-                                                 float4* __restrict__ hi, SegLevels L, uint32_t* __restrict__ nan_flag)
+                                                 float4* __restrict__ hi, SegLevels L, uint32_t* __restrict__ nan_flag, int32_t* __restrict__ marks)
 {
     __shared__ float4 s_lo[256], s_hi[256];
     const uint32_t t = threadIdx.x, base = blockIdx.x * 256u, j = base + t;
@@ -559,6 +564,8 @@ __global__ __launch_bounds__(256) void k_seg_low(const rt_bvh_node* __restrict__
         me.hi = make_float4(lf->boundsMax[0], lf->boundsMax[1], lf->boundsMax[2], 0.0f);
         if (me.lo.x != me.lo.x || me.lo.y != me.lo.y || me.lo.z != me.lo.z || me.hi.x != me.hi.x || me.hi.y != me.hi.y || me.hi.z != me.hi.z) atomicOr(nan_flag, 1u);
         lo[j] = me.lo; hi[j] = me.hi;                                     // level 0 (L.off[0] == 0)
+        marks[j] = 0;                                                     // (the span marks of k_seg_refit start at zero: no fill launch)
+        if (j + 1u == n) marks[n] = 0;
     }
     s_lo[t] = me.lo; s_hi[t] = me.hi;
     __syncthreads();
@@ -633,6 +640,67 @@ __global__ __launch_bounds__(256) void k_seg_refit(rt_bvh_node* __restrict__ nod
     atomicAdd(&marks[sp.y + 1u], -1);
 }
 
+// The tree depth = the largest number of spans covering a leaf position = the maximum of the running sums of the +1 / -1 marks.  One launch:
+// every block takes a tile of 4 096 marks (a thread 16 consecutive ones: its total and the maximum of its running sum, shifted by the
+// exclusive scan of the totals inside the block), leaves the tile's (total, maximum) where the others can see it, and the block that
+// finishes LAST (a ticket counter) combines the tiles in order.  (4a does this with the library's multi-launch scan and a maximum.)
+#define SEG_DEPTH_TILE 4096u
+__device__ __forceinline__ int32_t seg_block_exclusive(int32_t v, int32_t* sh /* 256 */, int32_t* total)
+{
+    const uint32_t t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
+        const int32_t o = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += o;
+        __syncthreads();
+    }
+    const int32_t inc = sh[t];
+    *total = sh[255];
+    __syncthreads();
+    return inc - v;
+}
+__global__ __launch_bounds__(256) void k_seg_depth(const int32_t* __restrict__ marks, uint32_t n, int32_t* tile_out /* 2 words per tile */, uint32_t* ticket,
+                                                   uint32_t* __restrict__ depth_out)
+{
+    __shared__ int32_t sh[256];
+    __shared__ int32_t sh_max[256];
+    __shared__ uint32_t s_last;
+    const uint32_t t = threadIdx.x, tiles = gridDim.x;
+    const uint32_t first = blockIdx.x * SEG_DEPTH_TILE + t * 16u;
+    int32_t run = 0, best = 0;
+    for (uint32_t k = 0; k < 16u; k++) { const uint32_t j = first + k; if (j < n) { run += marks[j]; best = run > best ? run : best; } }
+    int32_t total;
+    const int32_t off = seg_block_exclusive(run, sh, &total);
+    sh_max[t] = off + best;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) { if (t < o) sh_max[t] = sh_max[t] > sh_max[t + o] ? sh_max[t] : sh_max[t + o]; __syncthreads(); }
+    if (t == 0) {
+        __hip_atomic_store(&tile_out[2u * blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tile_out[2u * blockIdx.x + 1u], sh_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my tile stands in memory before my ticket is drawn
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    int32_t carry = 0, deepest = 0;
+    for (uint32_t base = 0; base < tiles; base += 256u) {
+        const uint32_t k = base + t;
+        const int32_t tot = k < tiles ? __hip_atomic_load(&tile_out[2u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int32_t mx = k < tiles ? __hip_atomic_load(&tile_out[2u * k + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int32_t round_total;
+        const int32_t ex = seg_block_exclusive(tot, sh, &round_total);
+        sh_max[t] = k < tiles ? carry + ex + mx : 0;
+        __syncthreads();
+        for (uint32_t o = 128; o > 0; o >>= 1) { if (t < o) sh_max[t] = sh_max[t] > sh_max[t + o] ? sh_max[t] : sh_max[t + o]; __syncthreads(); }
+        deepest = sh_max[0] > deepest ? sh_max[0] : deepest;
+        carry += round_total;
+        __syncthreads();
+    }
+    if (t == 0) { *depth_out = (uint32_t)deepest; *ticket = 0u; }             // (the ticket counter is left at zero for the next build)
+}
+
 size_t refit_span_scratch_bytes(uint32_t n)
 {
     return seg_entries(n) * 2 * sizeof(float4) + ((size_t)n + 1) * 2 * sizeof(uint32_t) + scan_scratch_words(n + 1) * sizeof(uint32_t) + 256;
@@ -648,15 +716,13 @@ void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, co
     int32_t* marks = (int32_t*)(hi + entries);
     uint32_t* covered = (uint32_t*)marks + (n + 1);
     uint32_t* scan_scratch = covered + (n + 1);
-    (void)hipMemsetAsync(marks, 0, ((size_t)n + 1) * sizeof(int32_t), s);
-    (void)hipMemsetAsync(nan_flag_out, 0, sizeof(uint32_t), s);
-    (void)hipMemsetAsync(depth_out, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_seg_low, dim3((n + 255) / 256), dim3(256), 0, s, nodes, pairs, n, lo, hi, L, nan_flag_out);
+    // (depth_out and nan_flag_out are consecutive words cleared by the k_radix_tree launch in front of this refit: launch_radix_tree's clear2)
+    hipLaunchKernelGGL(k_seg_low, dim3((n + 255) / 256), dim3(256), 0, s, nodes, pairs, n, lo, hi, L, nan_flag_out, marks);
     if (L.levels > 9u) hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, s, lo, hi, L);
     if (tight) hipLaunchKernelGGL(k_seg_refit<true>, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, spans, n, (const float4*)lo, (const float4*)hi, L, marks);
     else hipLaunchKernelGGL(k_seg_refit<false>, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, spans, n, (const float4*)lo, (const float4*)hi, L, marks);
-    launch_scan_inclusive(s, (const uint32_t*)marks, covered, n, scan_scratch);         // two's complement: the running sums are the cover counts
-    hipLaunchKernelGGL(k_rq_depth, dim3(256), dim3(256), 0, s, covered, n, depth_out);
+    // (covered[]: the tiles' (total, maximum) pairs; scan_scratch[0]: the ticket counter, zero between builds -- cleared once when the scratch is allocated)
+    hipLaunchKernelGGL(k_seg_depth, dim3((n + SEG_DEPTH_TILE - 1u) / SEG_DEPTH_TILE), dim3(256), 0, s, (const int32_t*)marks, n, (int32_t*)covered, scan_scratch, depth_out);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -767,11 +833,45 @@ __global__ __launch_bounds__(256) void k_leaf_positions(const uint2* pairs, uint
     if (j < n) pos[pairs[j].y] = j;
 }
 
-void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t id_offset)
+// relayout + leaf positions (+ the packed triangle records of the packet kernels, which hold the rank: trirec != null) in ONE launch: thread j
+// writes traversal record j and serves the leaf at sorted position j -- no thread reads what another writes
+__global__ __launch_bounds__(256) void k_relayout_all(const rt_bvh_node* nodes, const uint2* __restrict__ pairs, TravNode* trav, uint32_t* __restrict__ pos, uint32_t n,
+                                                      uint32_t id_offset, DeviceScene sc, TriRec* __restrict__ trirec)
 {
-    hipLaunchKernelGGL(k_relayout, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, trav, n, id_offset);
-    hipLaunchKernelGGL(k_leaf_positions, dim3((n + 255) / 256), dim3(256), 0, s, pairs, pos, n);
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n - 1u) {
+        const rt_bvh_node* nd = &nodes[n + j];
+        const uint32_t ca = nd->data[1], cb = nd->data[2];
+        TravNode t;
+        for (int k = 0; k < 3; k++) {
+            t.a_lo[k] = nodes[ca].boundsMin[k]; t.a_hi[k] = nodes[ca].boundsMax[k];
+            t.b_lo[k] = nodes[cb].boundsMin[k]; t.b_hi[k] = nodes[cb].boundsMax[k];
+        }
+        t.child_a = ca < n ? (RT_LEAF_FLAG | ca) : ca - n + id_offset;
+        t.child_b = cb < n ? (RT_LEAF_FLAG | cb) : cb - n + id_offset;
+        t.pad0 = 0; t.pad1 = 0;
+        trav[j] = t;
+    }
+    if (j < n) {
+        const uint32_t leaf = pairs[j].y;
+        pos[leaf] = j;
+        if (trirec != nullptr) {
+            const float4 v0 = sc.v0[leaf], e1 = sc.e1[leaf], e2 = sc.e2[leaf];
+            TriRec r;
+            r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z;
+            r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
+            r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
+            r.pos = j; r.material = __float_as_uint(v0.w); r.pad = 0u;
+            trirec[leaf] = r;
+        }
+    }
+}
+
+void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
+                     uint32_t n, uint32_t id_offset, const DeviceScene* sc, TriRec* trirec)
+{
+    DeviceScene none{};
+    hipLaunchKernelGGL(k_relayout_all, dim3((n + 255) / 256), dim3(256), 0, s, nodes, pairs, trav, pos, n, id_offset, sc ? *sc : none, sc ? trirec : nullptr);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -177,8 +177,10 @@ int rt_bvh_initialize_frame(rt_bvh* b)
         if (e == hipSuccess && refit_by_spans(ctx, n, b->mode)) {
             e = hipMalloc((void**)&b->d_spans, (size_t)(n - 1) * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc(&b->d_span_scratch, refit_span_scratch_bytes(n));
+            if (e == hipSuccess) e = hipMemsetAsync(b->d_span_scratch, 0, refit_span_scratch_bytes(n), ctx->stream);       // (its ticket counter starts at zero and is left at zero by every build)
             if (e == hipSuccess && want_search) e = hipMalloc((void**)&b->s_spans, (size_t)(n - 1) * sizeof(uint2));
             if (e == hipSuccess && want_search) e = hipMalloc(&b->s_span_scratch, refit_span_scratch_bytes(n));
+            if (e == hipSuccess && want_search) e = hipMemsetAsync(b->s_span_scratch, 0, refit_span_scratch_bytes(n), ctx->stream);
         }
         if (e != hipSuccess) {
             free_build_buffers(b);
@@ -208,15 +210,21 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
     rt_ctx* ctx = b->ctx;
     const DeviceScene& sc = b->scene->d;
     const uint32_t n = b->n, N = b->N;
-    // BVHManager.cpp:134-147 (initializeFrame): morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0; the node buffer is zeroed as well
-    RT_HIP(ctx, hipMemsetAsync(b->d_pairs, 0xFF, (size_t)N * sizeof(uint2), s));
-    RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), s));
-    RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
-    launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs);          // 1. BVHManager.cpp:183
+    // BVHManager.cpp:134-147 (initializeFrame): morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.  A build is a chain of dependent
+    // launches of a few microseconds each (rocprofv3: every launch of a 50 032-triangle build takes 4.5-6 us, the clearing fills included), so
+    // a clear that a kernel of the chain can do on its way is not launched: the pair buffer's padding is written by k_morton_leaves, the
+    // counters are cleared only where a climb will use them, and the node buffer -- zeroed in the reference's compatibility mode, whose
+    // never-built node must read as zeros -- is written whole by FIXED / FAST builds (leaves by k_morton_leaves, every field of all n - 1
+    // inner nodes by k_radix_tree, each node's parent link by its parent).
+    const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
+    const bool nan_possible = b->scene->has_nan;
+    const bool ref_climbs = literal || !b->d_spans || nan_possible;
+    if (ref_climbs) RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), s));
+    if (literal) RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
+    launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N);       // 1. BVHManager.cpp:183 (+ the padding of the pair buffer)
     // 2. :195 -- the reference's network (the order of equal Morton codes is part of its result: it decides the radix tree's topology and
     // the depth-first ranks that break ties between equal t).  RT_MODE_FAST: a stable radix sort instead (30-bit codes: four passes over
     // n pairs instead of ~log^2 N / 2 network levels over N) -- the same tree wherever codes differ, leaves with EQUAL codes in index order
-    const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
     const bool want_search = !ctx->no_search_tree && !literal;
     if (side && want_search) {                                     // fork: the search tree needs the leaves and nothing else of this chain
         RT_HIP(ctx, hipEventRecord(b->build_fork, s));
@@ -224,18 +232,17 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
     }
     if (b->mode == RT_MODE_FAST) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2 ? b->d_sort_tmp2 : b->d_sort_tmp, b->n, 30u, b->d_sort_scratch2 ? b->d_sort_scratch2 : b->d_sort_scratch);
     else launch_bitonic_sort(s, b->d_pairs, b->N);
-    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58)
+    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans, b->d_depth);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58); clears depth + NaN flag
     if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
     else if (b->d_spans) {
         // 4. by spans (or, on request, round 2's range queries); NaN boxes (not associative) send it back to the climb -- decided on the
         // device: the climb is launched behind it and runs only if the pass raised its flag
         if (b->d_span_scratch) launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_span_scratch, b->d_depth, b->d_depth + 1, false);
         else launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_rq_scratch, b->d_depth, b->d_depth + 1);
-        launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth, false, b->d_depth + 1);
+        if (nan_possible) launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth, false, b->d_depth + 1);     // (no NaN vertex in the scene: no NaN box, no launch)
     }
     else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
-    launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n);  // traversal records, DFS ranks
-    launch_pack_triangles(s, sc, b->d_pos, b->d_trirec);
+    launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n, 0u, &sc, b->d_trirec);  // traversal records, DFS ranks, packed triangle records
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], b->d_depth, 4, hipMemcpyDeviceToHost, s));
     // search tree for primary rays: same leaves, better order
@@ -248,18 +255,19 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
         RT_HIP(ctx, hipMemcpyAsync(s_nodes, b->d_nodes, (size_t)n * sizeof(rt_bvh_node), hipMemcpyDeviceToDevice, s));   // the leaves
         const bool search_bitonic = b->search_sort_bitonic || !b->d_sort_tmp;
         if (search_bitonic) RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));          // the network's padding
-        RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
+        const bool search_climbs = !(b->s_spans && b->s_span_scratch) || nan_possible;
+        if (search_climbs) RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
         launch_search_tree_keys(s, s_nodes, n, s_pairs, sc.bb_lo, sc.bb_hi);
         // the search tree's order is the library's own (any nested hierarchy over the reference's leaves gives the reference's contacts,
         // ties between equal t are broken by the REFERENCE rank, d_pos): a stable radix sort
         if (search_bitonic) launch_bitonic_sort(s, s_pairs, N);
         else launch_radix_sort(s, s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
-        launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u, b->s_spans);
         uint32_t* s_depth = s_counters + n;                     // spare words behind the counters ([0] depth, [1] NaN flag of the span refit)
+        launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u, b->s_spans, s_depth);
         const bool tight = !ctx->search_tree_reference_boxes;
         if (b->s_spans && b->s_span_scratch) {
             launch_refit_span(s, s_nodes, s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight);
-            launch_refit(s, s_nodes, s_counters, n, s_depth, tight, s_depth + 1);
+            if (nan_possible) launch_refit(s, s_nodes, s_counters, n, s_depth, tight, s_depth + 1);
         } else launch_refit(s, s_nodes, s_counters, n, s_depth, tight);
         launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());

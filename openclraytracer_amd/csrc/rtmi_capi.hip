@@ -324,6 +324,10 @@ int rt_scene_upload_indexed(rt_ctx* ctx, const void* h_scene_buffer, uint64_t by
             if (meshSize < 48 + 16 * nv + IB * ni || moff + meshSize > off + modelSize || mt * 3 > ni) {
                 delete sc; return RT_FAIL(ctx, "mesh sizes inconsistent");
             }
+            for (uint64_t v = 0; v < nv && !sc->has_nan; v++) {          // (a NaN coordinate makes boxes NaN: the refit by spans then keeps its fall-back)
+                float xyz[3]; std::memcpy(xyz, s + moff + 48 + 16 * v, 12);
+                if (xyz[0] != xyz[0] || xyz[1] != xyz[1] || xyz[2] != xyz[2]) sc->has_nan = true;
+            }
             const unsigned char* ib = s + moff + 48 + 16 * nv;
             for (uint64_t i = 0; i < mt * 3; i++) {
                 uint32_t v = 0; std::memcpy(&v, ib + IB * i, IB);

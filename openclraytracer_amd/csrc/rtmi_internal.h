@@ -144,6 +144,7 @@ struct rt_scene {
     void* d_meshes = nullptr;
     void* d_tri = nullptr;     // one allocation backing the SoA arrays
     float bb_w[2] = { 0, 0 };  // .w of SceneHeader.modelsBoundingBox bounds (carried into GridData.box verbatim)
+    bool has_nan = false;      // some vertex coordinate is NaN (seen at upload): only then can a leaf box be NaN and a refit by spans need its fall-back
 };
 
 struct rt_bvh {
@@ -286,8 +287,8 @@ extern "C" __attribute__((visibility("hidden"))) int rt_check_camera(rt_ctx* ctx
 // ---------------------------------------------------------------------------------------
 // build_kernels.hip
 void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
-void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs);
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr);   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO)
+void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded);   // also writes the padding pairs [n, padded)
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr, uint32_t* clear2 = nullptr);   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO); clear2: two words zeroed on the way
 size_t refit_rq_scratch_bytes(uint32_t n);
 void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
                      uint32_t* nan_flag_out);      // range-query refit (large scenes); *nan_flag_out != 0: NaN boxes, redo with launch_refit
@@ -297,7 +298,7 @@ void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, co
 void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false, const uint32_t* only_if = nullptr);   // boxes + tree depth; tight: plain unions (search tree); only_if: runs only when that device word is non-zero
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t id_offset = 0);
+                     uint32_t n, uint32_t id_offset = 0, const DeviceScene* sc = nullptr, TriRec* trirec = nullptr);   // + DFS ranks; sc / trirec: + the packed triangle records
 void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records);
 void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out);
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3]);
