@@ -97,11 +97,31 @@ __device__ __forceinline__ float normalize_scale(float oldMin, float oldMax, flo
 }
 
 // (threads beyond the last triangle write the pair buffer's padding, (UINT_MAX, UINT_MAX) up to the power of two N: BVHManager.cpp:134-140 clears
-//  the whole buffer to it before the kernel; every entry below n is overwritten here anyway, so the clearing pass is this kernel's tail)
-__global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded)
+//  the whole buffer to it before the kernel; every entry below n is overwritten here anyway, so the clearing pass is this kernel's tail.)
+// The same pass feeds the SEARCH tree (section 6 below) when the caller passes its buffers: a copy of the leaf node and the key of the box
+// centre normalised to the scene header's box -- both need the triangle and nothing else, so neither a copy of the leaves nor a key kernel
+// stands at the head of that hierarchy's chain of launches.
+struct KeyBox { float lo[3], hi[3]; };
+__device__ __forceinline__ uint32_t search_tree_key(const float lo[3], const float hi[3], const KeyBox& box)
+{
+    float u[3];
+    for (int k = 0; k < 3; k++) {
+        float c = (lo[k] + hi[k]) * 0.5f;
+        float ext = box.hi[k] - box.lo[k];
+        float v = (c - box.lo[k]) / ext;
+        u[k] = (v == v) ? v : 0.0f;                      // flat axis: 0/0
+    }
+    return morton3d(u[0], u[1], u[2]);
+}
+__global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
+                                                       rt_bvh_node* s_nodes, uint2* s_pairs, uint32_t s_padded, KeyBox box)
 {
     uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= sc.n_tris) { if (leaf < padded) pairs[leaf] = make_uint2(UINT_MAX, UINT_MAX); return; }
+    if (leaf >= sc.n_tris) {
+        if (nodes && leaf < padded) pairs[leaf] = make_uint2(UINT_MAX, UINT_MAX);
+        if (leaf < s_padded) s_pairs[leaf] = make_uint2(UINT_MAX, UINT_MAX);
+        return;
+    }
     float4 a = sc.v0[leaf], b = sc.v1[leaf], c = sc.v2[leaf];
     float lo[3] = { RMIN(RMIN(a.x, b.x), c.x), RMIN(RMIN(a.y, b.y), c.y), RMIN(RMIN(a.z, b.z), c.z) };
     float hi[3] = { RMAX(RMAX(a.x, b.x), c.x), RMAX(RMAX(a.y, b.y), c.y), RMAX(RMAX(a.z, b.z), c.z) };
@@ -124,14 +144,24 @@ __global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_no
     nd.data[3] = ref.z;        // modelIndex
     nd.boundsMin[0] = lo[0]; nd.boundsMin[1] = lo[1]; nd.boundsMin[2] = lo[2]; nd.boundsMin[3] = 1.0f; // LEAF_NODE
     nd.boundsMax[0] = hi[0]; nd.boundsMax[1] = hi[1]; nd.boundsMax[2] = hi[2]; nd.boundsMax[3] = 0.0f;
-    nodes[leaf] = nd;
-    pairs[leaf] = make_uint2(morton3d(nx, ny, nz), leaf);
+    if (nodes) {
+        nodes[leaf] = nd;
+        pairs[leaf] = make_uint2(morton3d(nx, ny, nz), leaf);
+    }
+    if (s_nodes) {
+        s_nodes[leaf] = nd;
+        s_pairs[leaf] = make_uint2(search_tree_key(lo, hi, box), leaf);
+    }
 }
 
-void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded)
+void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
+                          rt_bvh_node* s_nodes, uint2* s_pairs, uint32_t s_padded)
 {
-    const uint32_t threads = padded > sc.n_tris ? padded : sc.n_tris;
-    hipLaunchKernelGGL(k_morton_leaves, dim3((threads + 255) / 256), dim3(256), 0, s, sc, nodes, pairs, padded);
+    uint32_t threads = nodes && padded > sc.n_tris ? padded : sc.n_tris;            // (nodes == nullptr: the search tree's outputs only)
+    if (s_nodes && s_padded > threads) threads = s_padded;
+    KeyBox box;
+    for (int k = 0; k < 3; k++) { box.lo[k] = sc.bb_lo[k]; box.hi[k] = sc.bb_hi[k]; }
+    hipLaunchKernelGGL(k_morton_leaves, dim3((threads + 255) / 256), dim3(256), 0, s, sc, nodes, pairs, padded, s_nodes, s_pairs, s_nodes ? s_padded : 0u, box);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -885,19 +915,13 @@ void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs
 // (normalised to the MODEL's box of the scene header -- the box the reference's own codes are scaled by, RTKernelUtils.h:63-69, here with the
 //  minimum subtracted -- passed by value: the keys need the leaves and nothing of the reference tree, so the two hierarchies can be built
 //  side by side.  Through round 3 the reference ROOT's box was read, i.e. the reference refit had to finish first.)
-struct KeyBox { float lo[3], hi[3]; };
 __global__ __launch_bounds__(256) void k_search_tree_keys(const rt_bvh_node* nodes, uint32_t n, uint2* pairs, KeyBox box)
 {
     uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
-    float u[3];
-    for (int k = 0; k < 3; k++) {
-        float c = (nodes[leaf].boundsMin[k] + nodes[leaf].boundsMax[k]) * 0.5f;
-        float ext = box.hi[k] - box.lo[k];
-        float v = (c - box.lo[k]) / ext;
-        u[k] = (v == v) ? v : 0.0f;                      // flat axis: 0/0
-    }
-    pairs[leaf] = make_uint2(morton3d(u[0], u[1], u[2]), leaf);
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = nodes[leaf].boundsMin[k]; hi[k] = nodes[leaf].boundsMax[k]; }
+    pairs[leaf] = make_uint2(search_tree_key(lo, hi, box), leaf);
 }
 
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3])
@@ -912,11 +936,16 @@ void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t 
 //    inner children's own boxes is allowed for the same reason the search tree is (any nested hierarchy over the leaves
 //    reaches the same leaves); one wave step then descends two levels.
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t n_records, uint32_t greedy)
+// Records [first, first + count) (child ids are indices into the whole `trav` array).  A thread assembles one 128-byte record; the block hands its
+// 256 records over through LDS so that the eight 16-byte parts of a record are written by eight neighbouring lanes (whole lines per store
+// instruction instead of 64 lines touched by each of eight).
+__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t first, uint32_t count, uint32_t greedy)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_records) return;
-    const TravNode t = trav[i];
+    __shared__ float4 stage[256 * 9];
+    const uint32_t block_first = blockIdx.x * 256u;
+    const uint32_t i = first + block_first + threadIdx.x;
+    const bool live = block_first + threadIdx.x < count;
+    const TravNode t = trav[live ? i : first];
     float lo[4][3], hi[4][3];
     uint32_t id[4];
     int n = 0;
@@ -960,22 +989,25 @@ __global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restric
     // an unused slot: id = RT_SENTINEL and a box of NaN planes, which no ray enters under any of the kernels' tests (every compare with
     // a NaN is false; the camera-relative copies get an empty box of their own, k_prepare_camera)
     for (; n < 4; n++) { for (int k = 0; k < 3; k++) { lo[n][k] = __builtin_nanf(""); hi[n][k] = __builtin_nanf(""); } id[n] = RT_SENTINEL; }
-    QuadNode q;
-    q.q[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], __uint_as_float(id[0]));
-    q.q[1] = make_float4(hi[0][0], hi[0][1], hi[0][2], __uint_as_float(id[1]));
-    q.q[2] = make_float4(lo[1][0], lo[1][1], lo[1][2], __uint_as_float(id[2]));
-    q.q[3] = make_float4(hi[1][0], hi[1][1], hi[1][2], __uint_as_float(id[3]));
-    q.q[4] = make_float4(lo[2][0], lo[2][1], lo[2][2], 0.0f);
-    q.q[5] = make_float4(hi[2][0], hi[2][1], hi[2][2], 0.0f);
-    q.q[6] = make_float4(lo[3][0], lo[3][1], lo[3][2], 0.0f);
-    q.q[7] = make_float4(hi[3][0], hi[3][1], hi[3][2], 0.0f);
-    quad[i] = q;
+    float4* mine = stage + threadIdx.x * 9u;
+    mine[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], __uint_as_float(id[0]));
+    mine[1] = make_float4(hi[0][0], hi[0][1], hi[0][2], __uint_as_float(id[1]));
+    mine[2] = make_float4(lo[1][0], lo[1][1], lo[1][2], __uint_as_float(id[2]));
+    mine[3] = make_float4(hi[1][0], hi[1][1], hi[1][2], __uint_as_float(id[3]));
+    mine[4] = make_float4(lo[2][0], lo[2][1], lo[2][2], 0.0f);
+    mine[5] = make_float4(hi[2][0], hi[2][1], hi[2][2], 0.0f);
+    mine[6] = make_float4(lo[3][0], lo[3][1], lo[3][2], 0.0f);
+    mine[7] = make_float4(hi[3][0], hi[3][1], hi[3][2], 0.0f);
+    __syncthreads();
+    const uint32_t parts = (count - block_first < 256u ? count - block_first : 256u) * 8u;
+    float4* out = reinterpret_cast<float4*>(quad + first + block_first);
+    for (uint32_t p = threadIdx.x; p < parts; p += 256u) out[p] = stage[(p >> 3) * 9u + (p & 7u)];
 }
 
-void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records)
+void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count)
 {
     static const uint32_t greedy = [] { const char* e = getenv("RTMI_QUAD_BY_AREA"); return (e && e[0] == '0') ? 0u : 1u; }();
-    hipLaunchKernelGGL(k_relayout_quad, dim3((n_records + 255) / 256), dim3(256), 0, s, trav, quad, n_records, greedy);
+    if (count) hipLaunchKernelGGL(k_relayout_quad, dim3((count + 255) / 256), dim3(256), 0, s, trav, quad, first, count, greedy);
 }
 
 // ----------------------------------------------------------------------------------------

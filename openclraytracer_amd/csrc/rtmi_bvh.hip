@@ -219,17 +219,25 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
     const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
     const bool nan_possible = b->scene->has_nan;
     const bool ref_climbs = literal || !b->d_spans || nan_possible;
+    const bool want_search = !ctx->no_search_tree && !literal;
+    const bool search_bitonic = b->search_sort_bitonic || !b->d_sort_tmp;
+    // 1. BVHManager.cpp:183 (+ the padding of the pair buffer; + the search tree's leaves and keys, see there)
+    // Side by side (a replayed graph, from 4 096 triangles on): the search tree's chain forks HERE, before anything is launched, and writes its
+    // leaves and keys itself -- both chains are roots of the graph.  (Forked behind this kernel, the side stream's first kernel started 35 us
+    // after it had ended: a dependency between two queues costs that much, whatever it waits for.)
+    if (side && want_search) {
+        RT_HIP(ctx, hipEventRecord(b->build_fork, s));
+        RT_HIP(ctx, hipStreamWaitEvent(side, b->build_fork, 0));
+        launch_morton_leaves(side, sc, nullptr, nullptr, 0u, b->s_nodes, b->s_pairs, search_bitonic ? N : 0u);
+    }
     if (ref_climbs) RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), s));
     if (literal) RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
-    launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N);       // 1. BVHManager.cpp:183 (+ the padding of the pair buffer)
+    if (side && want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N);
+    else if (want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, b->s_nodes, b->s_pairs, search_bitonic ? N : 0u);
+    else launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N);
     // 2. :195 -- the reference's network (the order of equal Morton codes is part of its result: it decides the radix tree's topology and
     // the depth-first ranks that break ties between equal t).  RT_MODE_FAST: a stable radix sort instead (30-bit codes: four passes over
     // n pairs instead of ~log^2 N / 2 network levels over N) -- the same tree wherever codes differ, leaves with EQUAL codes in index order
-    const bool want_search = !ctx->no_search_tree && !literal;
-    if (side && want_search) {                                     // fork: the search tree needs the leaves and nothing else of this chain
-        RT_HIP(ctx, hipEventRecord(b->build_fork, s));
-        RT_HIP(ctx, hipStreamWaitEvent(side, b->build_fork, 0));
-    }
     if (b->mode == RT_MODE_FAST) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2 ? b->d_sort_tmp2 : b->d_sort_tmp, b->n, 30u, b->d_sort_scratch2 ? b->d_sort_scratch2 : b->d_sort_scratch);
     else launch_bitonic_sort(s, b->d_pairs, b->N);
     launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans, b->d_depth);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58); clears depth + NaN flag
@@ -251,13 +259,10 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
         if (side) s = side;                                        // (this block's launches go to the side stream; joined below)
         rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
         // (the inner nodes need no clearing: k_radix_tree writes every field of all n - 1 of them -- the parent link of a node comes from
-        //  its parent, the root's is set -- and the search tree is never read back as "the reference on zeroed buffers")
-        RT_HIP(ctx, hipMemcpyAsync(s_nodes, b->d_nodes, (size_t)n * sizeof(rt_bvh_node), hipMemcpyDeviceToDevice, s));   // the leaves
-        const bool search_bitonic = b->search_sort_bitonic || !b->d_sort_tmp;
-        if (search_bitonic) RT_HIP(ctx, hipMemsetAsync(s_pairs, 0xFF, (size_t)N * sizeof(uint2), s));          // the network's padding
+        //  its parent, the root's is set -- and the search tree is never read back as "the reference on zeroed buffers"; the leaves, the
+        //  keys -- Morton codes of the box centres normalised to the scene header's box -- and the network's padding were written by step 1)
         const bool search_climbs = !(b->s_spans && b->s_span_scratch) || nan_possible;
         if (search_climbs) RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
-        launch_search_tree_keys(s, s_nodes, n, s_pairs, sc.bb_lo, sc.bb_hi);
         // the search tree's order is the library's own (any nested hierarchy over the reference's leaves gives the reference's contacts,
         // ties between equal t are broken by the REFERENCE rank, d_pos): a stable radix sort
         if (search_bitonic) launch_bitonic_sort(s, s_pairs, N);
@@ -272,13 +277,16 @@ static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
         launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[1], s_depth, 4, hipMemcpyDeviceToHost, s));
-        if (side) {                                                // join: the four-wide records read both trees' binary records
+        // four-wide records: of the search tree only -- no kernel walks the reference tree four records wide (the policy's condition and
+        // `cur >= search_root` in the kernels), so that half of the buffer stays unwritten; at the end of this chain, not behind the join
+        if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, n - 1u, n - 1u);
+        if (side) {                                                // join
             RT_HIP(ctx, hipEventRecord(b->build_join, side));
             s = s_main;
             RT_HIP(ctx, hipStreamWaitEvent(s, b->build_join, 0));
         }
     }
-    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, (b->n - 1) * (want_search ? 2u : 1u));
+    else if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, 0u, n - 1u);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }

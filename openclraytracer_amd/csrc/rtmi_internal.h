@@ -287,7 +287,9 @@ extern "C" __attribute__((visibility("hidden"))) int rt_check_camera(rt_ctx* ctx
 // ---------------------------------------------------------------------------------------
 // build_kernels.hip
 void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
-void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded);   // also writes the padding pairs [n, padded)
+// leaves + Morton pairs (+ the padding pairs [n, padded) of the pair buffer); on request the search tree's leaves and keys as well
+void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
+                          rt_bvh_node* s_nodes = nullptr, uint2* s_pairs = nullptr, uint32_t s_padded = 0u);
 void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr, uint32_t* clear2 = nullptr);   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO); clear2: two words zeroed on the way
 size_t refit_rq_scratch_bytes(uint32_t n);
 void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
@@ -299,7 +301,7 @@ void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters,
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false, const uint32_t* only_if = nullptr);   // boxes + tree depth; tight: plain unions (search tree); only_if: runs only when that device word is non-zero
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t id_offset = 0, const DeviceScene* sc = nullptr, TriRec* trirec = nullptr);   // + DFS ranks; sc / trirec: + the packed triangle records
-void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t n_records);
+void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count);   // records [first, first + count)
 void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out);
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3]);
 // sort_scan_kernels.hip

@@ -38,7 +38,107 @@ __device__ __forceinline__ void lds_levels(uint2* tile, uint32_t tile_elems, uin
     }
 }
 
-// sorts every tile completely: lengths 1 .. tile_elems/2
+// ---- the levels inside a tile, eight elements per thread in registers ----
+// A tile of 2^B elements (B <= 12) is held by 2^(B-3) threads, eight elements each: three bits of an element's index select the register
+// (the "configuration" p: index bits p+2, p+1, p), the others the thread.  A compare-exchange level on one of the three bits is register
+// arithmetic; to reach other bits the tile is transposed through LDS (eight 8-byte writes, a barrier, eight reads).  The merge of length
+// 2^(m-1) -- levels on bits m-1 .. 0, in that order -- takes ceil(m / 3) configurations, the last one always (2, 1, 0), which is also how the
+// tile is read from and written to memory (64 contiguous bytes per thread): 27 transposes sort 4 096 elements where one level per LDS round
+// trip took 78 (44 -> see DESIGN.md, ClumsyDragon's 65 536 pairs).  Same comparators in the same order on every element as lds_levels
+// (levels of one merge commute within a level only), `reverse` from the global index of the pair's lower element: the same permutation.
+// LDS addresses are skewed by one element per eight (a thread's eight registers are 64 bytes apart in configuration 0).
+#define BT_THREADS 512u
+#define BT_PAD(e) ((e) + ((e) >> 3))
+#define BT_LDS_ELEMS (SORT_TILE + (SORT_TILE >> 3))
+__device__ __forceinline__ uint32_t bt_index(uint32_t t, uint32_t p, uint32_t j) { return ((t >> p) << (p + 3u)) | (t & ((1u << p) - 1u)) | (j << p); }
+
+__device__ __forceinline__ void bt_transpose(uint2 (&x)[8], uint2* lds, uint32_t t, bool active, uint32_t from, uint32_t to)
+{
+    if (active) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) lds[BT_PAD(bt_index(t, from, j))] = x[j];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) x[j] = lds[BT_PAD(bt_index(t, to, j))];
+    }
+    __syncthreads();
+}
+
+// the levels on the configuration's bits p + k for the k set in `mask` (descending), merge direction bit `dir`
+__device__ __forceinline__ void bt_levels(uint2 (&x)[8], uint32_t t, uint32_t p, uint32_t mask, uint32_t dir, uint32_t tile_base)
+{
+    const uint32_t mine = tile_base + bt_index(t, p, 0u);
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {
+        if (!((mask >> k) & 1u)) continue;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {
+            if (j & (1u << k)) continue;
+            const bool reverse = ((dir & (mine | (j << p))) == 0u);
+            order(x[j], x[j | (1u << k)], reverse);
+        }
+    }
+}
+
+// the merge with levels on bits m-1 .. 0 (direction bit `dir`); x is in configuration `cur` on entry and in configuration 0 on return
+__device__ __forceinline__ void bt_merge(uint2 (&x)[8], uint2* lds, uint32_t t, bool active, uint32_t B, uint32_t m, uint32_t dir, uint32_t tile_base, uint32_t cur)
+{
+    int top = (int)m - 1;
+    while (top >= 3) {
+        const uint32_t nb = (uint32_t)(top - 2) < 3u ? (uint32_t)(top - 2) : 3u;       // bits top .. top - nb + 1, all above bit 2
+        const uint32_t low = (uint32_t)top - nb + 1u;
+        const uint32_t p = low < B - 3u ? low : B - 3u;
+        if (cur != p) { bt_transpose(x, lds, t, active, cur, p); cur = p; }
+        bt_levels(x, t, p, ((1u << nb) - 1u) << (low - p), dir, tile_base);
+        top = (int)low - 1;
+    }
+    if (cur != 0u) bt_transpose(x, lds, t, active, cur, 0u);
+    bt_levels(x, t, 0u, (1u << (top + 1)) - 1u, dir, tile_base);
+}
+
+// sorts every tile completely: lengths 1 .. tile_elems/2 (tile_elems = 2^B >= 8)
+__global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_sort(uint2* data, uint32_t B)
+{
+    __shared__ uint2 lds[BT_LDS_ELEMS];
+    const uint32_t t = threadIdx.x, base = blockIdx.x << B;
+    const bool active = t < (1u << (B - 3u));
+    uint2 x[8];
+    if (active) {
+        const uint4* src = reinterpret_cast<const uint4*>(data + base + 8u * t);
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) { const uint4 v = src[q]; x[2 * q] = make_uint2(v.x, v.y); x[2 * q + 1] = make_uint2(v.z, v.w); }
+    }
+    for (uint32_t m = 1; m <= B; m++) bt_merge(x, lds, t, active, B, m, 1u << m, base, 0u);
+    if (active) {
+        uint4* dst = reinterpret_cast<uint4*>(data + base + 8u * t);
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) dst[q] = make_uint4(x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y);
+    }
+}
+
+// the tail (levels on bits B-1 .. 0) of the merge with the given length >= 2^B
+__global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_merge(uint2* data, uint32_t B, uint32_t dir)
+{
+    __shared__ uint2 lds[BT_LDS_ELEMS];
+    const uint32_t t = threadIdx.x, base = blockIdx.x << B;
+    const bool active = t < (1u << (B - 3u));
+    uint2 x[8];
+    const uint32_t p0 = B - 3u;                                   // read in the configuration of the first three levels: consecutive lanes, consecutive elements
+    if (active) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) x[j] = data[base + bt_index(t, p0, j)];
+    }
+    bt_merge(x, lds, t, active, B, B, dir, base, p0);
+    if (active) {
+        uint4* dst = reinterpret_cast<uint4*>(data + base + 8u * t);
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) dst[q] = make_uint4(x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y);
+    }
+}
+
+// (tiles of fewer than eight elements -- N = 2, 4 -- keep one level per LDS round trip)
 __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_lds_sort(uint2* data, uint32_t tile_elems)
 {
     __shared__ uint2 tile[SORT_TILE];
@@ -47,17 +147,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_lds_sort(uint2* data, 
     __syncthreads();
     for (uint32_t length = 1; length < tile_elems; length <<= 1)
         lds_levels(tile, tile_elems, base, length, length << 1);
-    for (uint32_t t = threadIdx.x; t < tile_elems; t += blockDim.x) data[base + t] = tile[t];
-}
-
-// the tail (inc = tile/2 .. 1) of the merge with the given length >= tile_elems
-__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_lds_merge(uint2* data, uint32_t tile_elems, uint32_t length)
-{
-    __shared__ uint2 tile[SORT_TILE];
-    uint32_t base = blockIdx.x * tile_elems;
-    for (uint32_t t = threadIdx.x; t < tile_elems; t += blockDim.x) tile[t] = data[base + t];
-    __syncthreads();
-    lds_levels(tile, tile_elems, base, tile_elems >> 1, length << 1);
     for (uint32_t t = threadIdx.x; t < tile_elems; t += blockDim.x) data[base + t] = tile[t];
 }
 
@@ -110,9 +199,11 @@ void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t N)
     if (N < 2) return;
     uint32_t tile = N < SORT_TILE ? N : SORT_TILE;
     uint32_t blocks = N / tile;
-    hipLaunchKernelGGL(k_bitonic_lds_sort, dim3(blocks), dim3(SORT_THREADS), 0, s, pairs, tile);
+    const uint32_t B = log2u(tile);
+    if (tile < 8u) hipLaunchKernelGGL(k_bitonic_lds_sort, dim3(blocks), dim3(SORT_THREADS), 0, s, pairs, tile);
+    else hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(blocks), dim3(BT_THREADS), 0, s, pairs, B);
     for (uint32_t length = tile; length < N; length <<= 1) {
-        // levels inc = length .. tile go through HBM, up to eight per pass; the rest of the merge runs in LDS
+        // levels inc = length .. tile go through HBM, up to eight per pass; the rest of the merge runs inside the tiles
         uint32_t top = log2u(length);
         uint32_t left = top - 12u + 1u;                     // tile == SORT_TILE == 2^12 here (N > tile)
         while (left) {
@@ -120,7 +211,7 @@ void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t N)
             hipLaunchKernelGGL(k_bitonic_strided, dim3(N / SORT_TILE), dim3(SORT_THREADS), 0, s, pairs, top, levels, length << 1);
             top -= levels; left -= levels;
         }
-        hipLaunchKernelGGL(k_bitonic_lds_merge, dim3(blocks), dim3(SORT_THREADS), 0, s, pairs, tile, length);
+        hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(blocks), dim3(BT_THREADS), 0, s, pairs, B, length << 1);
     }
 }
 
@@ -376,14 +467,15 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __re
     }
 }
 
-#define RDX_ONE_BLOCK 4096u       // up to here: all passes in one block, in LDS (R = 16)
+#define RDX_ONE_BLOCK 4096u       // up to here: all passes in one block, in LDS (R = 16; R = 4 up to 1 024 and R = 1 up to 256 elements: a
+                                  // dozen pairs do not pay for sixteen rounds of ballots per pass -- 21.6 -> 4 us on the cube's 12)
+template <uint32_t R>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_small(uint2* __restrict__ data, uint32_t n, uint32_t passes)
 {
-    constexpr uint32_t R = RDX_ONE_BLOCK / RDX_THREADS;
     __shared__ uint32_t cnt[RDX_WAVES][RDX_BINS];
     __shared__ uint32_t dig_start[RDX_BINS];
     __shared__ uint32_t wave_sums[RDX_WAVES];
-    __shared__ uint2 stage[RDX_ONE_BLOCK];
+    __shared__ uint2 stage[R * RDX_THREADS];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2 e[R];
 #pragma unroll
@@ -407,6 +499,13 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_small(uint2* __restrict__
     }
 }
 
+// (Round 4 tried to shorten the chain of a build-sized sort -- twelve launches of ~4-6 us -- with 10-bit digits and ONE launch per pass: the tile
+//  histograms of the next digit counted by the scatter itself, first with global atomics into the row of the tile an element lands in (a wave's 64
+//  elements land in one tile and share few next digits: 64 adds to two or three lines per instruction, 30 us per pass at 50 032 pairs), then as rows
+//  each tile publishes for the tiles behind it (count | 2^31 per word, device-scope stores and polls, tiles taken from a ticket).  Correct, and
+//  slower than the three small kernels: a block that sums 49 rows of 4 KB written by other XCDs a moment ago waits ~2.5 us per batch of sixteen
+//  loads, 10 us per pass for the digit totals and 10 more for the rows before it, on top of 8 us for the 1 024-bin bookkeeping alone -- 20-29 us
+//  per pass against 13.  Removed; the measurements are in DESIGN.md section 4.)
 static uint32_t radix_tile(uint32_t n) { return (n < RDX_SMALL_TILES_BELOW ? 4u : 16u) * RDX_THREADS; }
 // scratch words a sort of n pairs needs behind its n-pair ping-pong buffer: hist[256][tiles] + totals[256]
 size_t radix_sort_scratch_words(uint32_t n) { return (size_t)RDX_BINS * ((n + 1023u) / 1024u) + RDX_BINS; }
@@ -417,7 +516,12 @@ void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint
 {
     if (n < 2) return;
     const uint32_t passes = key_bits == 0 ? 1u : (key_bits + 7u) / 8u;
-    if (n <= RDX_ONE_BLOCK) { hipLaunchKernelGGL(k_radix_small, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes); return; }
+    if (n <= RDX_ONE_BLOCK) {
+        if (n <= RDX_THREADS) hipLaunchKernelGGL(k_radix_small<1u>, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes);
+        else if (n <= 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_small<4u>, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes);
+        else hipLaunchKernelGGL(k_radix_small<16u>, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes);
+        return;
+    }
     const uint32_t tile = radix_tile(n), tiles = (n + tile - 1u) / tile;
     uint32_t* hist = scratch; uint32_t* totals = scratch + (size_t)RDX_BINS * tiles;
     uint2* src = pairs; uint2* dst = tmp;

@@ -271,7 +271,7 @@ def test_radix_sort_is_a_stable_sort(gpu_ctx):
         order = np.argsort(pairs['key'], kind='stable')
         assert got.tobytes() == pairs[order].tobytes(), len(pairs)
 
-    for n in [0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12289, 65536, 100003, (1 << 20) + 17, 3000001]:
+    for n in [0, 1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 5121, 8191, 12289, 65535, 65536, 65537, 100003, 262144, 262145, (1 << 20) + 17, 3000001]:
         pairs = np.zeros(n, dtype=capi.PAIR)
         pairs['value'] = np.arange(n, dtype=np.uint32)
         pairs['key'] = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
