@@ -233,8 +233,15 @@ __device__ uint32_t span_split(const uint2* __restrict__ keys, KeySpan sp)
 }
 
 // (clear2: two words the refit behind this kernel accumulates into -- tree depth, NaN flag -- cleared here instead of by two fill launches)
-__global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const uint2* __restrict__ keys, uint32_t n, uint32_t built, uint2* __restrict__ spans, uint32_t* clear2)
+// (second: the search tree's buffers, built by the same launch -- blockIdx.y = 1; same n, same number of nodes)
+struct RadixTreeSet { rt_bvh_node* nodes; const uint2* keys; uint2* spans; uint32_t* clear2; };
+__global__ __launch_bounds__(256) void k_radix_tree(RadixTreeSet first, RadixTreeSet second, uint32_t n, uint32_t built)
 {
+    const RadixTreeSet set = blockIdx.y ? second : first;
+    rt_bvh_node* const nodes = set.nodes;
+    const uint2* const __restrict__ keys = set.keys;
+    uint2* const __restrict__ spans = set.spans;
+    uint32_t* const clear2 = set.clear2;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0u && clear2 != nullptr) { clear2[0] = 0u; clear2[1] = 0u; }
     if (i >= built) return;
@@ -257,10 +264,12 @@ __global__ __launch_bounds__(256) void k_radix_tree(rt_bvh_node* nodes, const ui
     nodes[child_b].data[0] = self;
 }
 
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans, uint32_t* clear2)
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans, uint32_t* clear2,
+                       rt_bvh_node* nodes2, const uint2* pairs2, uint2* spans2, uint32_t* clear2_2)
 {
     if (built == 0u) return;
-    hipLaunchKernelGGL(k_radix_tree, dim3((built + 255) / 256), dim3(256), 0, s, nodes, pairs, n, built, spans, clear2);
+    const RadixTreeSet first{ nodes, pairs, spans, clear2 }, second{ nodes2, pairs2, spans2, clear2_2 };
+    hipLaunchKernelGGL(k_radix_tree, dim3((built + 255) / 256, nodes2 ? 2u : 1u), dim3(256), 0, s, first, second, n, built);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -324,8 +333,10 @@ __device__ __forceinline__ float4 load16_sc1(const float* p)
 // Same merges in the same operand order as one walker per leaf with a counter at every node, hence the same bytes.
 // only_if != null: the launch does nothing unless *only_if is non-zero (the climb as the fall-back of the range-query refit, decided on the
 // device: no read-back in the middle of a build)
+// (k_refit carries the climbs of both hierarchies of a build: blockIdx.y = 1 walks the second set)
+struct RefitSet { rt_bvh_node* nodes; uint32_t* counters; uint32_t* depth_out; const uint32_t* only_if; uint32_t tight; };
 template <bool TIGHT>
-__global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, const uint32_t* only_if)
+__device__ __forceinline__ void refit_climb(rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, const uint32_t* only_if)
 {
     if (only_if != nullptr && *only_if == 0u) return;
     const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
@@ -407,10 +418,24 @@ __global__ __launch_bounds__(256) void k_refit(rt_bvh_node* nodes, uint32_t* cou
     }
 }
 
+__global__ __launch_bounds__(256) void k_refit(RefitSet first, RefitSet second, uint32_t n)
+{
+    const RefitSet a = blockIdx.y ? second : first;
+    if (a.tight) refit_climb<true>(a.nodes, a.counters, n, a.depth_out, a.only_if);
+    else refit_climb<false>(a.nodes, a.counters, n, a.depth_out, a.only_if);
+}
+
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight, const uint32_t* only_if)
 {
-    if (tight) hipLaunchKernelGGL(k_refit<true>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out, only_if);
-    else hipLaunchKernelGGL(k_refit<false>, dim3((n + 255) / 256), dim3(256), 0, s, nodes, counters, n, depth_out, only_if);
+    const RefitSet first{ nodes, counters, depth_out, only_if, tight ? 1u : 0u };
+    hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256, 1), dim3(256), 0, s, first, first, n);
+}
+// the reference tree (its own merge) and the search tree (plain unions) in one launch
+void launch_refit_pair(hipStream_t s, uint32_t n, rt_bvh_node* nodes, uint32_t* counters, uint32_t* depth_out, const uint32_t* only_if,
+                       rt_bvh_node* s_nodes, uint32_t* s_counters, uint32_t* s_depth_out, const uint32_t* s_only_if, bool s_tight)
+{
+    const RefitSet first{ nodes, counters, depth_out, only_if, 0u }, second{ s_nodes, s_counters, s_depth_out, s_only_if, s_tight ? 1u : 0u };
+    hipLaunchKernelGGL(k_refit, dim3((n + 255) / 256, 2), dim3(256), 0, s, first, second, n);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -581,10 +606,19 @@ static SegLevels seg_levels(uint32_t n)
 }
 static size_t seg_entries(uint32_t n) { const SegLevels L = seg_levels(n); return (size_t)L.off[L.levels - 1] + L.cnt[L.levels - 1]; }
 
-__global__ __launch_bounds__(256) void k_seg_low(const rt_bvh_node* __restrict__ nodes, const uint2* __restrict__ pairs, uint32_t n, float4* __restrict__ lo,
-                                                 float4* __restrict__ hi, SegLevels L, uint32_t* __restrict__ nan_flag, int32_t* __restrict__ marks)
+// (the four kernels carry both hierarchies of a build: blockIdx.y = 1 works on the second set -- same n, same levels)
+struct SegSet { rt_bvh_node* nodes; const uint2* pairs; const uint2* spans; float4* lo; float4* hi; int32_t* marks; int32_t* tiles; uint32_t* ticket;
+                uint32_t* depth_out; uint32_t* nan_flag; uint32_t tight; };
+__global__ __launch_bounds__(256) void k_seg_low(SegSet first, SegSet second, uint32_t n, SegLevels L)
 {
     __shared__ float4 s_lo[256], s_hi[256];
+    const SegSet set = blockIdx.y ? second : first;
+    const rt_bvh_node* const __restrict__ nodes = set.nodes;
+    const uint2* const __restrict__ pairs = set.pairs;
+    float4* const __restrict__ lo = set.lo;
+    float4* const __restrict__ hi = set.hi;
+    uint32_t* const __restrict__ nan_flag = set.nan_flag;
+    int32_t* const __restrict__ marks = set.marks;
     const uint32_t t = threadIdx.x, base = blockIdx.x * 256u, j = base + t;
     uint32_t live = n - base < 256u ? n - base : 256u;                   // entries of this block at the current level
     BoxPair me{};
@@ -617,8 +651,10 @@ __global__ __launch_bounds__(256) void k_seg_low(const rt_bvh_node* __restrict__
     }
 }
 
-__global__ __launch_bounds__(1024) void k_seg_top(float4* __restrict__ lo, float4* __restrict__ hi, SegLevels L)
+__global__ __launch_bounds__(1024) void k_seg_top(SegSet first, SegSet second, SegLevels L)
 {
+    float4* const __restrict__ lo = blockIdx.y ? second.lo : first.lo;
+    float4* const __restrict__ hi = blockIdx.y ? second.hi : first.hi;
     for (uint32_t k = 9; k < L.levels; k++) {
         const float4* plo = lo + L.off[k - 1]; const float4* phi = hi + L.off[k - 1];
         for (uint32_t m = threadIdx.x; m < L.cnt[k]; m += 1024u) {
@@ -631,10 +667,15 @@ __global__ __launch_bounds__(1024) void k_seg_top(float4* __restrict__ lo, float
     }
 }
 
-template <bool TIGHT>
-__global__ __launch_bounds__(256) void k_seg_refit(rt_bvh_node* __restrict__ nodes, const uint2* __restrict__ spans, uint32_t n, const float4* __restrict__ lo,
-                                                   const float4* __restrict__ hi, SegLevels L, int32_t* __restrict__ marks)
+__global__ __launch_bounds__(256) void k_seg_refit(SegSet first, SegSet second, uint32_t n, SegLevels L)
 {
+    const SegSet set = blockIdx.y ? second : first;
+    rt_bvh_node* const __restrict__ nodes = set.nodes;
+    const uint2* const __restrict__ spans = set.spans;
+    const float4* const __restrict__ lo = set.lo;
+    const float4* const __restrict__ hi = set.hi;
+    int32_t* const __restrict__ marks = set.marks;
+    const bool TIGHT = set.tight != 0u;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1u) return;
     const uint2 sp = spans[i];
@@ -691,9 +732,13 @@ __device__ __forceinline__ int32_t seg_block_exclusive(int32_t v, int32_t* sh /*
     __syncthreads();
     return inc - v;
 }
-__global__ __launch_bounds__(256) void k_seg_depth(const int32_t* __restrict__ marks, uint32_t n, int32_t* tile_out /* 2 words per tile */, uint32_t* ticket,
-                                                   uint32_t* __restrict__ depth_out)
+__global__ __launch_bounds__(256) void k_seg_depth(SegSet set0, SegSet set1, uint32_t n)
 {
+    const SegSet set = blockIdx.y ? set1 : set0;
+    const int32_t* const __restrict__ marks = set.marks;
+    int32_t* const tile_out = set.tiles;               // 2 words per tile
+    uint32_t* const ticket = set.ticket;
+    uint32_t* const __restrict__ depth_out = set.depth_out;
     __shared__ int32_t sh[256];
     __shared__ int32_t sh_max[256];
     __shared__ uint32_t s_last;
@@ -736,23 +781,34 @@ size_t refit_span_scratch_bytes(uint32_t n)
     return seg_entries(n) * 2 * sizeof(float4) + ((size_t)n + 1) * 2 * sizeof(uint32_t) + scan_scratch_words(n + 1) * sizeof(uint32_t) + 256;
 }
 
-// boxes of all inner nodes + the tree depth; *nan_flag_out (device word, zeroed here) != 0 afterwards: NaN boxes, the climb must redo it
+static SegSet seg_set(rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out, uint32_t* nan_flag_out, bool tight)
+{
+    const size_t entries = seg_entries(n);
+    SegSet a;
+    a.nodes = nodes; a.pairs = pairs; a.spans = spans;
+    a.lo = (float4*)scratch; a.hi = a.lo + entries;
+    a.marks = (int32_t*)(a.hi + entries);
+    // (tiles: the depth tiles' (total, maximum) pairs; ticket: zero between builds -- cleared once when the scratch is allocated)
+    a.tiles = a.marks + (n + 1);
+    a.ticket = (uint32_t*)a.tiles + (n + 1);
+    a.depth_out = depth_out; a.nan_flag = nan_flag_out; a.tight = tight ? 1u : 0u;
+    return a;
+}
+// boxes of all inner nodes + the tree depth; *nan_flag_out (device word) != 0 afterwards: NaN boxes, the climb must redo it.
+// (depth_out and nan_flag_out are consecutive words cleared by the k_radix_tree launch in front of this refit: launch_radix_tree's clear2.)
+// nodes2 != null: the second hierarchy of the build (same n) in the same four launches.
 void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
-                       uint32_t* nan_flag_out, bool tight)
+                       uint32_t* nan_flag_out, bool tight, rt_bvh_node* nodes2, const uint2* pairs2, const uint2* spans2, void* scratch2,
+                       uint32_t* depth_out2, uint32_t* nan_flag_out2, bool tight2)
 {
     const SegLevels L = seg_levels(n);
-    const size_t entries = seg_entries(n);
-    float4* lo = (float4*)scratch; float4* hi = lo + entries;
-    int32_t* marks = (int32_t*)(hi + entries);
-    uint32_t* covered = (uint32_t*)marks + (n + 1);
-    uint32_t* scan_scratch = covered + (n + 1);
-    // (depth_out and nan_flag_out are consecutive words cleared by the k_radix_tree launch in front of this refit: launch_radix_tree's clear2)
-    hipLaunchKernelGGL(k_seg_low, dim3((n + 255) / 256), dim3(256), 0, s, nodes, pairs, n, lo, hi, L, nan_flag_out, marks);
-    if (L.levels > 9u) hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, s, lo, hi, L);
-    if (tight) hipLaunchKernelGGL(k_seg_refit<true>, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, spans, n, (const float4*)lo, (const float4*)hi, L, marks);
-    else hipLaunchKernelGGL(k_seg_refit<false>, dim3((n - 1 + 255) / 256), dim3(256), 0, s, nodes, spans, n, (const float4*)lo, (const float4*)hi, L, marks);
-    // (covered[]: the tiles' (total, maximum) pairs; scan_scratch[0]: the ticket counter, zero between builds -- cleared once when the scratch is allocated)
-    hipLaunchKernelGGL(k_seg_depth, dim3((n + SEG_DEPTH_TILE - 1u) / SEG_DEPTH_TILE), dim3(256), 0, s, (const int32_t*)marks, n, (int32_t*)covered, scan_scratch, depth_out);
+    const SegSet first = seg_set(nodes, pairs, spans, n, scratch, depth_out, nan_flag_out, tight);
+    const SegSet second = nodes2 ? seg_set(nodes2, pairs2, spans2, n, scratch2, depth_out2, nan_flag_out2, tight2) : first;
+    const uint32_t sets = nodes2 ? 2u : 1u;
+    hipLaunchKernelGGL(k_seg_low, dim3((n + 255) / 256, sets), dim3(256), 0, s, first, second, n, L);
+    if (L.levels > 9u) hipLaunchKernelGGL(k_seg_top, dim3(1, sets), dim3(1024), 0, s, first, second, L);
+    hipLaunchKernelGGL(k_seg_refit, dim3((n - 1 + 255) / 256, sets), dim3(256), 0, s, first, second, n, L);
+    hipLaunchKernelGGL(k_seg_depth, dim3((n + SEG_DEPTH_TILE - 1u) / SEG_DEPTH_TILE, sets), dim3(256), 0, s, first, second, n);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -865,9 +921,17 @@ __global__ __launch_bounds__(256) void k_leaf_positions(const uint2* pairs, uint
 
 // relayout + leaf positions (+ the packed triangle records of the packet kernels, which hold the rank: trirec != null) in ONE launch: thread j
 // writes traversal record j and serves the leaf at sorted position j -- no thread reads what another writes
-__global__ __launch_bounds__(256) void k_relayout_all(const rt_bvh_node* nodes, const uint2* __restrict__ pairs, TravNode* trav, uint32_t* __restrict__ pos, uint32_t n,
-                                                      uint32_t id_offset, DeviceScene sc, TriRec* __restrict__ trirec)
+// (second: the search tree's records in the same launch, blockIdx.y = 1; the packed triangle records belong to the first set)
+struct RelayoutSet { const rt_bvh_node* nodes; const uint2* pairs; TravNode* trav; uint32_t* pos; uint32_t id_offset; };
+__global__ __launch_bounds__(256) void k_relayout_all(RelayoutSet first, RelayoutSet second, uint32_t n, DeviceScene sc, TriRec* __restrict__ trirec_first)
 {
+    const RelayoutSet set = blockIdx.y ? second : first;
+    const rt_bvh_node* const nodes = set.nodes;
+    const uint2* const __restrict__ pairs = set.pairs;
+    TravNode* const trav = set.trav;
+    uint32_t* const __restrict__ pos = set.pos;
+    const uint32_t id_offset = set.id_offset;
+    TriRec* const __restrict__ trirec = blockIdx.y ? nullptr : trirec_first;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n - 1u) {
         const rt_bvh_node* nd = &nodes[n + j];
@@ -898,10 +962,12 @@ __global__ __launch_bounds__(256) void k_relayout_all(const rt_bvh_node* nodes, 
 }
 
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t id_offset, const DeviceScene* sc, TriRec* trirec)
+                     uint32_t n, uint32_t id_offset, const DeviceScene* sc, TriRec* trirec,
+                     const rt_bvh_node* nodes2, const uint2* pairs2, TravNode* trav2, uint32_t* pos2, uint32_t id_offset2)
 {
     DeviceScene none{};
-    hipLaunchKernelGGL(k_relayout_all, dim3((n + 255) / 256), dim3(256), 0, s, nodes, pairs, trav, pos, n, id_offset, sc ? *sc : none, sc ? trirec : nullptr);
+    const RelayoutSet first{ nodes, pairs, trav, pos, id_offset }, second{ nodes2, pairs2, trav2, pos2, id_offset2 };
+    hipLaunchKernelGGL(k_relayout_all, dim3((n + 255) / 256, nodes2 ? 2u : 1u), dim3(256), 0, s, first, second, n, sc ? *sc : none, sc ? trirec : nullptr);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -37,7 +37,6 @@ int rt_bvh_create(rt_ctx* ctx, const rt_scene* scene, int parity_mode, rt_bvh** 
     rt_bvh* b = new (std::nothrow) rt_bvh();
     if (!b) return RT_FAIL(ctx, "out of host memory");
     b->ctx = ctx; b->scene = scene; b->mode = parity_mode; b->device_arith = device_arith;
-    if (const char* e = std::getenv("RTMI_SEARCH_SORT")) b->search_sort_bitonic = std::strcmp(e, "bitonic") == 0;
     *out = b;
     return RT_SUCCESS;
 }
@@ -99,9 +98,6 @@ void rt_bvh_destroy(rt_bvh* b)
     (void)hipStreamSynchronize(b->ctx->stream);
     free_build_buffers(b);
     if (b->h_depths) (void)hipHostFree(b->h_depths);
-    if (b->build_side_stream) (void)hipStreamDestroy(b->build_side_stream);
-    if (b->build_fork) (void)hipEventDestroy(b->build_fork);
-    if (b->build_join) (void)hipEventDestroy(b->build_join);
     block_order_free(b->block_order);
     delete b;
 }
@@ -166,7 +162,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             e = hipMalloc((void**)&b->d_sort_tmp, (size_t)n * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_sort_scratch, radix_sort_scratch_words(n) * sizeof(uint32_t));
         }
-        if (e == hipSuccess && want_search && b->mode == RT_MODE_FAST) {        // ... and the reference tree's own, so that the two sorts can overlap
+        if (e == hipSuccess && want_search && b->mode == RT_MODE_FAST) {        // ... and the reference tree's own: both sorts go through the same launches
             e = hipMalloc((void**)&b->d_sort_tmp2, (size_t)n * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_sort_scratch2, radix_sort_scratch_words(n) * sizeof(uint32_t));
         }
@@ -201,93 +197,103 @@ int rt_bvh_initialize_frame(rt_bvh* b)
 }
 
 // everything a build enqueues, in stream order and nothing else (no allocation, no synchronisation: it is also what a capture records)
-// side != null (only while the build is being captured): the search tree's chain -- keys, sort, tree, refit, records -- is enqueued on that
-// stream between a fork behind the leaves and a join before the four-wide records, so the replayed graph runs the two hierarchies side by
-// side (each is a chain of small dependent kernels that leaves most of the device idle).  Eagerly the same was measured in round 3 and not
-// kept (fork / join through the host's launch path cost what the overlap gained); inside a graph the dependencies are the graph's edges.
-static int enqueue_build(rt_bvh* b, hipStream_t s, hipStream_t side = nullptr)
+static int enqueue_build(rt_bvh* b, hipStream_t s)
 {
     rt_ctx* ctx = b->ctx;
     const DeviceScene& sc = b->scene->d;
     const uint32_t n = b->n, N = b->N;
     // BVHManager.cpp:134-147 (initializeFrame): morton buffer := (UINT_MAX,UINT_MAX), visit counters := 0.  A build is a chain of dependent
     // launches of a few microseconds each (rocprofv3: every launch of a 50 032-triangle build takes 4.5-6 us, the clearing fills included), so
-    // a clear that a kernel of the chain can do on its way is not launched: the pair buffer's padding is written by k_morton_leaves, the
-    // counters are cleared only where a climb will use them, and the node buffer -- zeroed in the reference's compatibility mode, whose
-    // never-built node must read as zeros -- is written whole by FIXED / FAST builds (leaves by k_morton_leaves, every field of all n - 1
-    // inner nodes by k_radix_tree, each node's parent link by its parent).
+    //  * a clear that a kernel of the chain can do on its way is not launched: the pair buffers' padding is written by k_morton_leaves, the
+    //    counters are cleared only where a climb will use them, and the node buffer -- zeroed in the reference's compatibility mode, whose
+    //    never-built node must read as zeros -- is written whole by FIXED / FAST builds (leaves by k_morton_leaves, every field of all n - 1
+    //    inner nodes by k_radix_tree, each node's parent link by its parent);
+    //  * the two hierarchies -- the reference tree and the search tree for primary rays (same leaves, better order) -- go
+    //    through the SAME launches: every kernel of the chain takes a second set of buffers and works on it in the blocks with blockIdx.y = 1.
+    //    (Two chains side by side on two queues of a graph were tried first: a dependency between two queues costs ~35 us where it is waited
+    //    for, the fork and the join together about what the overlap gained.)
     const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
     const bool nan_possible = b->scene->has_nan;
-    const bool ref_climbs = literal || !b->d_spans || nan_possible;
     const bool want_search = !ctx->no_search_tree && !literal;
-    const bool search_bitonic = b->search_sort_bitonic || !b->d_sort_tmp;
-    // 1. BVHManager.cpp:183 (+ the padding of the pair buffer; + the search tree's leaves and keys, see there)
-    // Side by side (a replayed graph, from 4 096 triangles on): the search tree's chain forks HERE, before anything is launched, and writes its
-    // leaves and keys itself -- both chains are roots of the graph.  (Forked behind this kernel, the side stream's first kernel started 35 us
-    // after it had ended: a dependency between two queues costs that much, whatever it waits for.)
-    if (side && want_search) {
-        RT_HIP(ctx, hipEventRecord(b->build_fork, s));
-        RT_HIP(ctx, hipStreamWaitEvent(side, b->build_fork, 0));
-        launch_morton_leaves(side, sc, nullptr, nullptr, 0u, b->s_nodes, b->s_pairs, search_bitonic ? N : 0u);
-    }
+    const bool fast = b->mode == RT_MODE_FAST;
+    // 2. the sort (BVHManager.cpp:195).  The reference's network for the reference tree (the order of equal Morton codes is part of its
+    // result: it decides the radix tree's topology and the depth-first ranks that break ties between equal t); RT_MODE_FAST: a stable radix
+    // sort instead (30-bit codes: four passes over n pairs instead of ~log^2 N / 2 network levels over N) -- the same tree wherever codes
+    // differ, leaves with EQUAL codes in index order.  The search tree's order is the library's own (any nested hierarchy over the reference's
+    // leaves gives the reference's contacts, ties between equal t are broken by the REFERENCE rank, d_pos): its keys ride along in whatever
+    // sorts the reference's -- the network up to 2^18 pairs, where a launch costs more than what it moves -- or take the radix sort.
+    const bool search_with_network = want_search && !fast && (N <= (1u << 18) || !b->d_sort_tmp);
+    const bool search_with_radix_pair = want_search && fast && b->d_sort_tmp2;
+    const bool ref_climbs = literal || !b->d_spans || nan_possible;
+    const bool search_spans = b->s_spans && b->s_span_scratch;
+    const bool search_climbs = want_search && (!search_spans || nan_possible);
+    uint32_t* const d_depth = b->d_depth;                     // [0] depth, [1] NaN flag of the span refit; [2], [3] the same of the search tree
+    uint32_t* const s_depth = b->d_depth + 2;
     if (ref_climbs) RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), s));
+    if (search_climbs) RT_HIP(ctx, hipMemsetAsync(b->s_counters, 0, (size_t)n * sizeof(uint32_t), s));
     if (literal) RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
-    if (side && want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N);
-    else if (want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, b->s_nodes, b->s_pairs, search_bitonic ? N : 0u);
+    // 1. BVHManager.cpp:183: leaves and Morton pairs (+ the padding of the pair buffer; + the search tree's copy of the leaves and its keys --
+    // Morton codes of the box centres normalised to the scene header's box -- and the padding its sort wants)
+    if (want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, b->s_nodes, b->s_pairs, search_with_network ? N : 0u);
     else launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N);
-    // 2. :195 -- the reference's network (the order of equal Morton codes is part of its result: it decides the radix tree's topology and
-    // the depth-first ranks that break ties between equal t).  RT_MODE_FAST: a stable radix sort instead (30-bit codes: four passes over
-    // n pairs instead of ~log^2 N / 2 network levels over N) -- the same tree wherever codes differ, leaves with EQUAL codes in index order
-    if (b->mode == RT_MODE_FAST) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2 ? b->d_sort_tmp2 : b->d_sort_tmp, b->n, 30u, b->d_sort_scratch2 ? b->d_sort_scratch2 : b->d_sort_scratch);
-    else launch_bitonic_sort(s, b->d_pairs, b->N);
-    launch_radix_tree(s, b->d_nodes, b->d_pairs, b->n, literal ? b->n - 2u : b->n - 1u, b->d_spans, b->d_depth);   // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58); clears depth + NaN flag
-    if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, b->n, b->d_depth);
-    else if (b->d_spans) {
-        // 4. by spans (or, on request, round 2's range queries); NaN boxes (not associative) send it back to the climb -- decided on the
-        // device: the climb is launched behind it and runs only if the pass raised its flag
-        if (b->d_span_scratch) launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_span_scratch, b->d_depth, b->d_depth + 1, false);
-        else launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, b->n, b->d_rq_scratch, b->d_depth, b->d_depth + 1);
-        if (nan_possible) launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth, false, b->d_depth + 1);     // (no NaN vertex in the scene: no NaN box, no launch)
+    if (fast) {
+        if (search_with_radix_pair) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2, n, 30u, b->d_sort_scratch2, b->s_pairs, b->d_sort_tmp, b->d_sort_scratch);
+        else launch_radix_sort(s, b->d_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
+    } else {
+        launch_bitonic_sort(s, b->d_pairs, N, search_with_network ? b->s_pairs : nullptr);
+        if (want_search && !search_with_network) launch_radix_sort(s, b->s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
     }
-    else launch_refit(s, b->d_nodes, b->d_counters, b->n, b->d_depth); // 4. :217 (+ the tree depth)
-    launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, b->n, 0u, &sc, b->d_trirec);  // traversal records, DFS ranks, packed triangle records
-    RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], b->d_depth, 4, hipMemcpyDeviceToHost, s));
-    // search tree for primary rays: same leaves, better order
-    if (want_search) {
-        hipStream_t s_main = s;
-        if (side) s = side;                                        // (this block's launches go to the side stream; joined below)
-        rt_bvh_node* s_nodes = b->s_nodes; uint2* s_pairs = b->s_pairs; uint32_t* s_counters = b->s_counters; uint32_t* s_pos = b->s_pos;
-        // (the inner nodes need no clearing: k_radix_tree writes every field of all n - 1 of them -- the parent link of a node comes from
-        //  its parent, the root's is set -- and the search tree is never read back as "the reference on zeroed buffers"; the leaves, the
-        //  keys -- Morton codes of the box centres normalised to the scene header's box -- and the network's padding were written by step 1)
-        const bool search_climbs = !(b->s_spans && b->s_span_scratch) || nan_possible;
-        if (search_climbs) RT_HIP(ctx, hipMemsetAsync(s_counters, 0, (size_t)n * sizeof(uint32_t) + 256, s));
-        // the search tree's order is the library's own (any nested hierarchy over the reference's leaves gives the reference's contacts,
-        // ties between equal t are broken by the REFERENCE rank, d_pos): a stable radix sort
-        if (search_bitonic) launch_bitonic_sort(s, s_pairs, N);
-        else launch_radix_sort(s, s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
-        uint32_t* s_depth = s_counters + n;                     // spare words behind the counters ([0] depth, [1] NaN flag of the span refit)
-        launch_radix_tree(s, s_nodes, s_pairs, n, n - 1u, b->s_spans, s_depth);
-        const bool tight = !ctx->search_tree_reference_boxes;
-        if (b->s_spans && b->s_span_scratch) {
-            launch_refit_span(s, s_nodes, s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight);
-            if (nan_possible) launch_refit(s, s_nodes, s_counters, n, s_depth, tight, s_depth + 1);
-        } else launch_refit(s, s_nodes, s_counters, n, s_depth, tight);
-        launch_relayout(s, s_nodes, s_pairs, b->d_trav + (n - 1), s_pos, n, n - 1);
-        RT_HIP(ctx, hipGetLastError());
-        RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[1], s_depth, 4, hipMemcpyDeviceToHost, s));
-        // four-wide records: of the search tree only -- no kernel walks the reference tree four records wide (the policy's condition and
-        // `cur >= search_root` in the kernels), so that half of the buffer stays unwritten; at the end of this chain, not behind the join
-        if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, n - 1u, n - 1u);
-        if (side) {                                                // join
-            RT_HIP(ctx, hipEventRecord(b->build_join, side));
-            s = s_main;
-            RT_HIP(ctx, hipStreamWaitEvent(s, b->build_join, 0));
+    // 3. :204 (LITERAL_ZERO: the guard as written, BVHKernels.cl:58); clears the depth + NaN flag words of the refit behind it
+    // (the search tree's inner nodes need no clearing either: k_radix_tree writes every field of all n - 1 of them, and that tree is never
+    //  read back as "the reference on zeroed buffers")
+    if (want_search) launch_radix_tree(s, b->d_nodes, b->d_pairs, n, n - 1u, b->d_spans, d_depth, b->s_nodes, b->s_pairs, b->s_spans, s_depth);
+    else launch_radix_tree(s, b->d_nodes, b->d_pairs, n, literal ? n - 2u : n - 1u, b->d_spans, d_depth);
+    // 4. :217 the boxes (+ the tree depths).  By spans (every scene from 256 triangles on; or, on request, round 2's range queries); NaN boxes
+    // (not associative) send it back to the climb -- decided on the device: the climb is launched behind it and runs only if the pass raised
+    // its flag, and only for scenes in which the upload saw a NaN vertex.  The search tree's boxes are plain unions (`tight`).
+    const bool tight = !ctx->search_tree_reference_boxes;
+    if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, n, d_depth);
+    else if (b->d_spans && b->d_span_scratch && (!want_search || search_spans)) {
+        if (want_search) launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false,
+                                           b->s_nodes, b->s_pairs, b->s_spans, b->s_span_scratch, s_depth, s_depth + 1, tight);
+        else launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false);
+        if (nan_possible) {
+            if (want_search) launch_refit_pair(s, n, b->d_nodes, b->d_counters, d_depth, d_depth + 1, b->s_nodes, b->s_counters, s_depth, s_depth + 1, tight);
+            else launch_refit(s, b->d_nodes, b->d_counters, n, d_depth, false, d_depth + 1);
+        }
+    } else {
+        if (b->d_spans && b->d_rq_scratch) {
+            launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_rq_scratch, d_depth, d_depth + 1);
+            if (nan_possible) launch_refit(s, b->d_nodes, b->d_counters, n, d_depth, false, d_depth + 1);
+            if (want_search) {
+                if (search_spans) {
+                    launch_refit_span(s, b->s_nodes, b->s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight);
+                    if (nan_possible) launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight, s_depth + 1);
+                } else launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight);
+            }
+        }
+        else if (want_search && !search_spans && !b->d_spans) launch_refit_pair(s, n, b->d_nodes, b->d_counters, d_depth, nullptr, b->s_nodes, b->s_counters, s_depth, nullptr, tight);
+        else {
+            if (b->d_spans && b->d_span_scratch) {
+                launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false);
+                if (nan_possible) launch_refit(s, b->d_nodes, b->d_counters, n, d_depth, false, d_depth + 1);
+            } else launch_refit(s, b->d_nodes, b->d_counters, n, d_depth);
+            if (want_search) {
+                if (search_spans) {
+                    launch_refit_span(s, b->s_nodes, b->s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight);
+                    if (nan_possible) launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight, s_depth + 1);
+                } else launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight);
+            }
         }
     }
-    else if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, 0u, n - 1u);
+    // 5. traversal records, depth-first ranks, packed triangle records (the search tree's records behind the reference tree's: TravNode[2(n-1)])
+    if (want_search) launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, n, 0u, &sc, b->d_trirec, b->s_nodes, b->s_pairs, b->d_trav + (n - 1), b->s_pos, n - 1);
+    else launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, n, 0u, &sc, b->d_trirec);
+    // four-wide records: of the search tree only -- no kernel walks the reference tree four records wide (the policy's condition and
+    // `cur >= search_root` in the kernels), so that half of the buffer stays unwritten
+    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, want_search ? n - 1u : 0u, n - 1u);
     RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], d_depth, 16, hipMemcpyDeviceToHost, s));
     return RT_SUCCESS;
 }
 
@@ -301,7 +307,7 @@ int rt_bvh_construct(rt_bvh* b)
     const bool literal = b->mode == RT_MODE_LITERAL_ZERO;
     const bool want_search = !ctx->no_search_tree && !literal;
     b->have_search_tree = false;
-    b->h_depths[0] = 0u; b->h_depths[1] = 0u;
+    for (int k = 0; k < 4; k++) b->h_depths[k] = 0u;
     // A scene that moves is rebuilt every frame (OpenCLRayTracerDemo.cpp:230-234): the same ~40 launches, clears and copies on the same
     // buffers.  The first build of an allocation is enqueued as it is, the second is captured into a graph, and from then on a build is
     // one graph launch (12 triangles: 0.108 -> see DESIGN.md; the host issued the launches more slowly than the device ran them).
@@ -312,17 +318,9 @@ int rt_bvh_construct(rt_bvh* b)
     if (graphs && b->builds_on_allocation >= 2u) {
         if (!b->build_exec) {
             hipGraph_t g = nullptr;
-            static const bool side_by_side = [] { const char* e = std::getenv("RTMI_BUILD_SIDE_BY_SIDE"); return !(e && e[0] == '0'); }();
-            // (a dozen triangles: the fork and the join cost more than two chains of 2 us kernels overlap -- Cube 0.088 -> 0.138 ms; from a few
-            //  thousand triangles on: ClumsyDragon 0.446 -> 0.357, FAST 0.298; atrium 0.75 -> 0.68 / 0.54)
-            const bool fork = side_by_side && want_search && b->n >= 4096u;
-            if (fork && !b->build_side_stream) {
-                if (hipStreamCreateWithFlags(&b->build_side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->build_fork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&b->build_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); if (b->build_side_stream) (void)hipStreamDestroy(b->build_side_stream); b->build_side_stream = nullptr; }
-            }
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
             if (e == hipSuccess) {
-                const int rc = enqueue_build(b, s, fork ? b->build_side_stream : nullptr);
+                const int rc = enqueue_build(b, s);
                 e = hipStreamEndCapture(s, &g);
                 if (rc == RT_SUCCESS && e == hipSuccess && g && hipGraphInstantiate(&b->build_exec, g, nullptr, nullptr, 0) == hipSuccess) b->build_graph = g;
                 else { if (g) (void)hipGraphDestroy(g); b->build_exec = nullptr; }
@@ -334,7 +332,7 @@ int rt_bvh_construct(rt_bvh* b)
     if (!launched && enqueue_build(b, s)) return RT_ERROR;
     b->clears_pending = false;
     RT_HIP(ctx, hipStreamSynchronize(s));                          // construct() returns with the build finished
-    const uint32_t depth = b->h_depths[0], search_depth = want_search ? b->h_depths[1] : 0u;
+    const uint32_t depth = b->h_depths[0], search_depth = want_search ? b->h_depths[2] : 0u;
     b->max_depth = depth;
     b->search_depth = search_depth;
     // (a degenerate model -- thousands of coincident box centres -- makes this tree as deep as the reference's: no gain then,

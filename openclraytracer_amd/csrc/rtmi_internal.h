@@ -162,7 +162,7 @@ struct rt_bvh {
     QuadNode* d_quad_cam = nullptr;    // the same records relative to the current camera position (k_prepare_camera): the general copy, then
     uint32_t quad_cam_variants = 1;    // (quad_cam_variants - 1 = 8) copies with the near / far planes in place per direction octant
     bool capture_no_unsafe_rays = false;   // set around a frame-graph capture whose camera is known to sit on no box plane
-    uint32_t* d_depth = nullptr;       // max depth (1 word)
+    uint32_t* d_depth = nullptr;       // [0] max depth, [1] NaN flag of the span refit; [2], [3]: the same of the search tree
     uint32_t* d_pos = nullptr;         // leaf -> position in d_pairs (DFS rank of the leaf)
     TriRec* d_trirec = nullptr;        // packed triangle records of the packet kernels (filled per build: they hold the rank)
     TriCam* d_tricam = nullptr;        // ... relative to the current camera position (with the four-wide records): k_prepare_camera
@@ -176,15 +176,13 @@ struct rt_bvh {
     // construct() as a HIP graph (rtmi_bvh.hip): the sequence of one build on this BVH's buffers, captured on the second build of an
     // allocation and replayed by the later ones (a scene rebuilt every frame, OpenCLRayTracerDemo.cpp:230-234)
     hipGraph_t build_graph = nullptr; hipGraphExec_t build_exec = nullptr;
-    hipStream_t build_side_stream = nullptr; hipEvent_t build_fork = nullptr, build_join = nullptr;   // the captured build runs its two trees side by side
     uint2* d_sort_tmp2 = nullptr; uint32_t* d_sort_scratch2 = nullptr;      // RT_MODE_FAST: the reference tree's radix sort has its own scratch (both sorts may run at once)
     uint32_t builds_on_allocation = 0;      // construct() calls since the buffers were (re)allocated
-    uint32_t* h_depths = nullptr;           // pinned: [0] reference tree depth, [1] search tree depth (read back at the end of a build)
+    uint32_t* h_depths = nullptr;           // pinned copy of d_depth[0..3] (read back at the end of a build)
     bool clears_pending = false;            // initializeFrame's clears, enqueued with the build
     uint32_t graph_builds = 0;              // construct() calls served by the graph (inspection)
     uint2* d_sort_tmp = nullptr;       // radix sort: n pairs to ping-pong with, then its histograms (launch_radix_sort)
     uint32_t* d_sort_scratch = nullptr;
-    bool search_sort_bitonic = false;  // knob RTMI_SEARCH_SORT=bitonic: the search tree's keys through the bitonic network, as in rounds 1-3
     uint2* s_spans = nullptr;          // the search tree's spans + scratch of its refit by spans
     void* s_span_scratch = nullptr;
     void* d_span_scratch = nullptr;    // the reference tree's (refit by spans)
@@ -290,24 +288,33 @@ void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
 // leaves + Morton pairs (+ the padding pairs [n, padded) of the pair buffer); on request the search tree's leaves and keys as well
 void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
                           rt_bvh_node* s_nodes = nullptr, uint2* s_pairs = nullptr, uint32_t s_padded = 0u);
-void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr, uint32_t* clear2 = nullptr);   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO); clear2: two words zeroed on the way
+// The kernels of a build carry BOTH hierarchies (the reference tree and the search tree: same leaves, same n) in one launch -- the arguments with a
+// trailing 2 are the second one's, blockIdx.y = 1; null: one hierarchy.  A build is a chain of dependent launches of ~5 us each whatever they do.
+void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr, uint32_t* clear2 = nullptr,   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO); clear2: two words zeroed on the way
+                       rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, uint2* spans2 = nullptr, uint32_t* clear2_2 = nullptr);
 size_t refit_rq_scratch_bytes(uint32_t n);
 void launch_refit_rq(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
                      uint32_t* nan_flag_out);      // range-query refit (large scenes); *nan_flag_out != 0: NaN boxes, redo with launch_refit
 size_t refit_span_scratch_bytes(uint32_t n);
 void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
-                       uint32_t* nan_flag_out, bool tight);   // refit by spans over a segment tree of the sorted leaf boxes (every size); *nan_flag_out != 0: redo with launch_refit
+                       uint32_t* nan_flag_out, bool tight,   // refit by spans over a segment tree of the sorted leaf boxes (every size); *nan_flag_out != 0: redo with launch_refit
+                       rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, const uint2* spans2 = nullptr, void* scratch2 = nullptr,
+                       uint32_t* depth_out2 = nullptr, uint32_t* nan_flag_out2 = nullptr, bool tight2 = false);
 void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false, const uint32_t* only_if = nullptr);   // boxes + tree depth; tight: plain unions (search tree); only_if: runs only when that device word is non-zero
+void launch_refit_pair(hipStream_t s, uint32_t n, rt_bvh_node* nodes, uint32_t* counters, uint32_t* depth_out, const uint32_t* only_if,
+                       rt_bvh_node* s_nodes, uint32_t* s_counters, uint32_t* s_depth_out, const uint32_t* s_only_if, bool s_tight);   // the climbs of both hierarchies
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t id_offset = 0, const DeviceScene* sc = nullptr, TriRec* trirec = nullptr);   // + DFS ranks; sc / trirec: + the packed triangle records
+                     uint32_t n, uint32_t id_offset = 0, const DeviceScene* sc = nullptr, TriRec* trirec = nullptr,   // + DFS ranks; sc / trirec: + the packed triangle records
+                     const rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, TravNode* trav2 = nullptr, uint32_t* pos2 = nullptr, uint32_t id_offset2 = 0);
 void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count);   // records [first, first + count)
 void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out);
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3]);
 // sort_scan_kernels.hip
-void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2);
+void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2, uint2* pairs2 = nullptr);   // (+ a second array of the same size in the same launches)
 size_t radix_sort_scratch_words(uint32_t n);
-void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint32_t key_bits, uint32_t* scratch);   // stable LSD radix sort by the low key_bits of .x
+void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint32_t key_bits, uint32_t* scratch,   // stable LSD radix sort by the low key_bits of .x
+                       uint2* pairs2 = nullptr, uint2* tmp2 = nullptr, uint32_t* scratch2 = nullptr);       // (+ a second sort of the same size in the same launches)
 void launch_plane_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint32_t axis, uint2* pairs, uint32_t n_pow2);   // sorted (key, .) of the 2n corner coordinates of one axis
 int  launch_scan_inclusive(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch);
 size_t scan_scratch_words(uint32_t n);

@@ -99,9 +99,12 @@ __device__ __forceinline__ void bt_merge(uint2 (&x)[8], uint2* lds, uint32_t t, 
 }
 
 // sorts every tile completely: lengths 1 .. tile_elems/2 (tile_elems = 2^B >= 8)
-__global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_sort(uint2* data, uint32_t B)
+// (data2: a second array of the same size sorted by the same launch, blockIdx.y = 1 -- a BVH build sorts the keys of its two hierarchies, and a
+//  launch costs its ~5 us whatever it carries)
+__global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_sort(uint2* data, uint2* data2, uint32_t B)
 {
     __shared__ uint2 lds[BT_LDS_ELEMS];
+    if (blockIdx.y) data = data2;
     const uint32_t t = threadIdx.x, base = blockIdx.x << B;
     const bool active = t < (1u << (B - 3u));
     uint2 x[8];
@@ -119,9 +122,10 @@ __global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_sort(uint2* data, u
 }
 
 // the tail (levels on bits B-1 .. 0) of the merge with the given length >= 2^B
-__global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_merge(uint2* data, uint32_t B, uint32_t dir)
+__global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_merge(uint2* data, uint2* data2, uint32_t B, uint32_t dir)
 {
     __shared__ uint2 lds[BT_LDS_ELEMS];
+    if (blockIdx.y) data = data2;
     const uint32_t t = threadIdx.x, base = blockIdx.x << B;
     const bool active = t < (1u << (B - 3u));
     uint2 x[8];
@@ -139,9 +143,10 @@ __global__ __launch_bounds__(BT_THREADS) void k_bitonic_tile_merge(uint2* data, 
 }
 
 // (tiles of fewer than eight elements -- N = 2, 4 -- keep one level per LDS round trip)
-__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_lds_sort(uint2* data, uint32_t tile_elems)
+__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_lds_sort(uint2* data, uint2* data2, uint32_t tile_elems)
 {
     __shared__ uint2 tile[SORT_TILE];
+    if (blockIdx.y) data = data2;
     uint32_t base = blockIdx.x * tile_elems;
     for (uint32_t t = threadIdx.x; t < tile_elems; t += blockDim.x) tile[t] = data[base + t];
     __syncthreads();
@@ -157,9 +162,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_lds_sort(uint2* data, 
 // R = 2^levels rows (one per combination of those bits) of C = SORT_TILE / R consecutive elements in LDS -- runs of C * 8
 // bytes (>= 128) in HBM -- and runs the levels there, row against row.  Same comparators, same `reverse` per pair (taken from
 // the global index of the pair's first element), hence the same permutation as one level per launch.
-__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_strided(uint2* data, uint32_t top, uint32_t levels, uint32_t dir)
+__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_strided(uint2* data, uint2* data2, uint32_t top, uint32_t levels, uint32_t dir)
 {
     __shared__ uint2 tile[SORT_TILE];
+    if (blockIdx.y) data = data2;
     const uint32_t low = top + 1u - levels;                 // lowest varying bit; low >= log2(SORT_TILE) >= log2(C)
     const uint32_t rows = 1u << levels, cols = SORT_TILE >> levels;
     const uint32_t cols_log = 12u - levels;                 // log2(SORT_TILE) = 12
@@ -194,24 +200,24 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_strided(uint2* data, u
 
 static uint32_t log2u(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) l++; return l; }
 
-void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t N)
+void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t N, uint2* pairs2)
 {
     if (N < 2) return;
     uint32_t tile = N < SORT_TILE ? N : SORT_TILE;
     uint32_t blocks = N / tile;
-    const uint32_t B = log2u(tile);
-    if (tile < 8u) hipLaunchKernelGGL(k_bitonic_lds_sort, dim3(blocks), dim3(SORT_THREADS), 0, s, pairs, tile);
-    else hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(blocks), dim3(BT_THREADS), 0, s, pairs, B);
+    const uint32_t B = log2u(tile), arrays = pairs2 ? 2u : 1u;
+    if (tile < 8u) hipLaunchKernelGGL(k_bitonic_lds_sort, dim3(blocks, arrays), dim3(SORT_THREADS), 0, s, pairs, pairs2, tile);
+    else hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(blocks, arrays), dim3(BT_THREADS), 0, s, pairs, pairs2, B);
     for (uint32_t length = tile; length < N; length <<= 1) {
         // levels inc = length .. tile go through HBM, up to eight per pass; the rest of the merge runs inside the tiles
         uint32_t top = log2u(length);
         uint32_t left = top - 12u + 1u;                     // tile == SORT_TILE == 2^12 here (N > tile)
         while (left) {
             const uint32_t levels = left < SORT_FUSED_LEVELS ? left : SORT_FUSED_LEVELS;
-            hipLaunchKernelGGL(k_bitonic_strided, dim3(N / SORT_TILE), dim3(SORT_THREADS), 0, s, pairs, top, levels, length << 1);
+            hipLaunchKernelGGL(k_bitonic_strided, dim3(N / SORT_TILE, arrays), dim3(SORT_THREADS), 0, s, pairs, pairs2, top, levels, length << 1);
             top -= levels; left -= levels;
         }
-        hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(blocks), dim3(BT_THREADS), 0, s, pairs, B, length << 1);
+        hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(blocks, arrays), dim3(BT_THREADS), 0, s, pairs, pairs2, B, length << 1);
     }
 }
 
@@ -351,10 +357,13 @@ __device__ __forceinline__ uint32_t rdx_block_exclusive(uint32_t v, uint32_t* wa
     return inc - v + prefix;
 }
 
+// (in2 / hist2 / ...: a second sort of the same size carried by the same launches, blockIdx.y = 1)
 template <uint32_t R>
-__global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const uint2* __restrict__ in, uint32_t n, uint32_t shift, uint32_t tiles, uint32_t* __restrict__ hist)
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const uint2* __restrict__ in, uint32_t n, uint32_t shift, uint32_t tiles, uint32_t* __restrict__ hist,
+                                                            const uint2* __restrict__ in2, uint32_t* __restrict__ hist2)
 {
     __shared__ uint32_t cnt[RDX_BINS];
+    if (blockIdx.y) { in = in2; hist = hist2; }
     cnt[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x * (R * RDX_THREADS);
@@ -367,9 +376,11 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const uint2* __restr
     hist[threadIdx.x * tiles + blockIdx.x] = cnt[threadIdx.x];
 }
 
-__global__ __launch_bounds__(RDX_THREADS) void k_radix_rows(uint32_t* __restrict__ hist, uint32_t tiles, uint32_t* __restrict__ totals)
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_rows(uint32_t* __restrict__ hist, uint32_t tiles, uint32_t* __restrict__ totals,
+                                                            uint32_t* __restrict__ hist2, uint32_t* __restrict__ totals2)
 {
     __shared__ uint32_t wave_sums[RDX_WAVES];
+    if (blockIdx.y) { hist = hist2; totals = totals2; }
     uint32_t* row = hist + (size_t)blockIdx.x * tiles;
     uint32_t carry = 0;
     for (uint32_t t0 = 0; t0 < tiles; t0 += RDX_THREADS) {
@@ -438,11 +449,14 @@ __device__ __forceinline__ void rdx_tile_pass(const uint2 (&e)[R], uint32_t coun
 
 template <uint32_t R>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __restrict__ in, uint2* __restrict__ out, uint32_t n, uint32_t shift,
-                                                               uint32_t tiles, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals)
+                                                               uint32_t tiles, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+                                                               const uint2* __restrict__ in2, uint2* __restrict__ out2, const uint32_t* __restrict__ hist2,
+                                                               const uint32_t* __restrict__ totals2)
 {
     __shared__ uint32_t cnt[RDX_WAVES][RDX_BINS];
     __shared__ uint32_t dig_start[RDX_BINS];
     __shared__ uint32_t gbase[RDX_BINS];
+    if (blockIdx.y) { in = in2; out = out2; hist = hist2; totals = totals2; }
     __shared__ uint32_t wave_sums[RDX_WAVES];
     __shared__ uint2 stage[R * RDX_THREADS];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -470,9 +484,10 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const uint2* __re
 #define RDX_ONE_BLOCK 4096u       // up to here: all passes in one block, in LDS (R = 16; R = 4 up to 1 024 and R = 1 up to 256 elements: a
                                   // dozen pairs do not pay for sixteen rounds of ballots per pass -- 21.6 -> 4 us on the cube's 12)
 template <uint32_t R>
-__global__ __launch_bounds__(RDX_THREADS) void k_radix_small(uint2* __restrict__ data, uint32_t n, uint32_t passes)
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_small(uint2* __restrict__ data, uint32_t n, uint32_t passes, uint2* __restrict__ data2)
 {
     __shared__ uint32_t cnt[RDX_WAVES][RDX_BINS];
+    if (blockIdx.y) data = data2;
     __shared__ uint32_t dig_start[RDX_BINS];
     __shared__ uint32_t wave_sums[RDX_WAVES];
     __shared__ uint2 stage[R * RDX_THREADS];
@@ -511,29 +526,39 @@ static uint32_t radix_tile(uint32_t n) { return (n < RDX_SMALL_TILES_BELOW ? 4u 
 size_t radix_sort_scratch_words(uint32_t n) { return (size_t)RDX_BINS * ((n + 1023u) / 1024u) + RDX_BINS; }
 
 // sorts pairs[0, n) by the low key_bits bits of .x (the bits above must be equal on all keys, e.g. zero), stable; tmp holds n pairs,
-// scratch radix_sort_scratch_words(n) words.  The result is in `pairs`.
-void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint32_t key_bits, uint32_t* scratch)
+// scratch radix_sort_scratch_words(n) words.  The result is in `pairs`.  pairs2 / tmp2 / scratch2: a second sort of the same size and key
+// width carried by the same launches.
+void launch_radix_sort(hipStream_t s, uint2* pairs, uint2* tmp, uint32_t n, uint32_t key_bits, uint32_t* scratch, uint2* pairs2, uint2* tmp2, uint32_t* scratch2)
 {
     if (n < 2) return;
     const uint32_t passes = key_bits == 0 ? 1u : (key_bits + 7u) / 8u;
+    const uint32_t arrays = pairs2 ? 2u : 1u;
     if (n <= RDX_ONE_BLOCK) {
-        if (n <= RDX_THREADS) hipLaunchKernelGGL(k_radix_small<1u>, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes);
-        else if (n <= 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_small<4u>, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes);
-        else hipLaunchKernelGGL(k_radix_small<16u>, dim3(1), dim3(RDX_THREADS), 0, s, pairs, n, passes);
+        if (n <= RDX_THREADS) hipLaunchKernelGGL(k_radix_small<1u>, dim3(1, arrays), dim3(RDX_THREADS), 0, s, pairs, n, passes, pairs2);
+        else if (n <= 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_small<4u>, dim3(1, arrays), dim3(RDX_THREADS), 0, s, pairs, n, passes, pairs2);
+        else hipLaunchKernelGGL(k_radix_small<16u>, dim3(1, arrays), dim3(RDX_THREADS), 0, s, pairs, n, passes, pairs2);
         return;
     }
     const uint32_t tile = radix_tile(n), tiles = (n + tile - 1u) / tile;
     uint32_t* hist = scratch; uint32_t* totals = scratch + (size_t)RDX_BINS * tiles;
+    uint32_t* hist2 = scratch2; uint32_t* totals2 = scratch2 ? scratch2 + (size_t)RDX_BINS * tiles : nullptr;
     uint2* src = pairs; uint2* dst = tmp;
+    uint2* src2 = pairs2; uint2* dst2 = tmp2;
     for (uint32_t p = 0; p < passes; p++) {
-        if (tile == 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_hist<4u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist);
-        else hipLaunchKernelGGL(k_radix_hist<16u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist);
-        hipLaunchKernelGGL(k_radix_rows, dim3(RDX_BINS), dim3(RDX_THREADS), 0, s, hist, tiles, totals);
-        if (tile == 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_scatter<4u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals);
-        else hipLaunchKernelGGL(k_radix_scatter<16u>, dim3(tiles), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals);
+        if (tile == 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_hist<4u>, dim3(tiles, arrays), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist, (const uint2*)src2, hist2);
+        else hipLaunchKernelGGL(k_radix_hist<16u>, dim3(tiles, arrays), dim3(RDX_THREADS), 0, s, (const uint2*)src, n, p * 8u, tiles, hist, (const uint2*)src2, hist2);
+        hipLaunchKernelGGL(k_radix_rows, dim3(RDX_BINS, arrays), dim3(RDX_THREADS), 0, s, hist, tiles, totals, hist2, totals2);
+        if (tile == 4u * RDX_THREADS) hipLaunchKernelGGL(k_radix_scatter<4u>, dim3(tiles, arrays), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals,
+                                                         (const uint2*)src2, dst2, (const uint32_t*)hist2, (const uint32_t*)totals2);
+        else hipLaunchKernelGGL(k_radix_scatter<16u>, dim3(tiles, arrays), dim3(RDX_THREADS), 0, s, (const uint2*)src, dst, n, p * 8u, tiles, (const uint32_t*)hist, (const uint32_t*)totals,
+                                (const uint2*)src2, dst2, (const uint32_t*)hist2, (const uint32_t*)totals2);
         uint2* t = src; src = dst; dst = t;
+        t = src2; src2 = dst2; dst2 = t;
     }
-    if (src != pairs) (void)hipMemcpyAsync(pairs, src, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, s);
+    if (src != pairs) {
+        (void)hipMemcpyAsync(pairs, src, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, s);
+        if (pairs2) (void)hipMemcpyAsync(pairs2, src2, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, s);
+    }
 }
 
 // rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
