@@ -667,7 +667,23 @@ __global__ __launch_bounds__(1024) void k_seg_top(SegSet first, SegSet second, S
     }
 }
 
-__global__ __launch_bounds__(256) void k_seg_refit(SegSet first, SegSet second, uint32_t n, SegLevels L)
+// marks[key] += sign, once per run of consecutive lanes with the same key: the nodes of a chain of equal Morton codes are consecutive and share
+// an end of their spans, i.e. a wave would send up to 64 adds to one address (the active lanes of a wave are a prefix of it here)
+__device__ __forceinline__ void seg_mark(int32_t* marks, uint32_t key, int32_t sign)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
+    const bool head = lane == 0u || prev != key;
+    const uint64_t active = __ballot(true), heads = __ballot(head);
+    if (head) {
+        const uint64_t above = (heads >> lane) >> 1;
+        const uint32_t run_end = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;
+        const uint32_t live_end = (uint32_t)__popcll(active);
+        atomicAdd(&marks[key], sign * (int32_t)((run_end < live_end ? run_end : live_end) - lane));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seg_refit(SegSet first, SegSet second, uint32_t n, SegLevels L, uint32_t top_in_lds)
 {
     const SegSet set = blockIdx.y ? second : first;
     rt_bvh_node* const __restrict__ nodes = set.nodes;
@@ -677,25 +693,62 @@ __global__ __launch_bounds__(256) void k_seg_refit(SegSet first, SegSet second, 
     int32_t* const __restrict__ marks = set.marks;
     const bool TIGHT = set.tight != 0u;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Up to 65 536 leaves the levels above the blocks' own (level 8: one entry per 256 leaves, at most 256 of them) are folded by every block
+    // for itself, in LDS, from the level-8 entries k_seg_low left -- the same folds in the same order as k_seg_top, which then is not launched
+    __shared__ float4 t_lo[512], t_hi[512];                  // level k >= 8 at SEG_TOP_AT(k): 0, 256, 384, 448, ...
+#define SEG_TOP_AT(k) (512u - (512u >> ((k) - 8u)))
+    if (top_in_lds) {
+        const uint32_t t = threadIdx.x;
+        if (t < L.cnt[8]) { t_lo[t] = lo[(size_t)L.off[8] + t]; t_hi[t] = hi[(size_t)L.off[8] + t]; }
+        __syncthreads();
+        for (uint32_t k = 9; k < L.levels; k++) {
+            if (t < L.cnt[k]) {
+                const uint32_t below = SEG_TOP_AT(k - 1u);
+                BoxPair x; x.lo = t_lo[below + 2u * t]; x.hi = t_hi[below + 2u * t];
+                if (2u * t + 1u < L.cnt[k - 1]) { BoxPair y; y.lo = t_lo[below + 2u * t + 1u]; y.hi = t_hi[below + 2u * t + 1u]; x = rm_fold(x, y); }
+                t_lo[SEG_TOP_AT(k) + t] = x.lo; t_hi[SEG_TOP_AT(k) + t] = x.hi;
+            }
+            __syncthreads();
+        }
+    }
     if (i >= n - 1u) return;
     const uint2 sp = spans[i];
-    uint32_t a = sp.x, b = sp.y, k = 0;
+    uint32_t a = sp.x, b = sp.y;
     BoxPair left{}, right{};
     bool have_left = false, have_right = false;
-    for (;;) {
-        if (a & 1u) {                                               // a right child: nothing to its left belongs to the span
-            BoxPair e; e.lo = lo[(size_t)L.off[k] + a]; e.hi = hi[(size_t)L.off[k] + a];
-            left = have_left ? rm_fold(left, e) : e; have_left = true;
-            a++;
+    // Which entries cover the span is arithmetic on (a, b) alone: six levels' worth of them are determined first, fetched together, and folded
+    // in the order of the one-level-at-a-time walk (left parts left to right, right parts right to left) -- three round trips through the
+    // cache hierarchy instead of one per level (50 032 leaves: 17 levels).
+    bool done = false;
+    for (uint32_t k0 = 0; k0 < L.levels && !done; k0 += 6u) {
+        bool tl[6], tr[6];
+        size_t il[6], ir[6];
+#pragma unroll
+        for (uint32_t j = 0; j < 6u; j++) {
+            tl[j] = false; tr[j] = false; il[j] = 0; ir[j] = 0;
+            const uint32_t k = k0 + j;
+            if (done || k >= L.levels) continue;
+            const size_t at = (top_in_lds && k >= 8u) ? (size_t)SEG_TOP_AT(k) : (size_t)L.off[k];
+            if (a & 1u) { tl[j] = true; il[j] = at + a; a++; }                        // a right child: nothing to its left belongs to the span
+            if (!(b & 1u)) {                                                          // a left child: nothing to its right belongs to the span
+                tr[j] = true; ir[j] = at + b;
+                if (b == 0u) done = true;                                             // (a > b follows: a >= 1 here unless the span was [0, 0], which no inner node has)
+                else b--;
+            }
+            if (!done) { if (a > b) done = true; else { a >>= 1; b >>= 1; } }
         }
-        if (!(b & 1u)) {                                            // a left child: nothing to its right belongs to the span
-            BoxPair e; e.lo = lo[(size_t)L.off[k] + b]; e.hi = hi[(size_t)L.off[k] + b];
-            right = have_right ? rm_fold(e, right) : e; have_right = true;
-            if (b == 0u) break;                                     // (a > b follows: a >= 1 here unless the span was [0, 0], which no inner node has)
-            b--;
+        BoxPair el[6], er[6];
+#pragma unroll
+        for (uint32_t j = 0; j < 6u; j++) {
+            const bool lds = top_in_lds && k0 + j >= 8u;
+            if (tl[j]) { if (lds) { el[j].lo = t_lo[il[j]]; el[j].hi = t_hi[il[j]]; } else { el[j].lo = lo[il[j]]; el[j].hi = hi[il[j]]; } }
+            if (tr[j]) { if (lds) { er[j].lo = t_lo[ir[j]]; er[j].hi = t_hi[ir[j]]; } else { er[j].lo = lo[ir[j]]; er[j].hi = hi[ir[j]]; } }
         }
-        if (a > b) break;
-        a >>= 1; b >>= 1; k++;
+#pragma unroll
+        for (uint32_t j = 0; j < 6u; j++) {
+            if (tl[j]) { left = have_left ? rm_fold(left, el[j]) : el[j]; have_left = true; }
+            if (tr[j]) { right = have_right ? rm_fold(er[j], right) : er[j]; have_right = true; }
+        }
     }
     const BoxPair acc = (have_left && have_right) ? rm_fold(left, right) : (have_left ? left : right);
     rt_bvh_node* nd = &nodes[n + i];
@@ -707,8 +760,8 @@ __global__ __launch_bounds__(256) void k_seg_refit(SegSet first, SegSet second, 
         nd->boundsMin[0] = RMIN(acc.lo.x, FLT_MAX); nd->boundsMin[1] = RMIN(acc.lo.y, FLT_MAX); nd->boundsMin[2] = RMIN(acc.lo.z, FLT_MAX); nd->boundsMin[3] = 0.0f;
         nd->boundsMax[0] = RMAX(acc.hi.x, FLT_MIN); nd->boundsMax[1] = RMAX(acc.hi.y, FLT_MIN); nd->boundsMax[2] = RMAX(acc.hi.z, FLT_MIN); nd->boundsMax[3] = 0.0f;
     }
-    atomicAdd(&marks[sp.x], 1);
-    atomicAdd(&marks[sp.y + 1u], -1);
+    seg_mark(marks, sp.x, 1);
+    seg_mark(marks, sp.y + 1u, -1);
 }
 
 // The tree depth = the largest number of spans covering a leaf position = the maximum of the running sums of the +1 / -1 marks.  One launch:
@@ -806,8 +859,9 @@ void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, co
     const SegSet second = nodes2 ? seg_set(nodes2, pairs2, spans2, n, scratch2, depth_out2, nan_flag_out2, tight2) : first;
     const uint32_t sets = nodes2 ? 2u : 1u;
     hipLaunchKernelGGL(k_seg_low, dim3((n + 255) / 256, sets), dim3(256), 0, s, first, second, n, L);
-    if (L.levels > 9u) hipLaunchKernelGGL(k_seg_top, dim3(1, sets), dim3(1024), 0, s, first, second, L);
-    hipLaunchKernelGGL(k_seg_refit, dim3((n - 1 + 255) / 256, sets), dim3(256), 0, s, first, second, n, L);
+    const uint32_t top_in_lds = (L.levels > 9u && L.cnt[8] <= 256u) ? 1u : 0u;
+    if (L.levels > 9u && !top_in_lds) hipLaunchKernelGGL(k_seg_top, dim3(1, sets), dim3(1024), 0, s, first, second, L);
+    hipLaunchKernelGGL(k_seg_refit, dim3((n - 1 + 255) / 256, sets), dim3(256), 0, s, first, second, n, L, top_in_lds);
     hipLaunchKernelGGL(k_seg_depth, dim3((n + SEG_DEPTH_TILE - 1u) / SEG_DEPTH_TILE, sets), dim3(256), 0, s, first, second, n);
 }
 
@@ -1005,9 +1059,13 @@ void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t 
 // Records [first, first + count) (child ids are indices into the whole `trav` array).  A thread assembles one 128-byte record; the block hands its
 // 256 records over through LDS so that the eight 16-byte parts of a record are written by eight neighbouring lanes (whole lines per store
 // instruction instead of 64 lines touched by each of eight).
-__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t first, uint32_t count, uint32_t greedy)
+// words_out != null: the build's four depth / flag words (words_in, device) are handed to the host (pinned memory) by this launch, the last of a
+// build -- a copy node behind it would be one more link of the chain.
+__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t first, uint32_t count, uint32_t greedy,
+                                                       const uint32_t* __restrict__ words_in, uint32_t* __restrict__ words_out)
 {
     __shared__ float4 stage[256 * 9];
+    if (words_out != nullptr && blockIdx.x == 0 && threadIdx.x < 4u) words_out[threadIdx.x] = words_in[threadIdx.x];
     const uint32_t block_first = blockIdx.x * 256u;
     const uint32_t i = first + block_first + threadIdx.x;
     const bool live = block_first + threadIdx.x < count;
@@ -1070,10 +1128,10 @@ __global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restric
     for (uint32_t p = threadIdx.x; p < parts; p += 256u) out[p] = stage[(p >> 3) * 9u + (p & 7u)];
 }
 
-void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count)
+void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count, const uint32_t* words_in, uint32_t* words_out)
 {
     static const uint32_t greedy = [] { const char* e = getenv("RTMI_QUAD_BY_AREA"); return (e && e[0] == '0') ? 0u : 1u; }();
-    if (count) hipLaunchKernelGGL(k_relayout_quad, dim3((count + 255) / 256), dim3(256), 0, s, trav, quad, first, count, greedy);
+    if (count) hipLaunchKernelGGL(k_relayout_quad, dim3((count + 255) / 256), dim3(256), 0, s, trav, quad, first, count, greedy, words_in, words_out);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -291,9 +291,11 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     else launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, n, 0u, &sc, b->d_trirec);
     // four-wide records: of the search tree only -- no kernel walks the reference tree four records wide (the policy's condition and
     // `cur >= search_root` in the kernels), so that half of the buffer stays unwritten
-    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, want_search ? n - 1u : 0u, n - 1u);
+    // (the depth words reach the host's pinned copy through that launch, the last of the chain; without it, through a copy)
+    const bool words_by_kernel = b->d_quad && n > 1u;
+    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, want_search ? n - 1u : 0u, n - 1u, d_depth, words_by_kernel ? b->h_depths : nullptr);
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], d_depth, 16, hipMemcpyDeviceToHost, s));
+    if (!words_by_kernel) RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], d_depth, 16, hipMemcpyDeviceToHost, s));
     return RT_SUCCESS;
 }
 

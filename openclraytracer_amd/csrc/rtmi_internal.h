@@ -307,7 +307,8 @@ void launch_refit_pair(hipStream_t s, uint32_t n, rt_bvh_node* nodes, uint32_t* 
 void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
                      uint32_t n, uint32_t id_offset = 0, const DeviceScene* sc = nullptr, TriRec* trirec = nullptr,   // + DFS ranks; sc / trirec: + the packed triangle records
                      const rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, TravNode* trav2 = nullptr, uint32_t* pos2 = nullptr, uint32_t id_offset2 = 0);
-void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count);   // records [first, first + count)
+void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count,   // records [first, first + count)
+                          const uint32_t* words_in = nullptr, uint32_t* words_out = nullptr);   // + four words copied to (pinned host) memory on the way
 void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out);
 void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3]);
 // sort_scan_kernels.hip
