@@ -785,50 +785,6 @@ __device__ __forceinline__ int32_t seg_block_exclusive(int32_t v, int32_t* sh /*
     __syncthreads();
     return inc - v;
 }
-__global__ __launch_bounds__(256) void k_seg_depth(SegSet set0, SegSet set1, uint32_t n)
-{
-    const SegSet set = blockIdx.y ? set1 : set0;
-    const int32_t* const __restrict__ marks = set.marks;
-    int32_t* const tile_out = set.tiles;               // 2 words per tile
-    uint32_t* const ticket = set.ticket;
-    uint32_t* const __restrict__ depth_out = set.depth_out;
-    __shared__ int32_t sh[256];
-    __shared__ int32_t sh_max[256];
-    __shared__ uint32_t s_last;
-    const uint32_t t = threadIdx.x, tiles = gridDim.x;
-    const uint32_t first = blockIdx.x * SEG_DEPTH_TILE + t * 16u;
-    int32_t run = 0, best = 0;
-    for (uint32_t k = 0; k < 16u; k++) { const uint32_t j = first + k; if (j < n) { run += marks[j]; best = run > best ? run : best; } }
-    int32_t total;
-    const int32_t off = seg_block_exclusive(run, sh, &total);
-    sh_max[t] = off + best;
-    __syncthreads();
-    for (uint32_t o = 128; o > 0; o >>= 1) { if (t < o) sh_max[t] = sh_max[t] > sh_max[t + o] ? sh_max[t] : sh_max[t + o]; __syncthreads(); }
-    if (t == 0) {
-        __hip_atomic_store(&tile_out[2u * blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&tile_out[2u * blockIdx.x + 1u], sh_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my tile stands in memory before my ticket is drawn
-        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    int32_t carry = 0, deepest = 0;
-    for (uint32_t base = 0; base < tiles; base += 256u) {
-        const uint32_t k = base + t;
-        const int32_t tot = k < tiles ? __hip_atomic_load(&tile_out[2u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        const int32_t mx = k < tiles ? __hip_atomic_load(&tile_out[2u * k + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        int32_t round_total;
-        const int32_t ex = seg_block_exclusive(tot, sh, &round_total);
-        sh_max[t] = k < tiles ? carry + ex + mx : 0;
-        __syncthreads();
-        for (uint32_t o = 128; o > 0; o >>= 1) { if (t < o) sh_max[t] = sh_max[t] > sh_max[t + o] ? sh_max[t] : sh_max[t + o]; __syncthreads(); }
-        deepest = sh_max[0] > deepest ? sh_max[0] : deepest;
-        carry += round_total;
-        __syncthreads();
-    }
-    if (t == 0) { *depth_out = (uint32_t)deepest; *ticket = 0u; }             // (the ticket counter is left at zero for the next build)
-}
-
 size_t refit_span_scratch_bytes(uint32_t n)
 {
     return seg_entries(n) * 2 * sizeof(float4) + ((size_t)n + 1) * 2 * sizeof(uint32_t) + scan_scratch_words(n + 1) * sizeof(uint32_t) + 256;
@@ -850,9 +806,10 @@ static SegSet seg_set(rt_bvh_node* nodes, const uint2* pairs, const uint2* spans
 // boxes of all inner nodes + the tree depth; *nan_flag_out (device word) != 0 afterwards: NaN boxes, the climb must redo it.
 // (depth_out and nan_flag_out are consecutive words cleared by the k_radix_tree launch in front of this refit: launch_radix_tree's clear2.)
 // nodes2 != null: the second hierarchy of the build (same n) in the same four launches.
+// depth_later: the marks are left for launch_finish, which turns them into the depth on its way (one launch less).
 void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
                        uint32_t* nan_flag_out, bool tight, rt_bvh_node* nodes2, const uint2* pairs2, const uint2* spans2, void* scratch2,
-                       uint32_t* depth_out2, uint32_t* nan_flag_out2, bool tight2)
+                       uint32_t* depth_out2, uint32_t* nan_flag_out2, bool tight2, bool depth_later)
 {
     const SegLevels L = seg_levels(n);
     const SegSet first = seg_set(nodes, pairs, spans, n, scratch, depth_out, nan_flag_out, tight);
@@ -862,7 +819,7 @@ void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, co
     const uint32_t top_in_lds = (L.levels > 9u && L.cnt[8] <= 256u) ? 1u : 0u;
     if (L.levels > 9u && !top_in_lds) hipLaunchKernelGGL(k_seg_top, dim3(1, sets), dim3(1024), 0, s, first, second, L);
     hipLaunchKernelGGL(k_seg_refit, dim3((n - 1 + 255) / 256, sets), dim3(256), 0, s, first, second, n, L, top_in_lds);
-    hipLaunchKernelGGL(k_seg_depth, dim3((n + SEG_DEPTH_TILE - 1u) / SEG_DEPTH_TILE, sets), dim3(256), 0, s, first, second, n);
+    (void)depth_later;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -948,81 +905,7 @@ void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters,
 // ----------------------------------------------------------------------------------------
 // 5. re-layout into 64-byte traversal records + tree depth (sizes the deep-stack spill area)
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_relayout(const rt_bvh_node* nodes, TravNode* trav, uint32_t n, uint32_t id_offset)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    const rt_bvh_node* nd = &nodes[n + i];
-    uint32_t ca = nd->data[1], cb = nd->data[2];
-    TravNode t;
-    for (int k = 0; k < 3; k++) {
-        t.a_lo[k] = nodes[ca].boundsMin[k]; t.a_hi[k] = nodes[ca].boundsMax[k];
-        t.b_lo[k] = nodes[cb].boundsMin[k]; t.b_hi[k] = nodes[cb].boundsMax[k];
-    }
-    t.child_a = ca < n ? (RT_LEAF_FLAG | ca) : ca - n + id_offset;    // id_offset: where this tree's records start in the array
-    t.child_b = cb < n ? (RT_LEAF_FLAG | cb) : cb - n + id_offset;
-    t.pad0 = 0; t.pad1 = 0;
-    trav[i] = t;
-}
-
-// leaf -> position in the sorted pair array.  The radix tree is built over that array, so this is
-// the leaf's rank in the reference's A-first depth-first order (the tie rule of BVH.h:392).
-__global__ __launch_bounds__(256) void k_leaf_positions(const uint2* pairs, uint32_t* pos, uint32_t n)
-{
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) pos[pairs[j].y] = j;
-}
-
-// relayout + leaf positions (+ the packed triangle records of the packet kernels, which hold the rank: trirec != null) in ONE launch: thread j
-// writes traversal record j and serves the leaf at sorted position j -- no thread reads what another writes
-// (second: the search tree's records in the same launch, blockIdx.y = 1; the packed triangle records belong to the first set)
-struct RelayoutSet { const rt_bvh_node* nodes; const uint2* pairs; TravNode* trav; uint32_t* pos; uint32_t id_offset; };
-__global__ __launch_bounds__(256) void k_relayout_all(RelayoutSet first, RelayoutSet second, uint32_t n, DeviceScene sc, TriRec* __restrict__ trirec_first)
-{
-    const RelayoutSet set = blockIdx.y ? second : first;
-    const rt_bvh_node* const nodes = set.nodes;
-    const uint2* const __restrict__ pairs = set.pairs;
-    TravNode* const trav = set.trav;
-    uint32_t* const __restrict__ pos = set.pos;
-    const uint32_t id_offset = set.id_offset;
-    TriRec* const __restrict__ trirec = blockIdx.y ? nullptr : trirec_first;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n - 1u) {
-        const rt_bvh_node* nd = &nodes[n + j];
-        const uint32_t ca = nd->data[1], cb = nd->data[2];
-        TravNode t;
-        for (int k = 0; k < 3; k++) {
-            t.a_lo[k] = nodes[ca].boundsMin[k]; t.a_hi[k] = nodes[ca].boundsMax[k];
-            t.b_lo[k] = nodes[cb].boundsMin[k]; t.b_hi[k] = nodes[cb].boundsMax[k];
-        }
-        t.child_a = ca < n ? (RT_LEAF_FLAG | ca) : ca - n + id_offset;
-        t.child_b = cb < n ? (RT_LEAF_FLAG | cb) : cb - n + id_offset;
-        t.pad0 = 0; t.pad1 = 0;
-        trav[j] = t;
-    }
-    if (j < n) {
-        const uint32_t leaf = pairs[j].y;
-        pos[leaf] = j;
-        if (trirec != nullptr) {
-            const float4 v0 = sc.v0[leaf], e1 = sc.e1[leaf], e2 = sc.e2[leaf];
-            TriRec r;
-            r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z;
-            r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
-            r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
-            r.pos = j; r.material = __float_as_uint(v0.w); r.pad = 0u;
-            trirec[leaf] = r;
-        }
-    }
-}
-
-void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t id_offset, const DeviceScene* sc, TriRec* trirec,
-                     const rt_bvh_node* nodes2, const uint2* pairs2, TravNode* trav2, uint32_t* pos2, uint32_t id_offset2)
-{
-    DeviceScene none{};
-    const RelayoutSet first{ nodes, pairs, trav, pos, id_offset }, second{ nodes2, pairs2, trav2, pos2, id_offset2 };
-    hipLaunchKernelGGL(k_relayout_all, dim3((n + 255) / 256, nodes2 ? 2u : 1u), dim3(256), 0, s, first, second, n, sc ? *sc : none, sc ? trirec : nullptr);
-}
+// (the kernel: k_finish, section 7a)
 
 // ----------------------------------------------------------------------------------------
 // 6. search tree: a second hierarchy over the SAME leaves (same 48-byte leaf nodes, same boxes), ordered by Morton codes
@@ -1035,124 +918,185 @@ void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs
 // (normalised to the MODEL's box of the scene header -- the box the reference's own codes are scaled by, RTKernelUtils.h:63-69, here with the
 //  minimum subtracted -- passed by value: the keys need the leaves and nothing of the reference tree, so the two hierarchies can be built
 //  side by side.  Through round 3 the reference ROOT's box was read, i.e. the reference refit had to finish first.)
-__global__ __launch_bounds__(256) void k_search_tree_keys(const rt_bvh_node* nodes, uint32_t n, uint2* pairs, KeyBox box)
-{
-    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= n) return;
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; k++) { lo[k] = nodes[leaf].boundsMin[k]; hi[k] = nodes[leaf].boundsMax[k]; }
-    pairs[leaf] = make_uint2(search_tree_key(lo, hi, box), leaf);
-}
-
-void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3])
-{
-    KeyBox b;
-    for (int k = 0; k < 3; k++) { b.lo[k] = box_lo[k]; b.hi[k] = box_hi[k]; }
-    hipLaunchKernelGGL(k_search_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, leaves, n, pairs, b);
-}
-
 // ----------------------------------------------------------------------------------------
 // 7. four-wide records for the packet kernel: node i with its inner children replaced by their children.  Skipping the
 //    inner children's own boxes is allowed for the same reason the search tree is (any nested hierarchy over the leaves
 //    reaches the same leaves); one wave step then descends two levels.
 // ----------------------------------------------------------------------------------------
-// Records [first, first + count) (child ids are indices into the whole `trav` array).  A thread assembles one 128-byte record; the block hands its
-// 256 records over through LDS so that the eight 16-byte parts of a record are written by eight neighbouring lanes (whole lines per store
-// instruction instead of 64 lines touched by each of eight).
-// words_out != null: the build's four depth / flag words (words_in, device) are handed to the host (pinned memory) by this launch, the last of a
-// build -- a copy node behind it would be one more link of the chain.
-__global__ __launch_bounds__(256) void k_relayout_quad(const TravNode* __restrict__ trav, QuadNode* __restrict__ quad, uint32_t first, uint32_t count, uint32_t greedy,
-                                                       const uint32_t* __restrict__ words_in, uint32_t* __restrict__ words_out)
+// (the kernel: k_finish below)
+
+// ----------------------------------------------------------------------------------------
+// 7a. the end of a build in ONE launch: what k_relayout_all, k_relayout_quad and k_seg_depth do, for both hierarchies (blockIdx.y), plus the
+//     hand-over of the depth / flag words to the host's pinned copy.  A block of 256 threads serves inner nodes / sorted positions / marks
+//     [256 b, 256 b + 256):
+//       * traversal record j, rank and packed triangle record of the leaf at sorted position j (k_relayout_all);
+//       * four-wide record j (sets with quad != null): the same cut as k_relayout_quad -- the slot with the largest surface area opened, twice --
+//         with the children's records assembled from the node buffer the way record j is, instead of read back from `trav` (which other blocks
+//         of this launch are still writing);
+//       * sets refitted by spans (marks != null): the block's 256 marks as one tile of the depth computation of k_seg_depth -- total and maximum of
+//         the running sum, left where the others see them; the block that finishes LAST combines the tiles in order.
+// ----------------------------------------------------------------------------------------
+struct FinishSet {
+    const rt_bvh_node* nodes; const uint2* pairs; TravNode* trav; uint32_t* pos; uint32_t id_offset;
+    QuadNode* quad;                                          // record j of this set at quad[j]; null: no four-wide records
+    const int32_t* marks; int32_t* tiles; uint32_t* ticket;  // marks == null: words[0] holds the depth already (a climb wrote it)
+    uint32_t* words;                                         // device: [0] depth, [1] NaN flag of the span refit
+    uint32_t* host_words;                                    // where the host reads them (pinned); null: a copy follows
+};
+__device__ __forceinline__ TravNode make_trav(const rt_bvh_node* nodes, uint32_t n, uint32_t id_offset, uint32_t j)
+{
+    const rt_bvh_node* nd = &nodes[n + j];
+    const uint32_t ca = nd->data[1], cb = nd->data[2];
+    TravNode t;
+    for (int k = 0; k < 3; k++) {
+        t.a_lo[k] = nodes[ca].boundsMin[k]; t.a_hi[k] = nodes[ca].boundsMax[k];
+        t.b_lo[k] = nodes[cb].boundsMin[k]; t.b_hi[k] = nodes[cb].boundsMax[k];
+    }
+    t.child_a = ca < n ? (RT_LEAF_FLAG | ca) : ca - n + id_offset;
+    t.child_b = cb < n ? (RT_LEAF_FLAG | cb) : cb - n + id_offset;
+    t.pad0 = 0; t.pad1 = 0;
+    return t;
+}
+__global__ __launch_bounds__(256) void k_finish(FinishSet set0, FinishSet set1, uint32_t n, DeviceScene sc, TriRec* __restrict__ trirec_first, uint32_t greedy)
 {
     __shared__ float4 stage[256 * 9];
-    if (words_out != nullptr && blockIdx.x == 0 && threadIdx.x < 4u) words_out[threadIdx.x] = words_in[threadIdx.x];
-    const uint32_t block_first = blockIdx.x * 256u;
-    const uint32_t i = first + block_first + threadIdx.x;
-    const bool live = block_first + threadIdx.x < count;
-    const TravNode t = trav[live ? i : first];
-    float lo[4][3], hi[4][3];
-    uint32_t id[4];
-    int n = 0;
-    if (greedy) {
-        // The slots are any cut of the node's sub-tree with at most four nodes (every leaf below the node is below exactly one
-        // slot, which is all the walk needs).  Instead of always replacing both children by theirs, the slot with the largest
-        // surface area is opened, twice: the boxes a ray is most likely to enter are the ones resolved further, so fewer steps
-        // end in a big box whose children all miss (the usual collapse of a binary hierarchy into a four-wide one).
-        for (int k = 0; k < 3; k++) { lo[0][k] = t.a_lo[k]; hi[0][k] = t.a_hi[k]; lo[1][k] = t.b_lo[k]; hi[1][k] = t.b_hi[k]; }
-        id[0] = t.child_a; id[1] = t.child_b; n = 2;
-        for (int round = 0; round < 2; round++) {
-            int best = -1; float best_area = -1.0f;
-            for (int c = 0; c < n; c++) {
-                if (id[c] & RT_LEAF_FLAG) continue;
-                const float dx = hi[c][0] - lo[c][0], dy = hi[c][1] - lo[c][1], dz = hi[c][2] - lo[c][2];
-                const float area = dx * dy + dy * dz + dz * dx;
-                if (!(area <= best_area)) { best = c; best_area = area; }       // (a NaN area is opened like any other)
-            }
-            if (best < 0) break;
-            const TravNode u = trav[id[best]];
-            for (int k = 0; k < 3; k++) { lo[best][k] = u.a_lo[k]; hi[best][k] = u.a_hi[k]; lo[n][k] = u.b_lo[k]; hi[n][k] = u.b_hi[k]; }
-            id[best] = u.child_a; id[n] = u.child_b; n++;
-        }
-    } else {
-        for (int c = 0; c < 2; c++) {
-            const uint32_t cid = c ? t.child_b : t.child_a;
-            const float* clo = c ? t.b_lo : t.a_lo;
-            const float* chi = c ? t.b_hi : t.a_hi;
-            if (cid & RT_LEAF_FLAG) {
-                for (int k = 0; k < 3; k++) { lo[n][k] = clo[k]; hi[n][k] = chi[k]; }
-                id[n++] = cid;
-            } else {
-                const TravNode u = trav[cid];
-                for (int k = 0; k < 3; k++) { lo[n][k] = u.a_lo[k]; hi[n][k] = u.a_hi[k]; }
-                id[n++] = u.child_a;
-                for (int k = 0; k < 3; k++) { lo[n][k] = u.b_lo[k]; hi[n][k] = u.b_hi[k]; }
-                id[n++] = u.child_b;
-            }
+    __shared__ int32_t sh[256];
+    __shared__ int32_t sh_max[256];
+    __shared__ uint32_t s_last;
+    const FinishSet set = blockIdx.y ? set1 : set0;
+    const rt_bvh_node* const nodes = set.nodes;
+    const uint32_t t = threadIdx.x, j = blockIdx.x * 256u + t;
+    TravNode rec{};
+    if (j < n - 1u) { rec = make_trav(nodes, n, set.id_offset, j); set.trav[j] = rec; }
+    if (j < n) {
+        const uint32_t leaf = set.pairs[j].y;
+        set.pos[leaf] = j;
+        if (blockIdx.y == 0u && trirec_first != nullptr) {
+            const float4 v0 = sc.v0[leaf], e1 = sc.e1[leaf], e2 = sc.e2[leaf];
+            TriRec r;
+            r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z;
+            r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
+            r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
+            r.pos = j; r.material = __float_as_uint(v0.w); r.pad = 0u;
+            trirec_first[leaf] = r;
         }
     }
-    // an unused slot: id = RT_SENTINEL and a box of NaN planes, which no ray enters under any of the kernels' tests (every compare with
-    // a NaN is false; the camera-relative copies get an empty box of their own, k_prepare_camera)
-    for (; n < 4; n++) { for (int k = 0; k < 3; k++) { lo[n][k] = __builtin_nanf(""); hi[n][k] = __builtin_nanf(""); } id[n] = RT_SENTINEL; }
-    float4* mine = stage + threadIdx.x * 9u;
-    mine[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], __uint_as_float(id[0]));
-    mine[1] = make_float4(hi[0][0], hi[0][1], hi[0][2], __uint_as_float(id[1]));
-    mine[2] = make_float4(lo[1][0], lo[1][1], lo[1][2], __uint_as_float(id[2]));
-    mine[3] = make_float4(hi[1][0], hi[1][1], hi[1][2], __uint_as_float(id[3]));
-    mine[4] = make_float4(lo[2][0], lo[2][1], lo[2][2], 0.0f);
-    mine[5] = make_float4(hi[2][0], hi[2][1], hi[2][2], 0.0f);
-    mine[6] = make_float4(lo[3][0], lo[3][1], lo[3][2], 0.0f);
-    mine[7] = make_float4(hi[3][0], hi[3][1], hi[3][2], 0.0f);
+    if (set.quad != nullptr) {                                            // (uniform per block)
+        float lo[4][3], hi[4][3];
+        uint32_t id[4];
+        int m = 0;
+        if (j < n - 1u) {
+            if (greedy) {
+                for (int k = 0; k < 3; k++) { lo[0][k] = rec.a_lo[k]; hi[0][k] = rec.a_hi[k]; lo[1][k] = rec.b_lo[k]; hi[1][k] = rec.b_hi[k]; }
+                id[0] = rec.child_a; id[1] = rec.child_b; m = 2;
+                for (int round = 0; round < 2; round++) {
+                    int best = -1; float best_area = -1.0f;
+                    for (int c = 0; c < m; c++) {
+                        if (id[c] & RT_LEAF_FLAG) continue;
+                        const float dx = hi[c][0] - lo[c][0], dy = hi[c][1] - lo[c][1], dz = hi[c][2] - lo[c][2];
+                        const float area = dx * dy + dy * dz + dz * dx;
+                        if (!(area <= best_area)) { best = c; best_area = area; }       // (a NaN area is opened like any other)
+                    }
+                    if (best < 0) break;
+                    const TravNode u = make_trav(nodes, n, set.id_offset, id[best] - set.id_offset);
+                    for (int k = 0; k < 3; k++) { lo[best][k] = u.a_lo[k]; hi[best][k] = u.a_hi[k]; lo[m][k] = u.b_lo[k]; hi[m][k] = u.b_hi[k]; }
+                    id[best] = u.child_a; id[m] = u.child_b; m++;
+                }
+            } else {
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t cid = c ? rec.child_b : rec.child_a;
+                    const float* clo = c ? rec.b_lo : rec.a_lo;
+                    const float* chi = c ? rec.b_hi : rec.a_hi;
+                    if (cid & RT_LEAF_FLAG) {
+                        for (int k = 0; k < 3; k++) { lo[m][k] = clo[k]; hi[m][k] = chi[k]; }
+                        id[m++] = cid;
+                    } else {
+                        const TravNode u = make_trav(nodes, n, set.id_offset, cid - set.id_offset);
+                        for (int k = 0; k < 3; k++) { lo[m][k] = u.a_lo[k]; hi[m][k] = u.a_hi[k]; }
+                        id[m++] = u.child_a;
+                        for (int k = 0; k < 3; k++) { lo[m][k] = u.b_lo[k]; hi[m][k] = u.b_hi[k]; }
+                        id[m++] = u.child_b;
+                    }
+                }
+            }
+        }
+        // an unused slot: id = RT_SENTINEL and a box of NaN planes (k_relayout_quad)
+        for (; m < 4; m++) { for (int k = 0; k < 3; k++) { lo[m][k] = __builtin_nanf(""); hi[m][k] = __builtin_nanf(""); } id[m] = RT_SENTINEL; }
+        float4* mine = stage + t * 9u;
+        mine[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], __uint_as_float(id[0]));
+        mine[1] = make_float4(hi[0][0], hi[0][1], hi[0][2], __uint_as_float(id[1]));
+        mine[2] = make_float4(lo[1][0], lo[1][1], lo[1][2], __uint_as_float(id[2]));
+        mine[3] = make_float4(hi[1][0], hi[1][1], hi[1][2], __uint_as_float(id[3]));
+        mine[4] = make_float4(lo[2][0], lo[2][1], lo[2][2], 0.0f);
+        mine[5] = make_float4(hi[2][0], hi[2][1], hi[2][2], 0.0f);
+        mine[6] = make_float4(lo[3][0], lo[3][1], lo[3][2], 0.0f);
+        mine[7] = make_float4(hi[3][0], hi[3][1], hi[3][2], 0.0f);
+        __syncthreads();
+        const uint32_t first = blockIdx.x * 256u;
+        const uint32_t live = first < n - 1u ? (n - 1u - first < 256u ? n - 1u - first : 256u) : 0u;
+        float4* out = reinterpret_cast<float4*>(set.quad + first);
+        for (uint32_t p = t; p < live * 8u; p += 256u) out[p] = stage[(p >> 3) * 9u + (p & 7u)];
+    }
+    if (blockIdx.x == 0u && t == 0u && set.host_words != nullptr) set.host_words[1] = set.words[1];
+    if (set.marks == nullptr) {
+        if (blockIdx.x == 0u && t == 0u && set.host_words != nullptr) set.host_words[0] = set.words[0];
+        return;
+    }
+    // the depth: this block's tile of the marks (k_seg_depth with one mark per thread)
+    const uint32_t tiles = gridDim.x;
+    const int32_t v = j < n ? set.marks[j] : 0;
+    int32_t total;
+    const int32_t ex = seg_block_exclusive(v, sh, &total);
+    sh_max[t] = ex + v;
     __syncthreads();
-    const uint32_t parts = (count - block_first < 256u ? count - block_first : 256u) * 8u;
-    float4* out = reinterpret_cast<float4*>(quad + first + block_first);
-    for (uint32_t p = threadIdx.x; p < parts; p += 256u) out[p] = stage[(p >> 3) * 9u + (p & 7u)];
+    for (uint32_t o = 128; o > 0; o >>= 1) { if (t < o) sh_max[t] = sh_max[t] > sh_max[t + o] ? sh_max[t] : sh_max[t + o]; __syncthreads(); }
+    if (t == 0) {
+        const int32_t mx = sh_max[0] > 0 ? sh_max[0] : 0;
+        __hip_atomic_store(&set.tiles[2u * blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&set.tiles[2u * blockIdx.x + 1u], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my tile stands in memory before my ticket is drawn
+        s_last = __hip_atomic_fetch_add(set.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    int32_t carry = 0, deepest = 0;
+    for (uint32_t base = 0; base < tiles; base += 256u) {
+        const uint32_t k = base + t;
+        const int32_t tot = k < tiles ? __hip_atomic_load(&set.tiles[2u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int32_t mx = k < tiles ? __hip_atomic_load(&set.tiles[2u * k + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int32_t round_total;
+        const int32_t exc = seg_block_exclusive(tot, sh, &round_total);
+        sh_max[t] = k < tiles ? carry + exc + mx : 0;
+        __syncthreads();
+        for (uint32_t o = 128; o > 0; o >>= 1) { if (t < o) sh_max[t] = sh_max[t] > sh_max[t + o] ? sh_max[t] : sh_max[t + o]; __syncthreads(); }
+        deepest = sh_max[0] > deepest ? sh_max[0] : deepest;
+        carry += round_total;
+        __syncthreads();
+    }
+    if (t == 0) {
+        set.words[0] = (uint32_t)deepest;
+        if (set.host_words != nullptr) set.host_words[0] = (uint32_t)deepest;
+        *set.ticket = 0u;                                                     // (left at zero for the next build)
+    }
 }
 
-void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count, const uint32_t* words_in, uint32_t* words_out)
+// span_scratch / span_scratch2: the scratch the span refit of that hierarchy ran on with depth_later (null: its depth word is final already)
+void launch_finish(hipStream_t s, uint32_t n, const DeviceScene& sc, TriRec* trirec,
+                   const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos, uint32_t id_offset, QuadNode* quad, void* span_scratch,
+                   uint32_t* words, uint32_t* host_words,
+                   const rt_bvh_node* nodes2, const uint2* pairs2, TravNode* trav2, uint32_t* pos2, uint32_t id_offset2, QuadNode* quad2, void* span_scratch2,
+                   uint32_t* words2, uint32_t* host_words2)
 {
     static const uint32_t greedy = [] { const char* e = getenv("RTMI_QUAD_BY_AREA"); return (e && e[0] == '0') ? 0u : 1u; }();
-    if (count) hipLaunchKernelGGL(k_relayout_quad, dim3((count + 255) / 256), dim3(256), 0, s, trav, quad, first, count, greedy, words_in, words_out);
-}
-
-// ----------------------------------------------------------------------------------------
-// 8. packed triangle records of the packet kernels (rtmi_internal.h, TriRec): bit copies of the SoA table + the leaf's rank
-// ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_triangles(DeviceScene sc, const uint32_t* __restrict__ pos, TriRec* __restrict__ out)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= sc.n_tris) return;
-    const float4 v0 = sc.v0[t], e1 = sc.e1[t], e2 = sc.e2[t];
-    TriRec r;
-    r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z;
-    r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
-    r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
-    r.pos = pos[t]; r.material = __float_as_uint(v0.w); r.pad = 0u;
-    out[t] = r;
-}
-
-void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out)
-{
-    if (sc.n_tris) hipLaunchKernelGGL(k_pack_triangles, dim3((sc.n_tris + 255) / 256), dim3(256), 0, s, sc, pos, out);
+    auto make = [n](const rt_bvh_node* nd, const uint2* pr, TravNode* tv, uint32_t* ps, uint32_t off, QuadNode* q, void* scratch, uint32_t* w, uint32_t* hw) {
+        FinishSet f{};
+        f.nodes = nd; f.pairs = pr; f.trav = tv; f.pos = ps; f.id_offset = off; f.quad = q; f.words = w; f.host_words = hw;
+        if (scratch) { const SegSet g = seg_set(nullptr, nullptr, nullptr, n, scratch, nullptr, nullptr, false); f.marks = g.marks; f.tiles = g.tiles; f.ticket = g.ticket; }
+        return f;
+    };
+    const FinishSet first = make(nodes, pairs, trav, pos, id_offset, quad, span_scratch, words, host_words);
+    const FinishSet second = nodes2 ? make(nodes2, pairs2, trav2, pos2, id_offset2, quad2, span_scratch2, words2, host_words2) : first;
+    hipLaunchKernelGGL(k_finish, dim3((n + 255) / 256, nodes2 ? 2u : 1u), dim3(256), 0, s, first, second, n, sc, trirec, greedy);
 }
 
 // rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first

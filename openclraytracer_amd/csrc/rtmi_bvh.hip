@@ -252,50 +252,39 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     // (not associative) send it back to the climb -- decided on the device: the climb is launched behind it and runs only if the pass raised
     // its flag, and only for scenes in which the upload saw a NaN vertex.  The search tree's boxes are plain unions (`tight`).
     const bool tight = !ctx->search_tree_reference_boxes;
+    const bool ref_by_spans = !literal && b->d_spans && b->d_span_scratch;
+    const bool search_by_spans = want_search && search_spans;
     if (literal) launch_refit_literal(s, b->d_nodes, b->d_counters, n, d_depth);
-    else if (b->d_spans && b->d_span_scratch && (!want_search || search_spans)) {
-        if (want_search) launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false,
-                                           b->s_nodes, b->s_pairs, b->s_spans, b->s_span_scratch, s_depth, s_depth + 1, tight);
-        else launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false);
-        if (nan_possible) {
-            if (want_search) launch_refit_pair(s, n, b->d_nodes, b->d_counters, d_depth, d_depth + 1, b->s_nodes, b->s_counters, s_depth, s_depth + 1, tight);
-            else launch_refit(s, b->d_nodes, b->d_counters, n, d_depth, false, d_depth + 1);
-        }
-    } else {
-        if (b->d_spans && b->d_rq_scratch) {
+    else if (ref_by_spans && search_by_spans) {
+        launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false,
+                          b->s_nodes, b->s_pairs, b->s_spans, b->s_span_scratch, s_depth, s_depth + 1, tight, true);
+        if (nan_possible) launch_refit_pair(s, n, b->d_nodes, b->d_counters, d_depth, d_depth + 1, b->s_nodes, b->s_counters, s_depth, s_depth + 1, tight);
+    }
+    else if (!ref_by_spans && !search_by_spans && want_search && !(b->d_spans && b->d_rq_scratch))
+        launch_refit_pair(s, n, b->d_nodes, b->d_counters, d_depth, nullptr, b->s_nodes, b->s_counters, s_depth, nullptr, tight);
+    else {          // one hierarchy, or the two refitted differently (RTMI_REFIT=rq: the reference tree by range queries)
+        if (ref_by_spans) {
+            launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, true);
+            if (nan_possible) launch_refit(s, b->d_nodes, b->d_counters, n, d_depth, false, d_depth + 1);
+        } else if (b->d_spans && b->d_rq_scratch) {
             launch_refit_rq(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_rq_scratch, d_depth, d_depth + 1);
             if (nan_possible) launch_refit(s, b->d_nodes, b->d_counters, n, d_depth, false, d_depth + 1);
-            if (want_search) {
-                if (search_spans) {
-                    launch_refit_span(s, b->s_nodes, b->s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight);
-                    if (nan_possible) launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight, s_depth + 1);
-                } else launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight);
-            }
-        }
-        else if (want_search && !search_spans && !b->d_spans) launch_refit_pair(s, n, b->d_nodes, b->d_counters, d_depth, nullptr, b->s_nodes, b->s_counters, s_depth, nullptr, tight);
-        else {
-            if (b->d_spans && b->d_span_scratch) {
-                launch_refit_span(s, b->d_nodes, b->d_pairs, b->d_spans, n, b->d_span_scratch, d_depth, d_depth + 1, false);
-                if (nan_possible) launch_refit(s, b->d_nodes, b->d_counters, n, d_depth, false, d_depth + 1);
-            } else launch_refit(s, b->d_nodes, b->d_counters, n, d_depth);
-            if (want_search) {
-                if (search_spans) {
-                    launch_refit_span(s, b->s_nodes, b->s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight);
-                    if (nan_possible) launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight, s_depth + 1);
-                } else launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight);
-            }
-        }
+        } else launch_refit(s, b->d_nodes, b->d_counters, n, d_depth);
+        if (search_by_spans) {
+            launch_refit_span(s, b->s_nodes, b->s_pairs, b->s_spans, n, b->s_span_scratch, s_depth, s_depth + 1, tight, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, true);
+            if (nan_possible) launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight, s_depth + 1);
+        } else if (want_search) launch_refit(s, b->s_nodes, b->s_counters, n, s_depth, tight);
     }
-    // 5. traversal records, depth-first ranks, packed triangle records (the search tree's records behind the reference tree's: TravNode[2(n-1)])
-    if (want_search) launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, n, 0u, &sc, b->d_trirec, b->s_nodes, b->s_pairs, b->d_trav + (n - 1), b->s_pos, n - 1);
-    else launch_relayout(s, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, n, 0u, &sc, b->d_trirec);
-    // four-wide records: of the search tree only -- no kernel walks the reference tree four records wide (the policy's condition and
-    // `cur >= search_root` in the kernels), so that half of the buffer stays unwritten
-    // (the depth words reach the host's pinned copy through that launch, the last of the chain; without it, through a copy)
-    const bool words_by_kernel = b->d_quad && n > 1u;
-    if (b->d_quad) launch_relayout_quad(s, b->d_trav, b->d_quad, want_search ? n - 1u : 0u, n - 1u, d_depth, words_by_kernel ? b->h_depths : nullptr);
+    // 5. the end of the chain in one launch (build_kernels.hip 7a): traversal records, depth-first ranks, packed triangle records (the search tree's
+    // records behind the reference tree's: TravNode[2(n-1)]); the four-wide records -- of the search tree only: no kernel walks the reference tree
+    // four records wide (the policy's condition and `cur >= search_root` in the kernels), so that half of the buffer stays unwritten --; the tree
+    // depths out of the span refit's marks; and the depth / flag words handed to the host's pinned copy.
+    void* const marks_ref = (ref_by_spans ? b->d_span_scratch : nullptr);
+    void* const marks_search = (search_by_spans ? b->s_span_scratch : nullptr);
+    if (want_search) launch_finish(s, n, sc, b->d_trirec, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, 0u, nullptr, marks_ref, d_depth, b->h_depths,
+                                   b->s_nodes, b->s_pairs, b->d_trav + (n - 1), b->s_pos, n - 1u, b->d_quad ? b->d_quad + (n - 1) : nullptr, marks_search, s_depth, b->h_depths + 2);
+    else launch_finish(s, n, sc, b->d_trirec, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, 0u, literal ? nullptr : b->d_quad, marks_ref, d_depth, b->h_depths);
     RT_HIP(ctx, hipGetLastError());
-    if (!words_by_kernel) RT_HIP(ctx, hipMemcpyAsync(&b->h_depths[0], d_depth, 16, hipMemcpyDeviceToHost, s));
     return RT_SUCCESS;
 }
 

@@ -299,18 +299,19 @@ size_t refit_span_scratch_bytes(uint32_t n);
 void launch_refit_span(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, const uint2* spans, uint32_t n, void* scratch, uint32_t* depth_out,
                        uint32_t* nan_flag_out, bool tight,   // refit by spans over a segment tree of the sorted leaf boxes (every size); *nan_flag_out != 0: redo with launch_refit
                        rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, const uint2* spans2 = nullptr, void* scratch2 = nullptr,
-                       uint32_t* depth_out2 = nullptr, uint32_t* nan_flag_out2 = nullptr, bool tight2 = false);
+                       uint32_t* depth_out2 = nullptr, uint32_t* nan_flag_out2 = nullptr, bool tight2 = false,
+                       bool depth_later = false);     // depth_later: the depth comes out of launch_finish (span_scratch there)
 void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out);
 void launch_refit(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters, uint32_t n, uint32_t* depth_out, bool tight = false, const uint32_t* only_if = nullptr);   // boxes + tree depth; tight: plain unions (search tree); only_if: runs only when that device word is non-zero
 void launch_refit_pair(hipStream_t s, uint32_t n, rt_bvh_node* nodes, uint32_t* counters, uint32_t* depth_out, const uint32_t* only_if,
                        rt_bvh_node* s_nodes, uint32_t* s_counters, uint32_t* s_depth_out, const uint32_t* s_only_if, bool s_tight);   // the climbs of both hierarchies
-void launch_relayout(hipStream_t s, const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos,
-                     uint32_t n, uint32_t id_offset = 0, const DeviceScene* sc = nullptr, TriRec* trirec = nullptr,   // + DFS ranks; sc / trirec: + the packed triangle records
-                     const rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, TravNode* trav2 = nullptr, uint32_t* pos2 = nullptr, uint32_t id_offset2 = 0);
-void launch_relayout_quad(hipStream_t s, const TravNode* trav, QuadNode* quad, uint32_t first, uint32_t count,   // records [first, first + count)
-                          const uint32_t* words_in = nullptr, uint32_t* words_out = nullptr);   // + four words copied to (pinned host) memory on the way
-void launch_pack_triangles(hipStream_t s, const DeviceScene& sc, const uint32_t* pos, TriRec* out);
-void launch_search_tree_keys(hipStream_t s, const rt_bvh_node* leaves, uint32_t n, uint2* pairs, const float box_lo[3], const float box_hi[3]);
+// the end of a build in one launch: traversal records + ranks + packed triangle records, four-wide records (quad != null), tree depth out of the
+// span refit's marks (span_scratch != null), and the depth / flag words (`words`, two per hierarchy) written to `host_words` as well
+void launch_finish(hipStream_t s, uint32_t n, const DeviceScene& sc, TriRec* trirec,
+                   const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos, uint32_t id_offset, QuadNode* quad, void* span_scratch,
+                   uint32_t* words, uint32_t* host_words,
+                   const rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, TravNode* trav2 = nullptr, uint32_t* pos2 = nullptr, uint32_t id_offset2 = 0,
+                   QuadNode* quad2 = nullptr, void* span_scratch2 = nullptr, uint32_t* words2 = nullptr, uint32_t* host_words2 = nullptr);
 // sort_scan_kernels.hip
 void launch_bitonic_sort(hipStream_t s, uint2* pairs, uint32_t n_pow2, uint2* pairs2 = nullptr);   // (+ a second array of the same size in the same launches)
 size_t radix_sort_scratch_words(uint32_t n);
