@@ -113,10 +113,13 @@ __device__ __forceinline__ uint32_t search_tree_key(const float lo[3], const flo
     }
     return morton3d(u[0], u[1], u[2]);
 }
+// (clear / s_clear: the arrival counters of a climbing refit behind this kernel, one word per leaf, zeroed on the way -- BVHManager.cpp:141-147 --
+//  instead of by a fill launch of their own)
 __global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
-                                                       rt_bvh_node* s_nodes, uint2* s_pairs, uint32_t s_padded, KeyBox box)
+                                                       rt_bvh_node* s_nodes, uint2* s_pairs, uint32_t s_padded, KeyBox box, uint32_t* clear, uint32_t* s_clear)
 {
     uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf < sc.n_tris) { if (clear) clear[leaf] = 0u; if (s_clear) s_clear[leaf] = 0u; }
     if (leaf >= sc.n_tris) {
         if (nodes && leaf < padded) pairs[leaf] = make_uint2(UINT_MAX, UINT_MAX);
         if (leaf < s_padded) s_pairs[leaf] = make_uint2(UINT_MAX, UINT_MAX);
@@ -155,13 +158,13 @@ __global__ __launch_bounds__(256) void k_morton_leaves(DeviceScene sc, rt_bvh_no
 }
 
 void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
-                          rt_bvh_node* s_nodes, uint2* s_pairs, uint32_t s_padded)
+                          rt_bvh_node* s_nodes, uint2* s_pairs, uint32_t s_padded, uint32_t* clear, uint32_t* s_clear)
 {
     uint32_t threads = nodes && padded > sc.n_tris ? padded : sc.n_tris;            // (nodes == nullptr: the search tree's outputs only)
     if (s_nodes && s_padded > threads) threads = s_padded;
     KeyBox box;
     for (int k = 0; k < 3; k++) { box.lo[k] = sc.bb_lo[k]; box.hi[k] = sc.bb_hi[k]; }
-    hipLaunchKernelGGL(k_morton_leaves, dim3((threads + 255) / 256), dim3(256), 0, s, sc, nodes, pairs, padded, s_nodes, s_pairs, s_nodes ? s_padded : 0u, box);
+    hipLaunchKernelGGL(k_morton_leaves, dim3((threads + 255) / 256), dim3(256), 0, s, sc, nodes, pairs, padded, s_nodes, s_pairs, s_nodes ? s_padded : 0u, box, clear, s_clear);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -229,13 +229,13 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     const bool search_climbs = want_search && (!search_spans || nan_possible);
     uint32_t* const d_depth = b->d_depth;                     // [0] depth, [1] NaN flag of the span refit; [2], [3] the same of the search tree
     uint32_t* const s_depth = b->d_depth + 2;
-    if (ref_climbs) RT_HIP(ctx, hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(uint32_t), s));
-    if (search_climbs) RT_HIP(ctx, hipMemsetAsync(b->s_counters, 0, (size_t)n * sizeof(uint32_t), s));
     if (literal) RT_HIP(ctx, hipMemsetAsync(b->d_nodes, 0, (size_t)(2 * n - 1) * sizeof(rt_bvh_node), s));
     // 1. BVHManager.cpp:183: leaves and Morton pairs (+ the padding of the pair buffer; + the search tree's copy of the leaves and its keys --
     // Morton codes of the box centres normalised to the scene header's box -- and the padding its sort wants)
-    if (want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, b->s_nodes, b->s_pairs, search_with_network ? N : 0u);
-    else launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N);
+    // (+ the arrival counters of the climbs, where a climb will run, zeroed on the way)
+    if (want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, b->s_nodes, b->s_pairs, search_with_network ? N : 0u,
+                                          ref_climbs ? b->d_counters : nullptr, search_climbs ? b->s_counters : nullptr);
+    else launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, nullptr, nullptr, 0u, ref_climbs ? b->d_counters : nullptr, nullptr);
     if (fast) {
         if (search_with_radix_pair) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2, n, 30u, b->d_sort_scratch2, b->s_pairs, b->d_sort_tmp, b->d_sort_scratch);
         else launch_radix_sort(s, b->d_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);

@@ -287,7 +287,8 @@ extern "C" __attribute__((visibility("hidden"))) int rt_check_camera(rt_ctx* ctx
 void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
 // leaves + Morton pairs (+ the padding pairs [n, padded) of the pair buffer); on request the search tree's leaves and keys as well
 void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
-                          rt_bvh_node* s_nodes = nullptr, uint2* s_pairs = nullptr, uint32_t s_padded = 0u);
+                          rt_bvh_node* s_nodes = nullptr, uint2* s_pairs = nullptr, uint32_t s_padded = 0u,
+                          uint32_t* clear = nullptr, uint32_t* s_clear = nullptr);      // + n words each zeroed on the way (the climbs' arrival counters)
 // The kernels of a build carry BOTH hierarchies (the reference tree and the search tree: same leaves, same n) in one launch -- the arguments with a
 // trailing 2 are the second one's, blockIdx.y = 1; null: one hierarchy.  A build is a chain of dependent launches of ~5 us each whatever they do.
 void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr, uint32_t* clear2 = nullptr,   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO); clear2: two words zeroed on the way
