@@ -28,7 +28,7 @@ The line printed by rank 0 also carries
                       on this box's host cores on the same five frames (rank 0, N = 1 only).  A reported baseline, not the target.
   config5             BASELINE.json configs[4]: the Sponza-class stand-in at 3840x2160, BVH, tiled over the N ranks.
   per_scene[..].rebuild_plus_trace_ms   the dynamic-scene frame (OpenCLRayTracerDemo.cpp:230-234): initializeFrame + construct +
-                      generateContacts + shade, every frame.
+                      generateContacts + shade (rt_render_frame: one eager sequence, the trace kernels shade what they store), every frame.
   moving_camera       the Demo's RTFrame loop (OpenCLRayTracerDemo.cpp:271-326: the camera is updated before every frame, :275-276):
                       every frame a new camera position and orientation, the per-camera preparation (k_prepare_camera) inside
                       the timed region; graph path (rt_frame_graph_set_camera + launch) and eager path, per scene and per step of
@@ -810,10 +810,9 @@ def main():
         if not tiled and not args.no_extra_legs:
             K = 8
 
-            def dyn(it=it, sctx=sctx):
+            def dyn(it=it, sctx=sctx):            # (rt_render_frame: contacts + colours as one eager sequence -- a frame graph does not survive construct())
                 it['bvh'].initialize_frame(); it['bvh'].construct()
-                it['bvh'].generate_contacts_primary_d(it['cam'], it['contacts'])
-                capi.shade_blinn_phong_frame_d(sctx, it['scene'], it['cam'], it['contacts'], it['rgba'])
+                capi.render_frame_d(it['bvh'], it['scene'], it['cam'], it['contacts'], it['rgba'])
             dyn(); dyn(); sctx.synchronize()
             tw = time.perf_counter()
             for _ in range(K):
@@ -837,8 +836,7 @@ def main():
 
             def dyn_fast():
                 fast.initialize_frame(); fast.construct()
-                fast.generate_contacts_primary_d(it['cam'], it['contacts'])
-                capi.shade_blinn_phong_frame_d(sctx, it['scene'], it['cam'], it['contacts'], it['rgba'])
+                capi.render_frame_d(fast, it['scene'], it['cam'], it['contacts'], it['rgba'])
             dyn_fast(); dyn_fast(); sctx.synchronize()
             tw = time.perf_counter()
             for _ in range(K):

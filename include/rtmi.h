@@ -366,6 +366,13 @@ int  rt_frame_graph_last_launch(const rt_frame_graph* g);
 #define RT_FRAME_GRAPH_STATE_WORDS 8
 int  rt_frame_graph_state(const rt_frame_graph* g, uint32_t* out, uint32_t n);
 void rt_frame_graph_destroy(rt_frame_graph* g);
+/* One frame, eagerly: what the Demo's RTFrame does per frame (OpenCLRayTracerDemo.cpp:287-319: generateContacts, then the colours) as ONE
+ * sequence in which the trace kernels shade what they store where the strategy allows it (else k_shade follows) -- the frame of a scene
+ * that is rebuilt every frame (OpenCLRayTracerDemo.cpp:230-234), which cannot keep a frame graph: a graph is stale after construct().
+ * Same layouts and buffers as rt_frame_graph_create; the contacts are those of rt_bvh_generate_contacts_primary[_tiled], the colours
+ * those of rt_shade_blinn_phong_frame / _tiled / _tiled_packed within 1e-5.  Asynchronous on the context's stream.                    */
+int  rt_render_frame(rt_bvh* bvh, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks, int layout,
+                     void* d_contacts, void* d_out, uint32_t slots_per_rank);
 
 /* ---- parallel primitives used by the builders ------------------------------------------- */
 /* BitonicSort::sort (Include/Algorithms/Sorting.h:77, BitonicSort.cpp:118-189): uint2 pairs, key = .x,

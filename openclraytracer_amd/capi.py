@@ -38,7 +38,7 @@ SYMBOLS = [
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct', 'rt_bvh_graph_builds',
     'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_rays_strategy', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_host_plane_reads', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
-    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_frame_graph_state', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
+    'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_frame_graph_state', 'rt_render_frame', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
     'rt_sort_pairs_bitonic', 'rt_sort_pairs', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_frames_in_flight', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
     L.rt_shade_blinn_phong_frame.argtypes = [vp, vp, vp, vp, vp]
     L.rt_frame_graph_create.argtypes = [vp, vp, vp, u32, u32, i32, vp, vp, u32, pvp]
     L.rt_frame_graph_launch.argtypes = [vp]
+    L.rt_render_frame.argtypes = [vp, vp, vp, u32, u32, i32, vp, vp, u32]
     L.rt_frame_graph_set_camera.argtypes = [vp, vp]
     L.rt_frame_graph_last_launch.argtypes = [vp]
     L.rt_frame_graph_destroy.argtypes = [vp]; L.rt_frame_graph_destroy.restype = None
@@ -620,6 +621,11 @@ class FrameGraph:
         if self.h:
             self.ctx.lib.rt_frame_graph_destroy(self.h)
             self.h = None
+
+
+def render_frame_d(bvh, scene, cam, d_contacts, d_out, rank=0, nranks=1, layout=0, slots_per_rank=0):
+    """rt_render_frame: one eager frame, contacts + colours, the trace kernels shading what they store where the strategy allows it"""
+    bvh.ctx.check(bvh.ctx.lib.rt_render_frame(bvh.h, scene.h, _p(cam), rank, nranks, layout, C.c_void_p(d_contacts), C.c_void_p(d_out), slots_per_rank))
 
 
 def shade_blinn_phong_frame_d(ctx, scene, cam, d_primary_contacts, d_rgba):

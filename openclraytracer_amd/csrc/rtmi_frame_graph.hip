@@ -77,7 +77,7 @@ static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, u
     FrameMode* m = mode ? mode : &plain;
     // (... and a captured frame of the lane-per-ray strategy lets its two kernels shade what they store)
     // (RT_MODE_DEVICE_ARITH: the trace kernels' dot() is the fused one; shading is host code in the reference and stays with k_shade)
-    m->fused = (b->capture_no_unsafe_rays || (m->fixed_strategy && !m->packet)) && !ctx->no_fused_frames && !b->device_arith ? &fused : nullptr;
+    m->fused = (b->capture_no_unsafe_rays || (m->fixed_strategy && !m->packet) || m->eager_fused) && !ctx->no_fused_frames && !b->device_arith ? &fused : nullptr;
     const bool update = m->update != nullptr;
     if (trace_primary_tuned(b, cam, tiled ? rank : 0u, tiled ? nranks : 1u, tiled, (rt_contact*)d_contacts, m)) return RT_ERROR;
     if (fused.done) { if (!update) RT_HIP(ctx, hipGetLastError()); return RT_SUCCESS; }
@@ -89,6 +89,30 @@ static int frame_issue(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, u
     if (update) return m->update->failed ? RT_FAIL(ctx, "frame graph: a kernel node could not be updated") : RT_SUCCESS;
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
+}
+
+// One frame, eagerly: generateContacts + shade as the Demo's RTFrame does (OpenCLRayTracerDemo.cpp:287-319: contacts, then colours), issued as
+// ONE sequence in which the trace kernels shade what they store where the strategy allows it (the four-wide and the lane-per-ray kernels with
+// the wave-per-ray kernel behind them; otherwise k_shade follows).  What a scene that is rebuilt every frame has instead of a frame graph (a
+// graph does not survive construct()): the same contacts as rt_bvh_generate_contacts_primary[_tiled], the same colours as
+// rt_shade_blinn_phong_frame / _tiled / _tiled_packed within the 1e-5 of the fused path.
+int rt_render_frame(rt_bvh* b, const rt_scene* scene, const rt_camera* cam, uint32_t rank, uint32_t nranks, int layout,
+                    void* d_contacts, void* d_out, uint32_t slots_per_rank)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    rt_ctx* ctx = b->ctx;
+    if (!scene || !d_contacts || !d_out) return RT_FAIL(ctx, "null argument");
+    if (!b->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    if (layout != RT_FRAME_UNTILED && layout != RT_FRAME_TILED && layout != RT_FRAME_TILED_PACKED) return RT_FAIL(ctx, "unknown frame layout");
+    if (layout == RT_FRAME_UNTILED) { rank = 0; nranks = 1; }
+    if (rt_nranks(nranks) == 0 || rank >= rt_nranks(nranks)) return RT_FAIL(ctx, "rank/nranks invalid");
+    if (layout == RT_FRAME_TILED_PACKED && slots_per_rank < rt_tiles_owned_pixels(cam, rank, nranks)) return RT_FAIL(ctx, "slots_per_rank too small");
+    RT_ENTER(ctx);
+    if (ensure_long_list(ctx, (uint64_t)rt_tiles_owned_pixels(cam, rank, nranks))) return RT_ERROR;
+    FrameMode m;
+    m.eager_fused = !ctx->profiling;          // (per-launch profiling times the trace kernels alone)
+    return frame_issue(b, scene, cam, rank, nranks, layout, d_contacts, d_out, slots_per_rank, &m);
 }
 
 static FrameMode graph_mode(rt_frame_graph* g, int which, bool update)

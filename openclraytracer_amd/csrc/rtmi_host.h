@@ -21,6 +21,7 @@ struct FrameMode {
     uint32_t waves_per_block = 0;           // with fixed_strategy: the workgroup size the graph was captured with
     uint32_t budget = 0;
     BlockOrder* block_order = nullptr;     // a captured frame's own start-order buffers (null: the BVH's)
+    bool eager_fused = false;              // rt_render_frame: an eager frame whose kernels shade what they store, whatever the strategy allows
 };
 
 extern "C" {

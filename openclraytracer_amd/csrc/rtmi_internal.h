@@ -385,9 +385,10 @@ struct TraceLaunch {
     const QuadNode* quad_cam;     // primary rays: the same records with the camera position subtracted from the boxes (+ thresholds)
     uint32_t quad_cam_variants;   // 1: the general copy only; 9: + one per direction octant (near / far planes in place)
     bool no_unsafe_rays;          // the caller knows that the camera sits on no box plane: the four-wide kernel hands no ray over
-    // Fused frame (frame graphs): the four-wide kernel shades every contact as it stores it (shade_math.h) -- asked for by
-    // fused_rgba != null, honoured (*fused_done = true) only by that kernel and only with no_unsafe_rays, since contacts that
-    // other kernels write would stay unshaded.  plane stride != 0: three float planes instead of float4 (shade_kernels.hip)
+    // Fused frame (frame graphs, rt_render_frame): the kernels shade every contact as they store it (shade_math.h) -- asked for by
+    // fused_rgba != null, honoured (*fused_done = true) by the four-wide kernel and by the lane-per-ray kernel, each together with the
+    // wave-per-ray kernel behind it (a ray is stored by exactly one of the two); the binary packet kernel leaves the colours to k_shade.
+    // plane stride != 0: three float planes instead of float4 (shade_kernels.hip)
     void* fused_rgba;
     uint32_t fused_plane_stride;
     bool* fused_done;

@@ -2013,9 +2013,9 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     const uint32_t grid1 = (uint32_t)t.compute_units * (uint32_t)b1;
     a.n_waves = grid1 * TRACE_WAVES;                     // resident waves of the wave-per-ray kernel
     if constexpr (PRIMARY == 1) if (t.packet && t.packet4 && t.quad && t.tricam && t.search_root) {   // (primary rays only: no instance for ray buffers)
-        if (t.fused_rgba && t.no_unsafe_rays) {
-            // every contact of this frame is stored by the kernel below: it shades them as well (one launch and one pass over
-            // the contacts less per frame)
+        if (t.fused_rgba) {
+            // every contact of this frame is stored by the kernel below -- or, for a ray it hands over whole (a camera on a box plane), by the
+            // wave-per-ray kernel behind it: each shades what it stores (one launch and one pass over the contacts less per frame)
             a.fused_rgba = (float4*)t.fused_rgba; a.fused_plane_stride = t.fused_plane_stride;
             a.fused_scene.scene = t.scene->bytes; a.fused_scene.n_lights = t.scene->n_lights; a.fused_scene.n_spheres = t.scene->n_spheres;
             a.fused_scene.n_materials = t.scene->n_materials;

@@ -489,6 +489,53 @@ def test_fused_frame_colours_at_full_hd(name):
         ctx.close()
 
 
+@pytest.mark.parametrize('name, knobs', [('cube', {}), ('tenryuu', {}), ('clumsydragon', {}), ('man', {'RTMI_PACKET': '4', 'RTMI_DEFER_BUDGET': '1048576'}),
+                                         ('man', {'RTMI_PACKET': '1', 'RTMI_DEFER_BUDGET': '256'})])
+def test_render_frame_is_generate_contacts_plus_shade(name, knobs, monkeypatch):
+    """rt_render_frame -- one eager frame whose trace kernels shade what they store (the frame of a scene that is rebuilt every frame: a frame
+    graph does not survive construct()) -- against the oracle: contacts bit for bit, colours within 1e-5, alpha and cleared pixels exact.  On a
+    fresh build, on a rebuilt one, and with the camera on a y and on a z plane of leaf boxes, where the four-wide kernel hands rays with a zero
+    direction component to the wave-per-ray kernel, which then shades them (forced strategies: the four-wide kernel, and the binary packet
+    kernel, which leaves the colours to k_shade)."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    import plane_rays as pr
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    osc, ob = oracle_bvh(name)
+    res = (320, 200)
+    cams = [osc.demo_camera(*res)]
+    rng = np.random.default_rng(5)
+    for axis in (1, 2):
+        value = 0.0
+        while value == 0.0:
+            value = ob.nodes['hi'][int(rng.integers(0, ob.n)), axis]
+        cams.append(pr.plane_camera(osc, res, axis, value))
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        bvh = capi.DeviceBVH(ctx, sc).build()
+        npx = res[0] * res[1]
+        dc, dr = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+        for round_ in range(2):
+            for k, cam in enumerate(cams):
+                want_c, _ = ob.trace_primary(cam)
+                want = orc.shade_frame(osc, cam, want_c)
+                ctx.fill_u32(dr, 0x7FC00000, npx * 4); ctx.fill_u32(dc, 0xDEADBEEF, npx * 8)
+                capi.render_frame_d(bvh, sc, as_capi_camera(cam), dc, dr)
+                ctx.synchronize()
+                assert ctx.download(dc, npx, capi.CONTACT).tobytes() == want_c.tobytes(), (name, round_, k)
+                got = ctx.download(dr, npx * 4, np.float32).reshape(npx, 4)
+                assert np.array_equal(got[:, 3], want[:, 3]), (name, round_, k)
+                err = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want.astype(np.float64)), 1e-30)
+                assert float(np.where(got == want, 0.0, err).max()) <= 1e-5, (name, round_, k)
+            bvh.build()                                    # the second round on a rebuilt BVH
+        ctx.free(dc); ctx.free(dr); bvh.close(); sc.close()
+    finally:
+        ctx.close()
+
+
 def test_rebuild_is_deterministic(gpu_ctx):
     """initializeFrame + construct can be repeated (per-frame rebuild, OpenCLRayTracerDemo.cpp:230-234)."""
     _, gb = gpu_bvh(gpu_ctx, 'man')
