@@ -398,6 +398,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--settle-ms', type=float, default=60.0,
+                    help='before the W warm-up steps: keep the device busy with the same steps for this long, untimed, so that the timed region runs on '
+                         'settled clocks (tools/tail_probe.py: a device that has idled for 20 ms needs more than a millisecond of work to get back to '
+                         'its clocks -- 20 steps behind 5 warm-up steps 0.28-0.29 ms per step, behind a busy 70 ms 0.25-0.26); 0: none')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic is then null)')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip config 5 and the rebuild-per-frame leg')
@@ -684,7 +688,22 @@ def main():
         if not ok:
             report('the first frames failed: %s' % (err or 'on another rank'))
             raise SystemExit(2)
-    else:
+    # device clocks: the set-up above is mostly host work (captures, uploads, digests), and a device that has idled runs its first milliseconds slower
+    settled = 0
+
+    def settle():
+        nonlocal settled
+        if args.settle_ms <= 0:
+            return
+        phase('settling the device clocks')
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(10):
+                step()
+            settled += 10
+            fence()
+    if not tiled:
+        settle()
         for _ in range(args.warmup):
             step()
     fence()
@@ -695,6 +714,8 @@ def main():
             note('verified before timing: %d assembled frames' % verify_timed('after the warm-up'))
         if args.check_frames:
             check_frames('after the warm-up')
+    if tiled:
+        settle()                        # (behind the warm-up steps and their verification: the digests are host work)
     phase('timed region')
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -1294,6 +1315,7 @@ def main():
                vs_baseline=None, dtype='f32', data='bundled TestModels OBJ scenes (shipped with the reference), demo default camera',
                config=dict(workload='5 bundled TestModels scenes x 1920x1080 primary rays, BVH traversal + Blinn-Phong shading',
                            rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES, parallelism=par,
+                           settle='%d untimed steps (%.0f ms) before the %d warm-up steps: device clocks (--settle-ms)' % (settled, args.settle_ms, args.warmup),
                            policy='timed region and moving-camera leg: rt_ctx_set_frames_in_flight(5); isolated frames, first frames, config5: the default (one frame at a time)'),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),

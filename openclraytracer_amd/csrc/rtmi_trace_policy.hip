@@ -369,6 +369,11 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
             // coarse: one of each family -- sub-trees shared, whole blocks, lane-per-ray with an early hand-over
             for (int ci : { first_cand, (int)P4_NONE, (int)LANE_16 })
                 if (ci >= 0 && cand_n[ci] == 0) sample(ci);
+            // Whole blocks are the strategy that costs the other frames in flight nothing, and one slow sample of it -- the first launches of a
+            // process run on idle clocks and an unsorted block order -- hands the scene to a sharing budget for the life of the BVH (seen once in
+            // a profile round: Tenryuu shared after 32 steps under the throughput policy, the five-scene step 0.302 instead of 0.245 ms): before
+            // whole blocks lose the coarse pass they get a second sample.
+            if (best_of(-1) != P4_NONE && cand_n[P4_NONE] == 1) sample(P4_NONE);
             const int first = best_of(-1);
             if (first == P4_64) { sample(P4_32); sample(P4_128); if (best_of(-1) == P4_128) sample(P4_256); }
             else if (first >= LANE_8 && first < LANE_NONE) refine_lane(first);

@@ -25,6 +25,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config3_stats -- py
 echo "config3 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raybuffer_stats -- python3 tools/rays_profile.py > $OUT/raybuffer.log 2>&1 || echo "ray-buffer stats pass failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/build_stats -- python3 tools/build_profile.py clumsydragon synth_atrium --k 20 > $OUT/build.log 2>&1 || echo "build stats pass failed"
+# construct() as a chain of launches: the last replayed build of a kernel trace, stage by stage against SURVEY.md 8(d)'s build-stage bytes
+for m in 0 2; do
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/build_tl_dragon_$m -- python3 tools/build_profile.py clumsydragon --k 5 --mode $m > $OUT/build_tl_dragon_$m.log 2>&1 && python3 tools/build_timeline.py $OUT/build_tl_dragon_$m --n 50032 --json $OUT/build_timeline_dragon_mode$m.json > $OUT/build_timeline_dragon_mode$m.txt || echo "build timeline (dragon, mode $m) failed"
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/build_tl_atrium_$m -- python3 tools/build_profile.py synth_atrium --k 5 --mode $m > $OUT/build_tl_atrium_$m.log 2>&1 && python3 tools/build_timeline.py $OUT/build_tl_atrium_$m --n 262656 --json $OUT/build_timeline_atrium_mode$m.json > $OUT/build_timeline_atrium_mode$m.txt || echo "build timeline (atrium, mode $m) failed"
+done
+# ... and host-timed, without a profiler: every bundled scene, the stand-ins and the 1 M-triangle height field, FIXED and FAST; the dynamic-scene frame
+python3 tools/build_profile.py cube gardenlight tenryuu man clumsydragon synth_bunny synth_atrium --k 50 --out $OUT/build_times_fixed.json > /dev/null 2> $OUT/build_times.err || echo "build times (FIXED) failed"
+python3 tools/build_profile.py cube gardenlight tenryuu man clumsydragon synth_bunny synth_atrium --k 50 --mode 2 --out $OUT/build_times_fast.json > /dev/null 2>> $OUT/build_times.err || echo "build times (FAST) failed"
+for s in cube gardenlight tenryuu man clumsydragon; do for m in 0 2; do python3 tools/dyn_profile.py $s --mode $m --in-flight 5 2>/dev/null | grep "static frame"; done; done > $OUT/dynamic_frames.txt
 echo "ray buffer + build done"
 # counter passes (BASELINE configs[2] asks for the HBM-bandwidth run of the Bunny-class frame): one pass per counter group
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
@@ -35,6 +44,7 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_INSTS_VALU SQ_
 done
 echo "config counter passes done"
 unset RTMI_PACKED
+python3 tools/build_profile.py heightfield --k 10 --out $OUT/build_times_heightfield_fixed.json > /dev/null 2>> $OUT/build_times.err; python3 tools/build_profile.py heightfield --k 10 --mode 2 --out $OUT/build_times_heightfield_fast.json > /dev/null 2>> $OUT/build_times.err
 python3 tools/config_report.py > $OUT/config_report.json 2> $OUT/config_report.err || echo "config report failed"
 python3 tools/rays_sweep.py --out $OUT/raybuffer_sweep.json > $OUT/raybuffer_sweep.log 2>&1 || echo "ray-buffer sweep failed"
 RTMI_BENCH_GROUP=4 python3 bench.py --steps 100 --warmup 5 --no-extra-legs > $OUT/bench_group4.json 2> $OUT/bench_group4.err || echo "group run failed"

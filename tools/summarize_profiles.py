@@ -109,6 +109,28 @@ for name, sub, log in (('raybuffer', 'raybuffer_stats', 'raybuffer.log'), ('buil
         open('profiles/%s_%s_line.json' % (R, name), 'w').write(txt + '\n')
     except Exception as e:
         print('no %s profile: %s' % (name, e))
+# construct(): the chain of launches stage by stage (tools/build_timeline.py), host-timed builds of every scene in both modes, the dynamic-scene frame
+try:
+    tl = {}
+    for scene in ('dragon', 'atrium'):
+        for m in (0, 2):
+            f = src + '/build_timeline_%s_mode%d.json' % (scene, m)
+            if os.path.exists(f):
+                tl['%s, %s' % (scene, 'FIXED' if m == 0 else 'FAST')] = json.load(open(f))
+    times = {}
+    for tag in ('fixed', 'fast', 'heightfield_fixed', 'heightfield_fast'):
+        f = src + '/build_times_%s.json' % tag
+        if os.path.exists(f):
+            for k, v in json.load(open(f)).items():
+                times.setdefault(k, {})['FAST' if tag.endswith('fast') else 'FIXED'] = v
+    dyn = [l.strip() for l in open(src + '/dynamic_frames.txt')] if os.path.exists(src + '/dynamic_frames.txt') else []
+    json.dump(dict(what='construct() at the end of the round: host-timed builds (initializeFrame + construct, replayed graph), the last build of a kernel trace '
+                        'stage by stage against SURVEY.md 8(d) build-stage bytes (both hierarchies), and the dynamic-scene frame (tools/dyn_profile.py, five frames '
+                        'in flight policy as in bench.py)', build_ms=times, dynamic_frames=dyn, timelines=tl), open('profiles/%s_build_timeline.json' % R, 'w'), indent=0)
+    for k, v in times.items():
+        print('build', k, {m: x['build_ms'] for m, x in v.items()})
+except Exception as e:
+    print('no build timeline: %s' % e)
 try:
     agg = collections.defaultdict(lambda: [0, 0.0])
     for tag in ('fetch', 'write', 'sq'):

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""When do the five streams of a short timed region finish?  Five scenes' frame graphs, K steps issued back to back, every stream's completion
+time taken by a thread of its own -- for a device that has just idled (warm-up of W steps, as the driver's `--steps 20 --warmup 5`) and for one
+that has been busy for a while.
+   python tools/tail_probe.py [K] [W]"""
+import os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from openclraytracer_amd import capi
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+RES = (1920, 1080)
+names = ['cube', 'gardenlight', 'tenryuu', 'man', 'clumsydragon']
+bufs = {n: bench.load_scene_bytes(n) for n in names}
+items = {}
+for n in names:
+    ctx = capi.Context(0)
+    ctx.set_frames_in_flight(5)
+    sc = capi.DeviceScene(ctx, bufs[n]); bvh = capi.DeviceBVH(ctx, sc).build()
+    cam = bench.demo_camera(bufs[n], *RES)
+    npx = RES[0] * RES[1]
+    dc, do = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
+    items[n] = dict(ctx=ctx, g=capi.FrameGraph(bvh, sc, cam, dc, do))
+
+
+def region(steps, warm, label):
+    for _ in range(warm):
+        for n in names:
+            items[n]['g'].launch()
+    capi.device_synchronize()
+    done = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for n in names:
+            items[n]['g'].launch()
+    issued = time.perf_counter() - t0
+
+    def wait(n):
+        items[n]['ctx'].synchronize(); done[n] = time.perf_counter() - t0
+    th = [threading.Thread(target=wait, args=(n,)) for n in names]
+    for t in th: t.start()
+    for t in th: t.join()
+    end = max(done.values())
+    print('%-28s %d steps: %.4f ms per step (issued in %.3f ms); streams done at %s ms' % (label, steps, end / steps * 1e3, issued * 1e3,
+          {n: round(done[n] * 1e3, 2) for n in names}), flush=True)
+
+
+time.sleep(0.3)
+region(K, W, 'after 0.3 s of idling')
+region(K, W, 'right behind the last')
+region(300, 5, 'long')
+region(K, W, 'right behind the long one')
+time.sleep(0.3)
+region(K, W, 'after 0.3 s of idling')
+time.sleep(0.02)
+region(K, W, 'after 20 ms of idling')
