@@ -12,10 +12,15 @@ from openclraytracer_amd import capi
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 RES = (1920, 1080)
-names = ['cube', 'gardenlight', 'tenryuu', 'man', 'clumsydragon']
+names = os.environ.get('PROBE_NAMES', 'cube,gardenlight,tenryuu,man,clumsydragon').split(',')        # (the order in which the contexts -- streams -- are created and the frames issued)
 bufs = {n: bench.load_scene_bytes(n) for n in names}
 items = {}
+FORCE = dict(kv.split(':') for kv in os.environ.get('PROBE_FORCE', '').split(',') if kv)      # e.g. clumsydragon:4/1048576 = RTMI_PACKET / RTMI_DEFER_BUDGET of that scene's context
 for n in names:
+    for k in ('RTMI_PACKET', 'RTMI_DEFER_BUDGET'):
+        os.environ.pop(k, None)
+    if n in FORCE:
+        os.environ['RTMI_PACKET'], os.environ['RTMI_DEFER_BUDGET'] = FORCE[n].split('/')
     ctx = capi.Context(0)
     ctx.set_frames_in_flight(5)
     sc = capi.DeviceScene(ctx, bufs[n]); bvh = capi.DeviceBVH(ctx, sc).build()
