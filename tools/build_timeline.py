@@ -41,10 +41,13 @@ def main():
         N = 1 << (n - 1).bit_length()
         lg = N.bit_length() - 1
         trees = 2
-        fast = any('k_radix_hist' in o['kernel'] or 'k_radix_small' in o['kernel'] for o in out)
+        radix = any('k_radix_hist' in o['kernel'] or 'k_radix_small' in o['kernel'] for o in out)
+        network = any('bitonic' in o['kernel'] for o in out)
+        # (FAST: both pair arrays through the radix sort; FIXED: both through the network up to 2^18 pairs, beyond that the search tree's through the radix sort)
+        sort_bytes = (N * 16 * lg * (lg + 1) // 2) * (trees if network and not radix else (1 if network else 0)) + (n * 16 * 4) * (trees if radix and not network else (1 if radix else 0))
         algo = {
             'morton + leaves': n * (36 + (8 + 48) * trees),
-            'sort': (n * 16 * 4 if fast else N * 16 * lg * (lg + 1) // 2) * trees,
+            'sort': sort_bytes,
             'radix tree': (n - 1) * (48 + 48) * trees,
             'refit': (2 * n - 1) * 48 * 2 * trees,
             'records (finish)': (n - 1) * 64 * trees + (n - 1) * 128 + n * (40 + 4 * trees),
