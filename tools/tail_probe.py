@@ -28,22 +28,30 @@ for n in names:
     npx = RES[0] * RES[1]
     dc, do = ctx.alloc(npx * 32), ctx.alloc(npx * 16)
     items[n] = dict(ctx=ctx, g=capi.FrameGraph(bvh, sc, cam, dc, do))
+    if n in os.environ.get('PROBE_DOUBLE', '').split(','):          # a second stream for this scene: its frames alternate between two contexts (two frames in flight)
+        ctx2 = capi.Context(0); ctx2.set_frames_in_flight(5)
+        sc2 = capi.DeviceScene(ctx2, bufs[n]); bvh2 = capi.DeviceBVH(ctx2, sc2).build()
+        items[n]['ctx2'] = ctx2
+        items[n]['g2'] = capi.FrameGraph(bvh2, sc2, cam, ctx2.alloc(npx * 32), ctx2.alloc(npx * 16))
 
 
 def region(steps, warm, label):
-    for _ in range(warm):
+    for k in range(warm):
         for n in names:
-            items[n]['g'].launch()
+            (items[n]['g2'] if (k & 1) and 'g2' in items[n] else items[n]['g']).launch()
     capi.device_synchronize()
     done = {}
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
         for n in names:
-            items[n]['g'].launch()
+            (items[n]['g2'] if (k & 1) and 'g2' in items[n] else items[n]['g']).launch()
     issued = time.perf_counter() - t0
 
     def wait(n):
-        items[n]['ctx'].synchronize(); done[n] = time.perf_counter() - t0
+        items[n]['ctx'].synchronize()
+        if 'ctx2' in items[n]:
+            items[n]['ctx2'].synchronize()
+        done[n] = time.perf_counter() - t0
     th = [threading.Thread(target=wait, args=(n,)) for n in names]
     for t in th: t.start()
     for t in th: t.join()
