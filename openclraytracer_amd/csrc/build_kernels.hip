@@ -767,11 +767,10 @@ __global__ __launch_bounds__(256) void k_seg_refit(SegSet first, SegSet second, 
     seg_mark(marks, sp.y + 1u, -1);
 }
 
-// The tree depth = the largest number of spans covering a leaf position = the maximum of the running sums of the +1 / -1 marks.  One launch:
-// every block takes a tile of 4 096 marks (a thread 16 consecutive ones: its total and the maximum of its running sum, shifted by the
-// exclusive scan of the totals inside the block), leaves the tile's (total, maximum) where the others can see it, and the block that
-// finishes LAST (a ticket counter) combines the tiles in order.  (4a does this with the library's multi-launch scan and a maximum.)
-#define SEG_DEPTH_TILE 4096u
+// The tree depth = the largest number of spans covering a leaf position = the maximum of the running sums of the +1 / -1 marks: computed by the
+// build's last kernel (k_finish, section 7a) -- every block takes a tile of 256 marks (total and maximum of the running sum), leaves the pair where
+// the others can see it, and the block that finishes LAST (a ticket counter) combines the tiles in order.  (4a does this with the library's
+// multi-launch scan and a maximum.)
 __device__ __forceinline__ int32_t seg_block_exclusive(int32_t v, int32_t* sh /* 256 */, int32_t* total)
 {
     const uint32_t t = threadIdx.x;
@@ -929,15 +928,17 @@ void launch_refit_literal(hipStream_t s, rt_bvh_node* nodes, uint32_t* counters,
 // (the kernel: k_finish below)
 
 // ----------------------------------------------------------------------------------------
-// 7a. the end of a build in ONE launch: what k_relayout_all, k_relayout_quad and k_seg_depth do, for both hierarchies (blockIdx.y), plus the
-//     hand-over of the depth / flag words to the host's pinned copy.  A block of 256 threads serves inner nodes / sorted positions / marks
-//     [256 b, 256 b + 256):
-//       * traversal record j, rank and packed triangle record of the leaf at sorted position j (k_relayout_all);
-//       * four-wide record j (sets with quad != null): the same cut as k_relayout_quad -- the slot with the largest surface area opened, twice --
-//         with the children's records assembled from the node buffer the way record j is, instead of read back from `trav` (which other blocks
-//         of this launch are still writing);
-//       * sets refitted by spans (marks != null): the block's 256 marks as one tile of the depth computation of k_seg_depth -- total and maximum of
-//         the running sum, left where the others see them; the block that finishes LAST combines the tiles in order.
+// 7a. the end of a build in ONE launch (through round 3 and most of round 4 three: re-layout, four-wide records, tree depth), for both
+//     hierarchies (blockIdx.y), plus the hand-over of the depth / flag words to the host's pinned copy.  A block of 256 threads serves inner
+//     nodes / sorted positions / marks [256 b, 256 b + 256):
+//       * traversal record j; rank and packed triangle record of the leaf at sorted position j -- no thread reads what another writes;
+//       * four-wide record j (sets with quad != null): the slot with the largest surface area opened, twice (section 7), with the children's
+//         records assembled from the node buffer the way record j is, instead of read back from `trav` (which other blocks of this launch are
+//         still writing); a thread assembles one 128-byte record, the block hands its 256 records over through LDS so that the eight 16-byte
+//         parts of a record are written by eight neighbouring lanes (whole lines per store instruction instead of 64 lines touched by each of
+//         eight: 36 -> 7 us at 100 062 records);
+//       * sets refitted by spans (marks != null): the block's 256 marks as one tile of the depth computation -- total and maximum of the running
+//         sum, left where the others see them; the block that finishes LAST (a ticket) combines the tiles in order.
 // ----------------------------------------------------------------------------------------
 struct FinishSet {
     const rt_bvh_node* nodes; const uint2* pairs; TravNode* trav; uint32_t* pos; uint32_t id_offset;
@@ -1023,7 +1024,8 @@ __global__ __launch_bounds__(256) void k_finish(FinishSet set0, FinishSet set1, 
                 }
             }
         }
-        // an unused slot: id = RT_SENTINEL and a box of NaN planes (k_relayout_quad)
+        // an unused slot: id = RT_SENTINEL and a box of NaN planes, which no ray enters under any of the kernels' tests (every compare with
+        // a NaN is false; the camera-relative copies get an empty box of their own, k_prepare_camera)
         for (; m < 4; m++) { for (int k = 0; k < 3; k++) { lo[m][k] = __builtin_nanf(""); hi[m][k] = __builtin_nanf(""); } id[m] = RT_SENTINEL; }
         float4* mine = stage + t * 9u;
         mine[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], __uint_as_float(id[0]));
@@ -1045,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishSet set0, FinishSet set1, 
         if (blockIdx.x == 0u && t == 0u && set.host_words != nullptr) set.host_words[0] = set.words[0];
         return;
     }
-    // the depth: this block's tile of the marks (k_seg_depth with one mark per thread)
+    // the depth: this block's tile of the marks, one mark per thread
     const uint32_t tiles = gridDim.x;
     const int32_t v = j < n ? set.marks[j] : 0;
     int32_t total;

@@ -337,7 +337,7 @@ __device__ __forceinline__ uint64_t child_mask_delta(float dlox, float dloy, flo
 // and the reference's decision  (flag && tmin > 0) || inside  (BVH.h:366-369) is
 //     tnear <= tfar  &&  (tnear > 0 || (tnear <= 0 && tfar >= 0))   ==   tnear <= tfar && tfar >= 0
 // -- the textbook test, here derived from the reference's.  (The equivalence needs lo <= hi; an unused slot's box is NaN on every
-// plane, k_relayout_quad: all its products are NaN, v_min / v_max return NaN for two NaN operands, and both compares are false.)
+// plane, k_finish: all its products are NaN, v_min / v_max return NaN for two NaN operands, and both compares are false.)
 __device__ __forceinline__ uint64_t child_mask_general(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayState& r)
 {
     const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SHARE ? (PRIMARY ? P4_MIN_WAVES : 6) 
                 m[2] = in & child_mask_delta(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r, q6.w);
                 m[3] = in & child_mask_delta(q6.x, q6.y, q6.z, q7.x, q7.y, q7.z, r, q7.w);
             } else {
-                // a ray buffer's packet on the records as built (k_relayout_quad): origins differ from lane to lane
+                // a ray buffer's packet on the records as built (k_finish): origins differ from lane to lane
                 m[0] = in & child_mask_general(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r);
                 m[1] = in & child_mask_general(q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, r);
                 m[2] = in & child_mask_general(q4.x, q4.y, q4.z, q5.x, q5.y, q5.z, r);
