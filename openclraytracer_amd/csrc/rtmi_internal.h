@@ -426,9 +426,10 @@ void launch_trace_rays(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, 
 // the same three from the second compilation of trace_kernels.hip (RT_MODE_DEVICE_ARITH: dot / cross as ROCm's OpenCL C library fuses them)
 void launch_trace_primary_devarith(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks, bool compact, rt_contact* out);
 void launch_trace_rays_devarith(hipStream_t s, const TraceLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
-void launch_prepare_camera_devarith(hipStream_t s, const TraceLaunch& t, const float origin[3]);
+bool launch_prepare_camera_devarith(hipStream_t s, const TraceLaunch& t, const float origin[3], void* clear_a = nullptr, size_t clear_a_bytes = 0, void* clear_b = nullptr, size_t clear_b_bytes = 0);
 bool rt_preload_trace_devarith();
-void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3]);   // t.prepare_parts
+bool launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3], void* clear_a = nullptr, size_t clear_a_bytes = 0,   // t.prepare_parts; true: launched
+                           void* clear_b = nullptr, size_t clear_b_bytes = 0);     // (+ two buffers zeroed on the way: an eager frame's fills)
 void launch_device_clock(hipStream_t s, unsigned long long* d_out);      // the clock the calibration deadlines are on (s_memrealtime)
 bool launch_block_order(hipStream_t s, const uint32_t* cost, uint32_t* order, uint32_t blocks, uint32_t group_log, bool identity);
 bool rt_preload_trace(); bool rt_preload_build(); bool rt_preload_secondary(); bool rt_preload_shade(); bool rt_preload_sort_scan(); bool rt_preload_tlg();

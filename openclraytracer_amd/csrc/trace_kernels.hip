@@ -169,6 +169,7 @@ struct TraceArgs {
     uint32_t plane_bits_known;                  // 0x80000000 | those bits when the host knows them (movable frame graphs): tree_select is not read
     uint32_t octant_mask;                       // four-wide kernel on per-octant records: bit o = the copy of octant o is valid for this camera
     uint32_t no_unsafe_rays;                    // the launcher left the wave-per-ray kernel out: a ray handed over would be lost (error bit 6)
+    uint32_t cleared_by_preparation;            // host only: the preparation kernel in front of this launch zeroed the control block and the task queues
     const uint32_t* __restrict__ block_order;   // four-wide kernel: wave -> 8x8 block (null: identity), the most expensive blocks of an earlier frame first
     uint32_t* block_cost;                       // ... steps per block of this frame, tasks included (null: not counted)
     unsigned long long cal_deadline;            // calibration launches (CAL = 1) only: device time (s_memrealtime) after which waves stop walking, 0 = none
@@ -401,6 +402,8 @@ struct PrepareArgs {
     uint32_t* select;
     uint32_t parts;
     uint32_t blocks_quads, blocks_marks;       // block ranges: quads, then marks, then triangles
+    uint32_t* clear_a; uint32_t clear_a_words; // words the trace launch behind this kernel wants zeroed (its control block, its task queues): an eager
+    uint32_t* clear_b; uint32_t clear_b_words; // frame's fills, done here on the way (a fill is a launch of its own, ~4 us)
 };
 __device__ __forceinline__ float4 shfl_xor4(const float4& v, int m)
 {
@@ -408,6 +411,11 @@ __device__ __forceinline__ float4 shfl_xor4(const float4& v, int m)
 }
 __global__ __launch_bounds__(256) void k_prepare_camera(PrepareArgs a)
 {
+    {
+        const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+        for (uint32_t i = first; i < a.clear_a_words; i += stride) a.clear_a[i] = 0u;
+        for (uint32_t i = first; i < a.clear_b_words; i += stride) a.clear_b[i] = 0u;
+    }
     const float ox = a.ox, oy = a.oy, oz = a.oz;
     if (blockIdx.x < a.blocks_quads) {
         // the four-wide record relative to this camera: every primary ray has the camera position as origin, so the slab
@@ -1995,7 +2003,8 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
     const bool four_wide = PRIMARY == 1 && t.packet && t.packet4 && t.quad && t.tricam && t.search_root;
     const bool shares = four_wide && t.task_shards && t.task_cap && a.defer_budget < (1u << 20);
     GraphNodes* const rec = t.graph_record; GraphNodes* const upd = t.graph_update;      // (update mode: arguments are set on captured nodes, nothing is enqueued)
-    if (!(four_wide && !shares && t.no_unsafe_rays) && !upd)
+    const bool cleared = a.cleared_by_preparation != 0u;          // (an eager frame's preparation kernel zeroed the control block and the task queues)
+    if (!(four_wide && !shares && t.no_unsafe_rays) && !upd && !cleared)
         (void)hipMemsetAsync(t.ctrl, 0, offsetof(TraceCtrl, error), s);      // the error word is sticky (host-cleared)
     // First-phase kernels: one wave per 64-ray block and the hardware dispatcher as the work queue.  (A persistent grid --
     // resident waves pulling blocks from sharded counters, idle lanes refilled -- measured 25-50 % slower on every bundled
@@ -2025,7 +2034,7 @@ static void launch_tagged(hipStream_t s, const TraceLaunch& t, TraceArgs& a)
         if (t.ev[0]) (void)hipEventRecord(t.ev[0], s);
         if (t.task_shards && t.task_cap && a.defer_budget < (1u << 20)) {
             // with a step budget: waves share their waiting sub-trees (see the kernel); queue state and valid marks start at zero
-            if (!upd) (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
+            if (!upd && !cleared) (void)hipMemsetAsync(t.task_shards, 0, trace_task_bytes(t.task_cap), s);
             const uint32_t helpers = (t.task_helper_blocks ? t.task_helper_blocks : 256u) * TRACE_WAVES / wpb;      // 256 x TRACE_WAVES waves = one per SIMD: far fewer than wave slots
 #if RTMI_P4_VARIANT == 3
             static unsigned long long* dbg = nullptr; static size_t dbg_n = 0;
@@ -2166,19 +2175,29 @@ void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& 
     a.block_order = t.block_order; a.block_cost = t.block_cost;
     if (t.prepare_parts) {
         const float origin[3] = { cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11] };
-        launch_prepare_camera(s, t, origin);
+        // an eager frame (nothing captured, nothing updated): the control block and the task queues the trace launch starts from are zeroed by
+        // the preparation kernel on its way instead of by two fills in front of the trace kernel (launch_tagged)
+        const bool eager = !t.graph_record && !t.graph_update;
+        const bool four_wide = t.packet && t.packet4 && t.quad && t.tricam && t.search_root;
+        const bool shares = four_wide && t.task_shards && t.task_cap && a.defer_budget < (1u << 20);
+        const bool wants_ctrl = !(four_wide && !shares && t.no_unsafe_rays);
+        if (eager && launch_prepare_camera(s, t, origin, wants_ctrl ? t.ctrl : nullptr, wants_ctrl ? trace_ctrl_error_offset() : 0u,
+                                           shares ? t.task_shards : nullptr, shares ? trace_task_bytes(t.task_cap) : 0u))
+            a.cleared_by_preparation = 1u;
+        else if (!eager) launch_prepare_camera(s, t, origin);
     }
     launch<1>(s, t, a);
 }
 
 // the per-camera records: t.prepare_parts says which (see k_prepare_camera)
-void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3])
+bool launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float origin[3], void* clear_a, size_t clear_a_bytes, void* clear_b, size_t clear_b_bytes)
 {
 #if RTMI_TRACE_HANDS_OVER
-    if (t.device_arith) { launch_prepare_camera_devarith(s, t, origin); return; }
+    if (t.device_arith) return launch_prepare_camera_devarith(s, t, origin, clear_a, clear_a_bytes, clear_b, clear_b_bytes);
 #endif
-    if (t.n_leaves < 2 || t.prepare_parts == 0u) return;
+    if (t.n_leaves < 2 || t.prepare_parts == 0u) return false;
     PrepareArgs a{};
+    a.clear_a = (uint32_t*)clear_a; a.clear_a_words = (uint32_t)(clear_a_bytes / 4u); a.clear_b = (uint32_t*)clear_b; a.clear_b_words = (uint32_t)(clear_b_bytes / 4u);
     const uint32_t n_ref = t.n_leaves - 1, n_all = n_ref * (t.search_root ? 2u : 1u);
     a.trav = const_cast<TravNode*>(t.trav); a.n_records = n_all; a.n_reference = n_ref;
     a.quad = t.quad; a.quad_cam = const_cast<QuadNode*>(t.quad_cam);
@@ -2195,9 +2214,10 @@ void launch_prepare_camera(hipStream_t s, const TraceLaunch& t, const float orig
     a.blocks_marks = (a.parts & RT_PREP_MARKS) ? (n_all + 255u) / 256u : 0u;
     const uint32_t blocks_tris = (a.parts & RT_PREP_TRIANGLES) ? (t.n_leaves + 255u) / 256u : 0u;
     const uint32_t grid = a.blocks_quads + a.blocks_marks + blocks_tris;
-    if (grid == 0u) return;
+    if (grid == 0u) return false;
     if ((a.parts & RT_PREP_MARKS) && !t.graph_update) (void)hipMemsetAsync(a.select, 0, sizeof(uint32_t), s);
     rt_launch_node(t.graph_record, t.graph_update, RT_NODE_PREP_CAMERA, k_prepare_camera, dim3(grid), dim3(256), s, a);
+    return true;
 }
 
 // Start order of the 8x8 blocks: a launch of one wave per block ends with its longest blocks, which the dispatcher hands out
