@@ -83,7 +83,9 @@ def _cameras(orc, osc, res, rng, tris):
 
 @pytest.mark.parametrize('seed,kind,n', [(1, 'uniform', 300), (2, 'clustered', 500), (3, 'lattice', 160), (4, 'degenerate', 400),
                                          (5, 'uniform', 2), (6, 'lattice', 40), (7, 'clustered', 3000), (8, 'uniform', 1500),
-                                         (9, 'lattice', 600), (10, 'lattice', 12), (11, 'degenerate', 2500), (12, 'lattice', 300)])
+                                         (9, 'lattice', 600), (10, 'lattice', 12), (11, 'degenerate', 2500), (12, 'lattice', 300),
+                                         # around the sizes at which construct() changes its path: refit by spans from 256 triangles, one-block sorts up to 4 096
+                                         (13, 'uniform', 255), (14, 'clustered', 256), (15, 'uniform', 257), (16, 'uniform', 4096), (17, 'clustered', 4097), (18, 'degenerate', 5000)])
 def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
     import oracle as orc
     from openclraytracer_amd import capi
