@@ -536,6 +536,53 @@ def test_render_frame_is_generate_contacts_plus_shade(name, knobs, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize('name', ['man', 'clumsydragon'])
+def test_render_frame_tiled_layouts(name):
+    """rt_render_frame with the tiled layouts a multi-GPU frame uses (compact contacts of a rank's 64x64 tiles; colours as compact float4 or as
+    three planes of slots_per_rank floats): the contacts of rt_bvh_generate_contacts_primary_tiled bit for bit, the colours of
+    rt_shade_blinn_phong_tiled / _tiled_packed within 1e-5 (the fused path evaluates the same function), for ranks 0 and 2 of 3."""
+    from openclraytracer_amd import capi
+    from conftest import packed_scene
+    osc, _ = oracle_bvh(name)
+    res = (400, 240)
+    cam = as_capi_camera(osc.demo_camera(*res))
+    ctx = capi.Context(0)
+    try:
+        sc = capi.DeviceScene(ctx, packed_scene(name))
+        bvh = capi.DeviceBVH(ctx, sc).build()
+        nranks = 3
+        for rank in (0, 2):
+            owned = capi.tiles_owned_pixels(cam, rank, nranks)
+            slots = owned + 128
+            dc, dc2 = ctx.alloc(owned * 32), ctx.alloc(owned * 32)
+            dr, dr2 = ctx.alloc(owned * 16), ctx.alloc(owned * 16)
+            dp, dp2 = ctx.alloc(slots * 12), ctx.alloc(slots * 12)
+            # the two calls
+            bvh.generate_contacts_primary_tiled_d(cam, rank, nranks, dc)
+            capi.shade_blinn_phong_tiled_d(ctx, sc, cam, rank, nranks, dc, dr)
+            ctx.fill_u32(dp, 0x7FC00000, slots * 3)
+            capi.shade_blinn_phong_tiled_packed_d(ctx, sc, cam, rank, nranks, dc, dp, slots)
+            ctx.synchronize()
+            want_c = ctx.download(dc, owned, capi.CONTACT).tobytes()
+            want_r = ctx.download(dr, owned * 4, np.float32)
+            want_p = ctx.download(dp, slots * 3, np.float32).reshape(3, slots)[:, :owned]
+            # one sequence
+            for layout, d_out, want in ((capi.FRAME_TILED, dr2, want_r), (capi.FRAME_TILED_PACKED, dp2, want_p)):
+                ctx.fill_u32(dc2, 0xDEADBEEF, owned * 8)
+                ctx.fill_u32(d_out, 0x7FC00000, owned * 4 if layout == capi.FRAME_TILED else slots * 3)
+                capi.render_frame_d(bvh, sc, cam, dc2, d_out, rank=rank, nranks=nranks, layout=layout, slots_per_rank=slots if layout == capi.FRAME_TILED_PACKED else 0)
+                ctx.synchronize()
+                assert ctx.download(dc2, owned, capi.CONTACT).tobytes() == want_c, (name, rank, layout)
+                got = ctx.download(d_out, owned * 4, np.float32) if layout == capi.FRAME_TILED else ctx.download(d_out, slots * 3, np.float32).reshape(3, slots)[:, :owned]
+                err = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want.astype(np.float64)), 1e-30)
+                assert float(np.where(got == want, 0.0, err).max()) <= 1e-5, (name, rank, layout)
+            for d in (dc, dc2, dr, dr2, dp, dp2):
+                ctx.free(d)
+        bvh.close(); sc.close()
+    finally:
+        ctx.close()
+
+
 def test_rebuild_is_deterministic(gpu_ctx):
     """initializeFrame + construct can be repeated (per-frame rebuild, OpenCLRayTracerDemo.cpp:230-234)."""
     _, gb = gpu_bvh(gpu_ctx, 'man')
