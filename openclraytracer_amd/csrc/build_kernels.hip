@@ -1086,13 +1086,13 @@ __global__ __launch_bounds__(256) void k_finish(FinishSet set0, FinishSet set1, 
 }
 
 // span_scratch / span_scratch2: the scratch the span refit of that hierarchy ran on with depth_later (null: its depth word is final already)
-void launch_finish(hipStream_t s, uint32_t n, const DeviceScene& sc, TriRec* trirec,
+void launch_finish(hipStream_t s, uint32_t n, bool quad_by_area, const DeviceScene& sc, TriRec* trirec,
                    const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos, uint32_t id_offset, QuadNode* quad, void* span_scratch,
                    uint32_t* words, uint32_t* host_words,
                    const rt_bvh_node* nodes2, const uint2* pairs2, TravNode* trav2, uint32_t* pos2, uint32_t id_offset2, QuadNode* quad2, void* span_scratch2,
                    uint32_t* words2, uint32_t* host_words2)
 {
-    static const uint32_t greedy = [] { const char* e = getenv("RTMI_QUAD_BY_AREA"); return (e && e[0] == '0') ? 0u : 1u; }();
+    const uint32_t greedy = quad_by_area ? 1u : 0u;             // (knob RTMI_QUAD_BY_AREA=0: both children opened instead of the largest slot, twice)
     auto make = [n](const rt_bvh_node* nd, const uint2* pr, TravNode* tv, uint32_t* ps, uint32_t off, QuadNode* q, void* scratch, uint32_t* w, uint32_t* hw) {
         FinishSet f{};
         f.nodes = nd; f.pairs = pr; f.trav = tv; f.pos = ps; f.id_offset = off; f.quad = q; f.words = w; f.host_words = hw;

@@ -148,7 +148,7 @@ int rt_bvh_initialize_frame(rt_bvh* b)
             // the camera-relative copy, and eight more with the near / far planes already in place for one direction octant
             // each (memory for vector instructions: 6 of the 16 per box test), unless that would be several GB
             const size_t one = (size_t)(n - 1) * sizeof(QuadNode) * trees;
-            b->quad_cam_variants = (one * 9 <= ((size_t)4 << 30) && !std::getenv("RTMI_NO_OCTANT_RECORDS")) ? 9u : 1u;
+            b->quad_cam_variants = (one * 9 <= ((size_t)4 << 30) && !ctx->no_octant_records) ? 9u : 1u;
             e = hipMalloc((void**)&b->d_quad_cam, one * b->quad_cam_variants);
         }
         if (e == hipSuccess && !ctx->no_packet4) e = hipMalloc((void**)&b->d_tricam, (size_t)n * sizeof(TriCam));
@@ -281,9 +281,9 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     // depths out of the span refit's marks; and the depth / flag words handed to the host's pinned copy.
     void* const marks_ref = (ref_by_spans ? b->d_span_scratch : nullptr);
     void* const marks_search = (search_by_spans ? b->s_span_scratch : nullptr);
-    if (want_search) launch_finish(s, n, sc, b->d_trirec, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, 0u, nullptr, marks_ref, d_depth, b->h_depths,
+    if (want_search) launch_finish(s, n, ctx->quad_by_area, sc, b->d_trirec, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, 0u, nullptr, marks_ref, d_depth, b->h_depths,
                                    b->s_nodes, b->s_pairs, b->d_trav + (n - 1), b->s_pos, n - 1u, b->d_quad ? b->d_quad + (n - 1) : nullptr, marks_search, s_depth, b->h_depths + 2);
-    else launch_finish(s, n, sc, b->d_trirec, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, 0u, literal ? nullptr : b->d_quad, marks_ref, d_depth, b->h_depths);
+    else launch_finish(s, n, ctx->quad_by_area, sc, b->d_trirec, b->d_nodes, b->d_pairs, b->d_trav, b->d_pos, 0u, literal ? nullptr : b->d_quad, marks_ref, d_depth, b->h_depths);
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }
@@ -303,7 +303,7 @@ int rt_bvh_construct(rt_bvh* b)
     // buffers.  The first build of an allocation is enqueued as it is, the second is captured into a graph, and from then on a build is
     // one graph launch (12 triangles: 0.108 -> see DESIGN.md; the host issued the launches more slowly than the device ran them).
     // RTMI_BUILD_GRAPH=0: always eager.
-    static const bool graphs = [] { const char* e = std::getenv("RTMI_BUILD_GRAPH"); return !(e && e[0] == '0'); }();
+    const bool graphs = !ctx->no_build_graph;          // knob RTMI_BUILD_GRAPH=0
     b->builds_on_allocation++;
     bool launched = false;
     if (graphs && b->builds_on_allocation >= 2u) {

@@ -176,6 +176,18 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_BLOCK_ORDER_GROUP")) { const uint32_t g = (uint32_t)std::strtoul(env, nullptr, 10); if (g && g <= 64u && !(g & (g - 1u))) { ctx->block_order_group_log = 0; while ((1u << ctx->block_order_group_log) < g) ctx->block_order_group_log++; } }
     if (const char* env = std::getenv("RTMI_SHARE_MIN_BUDGET")) ctx->share_min_budget = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("RTMI_TASK_HELPERS")) ctx->task_helper_blocks = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("RTMI_QUAD_BY_AREA")) ctx->quad_by_area = env[0] != '0';
+    ctx->no_octant_records = std::getenv("RTMI_NO_OCTANT_RECORDS") != nullptr;
+    if (const char* env = std::getenv("RTMI_BUILD_GRAPH")) ctx->no_build_graph = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_GRAPH_DIRECT")) ctx->no_graph_direct = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_GRAPH_DEBUG")) ctx->graph_debug = env[0] == '1' ? (std::getenv("RTMI_GRAPH_DEBUG_VERBOSE") ? 2 : 1) : 0;
+    if (const char* env = std::getenv("RTMI_RAYS")) ctx->rays_forced = env;
+    if (const char* env = std::getenv("RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES")) ctx->tlg_no_rebuild_on_previous = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_TLG_TRICAM")) ctx->tlg_no_tricam = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_CALIBRATION_DEADLINE")) ctx->no_calibration_deadline = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_IN_FLIGHT_SHARE_HANDICAP")) { const float v = (float)std::atof(env); if (v >= 1.0f) ctx->in_flight_share_handicap = v; }
+    if (const char* env = std::getenv("RTMI_CALIBRATE_ALL")) ctx->calibrate_all = env[0] == '1';
+    if (const char* env = std::getenv("RTMI_LONG_BATCH")) { const long v = std::strtol(env, nullptr, 10); if (v == 1 || v == 2 || v == 4) ctx->long_batch = (uint32_t)v; }
     *out = ctx;
     return RT_SUCCESS;
 }

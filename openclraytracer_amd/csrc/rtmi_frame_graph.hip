@@ -157,7 +157,7 @@ static int capture_frame(rt_frame_graph* g, int which)
         // recorded arguments: on one stream they follow each other with a shorter gap than graph launches do (a scene's frames back
         // to back: ManFigure 0.127 -> 0.090 ms per frame, cube 0.058 -> 0.049; five scenes' moving cameras 0.272 -> 0.263 ms per step).
         // RTMI_GRAPH_DIRECT=0 keeps hipGraphLaunch.
-        static const bool want_direct = [] { const char* e = std::getenv("RTMI_GRAPH_DIRECT"); return !(e && e[0] == '0'); }();
+        const bool want_direct = !ctx->no_graph_direct;
         size_t n_nodes = 0, n_kernels = 0;
         for (int kind = 0; kind < RT_NODE_KINDS; kind++) if (g->nodes[which].node[kind]) n_kernels++;
         g->direct[which] = want_direct && !g->nodes[which].failed && hipGraphGetNodes(g->graph[which], nullptr, &n_nodes) == hipSuccess && n_nodes == n_kernels && n_kernels != 0;
@@ -303,8 +303,8 @@ int rt_frame_graph_launch(rt_frame_graph* g)
     // this BVH in between, another strategy prepared other parts), replay the sequence that starts with the preparation
     const bool same = b->marked_valid && std::memcmp(b->marked_origin, g->origin, sizeof g->origin) == 0;
     const int which = (same && (b->marked_parts & g->parts) == g->parts) ? 0 : 1;
-    static const bool debug = [] { const char* e = std::getenv("RTMI_GRAPH_DEBUG"); return e && e[0] == '1'; }();
-    if (debug && std::getenv("RTMI_GRAPH_DEBUG_VERBOSE"))
+    const bool debug = ctx->graph_debug != 0;          // knob RTMI_GRAPH_DEBUG=1
+    if (ctx->graph_debug == 2)
         std::fprintf(stderr, "rtmi graph %p: launch exec[%d] dirty %d parts %#x marked %#x same %d strategy %d%d/%u no_unsafe %d plane %#x origin %.9g %.9g %.9g\n", (void*)g, which,
                      (int)g->dirty[which][g->slot[which]], g->parts, b->marked_parts, (int)same, (int)g->packet, (int)g->quad, g->budget, (int)g->no_unsafe, g->plane_bits_known,
                      g->origin[0], g->origin[1], g->origin[2]);
@@ -379,7 +379,7 @@ int rt_frame_graph_launch(rt_frame_graph* g)
 void rt_frame_graph_destroy(rt_frame_graph* g)
 {
     if (!g) return;
-    if (g->host_launches && std::getenv("RTMI_GRAPH_DEBUG"))
+    if (g->host_launches && g->ctx->graph_debug)
         std::fprintf(stderr, "rtmi graph %p (n = %u): host time per argument update %.2f us (%llu), per launch %.2f us (%llu)\n", (void*)g, g->bvh->n,
                      g->host_updates ? g->host_update_us / g->host_updates : 0.0, (unsigned long long)g->host_updates,
                      g->host_launch_us / g->host_launches, (unsigned long long)g->host_launches);

@@ -95,6 +95,20 @@ struct rt_ctx {
     bool task_cap_auto = false;
     uint32_t share_min_budget = 0;          // calibration: sharing candidates with a smaller budget are not tried
     bool no_fused_frames = false;           // knob RTMI_FUSED_FRAMES=0: frame graphs always shade with k_shade
+    // the knobs below used to be read where they are used, once per process; they are read with the others in rt_ctx_create (rtmi_capi.hip:
+    // the ONE place of the shipped library that looks at the environment), per context
+    bool quad_by_area = true;               // RTMI_QUAD_BY_AREA=0: four-wide records open both children instead of the largest slot twice
+    bool no_octant_records = false;         // RTMI_NO_OCTANT_RECORDS: one camera-relative copy of the four-wide records instead of nine
+    bool no_build_graph = false;            // RTMI_BUILD_GRAPH=0: every construct() is enqueued launch by launch
+    bool no_graph_direct = false;           // RTMI_GRAPH_DIRECT=0: frame graphs of kernels only go through hipGraphLaunch as well
+    int graph_debug = 0;                    // RTMI_GRAPH_DEBUG=1 (+ RTMI_GRAPH_DEBUG_VERBOSE: 2): host time per stage of the frame graphs, on stderr
+    std::string rays_forced;                // RTMI_RAYS=lane:N | p4 | p4s:N: the ray-buffer entry's strategy, forced
+    bool tlg_no_rebuild_on_previous = false;// RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES=0
+    bool tlg_no_tricam = false;             // RTMI_TLG_TRICAM=0
+    bool no_calibration_deadline = false;   // RTMI_CALIBRATION_DEADLINE=0
+    float in_flight_share_handicap = 1.6f;  // RTMI_IN_FLIGHT_SHARE_HANDICAP
+    bool calibrate_all = false;             // RTMI_CALIBRATE_ALL=1
+    uint32_t long_batch = 0;                // RTMI_LONG_BATCH=1|2|4: rays per wave of the wave-per-ray kernel (0: by the number of deferred rays)
     uint64_t scratch_generation = 0;        // bumped whenever one of the three buffers above is reallocated (frame graphs hold their addresses)
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
     uint32_t defer_budget = 0;    // tuning knob (env RTMI_DEFER_BUDGET), 0 = built-in default
@@ -308,7 +322,7 @@ void launch_refit_pair(hipStream_t s, uint32_t n, rt_bvh_node* nodes, uint32_t* 
                        rt_bvh_node* s_nodes, uint32_t* s_counters, uint32_t* s_depth_out, const uint32_t* s_only_if, bool s_tight);   // the climbs of both hierarchies
 // the end of a build in one launch: traversal records + ranks + packed triangle records, four-wide records (quad != null), tree depth out of the
 // span refit's marks (span_scratch != null), and the depth / flag words (`words`, two per hierarchy) written to `host_words` as well
-void launch_finish(hipStream_t s, uint32_t n, const DeviceScene& sc, TriRec* trirec,
+void launch_finish(hipStream_t s, uint32_t n, bool quad_by_area, const DeviceScene& sc, TriRec* trirec,
                    const rt_bvh_node* nodes, const uint2* pairs, TravNode* trav, uint32_t* pos, uint32_t id_offset, QuadNode* quad, void* span_scratch,
                    uint32_t* words, uint32_t* host_words,
                    const rt_bvh_node* nodes2 = nullptr, const uint2* pairs2 = nullptr, TravNode* trav2 = nullptr, uint32_t* pos2 = nullptr, uint32_t id_offset2 = 0,
@@ -419,6 +433,7 @@ struct TraceLaunch {
     void* task_shards;            // k_trace_packet4: queues of sub-tree tasks shared between waves (trace_task_bytes(task_cap)), may be null
     uint32_t task_cap;            // entries per queue
     uint32_t task_helper_blocks;  // 0 = default
+    uint32_t long_batch;          // rays per wave of the wave-per-ray kernel, 0 = by the number of deferred rays
 };
 void launch_trace_primary(hipStream_t s, const TraceLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks,
                           bool compact, rt_contact* out);

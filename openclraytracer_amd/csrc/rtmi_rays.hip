@@ -20,21 +20,16 @@ namespace {
 struct RayStrategy { bool packet; uint32_t budget; };
 #define RT_RAYS_CALIBRATE_FROM 32768u          // buffers below this are traced with what is known (default: lane-per-ray, 64 steps)
 
-bool forced_strategy(RayStrategy& out)
+bool forced_strategy(const rt_ctx* ctx, RayStrategy& out)       // knob RTMI_RAYS (read in rt_ctx_create)
 {
-    struct Forced { bool set; RayStrategy s; };
-    static const Forced f = [] {
-        Forced r = { false, { false, 64u } };
-        const char* e = std::getenv("RTMI_RAYS");
-        if (!e) return r;
-        if (std::strncmp(e, "lane:", 5) == 0) { r.set = true; r.s = { false, (uint32_t)std::strtoul(e + 5, nullptr, 10) }; }
-        else if (std::strncmp(e, "p4s:", 4) == 0) { r.set = true; r.s = { true, (uint32_t)std::strtoul(e + 4, nullptr, 10) }; }
-        else if (std::strcmp(e, "p4") == 0) { r.set = true; r.s = { true, 1u << 20 }; }
-        if (r.set && r.s.budget == 0u) r.s.budget = 1u << 20;
-        return r;
-    }();
-    out = f.s;
-    return f.set;
+    out = { false, 64u };
+    const char* e = ctx->rays_forced.c_str();
+    bool set = false;
+    if (std::strncmp(e, "lane:", 5) == 0) { set = true; out = { false, (uint32_t)std::strtoul(e + 5, nullptr, 10) }; }
+    else if (std::strncmp(e, "p4s:", 4) == 0) { set = true; out = { true, (uint32_t)std::strtoul(e + 4, nullptr, 10) }; }
+    else if (std::strcmp(e, "p4") == 0) { set = true; out = { true, 1u << 20 }; }
+    if (set && out.budget == 0u) out.budget = 1u << 20;
+    return set;
 }
 
 uint32_t size_class(uint32_t count) { uint32_t c = 0; while (count >>= 1) c++; return c; }       // floor(log2)
@@ -128,7 +123,7 @@ int rt_bvh_generate_contacts_rays(rt_bvh* b, const void* d_rays, uint32_t ray_co
     if (ensure_long_list(ctx, ray_count)) return RT_ERROR;
     RayStrategy st = { false, 64u };
     if (ctx->defer_budget) st = { ctx->force_packet4, ctx->defer_budget };            // RTMI_DEFER_BUDGET (+ RTMI_PACKET=4): as for primary frames
-    else if (!forced_strategy(st)) {
+    else if (!forced_strategy(ctx, st)) {
         if (ray_count >= RT_RAYS_CALIBRATE_FROM) {
             int i = find_tuned(b, ray_count);
             if (i < 0) { if (calibrate(b, (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts)) return RT_ERROR; i = b->rays_last; }
@@ -147,8 +142,8 @@ int rt_bvh_rays_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget, 
     if (!b) return RT_FAIL(nullptr, "bvh is null");
     RayStrategy st = { false, 0u };
     if (b->ctx->defer_budget) st = { b->ctx->force_packet4, b->ctx->defer_budget };
-    else if (!forced_strategy(st) && b->rays_last >= 0 && b->rays_tuned[b->rays_last].valid) st = { b->rays_tuned[b->rays_last].packet, b->rays_tuned[b->rays_last].budget };
-    else if (!forced_strategy(st)) st = { false, 0u };
+    else if (!forced_strategy(b->ctx, st) && b->rays_last >= 0 && b->rays_tuned[b->rays_last].valid) st = { b->rays_tuned[b->rays_last].packet, b->rays_tuned[b->rays_last].budget };
+    else if (!forced_strategy(b->ctx, st)) st = { false, 0u };
     if (packet_kernel) *packet_kernel = st.packet ? 2 : 0;
     if (budget) *budget = st.budget;
     if (calibration_launches) *calibration_launches = b->rays_calibration_launches;

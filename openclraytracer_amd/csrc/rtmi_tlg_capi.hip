@@ -282,7 +282,7 @@ int rt_tlg_construct(rt_tlg* g)
     rt_ctx* ctx = g->ctx;
     if (!g->frame_initialised) return RT_FAIL(ctx, "initializeFrame must precede construct");
     RT_ENTER(ctx);
-    static const bool allow = [] { const char* e = std::getenv("RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES"); return !(e && e[0] == '0'); }();
+    const bool allow = !ctx->tlg_no_rebuild_on_previous;          // knob RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES=0
     bool done = false;
     if (allow && g->d_pairs && g->d_leaf_pairs && g->d_leaf_ranges && g->pairs_cap && g->leaf_cap && g->counters_cap >= g->pairs_cap) {
         if (construct_on_previous_sizes(g, &done)) return RT_ERROR;
@@ -308,8 +308,7 @@ static TlgLaunch make_tlg_launch(const rt_tlg* g)
 // (construct() invalidates it); without it (allocation failed, knob RTMI_TLG_TRICAM=0) the kernel reads the scene's table.
 static void use_camera_triangles(rt_tlg* g, const rt_camera* cam, TlgLaunch& t)
 {
-    static const bool off = [] { const char* e = std::getenv("RTMI_TLG_TRICAM"); return e && e[0] == '0'; }();
-    if (off || g->n == 0) return;
+    if (g->ctx->tlg_no_tricam || g->n == 0) return;
     if (g->d_tricam && g->tricam_n != g->n) {           // another scene size since: a table of that size
         (void)hipStreamSynchronize(g->ctx->stream);
         (void)hipFree(g->d_tricam); g->d_tricam = nullptr; g->tricam_valid = false;

@@ -15,9 +15,8 @@
 
 void CalClock::sample(rt_ctx* ctx)
 {
-    static const bool off = [] { const char* e = std::getenv("RTMI_CALIBRATION_DEADLINE"); return e && e[0] == '0'; }();
     ticks_per_ms = 0.0;
-    if (off) return;
+    if (ctx->no_calibration_deadline) return;          // knob RTMI_CALIBRATION_DEADLINE=0
     if (!ctx->d_clock && hipMalloc((void**)&ctx->d_clock, 8) != hipSuccess) { (void)hipGetLastError(); ctx->d_clock = nullptr; return; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); return; }
@@ -133,7 +132,7 @@ TraceLaunch make_launch(rt_bvh* b, const rt_camera* cam, uint32_t parts, const F
     t.waves_per_block = (mode && mode->fixed_strategy) ? mode->waves_per_block
                         : b->ctx->trace_workgroup_waves ? b->ctx->trace_workgroup_waves : (b->ctx->frames_in_flight > 1u ? 1u : 0u);
     t.keys = b->ctx->d_keys; t.split_list = b->ctx->d_split_list; t.pairs = b->d_pairs;
-    t.task_shards = b->ctx->d_task_list; t.task_cap = b->ctx->task_cap; t.task_helper_blocks = b->ctx->task_helper_blocks;
+    t.task_shards = b->ctx->d_task_list; t.task_cap = b->ctx->task_cap; t.task_helper_blocks = b->ctx->task_helper_blocks; t.long_batch = b->ctx->long_batch;
     t.packet_spill = b->d_packet_spill; t.packet_spill_entries = b->packet_spill_entries; t.packet_spill_slots = b->packet_spill_slots;
     t.ev[0] = t.ev[1] = t.ev[2] = nullptr;
     if (b->ctx->profiling && !(mode && mode->update)) {
@@ -289,8 +288,7 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
             // several frames in flight (rt_ctx_set_frames_in_flight): the helper waves and queues of a sharing launch cost the OTHER frames
             // more than its own shorter tail gains (the bundled five: 0.284 ms per step with whole blocks, 0.316 with Tenryuu shared
             // after 64 steps, which alone is 0.15 against 0.19 ms) -- sharing must then win by far, as it does where whole blocks crawl
-            static const float in_flight = [] { const char* e = std::getenv("RTMI_IN_FLIGHT_SHARE_HANDICAP"); const float v = e ? (float)std::atof(e) : 0.f; return v >= 1.0f ? v : 1.6f; }();
-            if (ctx->frames_in_flight > 1u) h *= in_flight;
+            if (ctx->frames_in_flight > 1u) h *= ctx->in_flight_share_handicap;      // (1.6; knob RTMI_IN_FLIGHT_SHARE_HANDICAP)
             return h;
         };
         auto usable = [&](int ci) {
@@ -336,7 +334,7 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
         // picked it where the four-wide kernel was available); the lane-per-ray kernel does: ClumsyDragon's centre columns
         // walk ~80 records per ray against a mean of 3.6, and one wave per such ray (wave-per-ray kernel behind a lane-per-ray
         // budget of 16 steps) beats eight of them in one packet.  RTMI_CALIBRATE_ALL=1 restores the exhaustive pass over all 25.
-        static const bool calibrate_all = [] { const char* e = std::getenv("RTMI_CALIBRATE_ALL"); return e && e[0] == '1'; }();
+        const bool calibrate_all = ctx->calibrate_all;
         // The first candidate runs without a deadline, twice (an untimed warm-up, then its sample), so it should never be a
         // hopeless one: sharing after 64 steps has no tail (since the search tree's boxes are tight a 1080p block takes 3-13 steps on
         // average and 50-900 at most: Tenryuu whole blocks 0.173 ms, shared after 256 / 128 / 64 / 32 steps 0.195 / 0.18 / 0.132 /
@@ -532,7 +530,7 @@ int ensure_host_planes(rt_bvh* b)
     rt_ctx* ctx = b->ctx;
     if (b->h_planes_generation == b->build_generation && !b->h_planes[0].empty()) return RT_SUCCESS;
     // sorted on the device (launch_plane_keys), copied back per axis; FLT_MIN joins them here (BVH.h:310)
-    static const bool dbg_t = [] { const char* e = std::getenv("RTMI_GRAPH_DEBUG"); return e && e[0] == '1'; }();
+    const bool dbg_t = ctx->graph_debug != 0;
     const double t_begin = dbg_t ? now_us() : 0.0;
     uint32_t p2 = 1; while (p2 < 2u * b->n) p2 <<= 1;
     uint2* d_tmp = nullptr;

@@ -2146,7 +2146,7 @@ static void fill_common(const TraceLaunch& t, TraceArgs& a)
     a.n_records = (t.n_leaves - 1u) * (t.search_root ? 2u : 1u);
     a.n_leaves = t.n_leaves;
     a.packet_spill = t.packet_spill; a.packet_spill_entries = t.packet_spill_entries; a.packet_spill_slots = t.packet_spill_slots; a.diagnostics = t.diagnostics ? 1u : 0u;
-    { static int lb = -1; if (lb < 0) { const char* e = getenv("RTMI_LONG_BATCH"); lb = e ? atoi(e) : 0; if (lb < 0 || lb > (int)LONG_BATCH) lb = 0; } a.long_batch = (uint32_t)lb; }
+    a.long_batch = t.long_batch;            // knob RTMI_LONG_BATCH (0: by the number of deferred rays)
     a.keys = t.keys; a.split_list = t.split_list; a.pairs = t.pairs;
     a.task_shards = (TaskShard*)t.task_shards; a.task_cap = t.task_cap;
     a.defer_budget = t.defer_budget ? t.defer_budget : DEFER_BUDGET_DEFAULT;
