@@ -234,7 +234,7 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     // Morton codes of the box centres normalised to the scene header's box -- and the padding its sort wants)
     // (+ the arrival counters of the climbs, where a climb will run, zeroed on the way)
     if (want_search) launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, b->s_nodes, b->s_pairs, search_with_network ? N : 0u,
-                                          ref_climbs ? b->d_counters : nullptr, search_climbs ? b->s_counters : nullptr);
+                                          ref_climbs ? b->d_counters : nullptr, search_climbs ? b->s_counters : nullptr, !ctx->search_keys_ten_per_axis);
     else launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, nullptr, nullptr, 0u, ref_climbs ? b->d_counters : nullptr, nullptr);
     if (fast) {
         if (search_with_radix_pair) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2, n, 30u, b->d_sort_scratch2, b->s_pairs, b->d_sort_tmp, b->d_sort_scratch);

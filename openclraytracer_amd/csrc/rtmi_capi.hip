@@ -187,6 +187,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_CALIBRATION_DEADLINE")) ctx->no_calibration_deadline = env[0] == '0';
     if (const char* env = std::getenv("RTMI_IN_FLIGHT_SHARE_HANDICAP")) { const float v = (float)std::atof(env); if (v >= 1.0f) ctx->in_flight_share_handicap = v; }
     if (const char* env = std::getenv("RTMI_CALIBRATE_ALL")) ctx->calibrate_all = env[0] == '1';
+    if (const char* env = std::getenv("RTMI_SEARCH_KEYS")) ctx->search_keys_ten_per_axis = std::strcmp(env, "cubic") == 0;
     if (const char* env = std::getenv("RTMI_LONG_BATCH")) { const long v = std::strtol(env, nullptr, 10); if (v == 1 || v == 2 || v == 4) ctx->long_batch = (uint32_t)v; }
     *out = ctx;
     return RT_SUCCESS;

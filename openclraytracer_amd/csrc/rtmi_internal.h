@@ -108,6 +108,7 @@ struct rt_ctx {
     bool no_calibration_deadline = false;   // RTMI_CALIBRATION_DEADLINE=0
     float in_flight_share_handicap = 1.6f;  // RTMI_IN_FLIGHT_SHARE_HANDICAP
     bool calibrate_all = false;             // RTMI_CALIBRATE_ALL=1
+    bool search_keys_ten_per_axis = false;  // RTMI_SEARCH_KEYS=cubic: the search tree's keys with ten bits per axis whatever the box's shape (rounds 1-4)
     uint32_t long_batch = 0;                // RTMI_LONG_BATCH=1|2|4: rays per wave of the wave-per-ray kernel (0: by the number of deferred rays)
     uint64_t scratch_generation = 0;        // bumped whenever one of the three buffers above is reallocated (frame graphs hold their addresses)
     bool trace_launched = false;  // a trace launch has not been checked for its error word yet
@@ -302,7 +303,8 @@ void launch_gather_triangles(hipStream_t s, const DeviceScene& sc);
 // leaves + Morton pairs (+ the padding pairs [n, padded) of the pair buffer); on request the search tree's leaves and keys as well
 void launch_morton_leaves(hipStream_t s, const DeviceScene& sc, rt_bvh_node* nodes, uint2* pairs, uint32_t padded,
                           rt_bvh_node* s_nodes = nullptr, uint2* s_pairs = nullptr, uint32_t s_padded = 0u,
-                          uint32_t* clear = nullptr, uint32_t* s_clear = nullptr);      // + n words each zeroed on the way (the climbs' arrival counters)
+                          uint32_t* clear = nullptr, uint32_t* s_clear = nullptr,       // + n words each zeroed on the way (the climbs' arrival counters)
+                          bool adaptive_keys = true);   // the search tree's key bits allocated by the box's shape (false: ten per axis)
 // The kernels of a build carry BOTH hierarchies (the reference tree and the search tree: same leaves, same n) in one launch -- the arguments with a
 // trailing 2 are the second one's, blockIdx.y = 1; null: one hierarchy.  A build is a chain of dependent launches of ~5 us each whatever they do.
 void launch_radix_tree(hipStream_t s, rt_bvh_node* nodes, const uint2* pairs, uint32_t n, uint32_t built, uint2* spans = nullptr, uint32_t* clear2 = nullptr,   // built = n-1 (FIXED) / n-2 (LITERAL_ZERO); clear2: two words zeroed on the way

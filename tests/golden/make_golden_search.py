@@ -4,7 +4,7 @@ tree of librtmi.so (openclraytracer_amd/csrc/build_kernels.hip, section 6) inste
 
     python tests/golden/make_golden_search.py
 
-The search tree is restated here with the oracle's own building blocks: keys as k_search_tree_keys computes them (fp32),
+The search tree is restated here with the oracle's own building blocks: keys as k_morton_leaves computes them (fp32; search_tree_key, key_layout),
 the reference's bitonic network and radix-tree restatements (oracle/rt_oracle.c), inner boxes as plain unions (what k_refit<TIGHT> computes), then the oracle's traversal with
 its visit counters.  The leaf-test count and the contacts are those of the reference tree (asserted below: same reached
 leaves); only `inner_visits` differs.  bench.py uses the numbers for the `walked` fields of its roofline object.
@@ -29,7 +29,7 @@ def expand_bits(v):
     return v
 
 
-def search_tree(orc, b):
+def search_tree(orc, b, scene_box):
     """(nodes[2n-1], depth) of the search tree over the leaves of oracle BVH b"""
     L = orc.lib()
     L.orc_radix_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
@@ -37,13 +37,32 @@ def search_tree(orc, b):
     n = b.n
     f = np.float32
     lo, hi = b.nodes['lo'][:n, :3], b.nodes['hi'][:n, :3]
-    rlo, rhi = b.nodes['lo'][n, :3], b.nodes['hi'][n, :3]               # reference root = union of the leaf boxes
+    rlo, rhi = scene_box                                                  # the scene header's box (bytes 64 / 80 of the packed scene), as the library
     with np.errstate(all='ignore'):
         c = (lo + hi) * f(0.5)
         v = (c - rlo) / (rhi - rlo)
         v = np.where(v == v, v, f(0.0))
-        x = np.minimum(np.maximum(v * f(1024.0), f(0.0)), f(1023.0)).astype(np.uint32)
-    key = expand_bits(x[:, 0]) * np.uint32(4) + expand_bits(x[:, 1]) * np.uint32(2) + expand_bits(x[:, 2])
+    # the bits of the key: per level the axis along which the cell is longest (build_kernels.hip, key_layout); a box that stays within two bits
+    # between its axes keeps ten bits per axis, x, y, z interleaved
+    cell = np.maximum(rhi.astype(np.float64) - rlo.astype(np.float64), 0.0)
+    seq, nbits = [], [0, 0, 0]
+    for _ in range(30):
+        a = 0
+        if cell[1] > cell[a]: a = 1
+        if cell[2] > cell[a]: a = 2
+        seq.append(a); cell[a] *= 0.5; nbits[a] += 1
+    if max(nbits) - min(nbits) >= 3:
+        with np.errstate(all='ignore'):
+            q = [np.minimum(np.maximum(v[:, k] * f(1 << nbits[k]), f(0.0)), f((1 << nbits[k]) - 1)).astype(np.uint32) for k in range(3)]
+        left = list(nbits)
+        key = np.zeros(n, dtype=np.uint32)
+        for a in seq:
+            left[a] -= 1
+            key = (key << np.uint32(1)) | ((q[a] >> np.uint32(left[a])) & np.uint32(1))
+    else:
+        with np.errstate(all='ignore'):
+            x = np.minimum(np.maximum(v * f(1024.0), f(0.0)), f(1023.0)).astype(np.uint32)
+        key = expand_bits(x[:, 0]) * np.uint32(4) + expand_bits(x[:, 1]) * np.uint32(2) + expand_bits(x[:, 2])
     pairs = np.full(b.N, 0xFFFFFFFF, dtype=np.uint32).repeat(2).view(orc.PAIR).copy()
     pairs['key'][:n] = key
     pairs['value'][:n] = np.arange(n, dtype=np.uint32)
@@ -78,7 +97,8 @@ def main():
     for name in MODELS:
         sc = orc.Scene(packed_scene(name))
         b = orc.BVH(sc, 0)
-        nodes, depth = search_tree(orc, b)
+        hdr = np.frombuffer(sc.bytes, dtype=np.float32, count=24, offset=0)
+        nodes, depth = search_tree(orc, b, (hdr[16:19].copy(), hdr[20:23].copy()))
         cam = sc.demo_camera(1920, 1080)
         ref, st_ref = b.trace_primary(cam)
         got = np.zeros(1920 * 1080, dtype=orc.CONTACT)

@@ -26,7 +26,8 @@ def reached_sets(name, axis, n_planes, stride, seed=5):
     sc = orc.Scene(packed_scene(name))
     b = orc.BVH(sc, 0)
     n = b.n
-    snodes, _ = mgs.search_tree(orc, b)
+    hdr = np.frombuffer(sc.bytes, dtype=np.float32, count=24, offset=0)          # the scene header's box: bytes 64 / 80
+    snodes, _ = mgs.search_tree(orc, b, (hdr[16:19].copy(), hdr[20:23].copy()))
     lo, hi = b.nodes['lo'][:, :3], b.nodes['hi'][:, :3]
     slo, shi = snodes['lo'][:, :3], snodes['hi'][:, :3]
     rng = np.random.default_rng(seed)
