@@ -120,8 +120,9 @@ __device__ __forceinline__ uint32_t search_tree_key(const float lo[3], const flo
     if (box.seq == 0ull) return morton3d(u[0], u[1], u[2]);
     uint32_t q[3], left[3];
     for (int k = 0; k < 3; k++) {
-        const float top = (float)((1u << box.nbits[k]) - 1u);
-        q[k] = (uint32_t)RMIN(RMAX(u[k] * (float)(1u << box.nbits[k]), 0.0f), top);
+        const uint32_t cells = 1u << box.nbits[k];                      // (at most 2^30: one axis takes every bit of a box that is a line)
+        const uint32_t at = (uint32_t)RMIN(RMAX(u[k] * (float)cells, 0.0f), (float)cells);
+        q[k] = at < cells - 1u ? at : cells - 1u;                      // (an integer clamp: (float)(cells - 1) rounds up to cells from 2^25 on)
         left[k] = box.nbits[k];
     }
     uint32_t code = 0;
