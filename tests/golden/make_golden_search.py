@@ -53,7 +53,7 @@ def search_tree(orc, b, scene_box):
         seq.append(a); cell[a] *= 0.5; nbits[a] += 1
     if max(nbits) - min(nbits) >= 3:
         with np.errstate(all='ignore'):
-            q = [np.minimum(np.maximum(v[:, k] * f(1 << nbits[k]), f(0.0)), f((1 << nbits[k]) - 1)).astype(np.uint32) for k in range(3)]
+            q = [np.minimum(np.minimum(np.maximum(v[:, k] * f(1 << nbits[k]), f(0.0)), f(1 << nbits[k])).astype(np.uint32), np.uint32((1 << nbits[k]) - 1)) for k in range(3)]
         left = list(nbits)
         key = np.zeros(n, dtype=np.uint32)
         for a in seq:
