@@ -60,6 +60,18 @@ def _soup(rng, n, kind):
         t[3::11] = t[2::11][:len(t[3::11])]                  # exact duplicates
         t[5::13, 1] = t[5::13, 0] + np.float32(1e-7)
         return t
+    if kind == 'slab':                                       # a box far from a cube (40 x 2 x 0.2): the search tree's key bits follow its shape
+        c = rng.uniform(-1, 1, size=(n, 1, 3)) * np.array([20.0, 1.0, 0.1])
+        return (c + rng.normal(scale=0.05, size=(n, 3, 3))).astype(np.float32)
+    if kind == 'flat':                                       # every vertex in the plane z = 0.5: one axis of the box has no extent
+        t = _soup(rng, n, 'uniform')
+        t[:, :, 2] = np.float32(0.5)
+        return t
+    if kind == 'line':                                       # needles along x at y = z = 0: the box is a line, one axis takes every key bit
+        x = rng.uniform(-50, 50, size=(n, 1))
+        t = np.zeros((n, 3, 3), dtype=np.float32)
+        t[:, :, 0] = x + rng.normal(scale=0.01, size=(n, 3))
+        return t
     raise ValueError(kind)
 
 
@@ -85,7 +97,9 @@ def _cameras(orc, osc, res, rng, tris):
                                          (5, 'uniform', 2), (6, 'lattice', 40), (7, 'clustered', 3000), (8, 'uniform', 1500),
                                          (9, 'lattice', 600), (10, 'lattice', 12), (11, 'degenerate', 2500), (12, 'lattice', 300),
                                          # around the sizes at which construct() changes its path: refit by spans from 256 triangles, one-block sorts up to 4 096
-                                         (13, 'uniform', 255), (14, 'clustered', 256), (15, 'uniform', 257), (16, 'uniform', 4096), (17, 'clustered', 4097), (18, 'degenerate', 5000)])
+                                         (13, 'uniform', 255), (14, 'clustered', 256), (15, 'uniform', 257), (16, 'uniform', 4096), (17, 'clustered', 4097), (18, 'degenerate', 5000),
+                                         # boxes far from a cube: the allocation of the search tree's key bits (key_layout)
+                                         (19, 'slab', 700), (20, 'flat', 400), (21, 'line', 300)])
 def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
     import oracle as orc
     from openclraytracer_amd import capi
