@@ -391,7 +391,13 @@ int trace_primary_tuned(rt_bvh* b, const rt_camera* cam, uint32_t rank, uint32_t
             const int a = best_of(-1), c = best_of(a);
             sample(a); sample(c);
         }
-        const int best_ci = broken ? -1 : best_of(-1);
+        int best_ci = broken ? -1 : best_of(-1);
+        // Several frames in flight: a lane-per-ray frame is two dependent kernels, and the second one -- a wave per handed-over ray -- is as long as
+        // its heaviest ray whatever else the device does, while the first one's extra steps overlap with the other frames.  Between two budgets
+        // that are within 8 % of each other alone, the larger one (fewer rays handed over) is the better neighbour: ClumsyDragon 12 -> 16 steps,
+        // 0.081 -> 0.0845 ms alone, the five-scene step 0.231 -> 0.226 ms (tools/tail_probe.py).
+        if (ctx->frames_in_flight > 1u && best_ci >= LANE_8 && best_ci + 1 < LANE_NONE && cand_n[best_ci + 1] > 0 &&
+            cand_ms[best_ci + 1] <= 1.08f * cand_ms[best_ci]) best_ci++;
         const bool have = best_ci >= 0;
         const uint32_t best = have ? candidates[best_ci].budget : 1024u;
         const bool best_packet = have && candidates[best_ci].packet, best_quad = have && candidates[best_ci].quad;
