@@ -16,11 +16,15 @@ names = os.environ.get('PROBE_NAMES', 'cube,gardenlight,tenryuu,man,clumsydragon
 bufs = {n: bench.load_scene_bytes(n) for n in names}
 items = {}
 FORCE = dict(kv.split(':') for kv in os.environ.get('PROBE_FORCE', '').split(',') if kv)      # e.g. clumsydragon:4/1048576 = RTMI_PACKET / RTMI_DEFER_BUDGET of that scene's context
+KNOBS = set()
 for n in names:
-    for k in ('RTMI_PACKET', 'RTMI_DEFER_BUDGET'):
+    for k in ('RTMI_PACKET', 'RTMI_DEFER_BUDGET') + tuple(KNOBS):
         os.environ.pop(k, None)
     if n in FORCE:
         os.environ['RTMI_PACKET'], os.environ['RTMI_DEFER_BUDGET'] = FORCE[n].split('/')
+    for kv in os.environ.get('PROBE_ENV_' + n.upper(), '').split(','):            # e.g. PROBE_ENV_CLUMSYDRAGON=RTMI_LONG_BATCH=1 (knobs are read per context)
+        if kv:
+            os.environ[kv.split('=')[0]] = kv.split('=')[1]; KNOBS.add(kv.split('=')[0])
     ctx = capi.Context(0)
     ctx.set_frames_in_flight(5)
     sc = capi.DeviceScene(ctx, bufs[n]); bvh = capi.DeviceBVH(ctx, sc).build()
