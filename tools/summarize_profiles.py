@@ -91,6 +91,13 @@ for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve
                                 valu_issue_frac=(round(c.get('SQ_INSTS_VALU', 0.0) * 2.0 / (1024 * cycles), 4) if cycles else None),
                                 wave_time_split=(dict(executing=round(c.get('SQ_ACTIVE_INST_ANY', 0) / c['SQ_WAVE_CYCLES'], 3), parked_on_waitcnt=round(c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES'], 3),
                                                       issue_stall=round(c.get('SQ_WAIT_INST_ANY', 0) / c['SQ_WAVE_CYCLES'], 3)) if c.get('SQ_WAVE_CYCLES') else None))
+        if name == 'tlg_config4' and line.get('per_ray', {}).get('top_cells') and c.get('SQ_WAVES'):
+            # vector instructions a wave issues per top-level cell one of its rays walks (all loop levels below it included): what the verdict's
+            # "instructions per top cell" asks for; round 3 (profiles/r03_tlg_config4_line.json): 2 282 M / 32 640 waves / 152.2 cells = 459
+            line['counters']['valu_instructions_per_wave'] = round(c.get('SQ_INSTS_VALU', 0.0) / c['SQ_WAVES'], 1)
+            line['counters']['valu_instructions_per_top_cell'] = round(c.get('SQ_INSTS_VALU', 0.0) / c['SQ_WAVES'] / line['per_ray']['top_cells'], 1)
+            line['counters']['valu_instructions_per_top_cell_round3'] = 459.4
+            line['counters']['floor_ms_at_full_issue'] = round(c.get('SQ_INSTS_VALU', 0.0) * 2.0 / 1024.0 / (cycles / ms) , 3) if cycles and ms else None
         json.dump(line, open(line_path, 'w'), indent=1)
         print(name, 'counters:', json.dumps({k: line['counters'][k] for k in ('dominant_kernel', 'hbm_bytes_per_launch', 'measured_hbm_gbps', 'hbm_frac_of_8tbps', 'valu_issue_frac', 'wave_time_split')}))
     except Exception as e:
