@@ -583,6 +583,30 @@ def test_render_frame_tiled_layouts(name):
         ctx.close()
 
 
+@pytest.mark.parametrize('name', ['cube', 'gardenlight', 'tenryuu', 'man', 'clumsydragon'])
+def test_search_tree_equals_its_restatement(gpu_ctx, name):
+    """The search tree the library builds (rt_bvh_read_search_nodes) against its restatement with the oracle's building blocks
+    (tests/golden/make_golden_search.py: the keys of k_morton_leaves -- box centres in the scene header's box, the key bits allocated by the
+    box's shape (key_layout) --, the reference's network, radix tree, plain unions): every node byte.  Pins the fixture bench.py takes its
+    `walked` bytes from, and the key layout on boxes of three shapes (10/10/10, 9/12/9, 11/11/8 bits)."""
+    import sys
+    import oracle as orc
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import make_golden_search as mgs
+    from conftest import packed_scene
+    buf = packed_scene(name)
+    osc, ob = oracle_bvh(name)
+    hdr = np.frombuffer(buf, dtype=np.float32, count=24, offset=0)
+    want, depth = mgs.search_tree(orc, ob, (hdr[16:19].copy(), hdr[20:23].copy()))
+    _, gb = gpu_bvh(gpu_ctx, name)
+    got = gb.read_search_nodes()
+    assert gb.search_tree()['depth'] == depth
+    n = ob.n
+    assert got[:n].tobytes() == want[:n].tobytes()                                      # the leaves
+    assert np.array_equal(got['data'][n:, 1:3], want['data'][n:, 1:3]), 'children differ: another key or another order of equal keys'
+    assert np.array_equal(got['boundsMin'][n:, :3], want['lo'][n:, :3]) and np.array_equal(got['boundsMax'][n:, :3], want['hi'][n:, :3])
+
+
 def test_rebuild_is_deterministic(gpu_ctx):
     """initializeFrame + construct can be repeated (per-frame rebuild, OpenCLRayTracerDemo.cpp:230-234)."""
     _, gb = gpu_bvh(gpu_ctx, 'man')
