@@ -381,6 +381,71 @@ def ray_buffer_leg(ctx, bvh, cam, fx, frames=8):
     return out
 
 
+LINE_LIMIT = 4096      # bytes: a driver that keeps the tail of stdout must still find the whole line in it (round 4's 20 KB line was cut)
+
+
+def compact_line(out, details_path):
+    """The ONE line of stdout: the contract's keys, `roofline` and `cpu_baseline` with the numbers only, `verified` as counts, and one
+    figure per further leg.  The whole record (per scene, per kernel, counters, the wording of every formula) goes to `--details`."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype')
+    line = {k: out[k] for k in keep}
+    line['data'] = 'bundled TestModels scenes, demo camera'
+    cfg = out['config']
+    line['config'] = dict(workload=cfg['workload'], rays_per_step=cfg['rays_per_step'],
+                          parallelism=('single GPU, five frames in flight' if out['n_gpus'] == 1 and 'REHEARSAL' not in cfg['parallelism']
+                                       else '64x64 tiles over %d ranks, one gather per frame' % cfg.get('ranks', out['n_gpus'])))
+    rf = out['roofline']
+    line['roofline'] = {k: rf.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'compulsory_bytes_per_step',
+                                                'frac_of_output_floor', 'reference_algorithm_bytes_per_launch', 'walked_bytes_per_launch')}
+    line['roofline']['kernel'] = 'traversal launch of a frame (k_trace_packet4 / k_trace + k_trace_long)'
+    rv = out.get('roofline_valu_issue')
+    if rv:
+        line['roofline']['valu_issue_frac'] = rv['frac']
+        line['roofline']['valu_issue_kernel'] = rv['kernel'][:48]
+    cb = out.get('cpu_baseline')
+    if cb:
+        line['cpu_baseline'] = {k: cb[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'single_thread_value')}
+    else:
+        line['cpu_baseline'] = None
+    v = out.get('verified')
+    if v:
+        line['verified'] = {k: (x if not isinstance(x, str) else (x.startswith('frame equals'))) for k, x in v.items() if k != 'against'}
+    else:
+        line['verified'] = None
+    legs = {}
+    ps = out.get('per_scene') or {}
+    if ps:
+        legs['frame_ms'] = {n: q['trace_ms'] for n, q in ps.items()}
+        rb = [q['rebuild_plus_trace_ms'] / max(q['trace_ms'], 1e-9) for q in ps.values() if 'rebuild_plus_trace_ms' in q]
+        if rb:
+            legs['rebuild_plus_trace_over_static'] = [round(min(rb), 2), round(max(rb), 2)]
+    mv = out.get('moving_camera')
+    if mv:
+        legs['moving_camera_step_ms'] = mv['step_ms']
+    r = out.get('ray_buffer')
+    if r:
+        legs['ray_buffer_min_mrays'] = {k: r['min_mrays_per_s_' + k] for k in ('primary', 'reflect', 'shadow')}
+    if out.get('config3'):
+        legs['config3_ms'] = out['config3']['ms_per_frame']
+    if out.get('config4'):
+        c4 = out['config4']
+        legs['config4'] = dict(build_ms=c4['build_ms'], trace_shade_ms=c4['trace_plus_shade_ms'], mrays=c4['mrays_per_s_grid_kept'])
+    if out.get('config5'):
+        legs['config5'] = dict(ms=out['config5']['ms_per_frame'], mrays=out['config5']['mrays_per_s'])
+    line['legs'] = legs
+    if out.get('per_rank'):
+        line['per_rank'] = dict(columns=['trace_shade_ms_per_step', 'gather_ms_per_step', 'uses_rccl'],
+                                rows=[[r['trace_shade_ms_per_step'], r['gather_ms_per_step'], bool(r['uses_rccl'])] for r in out['per_rank']][:8])
+    line['details_file'] = (os.path.relpath(details_path, ROOT) if details_path else None)
+    # never above the limit: the optional parts go first
+    for drop in ('per_rank', 'legs'):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    assert len(json.dumps(line)) <= LINE_LIMIT, 'summary line too long'
+    return line
+
+
 def q_slots(work, name):
     for it in work:
         if it['name'] == name:
@@ -411,6 +476,10 @@ def main():
     ap.add_argument('--no-verify', action='store_true', help='skip the in-run comparison of the rendered frames with the oracle digests')
     ap.add_argument('--keep-pmc', default=None, help='directory that receives the raw counter rows of this run')
     ap.add_argument('--pmc-child', default=None, metavar='DIR', help=argparse.SUPPRESS)
+    ap.add_argument('--details', default=os.path.join(ROOT, 'gpurun_out', 'bench_details.json'),
+                    help='file that receives the whole record of the run (every leg, per scene, counters); the ONE line on stdout is its summary. '
+                         'Empty string: no file')
+    ap.add_argument('--full-line', action='store_true', help='print the whole record on stdout instead of the summary line (round 4\'s output: 20 KB)')
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args.pmc_child)
@@ -1197,9 +1266,15 @@ def main():
     if pmc is not None:
         # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide reads at 64 bytes: doubled
         # (MI355X_MICROARCH.md, HBM section).  Average over the five scenes, per traversal launch, like the duration.
-        fetch = sum(pmc['per_scene'][n].get('FETCH_SIZE', 0.0) for n in SCENES) / len(SCENES)
-        write = sum(pmc['per_scene'][n].get('WRITE_SIZE', 0.0) for n in SCENES) / len(SCENES)
+        # ... over the scenes whose counter pass ran the launch that is timed here (the child calibrates on its own: ADVICE r4)
+        matched = [n for n in SCENES if pmc['strategies'].get(n) == per_scene[n]['strategy']] or list(SCENES)
+        fetch = sum(pmc['per_scene'][n].get('FETCH_SIZE', 0.0) for n in matched) / len(matched)
+        write = sum(pmc['per_scene'][n].get('WRITE_SIZE', 0.0) for n in matched) / len(matched)
         traffic = int((2.0 * fetch + write) * 1024)
+        launch_s = sum(per_scene[n]['first_kernel_ms'] + per_scene[n]['wave_per_ray_ms'] for n in matched) / len(matched) * 1e-3
+        trace_ms_avg = launch_s * 1e3
+        alg_per_launch = sum(per_scene[n]['algorithmic_bytes'] for n in matched) / len(matched) * share
+        walked_per_launch = sum(per_scene[n]['walked_bytes'] for n in matched) / len(matched) * share
         for n in SCENES:
             c = pmc['per_scene'][n]
             per_scene[n]['counters_per_launch'] = {k: round(v, 1) for k, v in c.items()}
@@ -1231,6 +1306,7 @@ def main():
                     kernel='traversal launch of one frame: k_trace_packet4, k_trace_packet or k_trace, then k_trace_long (+ k_resolve_split) '
                            'where work was handed over; <1, 2> in profiles = these isolated launches, <1, 0> = the timed region, <1, 1> = calibration',
                     avg_launch_ms=round(trace_ms_avg, 4), isolated_launches=ISOLATED_FRAMES * len(SCENES),
+                    scenes_averaged=(matched if traffic is not None else list(SCENES)),
                     reference_algorithm_bytes_per_launch=int(alg_per_launch), walked_bytes_per_launch=int(walked_per_launch),
                     reference_algorithm_gbps=round(alg_per_launch / launch_s / 1e9, 1), walked_gbps=round(walked_per_launch / launch_s / 1e9, 1),
                     traffic_over_reference_algorithm=(round(traffic / alg_per_launch, 4) if traffic else None),
@@ -1254,6 +1330,13 @@ def main():
         f_floor = floor_ms / max(q['trace_ms'], 1e-9)
         f_hbm = (q['hbm_bytes_per_launch'] / (q['trace_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if 'hbm_bytes_per_launch' in q else None
         f_valu = q.get('valu_issue_frac')
+        if 'strategy_in_counter_pass' in q and q['strategy_in_counter_pass'] != q['strategy']:
+            # the profiled child calibrated on its own and settled on another launch than the one timed here: its counters divided by this
+            # process's duration would mix two launches -- no derived fraction for this scene
+            bound_per_scene[n] = dict(frac_of_output_floor=round(f_floor, 4), hbm_frac_measured=None, valu_issue_frac=None,
+                                      binds='not derived: the counter pass ran %s, the timed launch %s' % (q['strategy_in_counter_pass'], q['strategy']))
+            q['counters_are_of_another_strategy'] = True
+            continue
         cands = [('hbm (output writes)', f_hbm if f_hbm is not None else f_floor), ('valu_issue', f_valu or 0.0)]
         top = max(cands, key=lambda c: c[1])
         bound_per_scene[n] = dict(frac_of_output_floor=round(f_floor, 4), hbm_frac_measured=(round(f_hbm, 4) if f_hbm is not None else None),
@@ -1317,14 +1400,24 @@ def main():
                ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling='strong',
                vs_baseline=None, dtype='f32', data='bundled TestModels OBJ scenes (shipped with the reference), demo default camera',
                config=dict(workload='5 bundled TestModels scenes x 1920x1080 primary rays, BVH traversal + Blinn-Phong shading',
-                           rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES, parallelism=par,
+                           rays_per_step=rays_per_step, resolution=list(RES), scenes=SCENES, parallelism=par, ranks=nranks,
                            settle='%d untimed steps (%.0f ms) before the %d warm-up steps: device clocks (--settle-ms)' % (settled, args.settle_ms, args.warmup),
                            policy='timed region and moving-camera leg: rt_ctx_set_frames_in_flight(5); isolated frames, first frames, config5: the default (one frame at a time)'),
                ms_per_frame=round(elapsed / args.steps / len(SCENES) * 1e3, 4),
                host_issue_ms_per_step=round(issued / args.steps * 1e3, 4),
                verified=verified, roofline=roofline, roofline_valu_issue=rv, cpu_baseline=cpu_baseline, moving_camera=moving, ray_buffer=ray_buffer, config3=config3, config4=config4, config5=config5,
                per_rank=per_rank, per_scene=per_scene)
-    print(json.dumps(out))
+    line = compact_line(out, args.details)
+    if args.details:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.details)), exist_ok=True)
+            with open(args.details, 'w') as f:
+                json.dump(out, f)
+                f.write('\n')
+        except OSError as e:
+            print('bench: details file %s not written: %s' % (args.details, e), file=sys.stderr)
+            line['details_file'] = None
+    print(json.dumps(out if args.full_line else line))
     if dist is not None:
         dist.destroy_process_group()
 

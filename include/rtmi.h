@@ -142,6 +142,12 @@ int  rt_bvh_generate_contacts_rays(rt_bvh* bvh, const void* d_rays, uint32_t ray
  * handful of timed launches on it, reported here for the last calibration); reported: the strategy of the last such buffer traced.
  * Kept across rebuilds of the same triangle count; env RTMI_RAYS=lane:<steps> | p4 | p4s:<steps> fixes it.  A speed knob only.   */
 int  rt_bvh_rays_strategy(const rt_bvh* bvh, int* packet_kernel, uint32_t* budget, uint32_t* calibration_launches, float* calibration_gpu_ms);
+/* test / inspection: the ray-buffer entry's calibrations kept by this BVH.  A calibration belongs to a size class AND to what the buffer
+ * holds as far as the library can know it: buffers written by rt_generate_primary_rays / rt_generate_secondary_rays are camera rays, shadow
+ * rays or reflections (noted per address when they are generated), any other buffer is known by its address.  An entry whose launches
+ * twice in a row take more than twice its calibrated time (HIP events around every tuned launch, read back without waiting by the next
+ * call) is dropped and calibrated again on the buffer at hand.  *entries = calibrations held now, *recalibrations = entries dropped so. */
+int  rt_bvh_rays_calibrations(const rt_bvh* bvh, uint32_t* entries, uint32_t* recalibrations);
 /* parity/debug read-backs in the reference's own layouts (blocking) */
 int  rt_bvh_read_nodes(const rt_bvh* bvh, void* h_nodes /* (2n-1) * 48 B */);
 int  rt_bvh_read_morton_pairs(const rt_bvh* bvh, void* h_pairs /* N * 8 B */, uint32_t* n_pow2);

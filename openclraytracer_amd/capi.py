@@ -36,7 +36,7 @@ SYMBOLS = [
     'rt_ctx_synchronize', 'rt_device_synchronize', 'rt_ctx_device_info', 'rt_buf_alloc', 'rt_buf_free', 'rt_buf_upload', 'rt_buf_download',
     'rt_buf_fill_u32', 'rt_scene_upload', 'rt_scene_upload_indexed', 'rt_scene_destroy', 'rt_scene_device_ptr', 'rt_scene_bytes',
     'rt_scene_triangle_count', 'rt_bvh_create', 'rt_bvh_destroy', 'rt_bvh_initialize_frame', 'rt_bvh_construct', 'rt_bvh_graph_builds',
-    'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_rays_strategy', 'rt_bvh_read_nodes',
+    'rt_bvh_generate_contacts_primary', 'rt_bvh_generate_contacts_rays', 'rt_bvh_rays_strategy', 'rt_bvh_rays_calibrations', 'rt_bvh_read_nodes',
     'rt_bvh_read_morton_pairs', 'rt_bvh_read_search_nodes', 'rt_bvh_info', 'rt_bvh_trace_strategy', 'rt_bvh_calibration_launches', 'rt_bvh_host_plane_reads', 'rt_bvh_calibration_gpu_ms', 'rt_bvh_block_order', 'rt_bvh_search_tree', 'rt_shade_blinn_phong', 'rt_tiles_owned_pixels',
     'rt_bvh_generate_contacts_primary_tiled', 'rt_shade_blinn_phong_tiled', 'rt_untile_rgba', 'rt_frame_graph_create', 'rt_frame_graph_launch', 'rt_frame_graph_destroy', 'rt_frame_graph_set_camera', 'rt_frame_graph_last_launch', 'rt_frame_graph_state', 'rt_render_frame', 'rt_shade_blinn_phong_frame', 'rt_shade_blinn_phong_tiled_packed', 'rt_untile_rgba_packed',
     'rt_sort_pairs_bitonic', 'rt_sort_pairs', 'rt_scan_inclusive_u32', 'rt_ctx_set_profiling', 'rt_ctx_set_frames_in_flight', 'rt_ctx_trace_kernel_times', 'rt_ctx_last_trace_counters',
@@ -369,6 +369,13 @@ class DeviceBVH:
         self.ctx.lib.rt_bvh_rays_strategy.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         self.ctx.check(self.ctx.lib.rt_bvh_rays_strategy(self.h, C.byref(k), C.byref(v), C.byref(n), C.byref(ms)))
         return dict(kernel={0: 'lane-per-ray', 2: 'packet4'}[k.value], budget=v.value, calibration_launches=n.value, calibration_gpu_ms=round(ms.value, 4))
+
+    def rays_calibrations(self) -> dict:
+        """rt_bvh_rays_calibrations: calibrations of the ray-buffer entry held now, and how many were retired as stale"""
+        n, r = C.c_uint32(), C.c_uint32()
+        self.ctx.lib.rt_bvh_rays_calibrations.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        self.ctx.check(self.ctx.lib.rt_bvh_rays_calibrations(self.h, C.byref(n), C.byref(r)))
+        return dict(entries=n.value, recalibrations=r.value)
 
     def calibration_launches(self) -> int:
         self.ctx.lib.rt_bvh_calibration_launches.argtypes = [C.c_void_p]

@@ -46,7 +46,7 @@ static void drop_build_graph(rt_bvh* b)
 {
     if (b->build_exec) (void)hipGraphExecDestroy(b->build_exec);
     if (b->build_graph) (void)hipGraphDestroy(b->build_graph);
-    b->build_exec = nullptr; b->build_graph = nullptr; b->builds_on_allocation = 0;
+    b->build_exec = nullptr; b->build_graph = nullptr; b->builds_on_allocation = 0; b->build_graph_failed = false;
 }
 
 static void free_build_buffers(rt_bvh* b)
@@ -97,6 +97,7 @@ void rt_bvh_destroy(rt_bvh* b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     free_build_buffers(b);
+    drop_rays_tuned(b);
     if (b->h_depths) (void)hipHostFree(b->h_depths);
     block_order_free(b->block_order);
     delete b;
@@ -238,7 +239,11 @@ static int enqueue_build(rt_bvh* b, hipStream_t s)
     else launch_morton_leaves(s, sc, b->d_nodes, b->d_pairs, N, nullptr, nullptr, 0u, ref_climbs ? b->d_counters : nullptr, nullptr);
     if (fast) {
         if (search_with_radix_pair) launch_radix_sort(s, b->d_pairs, b->d_sort_tmp2, n, 30u, b->d_sort_scratch2, b->s_pairs, b->d_sort_tmp, b->d_sort_scratch);
-        else launch_radix_sort(s, b->d_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
+        else {
+            launch_radix_sort(s, b->d_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
+            // (no second set of sort buffers: the search tree's keys go through the same ones, behind the reference's -- never left unsorted)
+            if (want_search) launch_radix_sort(s, b->s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
+        }
     } else {
         launch_bitonic_sort(s, b->d_pairs, N, search_with_network ? b->s_pairs : nullptr);
         if (want_search && !search_with_network) launch_radix_sort(s, b->s_pairs, b->d_sort_tmp, n, 30u, b->d_sort_scratch);
@@ -307,7 +312,7 @@ int rt_bvh_construct(rt_bvh* b)
     b->builds_on_allocation++;
     bool launched = false;
     if (graphs && b->builds_on_allocation >= 2u) {
-        if (!b->build_exec) {
+        if (!b->build_exec && !b->build_graph_failed) {
             hipGraph_t g = nullptr;
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
             if (e == hipSuccess) {
@@ -316,6 +321,7 @@ int rt_bvh_construct(rt_bvh* b)
                 if (rc == RT_SUCCESS && e == hipSuccess && g && hipGraphInstantiate(&b->build_exec, g, nullptr, nullptr, 0) == hipSuccess) b->build_graph = g;
                 else { if (g) (void)hipGraphDestroy(g); b->build_exec = nullptr; }
             }
+            if (!b->build_exec) b->build_graph_failed = true;      // not tried again on this allocation (drop_build_graph resets it)
             (void)hipGetLastError();                   // a runtime that cannot capture this sequence: the build stays eager
         }
         if (b->build_exec) { RT_HIP(ctx, hipGraphLaunch(b->build_exec, s)); launched = true; b->graph_builds++; }
@@ -357,7 +363,7 @@ int rt_bvh_construct(rt_bvh* b)
     // and every strategy produces the same contacts anyway.  RTMI_RECALIBRATE=1 restores a calibration per construct().
     if (b->tuned_n != b->n || ctx->recalibrate) { b->tuned = false; for (auto& e : b->tuned_cache) e.valid = false; }
     b->tuned_n = b->n;
-    if (b->rays_tuned_n != b->n || ctx->recalibrate) { for (auto& e : b->rays_tuned) e.valid = false; b->rays_last = -1; }     // (the ray-buffer entry's strategies likewise)
+    if (b->rays_tuned_n != b->n || ctx->recalibrate) drop_rays_tuned(b);     // (the ray-buffer entry's strategies likewise)
     b->rays_tuned_n = b->n;
     return RT_SUCCESS;
 }

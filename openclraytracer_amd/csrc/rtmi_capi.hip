@@ -251,6 +251,7 @@ int rt_buf_free(rt_ctx* ctx, void* d_ptr)
     RT_ENTER(ctx);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RT_HIP(ctx, hipFree(d_ptr));
+    note_ray_buffer(ctx, d_ptr, RT_RAYKIND_FOREIGN);          // the address may come back as another buffer
     return RT_SUCCESS;
 }
 
@@ -261,6 +262,7 @@ int rt_buf_upload(rt_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes)
     RT_ENTER(ctx);
     RT_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the host buffer may be reused on return
+    note_ray_buffer(ctx, d_dst, RT_RAYKIND_FOREIGN);    // (if it was a ray buffer of the library's generators: the caller's bytes now)
     return RT_SUCCESS;
 }
 
@@ -601,6 +603,7 @@ int rt_generate_secondary_rays(rt_ctx* ctx, const rt_camera* cam, const void* d_
     (void)hipFree(tmp);
     if (e != hipSuccess) return RT_FAIL(ctx, std::string("secondary ray generation failed: ") + hipGetErrorString(e));
     *out_count = n;
+    note_ray_buffer(ctx, d_rays_out, kind == RT_RAYS_SHADOW ? RT_RAYKIND_SHADOW : RT_RAYKIND_REFLECT);
     return RT_SUCCESS;
 }
 
@@ -612,6 +615,7 @@ int rt_generate_primary_rays(rt_ctx* ctx, const rt_camera* cam, void* d_rays_out
     RT_ENTER(ctx);
     launch_primary_rays(ctx->stream, cam, (rt_ray*)d_rays_out);
     RT_HIP(ctx, hipGetLastError());
+    note_ray_buffer(ctx, d_rays_out, RT_RAYKIND_PRIMARY);
     return RT_SUCCESS;
 }
 

@@ -39,6 +39,10 @@ RT_HIDDEN void current_strategy(const rt_bvh* b, bool& packet, bool& quad);
 RT_HIDDEN int ensure_host_planes(rt_bvh* b);
 RT_HIDDEN uint32_t host_plane_bits(const rt_bvh* b, const float origin[3]);
 RT_HIDDEN const uint2* tile_table(rt_ctx* ctx, const rt_camera* cam, uint32_t rank, uint32_t nranks);
+// rtmi_rays.hip
+enum { RT_RAYKIND_FOREIGN = 0, RT_RAYKIND_SHADOW = 1, RT_RAYKIND_REFLECT = 2, RT_RAYKIND_PRIMARY = 3 };
+RT_HIDDEN void note_ray_buffer(rt_ctx* ctx, const void* d_rays, int raykind);      // a generator of the library wrote this buffer
+RT_HIDDEN void drop_rays_tuned(rt_bvh* b);                                          // forget the ray-buffer entry's calibrations (and their events)
 }
 // Deadlines of calibration launches on the device's own clock (trace_kernels.hip, cal_expired): a sample of that clock next to a host
 // time stamp maps "now + limit" onto it.  The sample's kernel ran before the read-back returned, so mapped deadlines come a few

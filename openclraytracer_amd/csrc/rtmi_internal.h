@@ -103,6 +103,10 @@ struct rt_ctx {
     bool no_graph_direct = false;           // RTMI_GRAPH_DIRECT=0: frame graphs of kernels only go through hipGraphLaunch as well
     int graph_debug = 0;                    // RTMI_GRAPH_DEBUG=1 (+ RTMI_GRAPH_DEBUG_VERBOSE: 2): host time per stage of the frame graphs, on stderr
     std::string rays_forced;                // RTMI_RAYS=lane:N | p4 | p4s:N: the ray-buffer entry's strategy, forced
+    // what the library's own generators last wrote to a ray buffer (rtmi_rays.hip: part of the ray-buffer entry's calibration key)
+    struct RayTag { const void* addr = nullptr; uint8_t kind = 0; };
+    RayTag ray_tags[8];
+    uint32_t ray_tags_next = 0;
     bool tlg_no_rebuild_on_previous = false;// RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES=0
     bool tlg_no_tricam = false;             // RTMI_TLG_TRICAM=0
     bool no_calibration_deadline = false;   // RTMI_CALIBRATION_DEADLINE=0
@@ -191,6 +195,7 @@ struct rt_bvh {
     // construct() as a HIP graph (rtmi_bvh.hip): the sequence of one build on this BVH's buffers, captured on the second build of an
     // allocation and replayed by the later ones (a scene rebuilt every frame, OpenCLRayTracerDemo.cpp:230-234)
     hipGraph_t build_graph = nullptr; hipGraphExec_t build_exec = nullptr;
+    bool build_graph_failed = false;        // this allocation's build could not be captured / instantiated: built eagerly from then on
     uint2* d_sort_tmp2 = nullptr; uint32_t* d_sort_scratch2 = nullptr;      // RT_MODE_FAST: the reference tree's radix sort has its own scratch (both sorts may run at once)
     uint32_t builds_on_allocation = 0;      // construct() calls since the buffers were (re)allocated
     uint32_t* h_depths = nullptr;           // pinned copy of d_depth[0..3] (read back at the end of a build)
@@ -232,12 +237,18 @@ struct rt_bvh {
     // the ray-buffer entry (rtmi_rays.hip): kernel and budget calibrated on the first large buffer traced through this BVH
     // ... one entry per size class (power of two) of the buffers: the buffers of one bounce of a frame loop keep their size class and their
     // character from frame to frame (a camera's 2 M rays, the 0.8 M reflections of their hits, ...), different bounces seldom share one
-    struct RaysTuned { uint32_t size_class = 0, budget = 0; bool packet = false, valid = false; };
-    enum { RT_RAYS_TUNED = 6 };
+    // ... keyed further by what the buffer holds, as far as the library knows it (a strategy calibrated on a camera's rays served the
+    // reflections of the same size class): buffers written by rt_generate_primary_rays / rt_generate_secondary_rays carry their kind
+    // (rt_ctx::ray_tags), a caller's own buffer is known by its address; and an entry whose launches come to take twice its calibrated time
+    // (events around every tuned launch, read without waiting by the next call) is calibrated again
+    struct RaysTuned { uint32_t size_class = 0, budget = 0; bool packet = false, valid = false; uint8_t kind = 0; const void* addr = nullptr;
+                       float ms = 0.f; uint32_t slow = 0; bool pending = false; hipEvent_t e0 = nullptr, e1 = nullptr; };
+    enum { RT_RAYS_TUNED = 8 };
     RaysTuned rays_tuned[RT_RAYS_TUNED];
     uint32_t rays_tuned_next = 0, rays_tuned_n = 0;
     int rays_last = -1;                      // entry the last large buffer was traced with (rt_bvh_rays_strategy)
     uint32_t rays_calibration_launches = 0; float rays_calibration_gpu_ms = 0.f;     // of the last calibration
+    uint32_t rays_recalibrations = 0;        // entries retired because their launches came to take twice their calibrated time
     uint64_t build_generation = 0;          // bumped by every construct() and every reallocation (frame graphs hold record addresses)
     uint32_t eager_frames = 0;              // eager four-wide frames traced on this build (from RT_EAGER_PLANES_AFTER on the host looks the plane bits up)
     bool frame_initialised = false;

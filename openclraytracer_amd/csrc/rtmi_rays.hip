@@ -33,10 +33,37 @@ bool forced_strategy(const rt_ctx* ctx, RayStrategy& out)       // knob RTMI_RAY
 }
 
 uint32_t size_class(uint32_t count) { uint32_t c = 0; while (count >>= 1) c++; return c; }       // floor(log2)
-int find_tuned(const rt_bvh* b, uint32_t count)
+int ray_buffer_kind(const rt_ctx* ctx, const void* d_rays)
 {
-    for (int i = 0; i < rt_bvh::RT_RAYS_TUNED; i++) if (b->rays_tuned[i].valid && b->rays_tuned[i].size_class == size_class(count)) return i;
+    for (const auto& t : ctx->ray_tags) if (t.addr == d_rays) return t.kind;
+    return RT_RAYKIND_FOREIGN;
+}
+// the calibration key: size class + what the buffer holds (a generator's kind; a caller's own buffer: its address)
+int find_tuned(const rt_bvh* b, uint32_t count, int kind, const void* d_rays)
+{
+    for (int i = 0; i < rt_bvh::RT_RAYS_TUNED; i++) {
+        const rt_bvh::RaysTuned& e = b->rays_tuned[i];
+        if (e.valid && e.size_class == size_class(count) && e.kind == (uint8_t)kind && (kind != RT_RAYKIND_FOREIGN || e.addr == d_rays)) return i;
+    }
     return -1;
+}
+void drop_entry(rt_bvh::RaysTuned& e)
+{
+    if (e.e0) (void)hipEventDestroy(e.e0);
+    if (e.e1) (void)hipEventDestroy(e.e1);
+    e = rt_bvh::RaysTuned();
+}
+// The tuned launch before this one, if it has finished: did it take about what the calibration measured?  Two launches in a row at more than
+// twice the calibrated time (+ 20 us) retire the entry: the buffer's rays are no longer what they were (never waits: hipEventQuery).
+bool entry_went_stale(rt_bvh::RaysTuned& e)
+{
+    if (!e.pending || !e.e0 || !e.e1) return false;
+    if (hipEventQuery(e.e1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    e.pending = false;
+    float m = 0.f;
+    if (hipEventElapsedTime(&m, e.e0, e.e1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (m > 2.0f * e.ms + 0.02f) e.slow++; else e.slow = 0;
+    return e.slow >= 2u;
 }
 
 void issue(rt_bvh* b, const RayStrategy& st, int tag, unsigned long long deadline, const rt_ray* rays, uint32_t count, rt_contact* out)
@@ -50,7 +77,7 @@ void issue(rt_bvh* b, const RayStrategy& st, int tag, unsigned long long deadlin
     launch_trace_rays(ctx->stream, t, rays, count, out);
 }
 
-int calibrate(rt_bvh* b, const rt_ray* rays, uint32_t count, rt_contact* out)
+int calibrate(rt_bvh* b, const rt_ray* rays, uint32_t count, rt_contact* out, int kind)
 {
     rt_ctx* ctx = b->ctx;
     static const RayStrategy cands[] = { { false, 64u }, { true, 64u }, { true, 1u << 20 }, { false, 16u }, { false, 256u },       // the coarse pass, in this order
@@ -62,7 +89,7 @@ int calibrate(rt_bvh* b, const rt_ray* rays, uint32_t count, rt_contact* out)
     for (int i = 0; i < N_CAND; i++) { ms[i] = 0.f; n[i] = (cands[i].packet && (!four_wide_ok || (cands[i].budget < (1u << 20) && !ctx->d_task_list))) ? -1 : 0; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     RT_HIP(ctx, hipEventCreate(&e0));
-    RT_HIP(ctx, hipEventCreate(&e1));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return RT_FAIL(ctx, "hipEventCreate failed"); }
     CalClock clock;
     uint32_t launches = 0; float gpu_ms = 0.f; bool broken = false;
     auto best_of = [&](int skip) { int best = -1; for (int i = 0; i < N_CAND; i++) if (i != skip && n[i] > 0 && (best < 0 || ms[i] < ms[best])) best = i; return best; };
@@ -104,13 +131,35 @@ int calibrate(rt_bvh* b, const rt_ray* rays, uint32_t count, rt_contact* out)
     rt_bvh::RaysTuned& slot = b->rays_tuned[b->rays_tuned_next % rt_bvh::RT_RAYS_TUNED];
     b->rays_last = (int)(b->rays_tuned_next % rt_bvh::RT_RAYS_TUNED);
     b->rays_tuned_next++;
+    drop_entry(slot);
     slot.size_class = size_class(count); slot.packet = cands[best].packet; slot.budget = cands[best].budget; slot.valid = true;
+    slot.kind = (uint8_t)kind; slot.addr = (kind == RT_RAYKIND_FOREIGN ? (const void*)rays : nullptr); slot.ms = ms[best];
+    if (hipEventCreate(&slot.e0) != hipSuccess || hipEventCreate(&slot.e1) != hipSuccess) {       // no events: the entry is never re-examined
+        (void)hipGetLastError();
+        if (slot.e0) (void)hipEventDestroy(slot.e0);
+        slot.e0 = slot.e1 = nullptr;
+    }
     b->rays_calibration_launches = launches; b->rays_calibration_gpu_ms = gpu_ms;
     return RT_SUCCESS;
 }
 }  // namespace
 
 extern "C" {
+
+void note_ray_buffer(rt_ctx* ctx, const void* d_rays, int raykind)
+{
+    if (!ctx || !d_rays) return;
+    for (auto& t : ctx->ray_tags) if (t.addr == d_rays) { t.kind = (uint8_t)raykind; if (raykind == RT_RAYKIND_FOREIGN) t.addr = nullptr; return; }
+    if (raykind == RT_RAYKIND_FOREIGN) return;
+    auto& t = ctx->ray_tags[ctx->ray_tags_next++ % (sizeof ctx->ray_tags / sizeof ctx->ray_tags[0])];
+    t.addr = d_rays; t.kind = (uint8_t)raykind;
+}
+
+void drop_rays_tuned(rt_bvh* b)
+{
+    for (auto& e : b->rays_tuned) drop_entry(e);
+    b->rays_last = -1;
+}
 
 int rt_bvh_generate_contacts_rays(rt_bvh* b, const void* d_rays, uint32_t ray_count, void* d_contacts)
 {
@@ -122,17 +171,23 @@ int rt_bvh_generate_contacts_rays(rt_bvh* b, const void* d_rays, uint32_t ray_co
     RT_ENTER(ctx);
     if (ensure_long_list(ctx, ray_count)) return RT_ERROR;
     RayStrategy st = { false, 64u };
+    rt_bvh::RaysTuned* timed = nullptr;
     if (ctx->defer_budget) st = { ctx->force_packet4, ctx->defer_budget };            // RTMI_DEFER_BUDGET (+ RTMI_PACKET=4): as for primary frames
     else if (!forced_strategy(ctx, st)) {
         if (ray_count >= RT_RAYS_CALIBRATE_FROM) {
-            int i = find_tuned(b, ray_count);
-            if (i < 0) { if (calibrate(b, (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts)) return RT_ERROR; i = b->rays_last; }
+            const int kind = ray_buffer_kind(ctx, d_rays);
+            int i = find_tuned(b, ray_count, kind, d_rays);
+            if (i >= 0 && entry_went_stale(b->rays_tuned[i])) { drop_entry(b->rays_tuned[i]); b->rays_recalibrations++; i = -1; }
+            if (i < 0) { if (calibrate(b, (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts, kind)) return RT_ERROR; i = b->rays_last; }
             b->rays_last = i;
             st = { b->rays_tuned[i].packet, b->rays_tuned[i].budget };
+            if (b->rays_tuned[i].e0 && !b->rays_tuned[i].pending) timed = &b->rays_tuned[i];
         }
     }
     // (after a calibration: once more with the strategy chosen -- the last launch above was some other candidate's and may have been cut off)
+    if (timed) (void)hipEventRecord(timed->e0, ctx->stream);
     issue(b, st, 0, 0ull, (const rt_ray*)d_rays, ray_count, (rt_contact*)d_contacts);
+    if (timed) { (void)hipEventRecord(timed->e1, ctx->stream); timed->pending = true; }
     RT_HIP(ctx, hipGetLastError());
     return RT_SUCCESS;
 }
@@ -148,6 +203,16 @@ int rt_bvh_rays_strategy(const rt_bvh* b, int* packet_kernel, uint32_t* budget, 
     if (budget) *budget = st.budget;
     if (calibration_launches) *calibration_launches = b->rays_calibration_launches;
     if (calibration_gpu_ms) *calibration_gpu_ms = b->rays_calibration_gpu_ms;
+    return RT_SUCCESS;
+}
+
+int rt_bvh_rays_calibrations(const rt_bvh* b, uint32_t* entries, uint32_t* recalibrations)
+{
+    if (!b) return RT_FAIL(nullptr, "bvh is null");
+    uint32_t n = 0;
+    for (const auto& e : b->rays_tuned) n += e.valid ? 1u : 0u;
+    if (entries) *entries = n;
+    if (recalibrations) *recalibrations = b->rays_recalibrations;
     return RT_SUCCESS;
 }
 

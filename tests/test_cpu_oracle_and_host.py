@@ -374,6 +374,32 @@ def test_bench_reads_the_tag_of_a_traversal_kernel_name():
     assert bench.kernel_tag('k_shade') is None
 
 
+def test_bench_summary_line_fits_a_stdout_tail():
+    """The ONE line bench.py prints is a summary of at most 4 096 bytes (round 4's 20 KB line outgrew the tail of stdout the driver
+    keeps, and its record of the run held no parsed line); the whole record goes to --details.  Checked on round 4's committed full
+    record and on its in-process rehearsal of four ranks: contract keys, the two added objects, one figure per further leg."""
+    import bench
+    for src, tiled in (('r04_bench_line.json', False), ('r04_bench_group4_rehearsal.json', True)):
+        full = json.loads(open(os.path.join(ROOT, 'profiles', src)).read())
+        line = bench.compact_line(full, os.path.join(ROOT, 'gpurun_out', 'bench_details.json'))
+        text = json.dumps(line)
+        assert len(text) <= bench.LINE_LIMIT == 4096
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+            assert k in line and (k == 'data' or line[k] == full[k]), k
+        assert line['config']['workload'] == full['config']['workload'] and 'model' not in line['config']
+        rf = line['roofline']
+        assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] == 'GB/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+        assert rf['traffic'] == full['roofline']['traffic'] and rf['frac_of_output_floor'] == full['roofline']['frac_of_output_floor']
+        assert line['details_file'] == 'gpurun_out/bench_details.json'
+        if tiled:
+            assert line['cpu_baseline'] is None and len(line['per_rank']['rows']) == 4
+        else:
+            cb = line['cpu_baseline']
+            assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['sample']
+            assert line['verified']['frames'] == 5 and line['verified']['config4'] is True
+            assert line['legs']['config4']['mrays'] == full['config4']['mrays_per_s_grid_kept']
+            assert set(line['legs']['frame_ms']) == set(MODELS)
+
 
 def test_host_cpu_shade_blinn_phong_equals_the_oracle():
     """the host mirror's cpuShadeBlinnPhong(Camera*, Contact*, char*, CL_FLOAT4&) (Include/CLData/Shading.h:74-166; what an unmodified

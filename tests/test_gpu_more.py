@@ -126,6 +126,71 @@ def test_ray_buffer_rays_parallel_to_the_yz_plane_on_box_planes(gpu_ctx, name, m
         assert got.tobytes() == want.tobytes(), strategy
 
 
+def test_ray_buffer_calibrations_are_keyed_by_what_the_buffer_holds(gpu_ctx):
+    """the ray-buffer entry kept ONE calibration per size class, so the strategy found on a camera's rays served the reflections
+    of the same size.  A calibration now belongs to (size class, what the buffer holds): the library's generators note what they wrote --
+    camera rays, shadow rays, reflections -- and a buffer of the caller's own is known by its address; an entry whose launches come to take
+    twice its calibrated time is retired (rt_bvh_rays_calibrations).  Contacts stay the oracle's through all of it."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    import bench
+    ctx = gpu_ctx
+    osc, ob = oracle_bvh('tenryuu')
+    sc = capi.DeviceScene(ctx, __import__('conftest').packed_scene('tenryuu'))
+    gb = capi.DeviceBVH(ctx, sc).build()              # a BVH of this test's own: its calibrations are counted
+    cam = osc.demo_camera(640, 360)
+    ccam = as_capi_camera(cam)
+    npx = 640 * 360
+    light, eps = bench.bench_fixture()['light'], bench.bench_fixture()['eps']
+    d_r0, d_r1, d_c0, d_c1 = ctx.alloc(npx * 48), ctx.alloc(npx * 48), ctx.alloc(npx * 32), ctx.alloc(npx * 32)
+    try:
+        assert gb.rays_calibrations() == dict(entries=0, recalibrations=0)
+        capi.generate_primary_rays_d(ctx, ccam, d_r0)
+        gb.generate_contacts_rays_d(d_r0, npx, d_c0); ctx.synchronize()
+        want0, _ = ob.trace_primary(cam)
+        assert ctx.download(d_c0, npx, capi.CONTACT).tobytes() == want0.tobytes()
+        assert gb.rays_calibrations()['entries'] == 1
+        gb.generate_contacts_rays_d(d_r0, npx, d_c0); ctx.synchronize()
+        assert gb.rays_calibrations()['entries'] == 1                                   # the same kind and size: no second calibration
+        rays0 = orc.generate_rays(cam)
+        entries = 1
+        for kind in (1, 0):                                                             # reflections, then shadow rays, through the SAME buffer
+            n = capi.generate_secondary_rays_d(ctx, d_c0, npx, kind, d_r1, light, eps, d_rays_in=d_r0)
+            want_r = orc.generate_secondary_rays(want0, kind, light, eps=eps, rays_in=rays0)
+            assert n == len(want_r) and n >= 32768
+            gb.generate_contacts_rays_d(d_r1, n, d_c1); ctx.synchronize()
+            want_c, _ = ob.trace_rays(want_r)
+            assert ctx.download(d_c1, n, capi.CONTACT).tobytes() == want_c.tobytes()
+            entries += 1
+            assert gb.rays_calibrations()['entries'] == entries, kind                  # its own calibration although size class and address repeat
+        # a buffer of the caller's own: known by its address; bytes uploaded over a generated buffer make it the caller's
+        rng = np.random.default_rng(5)
+        n = 200000
+        away = np.zeros(n, dtype=orc.RAY)
+        away['idx'] = np.arange(n)
+        away['origin'][:, :3] = (0.0, 0.0, -50.0)
+        away['direction'][:, :3] = (0.0, 0.0, -1.0)                                     # every ray leaves the scene: the cheapest buffer there is
+        ctx.upload(d_r1, away.view(np.uint8))
+        gb.generate_contacts_rays_d(d_r1, n, d_c1); ctx.synchronize()
+        assert gb.rays_calibrations() == dict(entries=entries + 1, recalibrations=0)
+        assert not ctx.download(d_c1, n, capi.CONTACT)['normalAndDistance'][:, 3].any()
+        heavy = away.copy()
+        heavy['origin'][:, :3] = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        heavy['direction'][:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        ctx.upload(d_r1, heavy.view(np.uint8))                                          # same address, same size class, another workload
+        want_h, _ = ob.trace_rays(heavy)
+        for _ in range(4):
+            gb.generate_contacts_rays_d(d_r1, n, d_c1); ctx.synchronize()
+            assert ctx.download(d_c1, n, capi.CONTACT).tobytes() == want_h.tobytes()
+        got = gb.rays_calibrations()
+        assert got['recalibrations'] == 1 and got['entries'] == entries + 1, got        # retired after two slow launches, calibrated again once
+    finally:
+        for d_ in (d_r0, d_r1, d_c0, d_c1):
+            ctx.free(d_)
+        gb.close(); sc.close()
+
+
 @pytest.mark.parametrize('name', MODELS)
 def test_shading_within_tolerance(gpu_ctx, name):
     """device Blinn-Phong vs cpuShadeBlinnPhong restatement: 1e-5 relative on RGB (pow differs in the last ulps),
@@ -958,6 +1023,24 @@ def test_secondary_rays_two_bounces(gpu_ctx, name, res):
     assert len(capi.generate_secondary_rays(gpu_ctx, none, 0, light, 1e-3, cam=ccam)) == 0
 
 
+def _tmp_path(name):
+    import tempfile
+    return os.path.join(tempfile.mkdtemp(prefix='rtmi_bench_'), name)
+
+
+def _bench_outputs(r, details):
+    """bench.py prints ONE summary line (<= 4096 bytes: the driver keeps the tail of stdout) and writes the whole record to --details"""
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1 and len(lines[0]) <= 4096, (len(lines), [len(l) for l in lines])
+    line = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+              'roofline', 'cpu_baseline', 'verified'):
+        assert k in line, k
+    full = json.load(open(details))
+    assert full['value'] == line['value'] and full['ms_per_step'] == line['ms_per_step']
+    return line, full
+
+
 def test_bench_group_rehearsal_assembles_identical_frames():
     """bench.py's N > 1 path on this one GPU: three ranks inside one process (RTMI_BENCH_GROUP=3; the library gathers by device
     copies because RCCL refuses several ranks on one device) trace and shade their tiles of all five 1080p frames through
@@ -968,14 +1051,14 @@ def test_bench_group_rehearsal_assembles_identical_frames():
     env = dict(os.environ, RTMI_BENCH_GROUP='3')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
-    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--check-frames'],
+    details = _tmp_path('bench_group3.json')
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--check-frames', '--details', details],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'frame check ok (after the warm-up): 5 assembled frames equal the untiled ones' in r.stderr
     assert 'frame check ok (after the timed steps): 5 assembled frames equal the untiled ones' in r.stderr
-    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(line) == 1
-    out = json.loads(line[0])
+    line, out = _bench_outputs(r, details)
+    assert line['per_rank']['rows'] and len(line['per_rank']['rows']) == 3
     assert out['scaling'] == 'strong' and out['unit'] == 'Mrays/s' and out['value'] > 0
     assert 'REHEARSAL' in out['config']['parallelism']
     assert out['cpu_baseline'] is None and out['roofline']['traffic'] is None      # rank-0-at-N=1-only fields
@@ -1008,11 +1091,12 @@ def test_bench_tiled_path_under_the_runtime_torch_bundles():
     env = dict(os.environ, RTMI_BENCH_FORCE_TILED='1', RTMI_BENCH_TORCH_FIRST='1')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RTMI_BENCH_GROUP'):
         env.pop(k, None)
+    details = _tmp_path('bench_torch_first.json')
     r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '7', '--warmup', '2', '--check-frames',
-                        '--no-cpu-baseline', '--no-extra-legs'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        '--no-cpu-baseline', '--no-extra-legs', '--details', details], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'frame check ok (after the timed steps): 5 assembled frames equal the untiled ones' in r.stderr
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    _, line = _bench_outputs(r, details)
     assert line['value'] > 0 and line['per_rank'] and line['per_rank'][0]['trace_shade_ms_per_step'] > 0
 
 
@@ -1056,10 +1140,11 @@ def test_moving_cameras_under_the_runtime_torch_bundles():
     env = dict(os.environ, RTMI_BENCH_TORCH_FIRST='1')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RTMI_BENCH_GROUP', 'RTMI_BENCH_FORCE_TILED'):
         env.pop(k, None)
-    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-pmc'],
+    details = _tmp_path('bench_moving.json')
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-pmc', '--details', details],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    _, line = _bench_outputs(r, details)
     mv = line['moving_camera']
     assert line['verified']['moving_camera_frames'] == 30
     assert mv['step_ms'] < 2.0 * mv['same_poses_still_step_ms'], mv            # (round 3 under this runtime: three times slower, then a stall)
@@ -1081,10 +1166,15 @@ def test_bench_default_line_has_measured_rooflines():
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     err_path = os.path.join(ROOT, 'gpurun_out', 'test_bench_default_line.err')
     with open(err_path, 'w') as err_file:
+        # (no --details: the default path, gpurun_out/bench_details.json, is what the driver's run leaves behind)
         r = subprocess.run([_sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '3'], cwd=ROOT, env=env,
                            stdout=subprocess.PIPE, stderr=err_file, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + open(err_path).read()[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    line, out = _bench_outputs(r, os.path.join(ROOT, 'gpurun_out', 'bench_details.json'))
+    assert line['details_file'] == 'gpurun_out/bench_details.json'
+    assert line['roofline']['frac'] == out['roofline']['frac'] and line['roofline']['traffic'] == out['roofline']['traffic']
+    assert line['cpu_baseline']['value'] == out['cpu_baseline']['value'] and line['verified']['frames'] == 5
+    assert line['legs']['config4']['mrays'] > 0 and line['legs']['config5']['mrays'] > 0
     rf, rv = out['roofline'], out['roofline_valu_issue']
     assert out['n_gpus'] == 1 and out['config']['rays_per_step'] == 5 * 1920 * 1080
     assert rf['bound'] == 'hbm' and rf['traffic'] is not None and 0 < rf['frac'] <= 1

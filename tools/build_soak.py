@@ -27,12 +27,15 @@ def main():
     ap.add_argument('scenes', nargs='*', default=bench.SCENES + ['synth_atrium'])
     a = ap.parse_args()
     bufs = {n: scene_bytes(n) for n in a.scenes}
+    # (the noise scene as well: every packer child runs before the first HIP call of this process)
+    nbuf = None
+    if a.stress:
+        nbuf = bench.load_scene_bytes('man') if os.environ.get('RTMI_PACKED') != '1' else scene_bytes('man')
     from openclraytracer_amd import capi
     ctx = capi.Context(0)
     noise = None
     if a.stress:
         nctx = capi.Context(0)
-        nbuf = bench.load_scene_bytes('man') if os.environ.get('RTMI_PACKED') != '1' else scene_bytes('man')
         nsc = capi.DeviceScene(nctx, nbuf); nbvh = capi.DeviceBVH(nctx, nsc).build()
         ncam = bench.demo_camera(nbuf, *bench.RES)
         npx = bench.RES[0] * bench.RES[1]

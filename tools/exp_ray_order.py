@@ -2,10 +2,13 @@ import sys, os, numpy as np, json
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import bench
 from openclraytracer_amd import capi
+NAMES = ['tenryuu', 'man', 'atrium']
+# every scene is packed BEFORE the GPU is touched (the packer is a child process: none is started behind a live HIP runtime)
+bufs = {name: (bench.load_atrium_bytes() if name == 'atrium' else bench.load_scene_bytes(name)) for name in NAMES}
 ctx = capi.Context(0)
 out = {}
-for name in ['tenryuu', 'man', 'atrium']:
-    buf = bench.load_atrium_bytes() if name == 'atrium' else bench.load_scene_bytes(name)
+for name in NAMES:
+    buf = bufs[name]
     sc = capi.DeviceScene(ctx, buf); bvh = capi.DeviceBVH(ctx, sc).build()
     cam = bench.demo_camera(buf, 1920, 1080)
     npx = 1920 * 1080

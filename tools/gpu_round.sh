@@ -15,13 +15,14 @@ fi
 rc=$?
 tail -5 gpurun_out/${tag}_tests.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "tests killed at their limit (rc $rc): stopping"; exit $rc; fi
-timeout -k 10 400 python bench.py --steps 100 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+timeout -k 10 400 python bench.py --steps 100 --details gpurun_out/${tag}_bench_details.json > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 brc=$?
 echo "bench rc $brc"; tail -3 gpurun_out/${tag}_bench.err
 python - <<PY
 import json
 try:
-    d = json.loads(open('gpurun_out/${tag}_bench.json').read().strip().splitlines()[-1])
+    print(open('gpurun_out/${tag}_bench.json').read().strip().splitlines()[-1])
+    d = json.load(open('gpurun_out/${tag}_bench_details.json'))
     print('value', d['value'], 'ms_per_step', d['ms_per_step'])
     print('moving', json.dumps({k: v for k, v in (d.get('moving_camera') or {}).items() if k != 'per_scene'}))
     for n, v in (d.get('moving_camera') or {}).get('per_scene', {}).items(): print(' ', n, v)

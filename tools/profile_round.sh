@@ -7,7 +7,7 @@
 # Every profiled program stands directly behind `--` and starts no process of its own: the scenes are packed ONCE, up front
 # (RTMI_PACKED=1 makes the tools refuse to spawn the packer; a failed packing aborts the round).
 set -o pipefail
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$R
 mkdir -p $OUT
@@ -15,7 +15,7 @@ python3 assets/synth/gen_scenes.py > /dev/null || exit 1
 for s in synth_bunny synth_atrium; do apps/bin/scene_pack_tool assets/synth/$s.txt /tmp/_$s.bin || { echo "packing $s failed"; exit 1; }; done
 for s in cube gardenlight tenryuu man clumsydragon; do apps/bin/scene_pack_tool assets/scenes/$s.txt /tmp/_$s.bin || { echo "packing $s failed"; exit 1; }; done
 export RTMI_PACKED=1
-python3 bench.py --keep-pmc $OUT/pmc > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
+python3 bench.py --keep-pmc $OUT/pmc --details $OUT/bench_details.json > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
 echo "bench line done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pmc > $OUT/bench_under_rocprof.log 2>&1 || exit 1
 echo "stats done"
@@ -47,6 +47,6 @@ unset RTMI_PACKED
 python3 tools/build_profile.py heightfield --k 10 --out $OUT/build_times_heightfield_fixed.json > /dev/null 2>> $OUT/build_times.err; python3 tools/build_profile.py heightfield --k 10 --mode 2 --out $OUT/build_times_heightfield_fast.json > /dev/null 2>> $OUT/build_times.err
 python3 tools/config_report.py > $OUT/config_report.json 2> $OUT/config_report.err || echo "config report failed"
 python3 tools/rays_sweep.py --out $OUT/raybuffer_sweep.json > $OUT/raybuffer_sweep.log 2>&1 || echo "ray-buffer sweep failed"
-RTMI_BENCH_GROUP=4 python3 bench.py --steps 100 --warmup 5 --no-extra-legs > $OUT/bench_group4.json 2> $OUT/bench_group4.err || echo "group run failed"
+RTMI_BENCH_GROUP=4 python3 bench.py --steps 100 --warmup 5 --no-extra-legs --details $OUT/bench_group4.json > $OUT/bench_group4_line.json 2> $OUT/bench_group4.err || echo "group run failed"
 echo "group done"
 find $OUT -name "*.csv" | head -40

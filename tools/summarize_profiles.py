@@ -3,13 +3,14 @@ import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as bench_mod
 newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
-R = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 src = 'gpurun_out/%s' % R
 stats = newest(src + '/stats/**/*_kernel_stats.csv')
 shutil.copy(stats, 'profiles/%s_bench_kernel_stats.csv' % R)
 line = [l for l in open(src + '/bench_line.json') if l.startswith('{')][-1]
 open('profiles/%s_bench_line.json' % R, 'w').write(line)
-bench = json.loads(line)
+shutil.copy(src + '/bench_details.json', 'profiles/%s_bench_details.json' % R)      # the whole record the line summarises (bench.py --details)
+bench = json.load(open(src + '/bench_details.json'))
 # the counter rows the bench line was computed from (bench.py --keep-pmc), summed per kernel and counter
 rows = []
 for ln in open(src + '/pmc/bench_pmc_rows.csv').read().splitlines()[1:]:
