@@ -135,8 +135,8 @@ def test_ray_buffer_calibrations_are_keyed_by_what_the_buffer_holds(gpu_ctx):
     from openclraytracer_amd import capi
     import bench
     ctx = gpu_ctx
-    osc, ob = oracle_bvh('tenryuu')
-    sc = capi.DeviceScene(ctx, __import__('conftest').packed_scene('tenryuu'))
+    osc, ob = oracle_bvh('cube')                       # (more than half of its pixels are hits: bounces of at least 32 768 rays)
+    sc = capi.DeviceScene(ctx, __import__('conftest').packed_scene('cube'))
     gb = capi.DeviceBVH(ctx, sc).build()              # a BVH of this test's own: its calibrations are counted
     cam = osc.demo_camera(640, 360)
     ccam = as_capi_camera(cam)
@@ -164,6 +164,12 @@ def test_ray_buffer_calibrations_are_keyed_by_what_the_buffer_holds(gpu_ctx):
             entries += 1
             assert gb.rays_calibrations()['entries'] == entries, kind                  # its own calibration although size class and address repeat
         # a buffer of the caller's own: known by its address; bytes uploaded over a generated buffer make it the caller's
+        # (on a model whose random rays cost many times what rays that leave the scene cost)
+        gb.close(); sc.close()
+        osc, ob = oracle_bvh('tenryuu')
+        sc = capi.DeviceScene(ctx, __import__('conftest').packed_scene('tenryuu'))
+        gb = capi.DeviceBVH(ctx, sc).build()
+        entries = 0
         rng = np.random.default_rng(5)
         n = 200000
         away = np.zeros(n, dtype=orc.RAY)
