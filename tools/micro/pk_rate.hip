@@ -29,7 +29,7 @@ __global__ void k(float* out, unsigned long long* cyc, float seed)
             if (KIND == 7) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(m) : "vcc");
             if (KIND == 8) asm volatile("v_div_fmas_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m) : "vcc");
             if (KIND == 9) asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
-            if (KIND == 10) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+            if (KIND == 10) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));
             if (KIND == 11) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(m));
             if (KIND == 12) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
             if (KIND == 13) asm volatile("v_min3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
