@@ -219,6 +219,13 @@ int  rt_tlg_info_get(const rt_tlg* tlg, rt_tlg_info* out);
  * is enqueued on the array sizes of the previous build with the counts kept on the device, and one read-back at the end
  * confirms that the sizes still fit (else the sequence with read-backs runs).  Same products either way.               */
 uint32_t rt_tlg_rebuilds_without_readback(const rt_tlg* tlg);
+/* test / inspection: 1 when this build's grid is walked with the walk's own records -- per top-level cell the resolution as floats, their
+ * correctly rounded reciprocals and the first leaf index, per plane index of an axis { lo, hi, 1 / (hi - lo) } -- so that the six divisions of
+ * every leaf-level DDA set-up (TwoLevelGrid.h:452-468) run as short multiply-add sequences that give the IEEE quotient bit for bit; 0 when the
+ * grid does not qualify (box or plane spacing beyond 2^+-30 / 2^+-20, a leaf grid finer than 1023 cells per axis, more than 512 planes, env
+ * RTMI_TLG_WALK_RECORDS=0) and it is walked with the reference's divisions.  Rays with a direction component outside [2^-20, 2^20] (zero
+ * included) or an origin beyond 2^30 take that walk in any case, wave by wave.  Same contacts either way.                                    */
+int  rt_tlg_walk_records(const rt_tlg* tlg);
 /* parity read-back of one build product into host memory (`bytes` must be its exact size, see rt_tlg_info) */
 int  rt_tlg_read(const rt_tlg* tlg, int what, void* h_dst, uint64_t bytes);
 /* pow(x, oneThird) as this library defines it for the grid resolutions (TwoLevelGrid.h:190-198,

@@ -46,7 +46,7 @@ SYMBOLS = [
     'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
     'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl', 'rt_comm_rccl_ranks', 'rt_multi_frame_create_rooted', 'rt_multi_frame_root', 'rt_multi_frame_set_camera', 'rt_multi_frame_set_timing', 'rt_multi_frame_times',
     'rt_multi_frame_create', 'rt_multi_frame_render', 'rt_multi_frame_wait', 'rt_multi_frame_pixels', 'rt_multi_frame_layout', 'rt_multi_frame_destroy',
-    'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays', 'rt_generate_primary_rays',
+    'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_walk_records', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays', 'rt_generate_primary_rays',
 ]
 
 
@@ -494,6 +494,11 @@ class DeviceTLG:
 
     def set_densities(self, top_density: float, leaf_density: float):
         self.ctx.check(self.ctx.lib.rt_tlg_set_densities(self.h, top_density, leaf_density))
+
+    def walk_records(self) -> bool:
+        """rt_tlg_walk_records: this build is walked with the walk's own cell / plane records (short division sequences)"""
+        self.ctx.lib.rt_tlg_walk_records.argtypes = [C.c_void_p]
+        return bool(self.ctx.lib.rt_tlg_walk_records(self.h))
 
     def rebuilds_without_readback(self) -> int:
         return int(self.ctx.lib.rt_tlg_rebuilds_without_readback(self.h))

@@ -184,6 +184,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* env = std::getenv("RTMI_RAYS")) ctx->rays_forced = env;
     if (const char* env = std::getenv("RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES")) ctx->tlg_no_rebuild_on_previous = env[0] == '0';
     if (const char* env = std::getenv("RTMI_TLG_TRICAM")) ctx->tlg_no_tricam = env[0] == '0';
+    if (const char* env = std::getenv("RTMI_TLG_WALK_RECORDS")) ctx->tlg_no_walk_records = env[0] == '0';
     if (const char* env = std::getenv("RTMI_CALIBRATION_DEADLINE")) ctx->no_calibration_deadline = env[0] == '0';
     if (const char* env = std::getenv("RTMI_IN_FLIGHT_SHARE_HANDICAP")) { const float v = (float)std::atof(env); if (v >= 1.0f) ctx->in_flight_share_handicap = v; }
     if (const char* env = std::getenv("RTMI_CALIBRATE_ALL")) ctx->calibrate_all = env[0] == '1';

@@ -109,6 +109,7 @@ struct rt_ctx {
     uint32_t ray_tags_next = 0;
     bool tlg_no_rebuild_on_previous = false;// RTMI_TLG_REBUILD_ON_PREVIOUS_SIZES=0
     bool tlg_no_tricam = false;             // RTMI_TLG_TRICAM=0
+    bool tlg_no_walk_records = false;       // RTMI_TLG_WALK_RECORDS=0: the grid walk of round 4 (no cell / plane records, IEEE divisions in every set-up)
     bool no_calibration_deadline = false;   // RTMI_CALIBRATION_DEADLINE=0
     float in_flight_share_handicap = 1.6f;  // RTMI_IN_FLIGHT_SHARE_HANDICAP
     bool calibrate_all = false;             // RTMI_CALIBRATE_ALL=1
@@ -255,6 +256,9 @@ struct rt_bvh {
     bool built = false;
 };
 
+// the grid walk's own record of a top-level cell (tlg_kernels.hip, k_tlg_trace_records)
+struct TlgTopRec { float fres[3]; uint32_t first_leaf; float rcp[3]; uint32_t packed; };
+static_assert(sizeof(TlgTopRec) == 32, "TlgTopRec");
 struct rt_tlg {
     rt_ctx* ctx = nullptr;
     const rt_scene* scene = nullptr;
@@ -276,6 +280,10 @@ struct rt_tlg {
     uint32_t pairs_cap = 0, leaf_cap = 0;   // elements d_pairs / d_leaf_pairs hold (kept across initializeFrame: a rebuild starts on them)
     uint32_t cells_cap = 0;                 // entries d_cell_ranges / d_top hold (the `cells` of the initializeFrame that allocated them)
     uint32_t rebuilds_without_readback = 0;   // diagnostics
+    TlgTopRec* d_toprec = nullptr;      // cells_cap records of the walk (null: not allocated, the walk of round 4)
+    float4* d_axis_tab = nullptr;       // axis_cap plane records
+    uint32_t axis_cap = 0;
+    bool walk_records = false;          // this build's records are usable (moderate box, no leaf grid finer than 1023 per axis)
     TriCam* d_tricam = nullptr;         // n camera-relative triangle records of the primary-ray trace (rtmi_internal.h, TriCam)
     float tricam_origin[3] = { 0, 0, 0 };
     bool tricam_valid = false;
@@ -478,7 +486,10 @@ struct TlgLaunch {
     const DeviceScene* scene;
     const TriCam* tricam;      // primary rays: the triangle records relative to the camera position (null: the scene's table)
     bool prepare_tricam;       // ... which this launch (re)computes first: the camera moved, or the scene was rebuilt
+    const TlgTopRec* toprec;   // the walk's records (null: none, the walk of round 4)
+    const float4* axis_tab;
 };
+void launch_tlg_trace_records(hipStream_t s, const rt_grid_data& g, const rt_top_cell* top, uint32_t cells, TlgTopRec* rec, float4* axis_tab, uint32_t* too_fine);
 void launch_tlg_count_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, uint32_t* counters);
 void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs,
                          uint32_t pairs_cap);

@@ -4,6 +4,7 @@
 #include "rtmi_internal.h"
 #include "tlg_math.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -32,9 +33,10 @@ int rt_tlg_create(rt_ctx* ctx, const rt_scene* scene, rt_tlg** out)
 static void free_tlg_buffers(rt_tlg* g)
 {
     void** ptrs[] = { (void**)&g->d_counters, (void**)&g->d_scan, (void**)&g->d_scan_scratch, (void**)&g->d_cell_ranges, (void**)&g->d_top,
-                      (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written, (void**)&g->d_tricam };
+                      (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written, (void**)&g->d_tricam,
+                      (void**)&g->d_toprec, (void**)&g->d_axis_tab };
     for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false;
+    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false; g->axis_cap = 0; g->walk_records = false;
 }
 
 void rt_tlg_destroy(rt_tlg* g)
@@ -122,7 +124,20 @@ int rt_tlg_initialize_frame(rt_tlg* g)
         RT_HIP(ctx, hipMalloc((void**)&g->d_cell_ranges, (size_t)cells * sizeof(uint2)));
         RT_HIP(ctx, hipMalloc((void**)&g->d_top, (size_t)cells * sizeof(rt_top_cell)));
         g->cells_cap = cells;
+        // the walk's own records of the cells (tlg_kernels.hip, k_tlg_trace_records): without them (allocation failed, knob RTMI_TLG_WALK_RECORDS=0,
+        // more planes than the kernel's table holds) the grid is walked as in round 4
+        if (g->d_toprec) { (void)hipFree(g->d_toprec); g->d_toprec = nullptr; }
+        if (!ctx->tlg_no_walk_records && hipMalloc((void**)&g->d_toprec, (size_t)cells * sizeof(TlgTopRec)) != hipSuccess) { (void)hipGetLastError(); g->d_toprec = nullptr; }
     }
+    {
+        const uint32_t planes = g->grid.resX + g->grid.resY + g->grid.resZ;
+        if (g->d_toprec && planes > g->axis_cap) {
+            if (g->d_axis_tab) { (void)hipFree(g->d_axis_tab); g->d_axis_tab = nullptr; g->axis_cap = 0; }
+            if (hipMalloc((void**)&g->d_axis_tab, (size_t)planes * sizeof(float4)) != hipSuccess) { (void)hipGetLastError(); g->d_axis_tab = nullptr; }
+            else g->axis_cap = planes;
+        }
+    }
+    g->walk_records = false;
     if (!g->d_written) RT_HIP(ctx, hipMalloc((void**)&g->d_written, 256));
     g->info = rt_tlg_info{};
     g->info.cells = cells;
@@ -140,6 +155,19 @@ static int read_word(rt_ctx* ctx, const uint32_t* d_src, uint32_t* out)
     RT_HIP(ctx, hipMemcpyAsync(out, d_src, 4, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_SUCCESS;
+}
+
+// The last launch of a build: the walk's records from the finished top-level cells (flag word d_written[8]: a plane or a leaf grid outside
+// the bounds of the short division sequences).  false: no records for this build.
+#define TLG_AXIS_MAX_HOST 512u            // = TLG_AXIS_MAX of tlg_kernels.hip: planes the trace kernel's LDS table holds
+static bool enqueue_walk_records(rt_tlg* g)
+{
+    const uint32_t planes = g->grid.resX + g->grid.resY + g->grid.resZ;
+    if (!g->d_toprec || !g->d_axis_tab || planes > g->axis_cap || planes > TLG_AXIS_MAX_HOST) return false;
+    const float* lo = g->grid.box_lo; const float* hi = g->grid.box_hi;
+    for (int k = 0; k < 3; k++) if (!(std::fabs(lo[k]) <= 0x1p30f) || !(std::fabs(hi[k]) <= 0x1p30f)) return false;
+    launch_tlg_trace_records(g->ctx->stream, g->grid, g->d_top, g->info.cells, g->d_toprec, g->d_axis_tab, g->d_written + 8);
+    return true;
 }
 
 // The reference's sequence with its three 4-byte read-backs: they size the pair arrays, and the sizes of the bitonic
@@ -208,9 +236,13 @@ static int construct_with_readbacks(rt_tlg* g)
     launch_tlg_emit_leaf(s, G, g->d_pairs, pairs, nullptr, g->d_top, sc, g->d_scan, g->d_counters, g->d_leaf_pairs, leaf_pow2, g->d_written);
     launch_bitonic_sort(s, g->d_leaf_pairs, leaf_pow2);
     launch_segment_bounds(s, g->d_leaf_pairs, leaf_pairs, nullptr, g->d_leaf_ranges, leaf_cells);
-    uint32_t written = 0;
-    if (read_word(ctx, g->d_written, &written)) return RT_ERROR;        // construct() returns with the build finished
-    g->info.written_leaf_pairs = written;
+    const bool records = enqueue_walk_records(g);
+    uint32_t h[12] = { 0 };
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(h, g->d_written, sizeof h, hipMemcpyDeviceToHost, s));
+    RT_HIP(ctx, hipStreamSynchronize(s));                                // construct() returns with the build finished
+    g->info.written_leaf_pairs = h[0];
+    g->walk_records = records && h[8] == 0u;
     return RT_SUCCESS;
 }
 
@@ -261,8 +293,9 @@ static int construct_on_previous_sizes(rt_tlg* g, bool* accepted)
     launch_tlg_emit_leaf(s, G, g->d_pairs, P, d_cnt + 0, g->d_top, sc, g->d_scan, g->d_counters, g->d_leaf_pairs, L, g->d_written);
     launch_bitonic_sort(s, g->d_leaf_pairs, L);
     launch_segment_bounds(s, g->d_leaf_pairs, L, d_cnt + 2, g->d_leaf_ranges, g->leaf_ranges_cap);
+    const bool records = enqueue_walk_records(g);
     RT_HIP(ctx, hipGetLastError());
-    uint32_t h[8] = { 0 };
+    uint32_t h[12] = { 0 };
     RT_HIP(ctx, hipMemcpyAsync(h, g->d_written, sizeof h, hipMemcpyDeviceToHost, s));
     RT_HIP(ctx, hipStreamSynchronize(s));
     const uint32_t pairs = h[4], leaf_cells = h[5], leaf_pairs = h[6];
@@ -272,6 +305,7 @@ static int construct_on_previous_sizes(rt_tlg* g, bool* accepted)
     g->info.leaf_cells_count = leaf_cells;
     g->info.leaf_pairs_count = leaf_pairs; g->info.leaf_pairs_pow2 = L;
     g->info.written_leaf_pairs = h[0];
+    g->walk_records = records && h[8] == 0u;
     *accepted = true;
     return RT_SUCCESS;
 }
@@ -300,6 +334,7 @@ static TlgLaunch make_tlg_launch(const rt_tlg* g)
 {
     TlgLaunch t{};
     t.grid = g->grid; t.top = g->d_top; t.leaf_ranges = g->d_leaf_ranges; t.leaf_pairs = g->d_leaf_pairs; t.scene = &g->scene->d;
+    if (g->walk_records) { t.toprec = g->d_toprec; t.axis_tab = g->d_axis_tab; }
     return t;
 }
 
@@ -377,6 +412,7 @@ int rt_tlg_info_get(const rt_tlg* g, rt_tlg_info* out)
 }
 
 uint32_t rt_tlg_rebuilds_without_readback(const rt_tlg* g) { return g ? g->rebuilds_without_readback : 0u; }
+int rt_tlg_walk_records(const rt_tlg* g) { return g && g->built && g->walk_records ? 1 : 0; }
 
 int rt_tlg_read(const rt_tlg* g, int what, void* h_dst, uint64_t bytes)
 {

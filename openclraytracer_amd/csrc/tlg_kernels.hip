@@ -296,12 +296,66 @@ struct TlgTraceArgs {
     const float4* __restrict__ e2;
     const float4* __restrict__ nrm;
     const TriCam* __restrict__ tricam;      // primary rays: camera-relative triangle records (null: v0 / e1 / e2)
+    const TlgTopRec* __restrict__ toprec;   // the walk's own records of the top-level cells and planes (null: the walk of round 4)
+    const float4* __restrict__ axis_tab;    // resX + resY + resZ entries { lo, hi, RN(1 / (hi - lo)), 0 }
     uint32_t total_work;
     rt_camera cam;
     uint32_t rank, nranks, tiles_x, compact;
     const rt_ray* __restrict__ rays;
     rt_contact* __restrict__ out;
 };
+
+// ---- the walk's own records (round 5) ---------------------------------------------------------------------------------------------
+// A ray of config 4 walks through ~150 non-empty top-level cells and sets a leaf-level DDA up in each: six IEEE divisions per set-up,
+// x * res / (hi - lo) and (tmax - tmin) / res per axis, whose quotients fix the cells visited and must be the reference's bit for bit.
+// The divisors are no property of the ray: `res` belongs to the cell and (hi - lo) to the plane index.  With r = RN(1 / y) at hand a
+// correctly rounded x / y takes five plain operations (Markstein: q0 = x r; e0 = fma(-y, q0, x); q1 = fma(e0, r, q0) is within an ulp,
+// e1 = fma(-y, q1, x) is exact, q2 = fma(e1, r, q1) rounds correctly -- tools/micro/div_check.hip compares it with the IEEE division over
+// every x for res = 1..2048 and over 2^36 (x, y) pairs) instead of the compiler's twelve (two v_div_scale, v_rcp, five FMAs, a multiply,
+// v_div_fmas, v_div_fixup: 18.4 against 7.7 ns per wave-instruction-slot, tools/micro/pk_rate.hip).  It holds for operands away from
+// overflow, underflow, zero divisors and non-numbers: a wave takes this walk only when all of its rays have |d| > 2^-40 on every axis
+// and moderate origins, and a grid only when its box and steps are moderate (host check) -- everything else walks as in round 4.  (Bounds: |o|, |lo|, |hi| <= 2^30, |d| and hi - lo in [2^-20, 2^20], res <= 1023.)
+// The records: per top-level cell { (float)res x3, firstLeafIdx, RN(1 / (float)res) x3, res packed 10:10:10 (0: empty cell) } and per
+// plane index of an axis { lo, hi, RN(1 / (hi - lo)) } exactly as the walk computes lo and hi (glo + (float)i * step, lo + step).
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace_records(rt_grid_data g, const rt_top_cell* __restrict__ top, uint32_t cells,
+                                                                 TlgTopRec* __restrict__ rec, float4* __restrict__ axis_tab, uint32_t* __restrict__ too_fine)
+{
+    const uint32_t c = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (c < g.resX + g.resY + g.resZ) {
+        uint32_t i = c; float org = g.box_lo[0], step = g.stepX;
+        if (i >= g.resX) { i -= g.resX; org = g.box_lo[1]; step = g.stepY; if (i >= g.resY) { i -= g.resY; org = g.box_lo[2]; step = g.stepZ; } }
+        const float lo = org + (float)i * step, hi = lo + step, w = hi - lo;
+        // (a divisor whose significand is all ones is the one case the proofs of the sequence exclude; a width that is no ordinary number
+        //  anyway: the whole grid then walks as in round 4)
+        if (!(w >= 0x1p-20f && w <= 0x1p20f) || (__float_as_uint(w) & 0x7FFFFFu) == 0x7FFFFFu || !(fabsf(lo) <= 0x1p30f) || !(fabsf(hi) <= 0x1p30f)) atomicOr(too_fine, 1u);
+        axis_tab[c] = make_float4(lo, hi, 1.0f / w, 0.0f);
+    }
+    if (c >= cells) return;
+    const rt_top_cell t = top[c];
+    TlgTopRec r;
+    const bool empty = t.resX == 0 || t.resY == 0 || t.resZ == 0;
+    if (!empty && (t.resX > 1023u || t.resY > 1023u || t.resZ > 1023u)) atomicOr(too_fine, 1u);
+    r.fres[0] = (float)t.resX; r.fres[1] = (float)t.resY; r.fres[2] = (float)t.resZ;
+    r.first_leaf = t.firstLeafIdx;
+    r.rcp[0] = 1.0f / r.fres[0]; r.rcp[1] = 1.0f / r.fres[1]; r.rcp[2] = 1.0f / r.fres[2];
+    r.packed = empty ? 0u : (t.resX | (t.resY << 10) | (t.resZ << 20));
+    rec[c] = r;
+}
+void launch_tlg_trace_records(hipStream_t s, const rt_grid_data& g, const rt_top_cell* top, uint32_t cells, TlgTopRec* rec, float4* axis_tab, uint32_t* too_fine)
+{
+    const uint32_t planes = g.resX + g.resY + g.resZ;
+    hipLaunchKernelGGL(k_tlg_trace_records, dim3(((cells > planes ? cells : planes) + TLG_BLOCK - 1) / TLG_BLOCK), dim3(TLG_BLOCK), 0, s, g, top, cells, rec, axis_tab, too_fine);
+}
+
+// x / y given r = RN(1 / y), for operands as described above
+__device__ __forceinline__ float div_by(float x, float y, float r)
+{
+    const float q0 = x * r;
+    const float e0 = __builtin_fmaf(-y, q0, x);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-y, q1, x);
+    return __builtin_fmaf(e1, r, q1);
+}
 
 // the DDA set-up both levels share: TwoLevelGrid.h:436-500 (leaf level) and :575-640 (top level)
 struct Dda {
@@ -385,66 +439,73 @@ __device__ unsigned long long g_tlg_diag[96];
 #define TLG_DIAG_HIST(n)
 #endif
 
-// Registers set this kernel's occupancy (round 3's counters: a wave issues for 35 % of its life and is parked on loads for 43 %; five
-// waves per SIMD kept the vector unit 50 % busy).  Six waves per SIMD = 80 VGPRs (86 before), reached by (a) step[] / stop[] as
-// functions of three sign bits (DdaSigns) and (b) the pixel located again for the store instead of kept: config 4's trace 3.57 ->
-// 3.36-3.41 ms.  Measured beyond that and not kept: seven waves (72 VGPRs: the top level's next[] / dt[] / idx[] in LDS, [k][lane]
-// with the axis as the index, 16-bit mailbox tags so that nine blocks fit a CU's LDS) 3.35-3.47; eight (spills) 3.77; fetching the next
-// top-level cell / the next leaf range before the current one is worked on 3.62 / 3.63 (the copies of the DDA state cost what the
-// overlap gains) -- only the next PAIR id is fetched early (3.56 -> 3.48).
-#ifndef TLG_WAVES
-#define TLG_WAVES 6
-#endif
-template <int PRIMARY>
-__global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_WAVES, TLG_WAVES))) void k_tlg_trace(TlgTraceArgs a)
+typedef uint32_t mail_t;
+#define TLG_AXIS_MAX 512u
+// |o| <= 2^30 and 2^-20 <= |d| <= 2^20 (false for NaN): with a grid that passed k_tlg_trace_records' check every operand of the short division
+// sequences lies between 2^-90 and 2^90 or is a numerator so small that its quotient truncates to cell 0 either way
+__device__ __forceinline__ bool tlg_moderate(float o, float d) { return fabsf(o) <= 0x1p30f && fabsf(d) >= 0x1p-20f && fabsf(d) <= 0x1p20f; }
+__device__ __forceinline__ float rcp_near(float x)
 {
-    // Mailbox: a triangle lies in every leaf cell it overlaps, so a ray marching through the grid meets it again and again
-    // (61 % of all tests on the atrium).  The reference returns from the first leaf cell in which ANY triangle is hit
-    // (TwoLevelGrid.h:528-540), so whatever this ray tested before the current cell was a miss, and testing it again gives
-    // the same miss: the test is skipped when the triangle sits in a 16-entry direct-mapped table of tested triangles
-    // (per lane, LDS [entry][lane]; entry = id & 15, tag = id >> 4).  Results are unchanged by construction.
-    typedef uint32_t mail_t;
-    __shared__ mail_t s_mailbox[16][TLG_BLOCK];
-    const uint32_t w = blockIdx.x * TLG_BLOCK + threadIdx.x;
-    if (w >= a.total_work) return;
-#pragma unroll
-    for (int k = 0; k < 16; k++) s_mailbox[k][threadIdx.x] = (mail_t)~0u;
-    f3 o, d;
-    // work item -> pixel: this rank's 64x64 tiles, inside a tile 8x8 blocks (one wave = one block), as in trace_kernels.hip; evaluated
-    // here for the ray and again for the store (two registers that would live through the whole walk otherwise)
-    auto locate = [&](uint32_t& x, uint32_t& y, uint32_t& slot) {
-        const uint32_t ordinal = w >> 12, within = w & 4095u;
-        const uint32_t tile = rt_tile_of(a.rank, ordinal, a.nranks);
-        const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const uint32_t blk = within >> 6, lp = within & 63u;
-        const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3), lx = ((blk & 7u) << 3) + (lp & 7u);
-        x = tx * RT_TILE + lx; y = ty * RT_TILE + ly;
-        slot = (ordinal << 12) + ly * RT_TILE + lx;
-    };
-    if (PRIMARY) {
-        uint32_t x, y, slot;
-        locate(x, y, slot);
-        if (x >= a.cam.resX || y >= a.cam.resY) {
-            if (a.compact) {         // slot of a border tile outside the frame: defined as "no contact", as in the BVH kernels
-                float4* z = reinterpret_cast<float4*>(a.out + slot);
-                z[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                z[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            return;
-        }
-        generate_ray_xy(a.cam, x, y, o, d);
-    } else {
-        const float4* p = reinterpret_cast<const float4*>(a.rays + w);
-        const float4 ro = p[1], rd = p[2];
-        o = f3{ ro.x, ro.y, ro.z }; d = f3{ rd.x, rd.y, rd.z };
-    }
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+// x / (float)res with r = RN(1 / (float)res): three operations give the IEEE quotient for every res <= 2048 and every |x| in [2^-90, 2^90]
+// (enumerated: tools/micro/div_check.hip)
+__device__ __forceinline__ float div_by_res(float x, float y, float r)
+{
+    const float q0 = x * r;
+    const float e0 = __builtin_fmaf(-y, q0, x);
+    return __builtin_fmaf(e0, r, q0);
+}
+// dda_setup for a top-level cell whose planes and resolution come from the walk's records.  The operations of dda_axis_setup / dda_axis_finish in
+// their order; 1 / d per ray; the two divisions per axis by the short sequences; no d == 0 case (such rays do not come here).
+__device__ __forceinline__ void dda_axis_fast(float o, float d, float a, float4 plane, float fres, float rres, float& tmin, float& tmax)
+{
+    const float lo = plane.x, hi = plane.y;
+    tmin = ((a >= 0.0f ? lo : hi) - o) * a;
+    tmax = ((a >= 0.0f ? hi : lo) - o) * a;
+}
+__device__ __forceinline__ void dda_finish_fast(float p, float d, float4 plane, int res, float fres, float rres, float tmin, float tmax, float& next, float& dt, int& idx)
+{
+    const float lo = plane.x, hi = plane.y;
+    float f = div_by((p - lo) * fres, hi - lo, plane.z);
+    const float top = fres - 1;
+    f = RMAX(f, 0.0f); f = RMIN(f, top);
+    idx = (int)f;
+    dt = div_by_res(tmax - tmin, fres, rres);
+    const int k = d > 0.0f ? idx + 1 : res - idx;                    // (float)(idx + 1) / (float)(res - (uint32_t)idx)
+    next = tmin + (float)k * dt;
+}
+__device__ __forceinline__ void dda_setup_fast(f3 o, f3 d, f3 a, float4 px, float4 py, float4 pz, const TlgTopRec& r, Dda& s)
+{
+    float txmin, txmax, tymin, tymax, tzmin, tzmax;
+    dda_axis_fast(o.x, d.x, a.x, px, r.fres[0], r.rcp[0], txmin, txmax);
+    dda_axis_fast(o.y, d.y, a.y, py, r.fres[1], r.rcp[1], tymin, tymax);
+    dda_axis_fast(o.z, d.z, a.z, pz, r.fres[2], r.rcp[2], tzmin, tzmax);
+    s.t0 = RMIN(txmin, RMIN(tymin, tzmin));
+    s.tmaxmax = RMAX(txmax, RMAX(tymax, tzmax));
+    const bool inside = (px.x <= o.x) && (o.x <= px.y) && (py.x <= o.y) && (o.y <= py.y) && (pz.x <= o.z) && (o.z <= pz.y);
+    f3 p = o;
+    if (!inside) p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
+    dda_finish_fast(p.x, d.x, px, (int)(r.packed & 1023u), r.fres[0], r.rcp[0], txmin, txmax, s.nx, s.dtx, s.ix);
+    dda_finish_fast(p.y, d.y, py, (int)((r.packed >> 10) & 1023u), r.fres[1], r.rcp[1], tymin, tymax, s.ny, s.dty, s.iy);
+    dda_finish_fast(p.z, d.z, pz, (int)(r.packed >> 20), r.fres[2], r.rcp[2], tzmin, tzmax, s.nz, s.dtz, s.iz);
+}
+
+// The walk of one ray (tlg_generate_contact, TwoLevelGrid.h:548-678).  FAST: every ray of this wave and the grid qualify for the walk's own
+// records (see k_tlg_trace_records): the leaf-level set-up takes its cell from a 32-byte record and its planes from a table in LDS, divides by
+// the sequences above, and the triangle test takes 1 / det from v_rcp_f32 + one Newton step (equal to the IEEE quotient for every operand
+// between 2^-90 and 2^90, tools/micro/div_check.hip; |det| >= FLT_EPSILON is what the test asks for anyway).  Same values, fewer instructions.
+template <int PRIMARY, int FAST>
+__device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, const f3 d, mail_t (*s_mailbox)[TLG_BLOCK], const float4* s_axis,
+                                         float& best_t, uint32_t& best_tri)
+{
     const rt_grid_data& g = a.grid;
     const f3 glo = f3{ g.box_lo[0], g.box_lo[1], g.box_lo[2] }, ghi = f3{ g.box_hi[0], g.box_hi[1], g.box_hi[2] };
 
-    float best_t = 0.0f;                    // NO_CONTACT (CLStructs.h:124)
-    uint32_t best_tri = 0xFFFFFFFFu;
-
     const DdaSigns sg = DdaSigns{ d.x > 0.0f, d.y > 0.0f, d.z > 0.0f };
+    const f3 inv_d = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };          // (what dda_axis_setup divides per cell; the compiler hoists it there as well)
     bool done;
     Dda T;
     dda_setup(o, d, glo, ghi, g.resX, g.resY, g.resZ, T);
@@ -452,15 +513,31 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     while (!done) {
         TLG_DIAG(0, 1);
         const int tix = T.ix, tiy = T.iy, tiz = T.iz;
-        const rt_top_cell tc = a.top[(uint32_t)tiz * g.resX * g.resY + (uint32_t)tiy * g.resX + (uint32_t)tix];
-        if (!(tc.resX == 0 || tc.resY == 0 || tc.resZ == 0)) {
+        const uint32_t cell = (uint32_t)tiz * g.resX * g.resY + (uint32_t)tiy * g.resX + (uint32_t)tix;
+        rt_top_cell tc;
+        TlgTopRec rec;
+        if (FAST) {
+            const float4* rp = reinterpret_cast<const float4*>(a.toprec + cell);
+            const float4 r0 = rp[0], r1 = rp[1];
+            rec.fres[0] = r0.x; rec.fres[1] = r0.y; rec.fres[2] = r0.z; rec.first_leaf = __float_as_uint(r0.w);
+            rec.rcp[0] = r1.x; rec.rcp[1] = r1.y; rec.rcp[2] = r1.z; rec.packed = __float_as_uint(r1.w);
+            tc.resX = rec.packed & 1023u; tc.resY = (rec.packed >> 10) & 1023u; tc.resZ = rec.packed >> 20; tc.firstLeafIdx = rec.first_leaf;
+        } else {
+            tc = a.top[cell];
+        }
+        if (FAST ? rec.packed != 0u : !(tc.resX == 0 || tc.resY == 0 || tc.resZ == 0)) {
             TLG_DIAG(2, 3);
             // processTopLevelCell, TwoLevelGrid.h:419-545
-            f3 clo, chi;
-            clo.x = glo.x + (float)tix * g.stepX; clo.y = glo.y + (float)tiy * g.stepY; clo.z = glo.z + (float)tiz * g.stepZ;
-            chi.x = clo.x + g.stepX; chi.y = clo.y + g.stepY; chi.z = clo.z + g.stepZ;
             Dda Lf;
-            dda_setup(o, d, clo, chi, tc.resX, tc.resY, tc.resZ, Lf);
+            if (FAST) {
+                const float4 px = s_axis[tix], py = s_axis[g.resX + (uint32_t)tiy], pz = s_axis[g.resX + g.resY + (uint32_t)tiz];     // { lo, hi, 1 / (hi - lo) }
+                dda_setup_fast(o, d, inv_d, px, py, pz, rec, Lf);
+            } else {
+                f3 clo, chi;
+                clo.x = glo.x + (float)tix * g.stepX; clo.y = glo.y + (float)tiy * g.stepY; clo.z = glo.z + (float)tiz * g.stepZ;
+                chi.x = clo.x + g.stepX; chi.y = clo.y + g.stepY; chi.z = clo.z + g.stepZ;
+                dda_setup(o, d, clo, chi, tc.resX, tc.resY, tc.resZ, Lf);
+            }
             float cell_t = FLT_MAX;
             uint32_t cell_tri = 0xFFFFFFFFu;
             for (;;) {
@@ -499,7 +576,7 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
                     const f3 pvec = f3_cross(d, edge2);
                     const float det = f3_dot(edge1, pvec);
                     bool flag = fabsf(det) >= FLT_EPSILON;
-                    const float inv_det = 1.0f / det;
+                    const float inv_det = FAST ? rcp_near(det) : 1.0f / det;
                     const float u = f3_dot(tvec, pvec) * inv_det;
                     flag = flag & (u < 1.0f) & (u >= 0.0f);
                     const float v = f3_dot(d, qvec) * inv_det;
@@ -519,6 +596,74 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
         if (taxis < 0) break;
         if (dda_advance(T, taxis, sg, g.resX, g.resY, g.resZ)) break;
     }
+
+}
+
+// Registers set this kernel's occupancy (round 3's counters: a wave issues for 35 % of its life and is parked on loads for 43 %; five
+// waves per SIMD kept the vector unit 50 % busy).  Six waves per SIMD = 80 VGPRs (86 before), reached by (a) step[] / stop[] as
+// functions of three sign bits (DdaSigns) and (b) the pixel located again for the store instead of kept: config 4's trace 3.57 ->
+// 3.36-3.41 ms.  Measured beyond that and not kept: seven waves (72 VGPRs: the top level's next[] / dt[] / idx[] in LDS, [k][lane]
+// with the axis as the index, 16-bit mailbox tags so that nine blocks fit a CU's LDS) 3.35-3.47; eight (spills) 3.77; fetching the next
+// top-level cell / the next leaf range before the current one is worked on 3.62 / 3.63 (the copies of the DDA state cost what the
+// overlap gains) -- only the next PAIR id is fetched early (3.56 -> 3.48).
+#ifndef TLG_WAVES
+#define TLG_WAVES 6
+#endif
+template <int PRIMARY>
+__global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_WAVES, TLG_WAVES))) void k_tlg_trace(TlgTraceArgs a)
+{
+    // Mailbox: a triangle lies in every leaf cell it overlaps, so a ray marching through the grid meets it again and again
+    // (61 % of all tests on the atrium).  The reference returns from the first leaf cell in which ANY triangle is hit
+    // (TwoLevelGrid.h:528-540), so whatever this ray tested before the current cell was a miss, and testing it again gives
+    // the same miss: the test is skipped when the triangle sits in a 16-entry direct-mapped table of tested triangles
+    // (per lane, LDS [entry][lane]; entry = id & 15, tag = id >> 4).  Results are unchanged by construction.
+    __shared__ mail_t s_mailbox[16][TLG_BLOCK];
+    // the planes of the three axes for the walk with its own records (k_tlg_trace_records; at most TLG_AXIS_MAX of them, else a.toprec is null)
+    __shared__ float4 s_axis[TLG_AXIS_MAX];
+    if (a.toprec) {
+        const uint32_t planes = a.grid.resX + a.grid.resY + a.grid.resZ;
+        for (uint32_t i = threadIdx.x; i < planes; i += TLG_BLOCK) s_axis[i] = a.axis_tab[i];
+        __syncthreads();
+    }
+    const uint32_t w = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (w >= a.total_work) return;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s_mailbox[k][threadIdx.x] = (mail_t)~0u;
+    f3 o, d;
+    // work item -> pixel: this rank's 64x64 tiles, inside a tile 8x8 blocks (one wave = one block), as in trace_kernels.hip; evaluated
+    // here for the ray and again for the store (two registers that would live through the whole walk otherwise)
+    auto locate = [&](uint32_t& x, uint32_t& y, uint32_t& slot) {
+        const uint32_t ordinal = w >> 12, within = w & 4095u;
+        const uint32_t tile = rt_tile_of(a.rank, ordinal, a.nranks);
+        const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const uint32_t blk = within >> 6, lp = within & 63u;
+        const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3), lx = ((blk & 7u) << 3) + (lp & 7u);
+        x = tx * RT_TILE + lx; y = ty * RT_TILE + ly;
+        slot = (ordinal << 12) + ly * RT_TILE + lx;
+    };
+    if (PRIMARY) {
+        uint32_t x, y, slot;
+        locate(x, y, slot);
+        if (x >= a.cam.resX || y >= a.cam.resY) {
+            if (a.compact) {         // slot of a border tile outside the frame: defined as "no contact", as in the BVH kernels
+                float4* z = reinterpret_cast<float4*>(a.out + slot);
+                z[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                z[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            return;
+        }
+        generate_ray_xy(a.cam, x, y, o, d);
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(a.rays + w);
+        const float4 ro = p[1], rd = p[2];
+        o = f3{ ro.x, ro.y, ro.z }; d = f3{ rd.x, rd.y, rd.z };
+    }
+    float best_t = 0.0f;                    // NO_CONTACT (CLStructs.h:124)
+    uint32_t best_tri = 0xFFFFFFFFu;
+    // the walk with its own records where the whole wave qualifies (wave-uniform: one of the two instances runs)
+    const bool ray_ok = a.toprec != nullptr && tlg_moderate(o.x, d.x) && tlg_moderate(o.y, d.y) && tlg_moderate(o.z, d.z);
+    if (__all(ray_ok)) tlg_walk<PRIMARY, 1>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
+    else tlg_walk<PRIMARY, 0>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
 
     float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t material = 0;
@@ -608,6 +753,7 @@ static TlgTraceArgs tlg_args(const TlgLaunch& t)
     TlgTraceArgs a{};
     a.grid = t.grid; a.top = t.top; a.leaf_ranges = t.leaf_ranges; a.leaf_pairs = t.leaf_pairs;
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
+    a.toprec = t.toprec; a.axis_tab = t.axis_tab;
     return a;
 }
 

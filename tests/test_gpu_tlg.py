@@ -199,3 +199,101 @@ def test_rebuild_runs_without_mid_build_readbacks_and_gives_the_same_products(gp
     assert gg.rebuilds_without_readback() == before + 1
     check(orc.TLG(osc, 3.1, 1.3))
     gg.close(); sc.close()
+
+
+@pytest.mark.parametrize('name', ['gardenlight', 'tenryuu'])
+def test_walk_records_are_in_use_and_change_no_contact(gpu_ctx, name):
+    """Round 5: the grid walk divides by short multiply-add sequences on the walk's own cell / plane records (rt_tlg_walk_records,
+    tlg_kernels.hip k_tlg_trace_records; tools/micro/div_check.hip compares the sequences with the IEEE division).  The bundled scenes
+    qualify; with the records switched off (RTMI_TLG_WALK_RECORDS=0, a process of its own: the knob is read by rt_ctx_create) the
+    reference's divisions run and every contact is the same -- and the oracle's."""
+    import hashlib, os, subprocess, sys, tempfile
+    from conftest import ROOT
+    osc, og = oracle_tlg(name)
+    _, gg = gpu_tlg(gpu_ctx, name)
+    assert gg.walk_records()
+    cam = osc.demo_camera(640, 480)
+    want, _ = og.trace_primary(cam)
+    assert gg.generate_contacts_primary(as_capi_camera(cam)).tobytes() == want.tobytes()
+    with tempfile.TemporaryDirectory(prefix='rtmi_test_') as d:
+        open(os.path.join(d, 's.bin'), 'wb').write(packed_scene(name))
+        np.save(os.path.join(d, 'cam.npy'), cam.view(np.uint8))
+        code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); from openclraytracer_amd import capi; ctx = capi.Context(0); "
+                "sc = capi.DeviceScene(ctx, open(sys.argv[1], 'rb').read()); g = capi.DeviceTLG(ctx, sc).build(); "
+                "c = g.generate_contacts_primary(np.load(sys.argv[2]).view(capi.CAMERA)); "
+                "print('RESULT', int(g.walk_records()), hashlib.sha256(c.tobytes()).hexdigest())" % ROOT)
+        r = subprocess.run([sys.executable, '-c', code, os.path.join(d, 's.bin'), os.path.join(d, 'cam.npy')],
+                           env=dict(os.environ, RTMI_TLG_WALK_RECORDS='0'), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    flag, digest = [l for l in r.stdout.splitlines() if l.startswith('RESULT')][0].split()[1:]
+    assert flag == '0' and digest == hashlib.sha256(want.tobytes()).hexdigest()
+
+
+def test_walk_records_rays_at_the_edges_of_what_qualifies(gpu_ctx):
+    """Waves of rays that just qualify for the short division sequences, that just do not, and mixtures: direction components of exactly
+    2^-20 and one ulp below, 2^20 and above (unnormalised directions), origins at 2^30 and beyond, origins exactly ON planes of the
+    top-level grid (numerators of exactly zero), origins inside cells, and rays parallel to an axis in every other lane.  The oracle's
+    contacts, bit for bit."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, og = oracle_tlg('tenryuu')
+    _, gg = gpu_tlg(gpu_ctx, 'tenryuu')
+    assert gg.walk_records()
+    grid = og.grid
+    lo = grid['lo'][0][:3].astype(np.float32)
+    step = grid['step'][0].astype(np.float32)
+    res = grid['res'][0]
+    rng = np.random.default_rng(21)
+    groups = []
+
+    def group(n=64):
+        r = np.zeros(n, dtype=orc.RAY)
+        r['origin'][:, :3] = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        r['direction'][:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        return r
+    tiny = np.float32(2.0 ** -20)
+    for k in range(3):
+        g = group(); g['direction'][:, k] = tiny * np.where(rng.integers(0, 2, 64) == 0, 1, -1).astype(np.float32); groups.append(g)      # qualifies
+        g = group(); g['direction'][:, k] = np.nextafter(tiny, np.float32(0)); groups.append(g)                                          # does not
+        g = group(); g['direction'][::2, k] = 0.0; groups.append(g)                                                                      # every other lane parallel to a plane
+        g = group(); g['direction'][:, :3] *= np.float32(2.0 ** 20) / np.abs(g['direction'][:, :3]).max(axis=1, keepdims=True); groups.append(g)   # largest component exactly 2^20
+        g = group(); g['direction'][:, :3] *= np.float32(2.0 ** 21); groups.append(g)
+        # origins exactly on top-level planes of axis k (inside the grid and on its faces), directions arbitrary
+        g = group(); g['origin'][:, k] = (lo[k] + rng.integers(0, res[k] + 1, 64).astype(np.float32) * step[k]).astype(np.float32); groups.append(g)
+        # far origins looking at the model: 2^30 qualifies, 2^31 does not
+        for far in (2.0 ** 30, 2.0 ** 31, 1.0e6):
+            g = group(); g['origin'][:, :3] = 0; g['origin'][:, k] = np.float32(far)
+            tgt = rng.uniform(-0.5, 0.5, size=(64, 3)).astype(np.float32)
+            d = (tgt.astype(np.float64) - g['origin'][:, :3].astype(np.float64)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+            g['direction'][:, :3] = d.astype(np.float32); groups.append(g)
+    g = group(640); groups.append(g)
+    rays = np.concatenate(groups)
+    rays['idx'] = np.arange(len(rays))
+    want, st = og.trace_rays(rays)
+    got = gg.generate_contacts_rays(rays.view(capi.RAY))
+    assert got.tobytes() == want.tobytes()
+    assert st['hits'] > 50
+
+
+def test_walk_records_are_refused_by_grids_that_do_not_qualify(gpu_ctx):
+    """More planes than the trace kernel's table holds (a top-level density that gives ~200 cells per axis): the build keeps no records,
+    the walk is the reference's, the contacts are the oracle's."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc = orc.Scene(packed_scene('cube'))
+    dens = (700000.0, 0.5)
+    og = orc.TLG(osc, *dens)
+    assert int(og.grid['res'][0].sum()) > 512
+    sc = capi.DeviceScene(gpu_ctx, packed_scene('cube'))
+    g = capi.DeviceTLG(gpu_ctx, sc, *dens).build()
+    try:
+        assert not g.walk_records()
+        cam = osc.demo_camera(96, 64)
+        assert g.generate_contacts_primary(as_capi_camera(cam)).tobytes() == og.trace_primary(cam)[0].tobytes()
+        g.set_densities(2.0, 2.0)
+        g.build()
+        assert g.walk_records()
+        assert g.generate_contacts_primary(as_capi_camera(cam)).tobytes() == oracle_tlg('cube')[1].trace_primary(cam)[0].tobytes()
+    finally:
+        g.close(); sc.close()

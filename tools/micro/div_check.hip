@@ -5,7 +5,7 @@
 //     ("three operations") and one more round of the last two ("five operations"), every x, res = 1 .. RES_MAX;
 // (c) the same two sequences on 2^14 arbitrary divisors y in [2^-24, 2^24) x 2^22 arbitrary x.
 // A result counts as equal when the bits are equal or both are NaN.  Mismatches are counted per class of the operand x:
-// [0] |x| in [2^-60, 2^60], [1] smaller non-zero, [2] larger finite, [3] zero, [4] infinite, [5] NaN.
+// [0] |x| in [2^-90, 2^90], [1] smaller non-zero, [2] larger finite, [3] zero, [4] infinite, [5] NaN.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -20,7 +20,7 @@ __device__ __forceinline__ int klass(float x)
     if (u == 0x7F800000u) return 4;
     if (u > 0x7F800000u) return 5;
     const float a = fabsf(x);
-    return a < 0x1p-60f ? 1 : (a > 0x1p60f ? 2 : 0);
+    return a < 0x1p-90f ? 1 : (a > 0x1p90f ? 2 : 0);
 }
 __device__ __forceinline__ bool same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
 __device__ __forceinline__ float rcp_nr(float x)
@@ -86,7 +86,7 @@ __global__ void k_div_any(unsigned long long* bad3, unsigned long long* bad5, ui
 
 static void show(const char* what, const unsigned long long* b)
 {
-    printf("%-44s mismatches: |x| in [2^-60, 2^60] %llu, smaller %llu, larger %llu, zero %llu, inf %llu, NaN %llu\n", what, b[0], b[1], b[2], b[3], b[4], b[5]);
+    printf("%-44s mismatches: |x| in [2^-90, 2^90] %llu, smaller %llu, larger %llu, zero %llu, inf %llu, NaN %llu\n", what, b[0], b[1], b[2], b[3], b[4], b[5]);
 }
 int main()
 {

@@ -15,6 +15,7 @@ __global__ void k(float* out, unsigned long long* cyc, float seed)
 #pragma unroll
     for (int i = 0; i < 16; i++) { a[i] = seed + (float)i + threadIdx.x; p[i] = float2v{ a[i], a[i] + 0.5f }; }
     const float m = 1.0000001f; const float2v mp = { m, m };
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\ts_mov_b32 s20, 0x33333333\n\ts_mov_b32 s21, 0x33333333" : : : "vcc", "s20", "s21");
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITER; it++) {
 #pragma unroll
@@ -33,6 +34,20 @@ __global__ void k(float* out, unsigned long long* cyc, float seed)
             if (KIND == 11) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(m));
             if (KIND == 12) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
             if (KIND == 13) asm volatile("v_min3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 14) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(m));
+            if (KIND == 15) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(m) : "vcc");
+            if (KIND == 16) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+            if (KIND == 17) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 18) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == 19) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 20) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 21) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 22) asm volatile("v_cmp_lt_f32 s[22:23], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(a[i]) : "v"(m) : "s22", "s23");
+            if (KIND == 23) asm volatile("v_cmp_lt_f32 s[22:23], %0, %1" : : "v"(a[i]), "v"(m) : "s22", "s23");
+            if (KIND == 24) asm volatile("v_cmpx_lt_f32 exec, %0, %0\n\ts_mov_b64 exec, -1" : : "v"(a[i]) : "exec");
+            if (KIND == 25) asm volatile("s_and_saveexec_b64 s[22:23], vcc\n\ts_mov_b64 exec, s[22:23]" : : : "s22", "s23", "exec");
+            if (KIND == 26) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 27) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -70,5 +85,9 @@ int main()
     run<4>("v_fma_f32", 1); run<5>("v_pk_fma_f32", 2); run<6>("v_rcp_f32", 1); run<7>("v_div_scale_f32", 1);
     run<8>("v_div_fmas_f32", 1); run<9>("v_div_fixup_f32", 1); run<10>("v_cndmask_b32", 1); run<11>("v_mov_b32", 1);
     run<12>("v_cvt_f32_u32", 1); run<13>("v_min3_f32", 1);
+    run<14>("v_cndmask_e64 sgpr", 1); run<15>("v_cmp_lt_f32 vcc", 1); run<16>("v_cmp+v_cndmask vcc", 1); run<17>("v_max_f32", 1);
+    run<18>("v_cvt_i32_f32", 1); run<19>("v_mul_lo_u32", 1); run<20>("v_lshl_add_u32", 1); run<21>("v_add_u32", 1);
+    run<22>("v_cmp+v_cndmask sgpr", 1); run<23>("v_cmp_lt_f32 sgpr", 1); run<24>("v_cmpx + s_mov exec", 1); run<25>("s_and_saveexec + s_mov", 1);
+    run<26>("v_sub_f32", 1); run<27>("v_med3_f32", 1);
     return 0;
 }
