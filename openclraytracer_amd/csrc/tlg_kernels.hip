@@ -440,7 +440,9 @@ __device__ unsigned long long g_tlg_diag[96];
 #endif
 
 typedef uint32_t mail_t;
+#ifndef TLG_AXIS_MAX
 #define TLG_AXIS_MAX 512u
+#endif
 // |o| <= 2^30 and 2^-20 <= |d| <= 2^20 (false for NaN): with a grid that passed k_tlg_trace_records' check every operand of the short division
 // sequences lies between 2^-90 and 2^90 or is a numerator so small that its quotient truncates to cell 0 either way
 __device__ __forceinline__ bool tlg_moderate(float o, float d) { return fabsf(o) <= 0x1p30f && fabsf(d) >= 0x1p-20f && fabsf(d) <= 0x1p20f; }
@@ -518,7 +520,10 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         TlgTopRec rec;
         if (FAST) {
             const float4* rp = reinterpret_cast<const float4*>(a.toprec + cell);
-            const float4 r0 = rp[0], r1 = rp[1];
+            float4 r0 = rp[0], r1 = rp[1];
+            // (both halves and the planes are fetched BEFORE the cell is known to be non-empty -- nearly every cell a ray meets is: left to itself the
+            //  compiler fetches the last word, waits, branches and only then fetches the rest: two trips to the L2 in a row per cell)
+            asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
             rec.fres[0] = r0.x; rec.fres[1] = r0.y; rec.fres[2] = r0.z; rec.first_leaf = __float_as_uint(r0.w);
             rec.rcp[0] = r1.x; rec.rcp[1] = r1.y; rec.rcp[2] = r1.z; rec.packed = __float_as_uint(r1.w);
             tc.resX = rec.packed & 1023u; tc.resY = (rec.packed >> 10) & 1023u; tc.resZ = rec.packed >> 20; tc.firstLeafIdx = rec.first_leaf;
@@ -607,7 +612,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
 // top-level cell / the next leaf range before the current one is worked on 3.62 / 3.63 (the copies of the DDA state cost what the
 // overlap gains) -- only the next PAIR id is fetched early (3.56 -> 3.48).
 #ifndef TLG_WAVES
-#define TLG_WAVES 6
+#define TLG_WAVES 7
 #endif
 template <int PRIMARY>
 __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_WAVES, TLG_WAVES))) void k_tlg_trace(TlgTraceArgs a)
@@ -619,7 +624,8 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     // (per lane, LDS [entry][lane]; entry = id & 15, tag = id >> 4).  Results are unchanged by construction.
     __shared__ mail_t s_mailbox[16][TLG_BLOCK];
     // the planes of the three axes for the walk with its own records (k_tlg_trace_records; at most TLG_AXIS_MAX of them, else a.toprec is null)
-    __shared__ float4 s_axis[TLG_AXIS_MAX];
+    // (dynamic: its size is the grid's -- 16 bytes per plane; the launch passes it, so that small grids leave the LDS to more waves)
+    extern __shared__ float4 s_axis[];
     if (a.toprec) {
         const uint32_t planes = a.grid.resX + a.grid.resY + a.grid.resZ;
         for (uint32_t i = threadIdx.x; i < planes; i += TLG_BLOCK) s_axis[i] = a.axis_tab[i];
@@ -748,6 +754,7 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_prepare_triangles(const float
     out[i] = c;
 }
 
+static uint32_t tlg_axis_bytes(const TlgTraceArgs& a) { return a.toprec ? (a.grid.resX + a.grid.resY + a.grid.resZ) * (uint32_t)sizeof(float4) : 0u; }
 static TlgTraceArgs tlg_args(const TlgLaunch& t)
 {
     TlgTraceArgs a{};
@@ -774,7 +781,7 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
     static unsigned long long zero[96] = { 0 };
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tlg_diag), zero, sizeof zero, 0, hipMemcpyHostToDevice, s);
 #endif
-    if (a.total_work) hipLaunchKernelGGL(k_tlg_trace<1>, blocks_for(a.total_work), dim3(TLG_BLOCK), 0, s, a);
+    if (a.total_work) hipLaunchKernelGGL(k_tlg_trace<1>, blocks_for(a.total_work), dim3(TLG_BLOCK), tlg_axis_bytes(a), s, a);
 #ifdef RTMI_TLG_DIAG
     if (getenv("RTMI_TLG_DIAG_PRINT")) {
         unsigned long long h[96];
@@ -795,7 +802,7 @@ void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays
 {
     TlgTraceArgs a = tlg_args(t);
     a.rays = rays; a.total_work = count; a.out = out;
-    if (count) hipLaunchKernelGGL(k_tlg_trace<0>, blocks_for(count), dim3(TLG_BLOCK), 0, s, a);
+    if (count) hipLaunchKernelGGL(k_tlg_trace<0>, blocks_for(count), dim3(TLG_BLOCK), tlg_axis_bytes(a), s, a);
 }
 
 // rt_ctx_create loads this file's code object up front (HIP loads a code object on the first use of one of its kernels: the first
