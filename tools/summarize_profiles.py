@@ -103,6 +103,40 @@ for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve
         print(name, 'counters:', json.dumps({k: line['counters'][k] for k in ('dominant_kernel', 'hbm_bytes_per_launch', 'measured_hbm_gbps', 'hbm_frac_of_8tbps', 'valu_issue_frac', 'wave_time_split')}))
     except Exception as e:
         print('no %s counters: %s' % (name, e))
+# the grid walk's vector instructions by class (one more counter pass), priced with the issue cost of each class at full occupancy
+# (tools/micro/pk_rate.hip, ns per wave-instruction per SIMD with eight waves per SIMD): what the launch costs in issue slots alone
+try:
+    mix = collections.defaultdict(lambda: [0, 0.0])
+    for tag in ('mix', 'cyc'):
+        f = newest(src + '/tlg_pmc_%s/**/*counter_collection.csv' % tag)
+        by = collections.defaultdict(lambda: collections.defaultdict(float))
+        for row in csv.DictReader(open(f)):
+            if 'k_tlg_trace' in row['Kernel_Name']:
+                by[row['Counter_Name']][int(row['Dispatch_Id'])] += float(row['Counter_Value'])
+        for c, d in by.items():
+            vals = [d[x] for x in sorted(d)][1:] or list(d.values())
+            mix[c] = sum(vals) / len(vals)
+    cost = dict(add=1.2, mul=1.2, fma=1.6, trans=3.4, int32=1.5, cvt=1.75, other=1.8)         # ns per wave-instruction per SIMD (r05_valu_issue_costs.txt)
+    cnt = dict(add=mix.get('SQ_INSTS_VALU_ADD_F32', 0.0), mul=mix.get('SQ_INSTS_VALU_MUL_F32', 0.0), fma=mix.get('SQ_INSTS_VALU_FMA_F32', 0.0),
+               trans=mix.get('SQ_INSTS_VALU_TRANS_F32', 0.0), int32=mix.get('SQ_INSTS_VALU_INT32', 0.0), cvt=mix.get('SQ_INSTS_VALU_CVT', 0.0))
+    cnt['other'] = max(mix.get('SQ_INSTS_VALU', 0.0) - sum(cnt.values()), 0.0)
+    line_path = 'profiles/%s_tlg_config4_line.json' % R
+    line = json.load(open(line_path))
+    issue_ms = sum(cnt[k] * cost[k] for k in cnt) / 1024.0 * 1e-6
+    line['valu_issue_roof'] = dict(what='vector instructions per launch by class (rocprofv3 --pmc SQ_INSTS_VALU_*) x the issue cost of the class with all wave slots busy '
+                                        '(tools/micro/pk_rate.hip; two simple f32 operations of different waves issue side by side, everything else one at a time), / 1 024 SIMDs',
+                                   counts={k: round(v) for k, v in cnt.items()}, cost_ns_per_wave_instruction_per_simd=cost, issue_ms=round(issue_ms, 3),
+                                   trace_ms=line.get('trace_ms'), frac=(round(issue_ms / line['trace_ms'], 3) if line.get('trace_ms') else None),
+                                   raw={k: round(v, 1) for k, v in mix.items()})
+    json.dump(line, open(line_path, 'w'), indent=1)
+    print('tlg issue roof', line['valu_issue_roof']['issue_ms'], 'of', line.get('trace_ms'))
+except Exception as e:
+    print('no instruction mix of the grid walk: %s' % e)
+for f in ('pk_rate.txt', 'div_check.txt'):
+    try:
+        shutil.copy(src + '/' + f, 'profiles/%s_%s' % (R, {'pk_rate.txt': 'valu_issue_costs.txt', 'div_check.txt': 'division_sequences_check.txt'}[f]))
+    except Exception as e:
+        print('no %s: %s' % (f, e))
 for f, dst in (('config_report.json', '%s_config_report.json' % R), ('bench_group4.json', '%s_bench_group4_rehearsal.json' % R)):
     try:
         txt = open(src + '/' + f).read()
