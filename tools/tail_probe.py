@@ -26,6 +26,17 @@ for n in names:
         if kv:
             os.environ[kv.split('=')[0]] = kv.split('=')[1]; KNOBS.add(kv.split('=')[0])
     ctx = capi.Context(0)
+    # PROBE_PRIORITY=tenryuu:high,man:high,cube:low: that scene's frames on a stream of that priority (hipStreamCreateWithPriority)
+    pr = dict(kv.split(':') for kv in os.environ.get('PROBE_PRIORITY', '').split(',') if kv).get(n)
+    if pr:
+        import ctypes as C
+        hip = C.CDLL('libamdhip64.so')
+        lo, hi = C.c_int(), C.c_int()
+        assert hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)) == 0
+        st = C.c_void_p()
+        assert hip.hipStreamCreateWithPriority(C.byref(st), 1, {'high': hi.value, 'low': lo.value, 'normal': (lo.value + hi.value) // 2}[pr]) == 0      # 1 = non-blocking
+        ctx.set_stream(st.value)
+        print('stream priority', n, pr, (lo.value, hi.value), flush=True)
     ctx.set_frames_in_flight(5)
     sc = capi.DeviceScene(ctx, bufs[n]); bvh = capi.DeviceBVH(ctx, sc).build()
     cam = bench.demo_camera(bufs[n], *RES)
