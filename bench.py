@@ -446,6 +446,14 @@ def compact_line(out, details_path):
     return line
 
 
+def same_launch(a, b):
+    """two calibrated strategies that are the same launch as far as its counters go: the same kernel, and either both without a hand-over / sharing
+    budget (2^20 = never) or both with one (neighbouring budgets -- 12 or 16 steps, 32 or 64 -- are the same instance doing nearly the same work)"""
+    if not a or not b or a['kernel'] != b['kernel']:
+        return False
+    return (a['budget'] >= 1 << 20) == (b['budget'] >= 1 << 20)
+
+
 def q_slots(work, name):
     for it in work:
         if it['name'] == name:
@@ -1267,7 +1275,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide reads at 64 bytes: doubled
         # (MI355X_MICROARCH.md, HBM section).  Average over the five scenes, per traversal launch, like the duration.
         # ... over the scenes whose counter pass ran the launch that is timed here (the child calibrates on its own: ADVICE r4)
-        matched = [n for n in SCENES if pmc['strategies'].get(n) == per_scene[n]['strategy']] or list(SCENES)
+        matched = [n for n in SCENES if same_launch(pmc['strategies'].get(n), per_scene[n]['strategy'])] or list(SCENES)
         fetch = sum(pmc['per_scene'][n].get('FETCH_SIZE', 0.0) for n in matched) / len(matched)
         write = sum(pmc['per_scene'][n].get('WRITE_SIZE', 0.0) for n in matched) / len(matched)
         traffic = int((2.0 * fetch + write) * 1024)
@@ -1330,7 +1338,7 @@ def main():
         f_floor = floor_ms / max(q['trace_ms'], 1e-9)
         f_hbm = (q['hbm_bytes_per_launch'] / (q['trace_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if 'hbm_bytes_per_launch' in q else None
         f_valu = q.get('valu_issue_frac')
-        if 'strategy_in_counter_pass' in q and q['strategy_in_counter_pass'] != q['strategy']:
+        if 'strategy_in_counter_pass' in q and not same_launch(q['strategy_in_counter_pass'], q['strategy']):
             # the profiled child calibrated on its own and settled on another launch than the one timed here: its counters divided by this
             # process's duration would mix two launches -- no derived fraction for this scene
             bound_per_scene[n] = dict(frac_of_output_floor=round(f_floor, 4), hbm_frac_measured=None, valu_issue_frac=None,
