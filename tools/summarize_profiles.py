@@ -95,8 +95,10 @@ for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve
         if name == 'tlg_config4' and line.get('per_ray', {}).get('top_cells') and c.get('SQ_WAVES'):
             # vector instructions a wave issues per top-level cell one of its rays walks (all loop levels below it included): what the verdict's
             # "instructions per top cell" asks for; round 3 (profiles/r03_tlg_config4_line.json): 2 282 M / 32 640 waves / 152.2 cells = 459
-            line['counters']['valu_instructions_per_wave'] = round(c.get('SQ_INSTS_VALU', 0.0) / c['SQ_WAVES'], 1)
-            line['counters']['valu_instructions_per_top_cell'] = round(c.get('SQ_INSTS_VALU', 0.0) / c['SQ_WAVES'] / line['per_ray']['top_cells'], 1)
+            # (waves of a launch = rays / 64: SQ_WAVES is sampled per shader engine and reads low on some passes of round 5)
+            waves = 1920 * 1080 / 64.0
+            line['counters']['valu_instructions_per_wave'] = round(c.get('SQ_INSTS_VALU', 0.0) / waves, 1)
+            line['counters']['valu_instructions_per_top_cell'] = round(c.get('SQ_INSTS_VALU', 0.0) / waves / line['per_ray']['top_cells'], 1)
             line['counters']['valu_instructions_per_top_cell_round3'] = 459.4
             line['counters']['floor_ms_at_full_issue'] = round(c.get('SQ_INSTS_VALU', 0.0) * 2.0 / 1024.0 / (cycles / ms) , 3) if cycles and ms else None
         json.dump(line, open(line_path, 'w'), indent=1)
