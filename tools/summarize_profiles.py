@@ -72,7 +72,7 @@ def counter_pass(prefix, kernel_prefixes, skip_first):
             d[c] = sum(steady) / len(steady)
         out[k] = d
     return out
-for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve'), 1), ('tlg_config4', 'tlg_pmc', ('k_tlg_trace',), 1)):
+for name, prefix, kp, skip in (('config3', 'config3_pmc', ('k_trace', 'k_resolve'), 1), ('tlg_config4', 'tlg_pmc', ('k_tlg_trace<',), 1)):
     try:
         pk = counter_pass(prefix, kp, skip)
         if not pk:
@@ -113,7 +113,7 @@ try:
         f = newest(src + '/tlg_pmc_%s/**/*counter_collection.csv' % tag)
         by = collections.defaultdict(lambda: collections.defaultdict(float))
         for row in csv.DictReader(open(f)):
-            if 'k_tlg_trace' in row['Kernel_Name']:
+            if row['Kernel_Name'].split('(')[0].replace('void ', '').strip().startswith('k_tlg_trace<'):      # (not k_tlg_trace_records, the build's last launch)
                 by[row['Counter_Name']][int(row['Dispatch_Id'])] += float(row['Counter_Value'])
         for c, d in by.items():
             vals = [d[x] for x in sorted(d)][1:] or list(d.values())
@@ -124,14 +124,20 @@ try:
     cnt['other'] = max(mix.get('SQ_INSTS_VALU', 0.0) - sum(cnt.values()), 0.0)
     line_path = 'profiles/%s_tlg_config4_line.json' % R
     line = json.load(open(line_path))
-    issue_ms = sum(cnt[k] * cost[k] for k in cnt) / 1024.0 * 1e-6
-    line['valu_issue_roof'] = dict(what='vector instructions per launch by class (rocprofv3 --pmc SQ_INSTS_VALU_*) x the issue cost of the class with all wave slots busy '
-                                        '(tools/micro/pk_rate.hip; two simple f32 operations of different waves issue side by side, everything else one at a time), / 1 024 SIMDs',
-                                   counts={k: round(v) for k, v in cnt.items()}, cost_ns_per_wave_instruction_per_simd=cost, issue_ms=round(issue_ms, 3),
-                                   trace_ms=line.get('trace_ms'), frac=(round(issue_ms / line['trace_ms'], 3) if line.get('trace_ms') else None),
+    priced_ms = sum(cnt[k] * cost[k] for k in cnt) / 1024.0 * 1e-6
+    floor_ms = (sum(cnt.values()) + cnt['trans'] * (cost['trans'] / cost['add'] - 1.0)) * cost['add'] / 1024.0 * 1e-6
+    line['valu_issue_roof'] = dict(what='vector instructions per launch by class (rocprofv3 --pmc SQ_INSTS_VALU_*) against the issue costs of tools/micro/pk_rate.hip (ns per '
+                                        'wave-instruction per SIMD with all wave slots busy).  floor_ms: EVERY instruction at the rate of the cheapest class (v_add / v_mul / v_mov: two '
+                                        'of different waves issue side by side), transcendentals at theirs -- no instruction stream of this length runs faster.  priced_by_class_ms: every '
+                                        'class at the cost it shows alone; it exceeds the measured time (classes overlap in the two pipes, and "other" / int32 hold cheap moves and adds), '
+                                        'so it is an estimate, not a bound',
+                                   counts={k: round(v) for k, v in cnt.items()}, cost_ns_per_wave_instruction_per_simd=cost,
+                                   floor_ms=round(floor_ms, 3), priced_by_class_ms=round(priced_ms, 3), trace_ms=line.get('trace_ms'),
+                                   frac=(round(floor_ms / line['trace_ms'], 3) if line.get('trace_ms') else None),
+                                   cycles_per_instruction_per_simd=(round(mix['GRBM_GUI_ACTIVE'] / 8.0 / (sum(cnt.values()) / 1024.0), 2) if mix.get('GRBM_GUI_ACTIVE') else None),
                                    raw={k: round(v, 1) for k, v in mix.items()})
     json.dump(line, open(line_path, 'w'), indent=1)
-    print('tlg issue roof', line['valu_issue_roof']['issue_ms'], 'of', line.get('trace_ms'))
+    print('tlg issue floor', line['valu_issue_roof']['floor_ms'], 'priced', line['valu_issue_roof']['priced_by_class_ms'], 'of', line.get('trace_ms'))
 except Exception as e:
     print('no instruction mix of the grid walk: %s' % e)
 for f in ('pk_rate.txt', 'div_check.txt'):
