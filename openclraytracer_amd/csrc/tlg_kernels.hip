@@ -473,7 +473,7 @@ __device__ __forceinline__ void dda_finish_fast(float p, float d, float4 plane, 
     const float lo = plane.x, hi = plane.y;
     float f = div_by((p - lo) * fres, hi - lo, plane.z);
     const float top = fres - 1;
-    f = RMAX(f, 0.0f); f = RMIN(f, top);
+    f = __builtin_amdgcn_fmed3f(f, 0.0f, top);                       // min(max(f, 0), top) for a finite f and top >= 0 (a -0 gives cell 0 either way)
     idx = (int)f;
     dt = div_by_res(tmax - tmin, fres, rres);
     const int k = d > 0.0f ? idx + 1 : res - idx;                    // (float)(idx + 1) / (float)(res - (uint32_t)idx)
@@ -495,6 +495,41 @@ __device__ __forceinline__ void dda_setup_fast(f3 o, f3 d, f3 a, float4 px, floa
     dda_finish_fast(p.z, d.z, pz, (int)(r.packed >> 20), r.fres[2], r.rcp[2], tzmin, tzmax, s.nz, s.dtz, s.iz);
 }
 
+// One DDA step of the walk with its own records (TwoLevelGrid.h:542-545 / :660-676), every next[] finite.  The axis: the reference scans for
+// the first axis whose next[] equals min(next[x], min(next[y], next[z])) -- x if next[x] <= both others, else y if next[y] <= next[z], else z:
+// three compares instead of two selects and three equality tests.  next[axis] += dt[axis]; idx[axis] += step[axis] runs under the lanes of
+// that axis (three masked pairs of additions instead of nine selects: the compiler would turn the masks into selects).  The ray leaves the
+// grid when idx[axis] reaches res (step +1) or -1 (step -1): idx starts inside [0, res) and moves by one, so that is (unsigned)idx >= res.
+__device__ __forceinline__ bool dda_step_fast(Dda& s, int sx, int sy, int sz, uint32_t rx, uint32_t ry, uint32_t rz)
+{
+    // (one block of assembly: the three compares write their lane masks where the scalar unit combines them -- m0 = x, m1 = y & ~x, m2 = the
+    //  rest of exec -- and exec takes each in turn; handed three bools the compiler rebuilds every mask through a vector register)
+    unsigned long long t0, t1, t2, saved;
+    asm volatile("v_cmp_le_f32_e64 %[t0], %[nx], %[ny]\n\t"
+                 "v_cmp_le_f32_e64 %[t1], %[nx], %[nz]\n\t"
+                 "v_cmp_le_f32_e64 %[t2], %[ny], %[nz]\n\t"
+                 "s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 %[t0], %[t0], %[t1]\n\t"            // x
+                 "s_andn2_b64 %[t1], %[t2], %[t0]\n\t"          // y and not x
+                 "s_or_b64 %[t2], %[t0], %[t1]\n\t"
+                 "s_andn2_b64 %[t2], %[sv], %[t2]\n\t"          // neither: z
+                 "s_mov_b64 exec, %[t0]\n\t"
+                 "v_add_f32 %[nx], %[nx], %[dx]\n\t"
+                 "v_add_u32 %[ix], %[ix], %[sx]\n\t"
+                 "s_mov_b64 exec, %[t1]\n\t"
+                 "v_add_f32 %[ny], %[ny], %[dy]\n\t"
+                 "v_add_u32 %[iy], %[iy], %[sy]\n\t"
+                 "s_mov_b64 exec, %[t2]\n\t"
+                 "v_add_f32 %[nz], %[nz], %[dz]\n\t"
+                 "v_add_u32 %[iz], %[iz], %[sz]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [nx] "+v"(s.nx), [ny] "+v"(s.ny), [nz] "+v"(s.nz), [ix] "+v"(s.ix), [iy] "+v"(s.iy), [iz] "+v"(s.iz),
+                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(saved)
+                 : [dx] "v"(s.dtx), [dy] "v"(s.dty), [dz] "v"(s.dtz), [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz)
+                 : "scc");
+    return ((uint32_t)s.ix >= rx) | ((uint32_t)s.iy >= ry) | ((uint32_t)s.iz >= rz);
+}
+
 // The walk of one ray (tlg_generate_contact, TwoLevelGrid.h:548-678).  FAST: every ray of this wave and the grid qualify for the walk's own
 // records (see k_tlg_trace_records): the leaf-level set-up takes its cell from a 32-byte record and its planes from a table in LDS, divides by
 // the sequences above, and the triangle test takes 1 / det from v_rcp_f32 + one Newton step (equal to the IEEE quotient for every operand
@@ -507,6 +542,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
     const f3 glo = f3{ g.box_lo[0], g.box_lo[1], g.box_lo[2] }, ghi = f3{ g.box_hi[0], g.box_hi[1], g.box_hi[2] };
 
     const DdaSigns sg = DdaSigns{ d.x > 0.0f, d.y > 0.0f, d.z > 0.0f };
+    const int step_x = sg.px ? 1 : -1, step_y = sg.py ? 1 : -1, step_z = sg.pz ? 1 : -1;         // step[] of :470-490 / :610-630
     const f3 inv_d = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };          // (what dda_axis_setup divides per cell; the compiler hoists it there as well)
     bool done;
     Dda T;
@@ -515,7 +551,9 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
     while (!done) {
         TLG_DIAG(0, 1);
         const int tix = T.ix, tiy = T.iy, tiz = T.iz;
-        const uint32_t cell = (uint32_t)tiz * g.resX * g.resY + (uint32_t)tiy * g.resX + (uint32_t)tix;
+        // (at most 512 planes with the walk's records: every top-level resolution is below 512)
+        const uint32_t cell = FAST ? __umul24(__umul24((uint32_t)tiz, g.resY) + (uint32_t)tiy, g.resX) + (uint32_t)tix
+                                   : (uint32_t)tiz * g.resX * g.resY + (uint32_t)tiy * g.resX + (uint32_t)tix;
         rt_top_cell tc;
         TlgTopRec rec;
         if (FAST) {
@@ -547,8 +585,10 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
             uint32_t cell_tri = 0xFFFFFFFFu;
             for (;;) {
                 TLG_DIAG(4, 5);
-                const int laxis = dda_axis(Lf);
-                const uint32_t leaf = (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
+                const int laxis = FAST ? 0 : dda_axis(Lf);
+                // (with the walk's records every leaf resolution is below 1024 and every index below it: the same sum by 24-bit multiply-adds)
+                const uint32_t leaf = FAST ? __umul24(__umul24((uint32_t)Lf.iz, tc.resY) + (uint32_t)Lf.iy, tc.resX) + (uint32_t)Lf.ix + tc.firstLeafIdx
+                                           : (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
                 const uint2 range = a.leaf_ranges[leaf];
                 TLG_DIAG_HIST(range.y - range.x);
                 // (the next pair id is fetched while this triangle is tested: one dependent load less per entry)
@@ -590,16 +630,22 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
                 }
                 if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
-                if (laxis < 0) break;
-                if (dda_advance(Lf, laxis, sg, tc.resX, tc.resY, tc.resZ)) break;   // :542-545
+                if (FAST) { if (dda_step_fast(Lf, step_x, step_y, step_z, tc.resX, tc.resY, tc.resZ)) break; }
+                else {
+                    if (laxis < 0) break;
+                    if (dda_advance(Lf, laxis, sg, tc.resX, tc.resY, tc.resZ)) break;   // :542-545
+                }
             }
             if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
         }
         // :660-676 -- the axis of the smallest next[] (chosen before the cell is processed in the reference; nothing in between changes
         // next[]), `next[axis] += dt[axis]; idx[axis] += step[axis]; if (idx[axis] == stop[axis]) break`
-        const int taxis = dda_axis(T);
-        if (taxis < 0) break;
-        if (dda_advance(T, taxis, sg, g.resX, g.resY, g.resZ)) break;
+        if (FAST) { if (dda_step_fast(T, step_x, step_y, step_z, g.resX, g.resY, g.resZ)) break; }
+        else {
+            const int taxis = dda_axis(T);
+            if (taxis < 0) break;
+            if (dda_advance(T, taxis, sg, g.resX, g.resY, g.resZ)) break;
+        }
     }
 
 }
