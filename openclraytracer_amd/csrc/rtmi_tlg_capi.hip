@@ -164,6 +164,9 @@ static bool enqueue_walk_records(rt_tlg* g)
 {
     const uint32_t planes = g->grid.resX + g->grid.resY + g->grid.resZ;
     if (!g->d_toprec || !g->d_axis_tab || planes > g->axis_cap || planes > TLG_AXIS_MAX_HOST) return false;
+    // (the walk with the records addresses its buffers by 32-bit byte offsets: each of them below 4 GB)
+    if ((uint64_t)g->info.cells * sizeof(TlgTopRec) >= (1ull << 32) || (uint64_t)g->leaf_ranges_cap * sizeof(uint2) >= (1ull << 32) ||
+        (uint64_t)g->leaf_cap * sizeof(uint2) >= (1ull << 32) || (uint64_t)g->n * sizeof(TriCam) >= (1ull << 32)) return false;
     const float* lo = g->grid.box_lo; const float* hi = g->grid.box_hi;
     for (int k = 0; k < 3; k++) if (!(std::fabs(lo[k]) <= 0x1p30f) || !(std::fabs(hi[k]) <= 0x1p30f)) return false;
     launch_tlg_trace_records(g->ctx->stream, g->grid, g->d_top, g->info.cells, g->d_toprec, g->d_axis_tab, g->d_written + 8);

@@ -347,6 +347,13 @@ void launch_tlg_trace_records(hipStream_t s, const rt_grid_data& g, const rt_top
     hipLaunchKernelGGL(k_tlg_trace_records, dim3(((cells > planes ? cells : planes) + TLG_BLOCK - 1) / TLG_BLOCK), dim3(TLG_BLOCK), 0, s, g, top, cells, rec, axis_tab, too_fine);
 }
 
+// a load at a 32-bit byte offset from a buffer's base (the walk with its own records: every buffer it reads is below 4 GB, host check): the
+// base stays in scalar registers and the address costs the one multiply / shift of the offset instead of 64-bit vector arithmetic per load
+template <typename T> __device__ __forceinline__ T ld_off(const void* base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+
 // x / y given r = RN(1 / y), for operands as described above
 __device__ __forceinline__ float div_by(float x, float y, float r)
 {
@@ -557,8 +564,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         rt_top_cell tc;
         TlgTopRec rec;
         if (FAST) {
-            const float4* rp = reinterpret_cast<const float4*>(a.toprec + cell);
-            float4 r0 = rp[0], r1 = rp[1];
+            float4 r0 = ld_off<float4>(a.toprec, cell * 32u), r1 = ld_off<float4>(a.toprec, cell * 32u + 16u);
             // (both halves and the planes are fetched BEFORE the cell is known to be non-empty -- nearly every cell a ray meets is: left to itself the
             //  compiler fetches the last word, waits, branches and only then fetches the rest: two trips to the L2 in a row per cell)
             asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
@@ -589,14 +595,14 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 // (with the walk's records every leaf resolution is below 1024 and every index below it: the same sum by 24-bit multiply-adds)
                 const uint32_t leaf = FAST ? __umul24(__umul24((uint32_t)Lf.iz, tc.resY) + (uint32_t)Lf.iy, tc.resX) + (uint32_t)Lf.ix + tc.firstLeafIdx
                                            : (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
-                const uint2 range = a.leaf_ranges[leaf];
+                const uint2 range = FAST ? ld_off<uint2>(a.leaf_ranges, leaf * 8u) : a.leaf_ranges[leaf];
                 TLG_DIAG_HIST(range.y - range.x);
                 // (the next pair id is fetched while this triangle is tested: one dependent load less per entry)
-                uint32_t tri_next = range.x < range.y ? a.leaf_pairs[range.x].y : 0u;
+                uint32_t tri_next = range.x < range.y ? (FAST ? ld_off<uint32_t>(a.leaf_pairs, range.x * 8u + 4u) : a.leaf_pairs[range.x].y) : 0u;
                 for (uint32_t i = range.x; i < range.y; i++) {
                     TLG_DIAG(6, 7);
                     const uint32_t tri = tri_next;
-                    if (i + 1u < range.y) tri_next = a.leaf_pairs[i + 1u].y;
+                    if (i + 1u < range.y) tri_next = FAST ? ld_off<uint32_t>(a.leaf_pairs, i * 8u + 12u) : a.leaf_pairs[i + 1u].y;
                     mail_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
                     const mail_t tag = (mail_t)(tri >> 4);
                     if (*slot == tag) continue;                // tested in an earlier cell: a miss, again
@@ -606,7 +612,12 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
                     f3 edge1, edge2, tvec, qvec;
                     float e2q;
-                    if (PRIMARY && a.tricam) {
+                    if (PRIMARY && a.tricam && FAST) {
+                        const uint32_t at = tri * 64u;
+                        const float4 w0 = ld_off<float4>(a.tricam, at), w1 = ld_off<float4>(a.tricam, at + 16u), w2 = ld_off<float4>(a.tricam, at + 32u);
+                        edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
+                        e2q = ld_off<float>(a.tricam, at + 48u);
+                    } else if (PRIMARY && a.tricam) {
                         const float4* p = reinterpret_cast<const float4*>(a.tricam + tri);
                         const float4 w0 = p[0], w1 = p[1], w2 = p[2];
                         edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
