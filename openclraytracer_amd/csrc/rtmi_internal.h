@@ -282,6 +282,8 @@ struct rt_tlg {
     uint32_t rebuilds_without_readback = 0;   // diagnostics
     TlgTopRec* d_toprec = nullptr;      // cells_cap records of the walk (null: not allocated, the walk of round 4)
     float4* d_axis_tab = nullptr;       // axis_cap plane records
+    uint4* d_leafrec = nullptr;         // leafrec_cap leaf-cell records of the walk
+    uint32_t leafrec_cap = 0;
     uint32_t axis_cap = 0;
     bool walk_records = false;          // this build's records are usable (moderate box, no leaf grid finer than 1023 per axis)
     TriCam* d_tricam = nullptr;         // n camera-relative triangle records of the primary-ray trace (rtmi_internal.h, TriCam)
@@ -488,7 +490,9 @@ struct TlgLaunch {
     bool prepare_tricam;       // ... which this launch (re)computes first: the camera moved, or the scene was rebuilt
     const TlgTopRec* toprec;   // the walk's records (null: none, the walk of round 4)
     const float4* axis_tab;
+    const uint4* leafrec;
 };
+void launch_tlg_leaf_records(hipStream_t s, const uint2* leaf_ranges, const uint2* leaf_pairs, uint32_t leaf_cells, uint32_t pairs_cap, uint4* rec);
 void launch_tlg_trace_records(hipStream_t s, const rt_grid_data& g, const rt_top_cell* top, uint32_t cells, TlgTopRec* rec, float4* axis_tab, uint32_t* too_fine);
 void launch_tlg_count_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, uint32_t* counters);
 void launch_tlg_emit_top(hipStream_t s, const rt_grid_data& g, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* pairs,

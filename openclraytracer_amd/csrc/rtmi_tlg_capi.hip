@@ -34,9 +34,9 @@ static void free_tlg_buffers(rt_tlg* g)
 {
     void** ptrs[] = { (void**)&g->d_counters, (void**)&g->d_scan, (void**)&g->d_scan_scratch, (void**)&g->d_cell_ranges, (void**)&g->d_top,
                       (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written, (void**)&g->d_tricam,
-                      (void**)&g->d_toprec, (void**)&g->d_axis_tab };
+                      (void**)&g->d_toprec, (void**)&g->d_axis_tab, (void**)&g->d_leafrec };
     for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false; g->axis_cap = 0; g->walk_records = false;
+    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false; g->axis_cap = 0; g->leafrec_cap = 0; g->walk_records = false;
 }
 
 void rt_tlg_destroy(rt_tlg* g)
@@ -169,6 +169,15 @@ static bool enqueue_walk_records(rt_tlg* g)
         (uint64_t)g->leaf_cap * sizeof(uint2) >= (1ull << 32) || (uint64_t)g->n * sizeof(TriCam) >= (1ull << 32)) return false;
     const float* lo = g->grid.box_lo; const float* hi = g->grid.box_hi;
     for (int k = 0; k < 3; k++) if (!(std::fabs(lo[k]) <= 0x1p30f) || !(std::fabs(hi[k]) <= 0x1p30f)) return false;
+    // the leaf-cell records cover the leaf-range array as allocated (ranges beyond this build's leaf cells are zero: empty records)
+    if (g->leafrec_cap != g->leaf_ranges_cap || !g->d_leafrec) {
+        (void)hipStreamSynchronize(g->ctx->stream);
+        if (g->d_leafrec) { (void)hipFree(g->d_leafrec); g->d_leafrec = nullptr; g->leafrec_cap = 0; }
+        if ((uint64_t)g->leaf_ranges_cap * sizeof(uint4) >= (1ull << 32)) return false;
+        if (hipMalloc((void**)&g->d_leafrec, (size_t)g->leaf_ranges_cap * sizeof(uint4)) != hipSuccess) { (void)hipGetLastError(); g->d_leafrec = nullptr; return false; }
+        g->leafrec_cap = g->leaf_ranges_cap;
+    }
+    launch_tlg_leaf_records(g->ctx->stream, g->d_leaf_ranges, g->d_leaf_pairs, g->leaf_ranges_cap, g->leaf_cap, g->d_leafrec);
     launch_tlg_trace_records(g->ctx->stream, g->grid, g->d_top, g->info.cells, g->d_toprec, g->d_axis_tab, g->d_written + 8);
     return true;
 }
@@ -337,7 +346,7 @@ static TlgLaunch make_tlg_launch(const rt_tlg* g)
 {
     TlgLaunch t{};
     t.grid = g->grid; t.top = g->d_top; t.leaf_ranges = g->d_leaf_ranges; t.leaf_pairs = g->d_leaf_pairs; t.scene = &g->scene->d;
-    if (g->walk_records) { t.toprec = g->d_toprec; t.axis_tab = g->d_axis_tab; }
+    if (g->walk_records) { t.toprec = g->d_toprec; t.axis_tab = g->d_axis_tab; t.leafrec = g->d_leafrec; }
     return t;
 }
 

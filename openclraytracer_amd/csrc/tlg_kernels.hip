@@ -298,6 +298,7 @@ struct TlgTraceArgs {
     const TriCam* __restrict__ tricam;      // primary rays: camera-relative triangle records (null: v0 / e1 / e2)
     const TlgTopRec* __restrict__ toprec;   // the walk's own records of the top-level cells and planes (null: the walk of round 4)
     const float4* __restrict__ axis_tab;    // resX + resY + resZ entries { lo, hi, RN(1 / (hi - lo)), 0 }
+    const uint4* __restrict__ leafrec;      // per leaf cell { entries, triangle of entry 0, of entry 1, first entry in leaf_pairs }
     uint32_t total_work;
     rt_camera cam;
     uint32_t rank, nranks, tiles_x, compact;
@@ -340,6 +341,27 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace_records(rt_grid_data g,
     r.rcp[0] = 1.0f / r.fres[0]; r.rcp[1] = 1.0f / r.fres[1]; r.rcp[2] = 1.0f / r.fres[2];
     r.packed = empty ? 0u : (t.resX | (t.resY << 10) | (t.resZ << 20));
     rec[c] = r;
+}
+// ... and per leaf cell { entries, the triangles of its first two entries, where its entries start }: the walk meets a leaf cell's first triangles
+// with ONE fetch instead of the range and then the pair behind it (two trips to the L2 in a row per leaf cell; 20 % of the leaf cells a ray
+// meets hold one or two triangles, and for the others the third entry's fetch overlaps the first tests)
+__global__ __launch_bounds__(TLG_BLOCK) void k_tlg_leaf_records(const uint2* __restrict__ leaf_ranges, const uint2* __restrict__ leaf_pairs, uint32_t leaf_cells,
+                                                                uint32_t pairs_cap, uint4* __restrict__ rec)
+{
+    const uint32_t c = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    if (c >= leaf_cells) return;
+    const uint2 r = leaf_ranges[c];
+    uint4 o = make_uint4(0u, 0u, 0u, r.x);
+    if (r.x < r.y && r.y <= pairs_cap) {
+        o.x = r.y - r.x;
+        o.y = leaf_pairs[r.x].y;
+        if (o.x > 1u) o.z = leaf_pairs[r.x + 1u].y;
+    }
+    rec[c] = o;
+}
+void launch_tlg_leaf_records(hipStream_t s, const uint2* leaf_ranges, const uint2* leaf_pairs, uint32_t leaf_cells, uint32_t pairs_cap, uint4* rec)
+{
+    if (leaf_cells) hipLaunchKernelGGL(k_tlg_leaf_records, dim3((leaf_cells + TLG_BLOCK - 1) / TLG_BLOCK), dim3(TLG_BLOCK), 0, s, leaf_ranges, leaf_pairs, leaf_cells, pairs_cap, rec);
 }
 void launch_tlg_trace_records(hipStream_t s, const rt_grid_data& g, const rt_top_cell* top, uint32_t cells, TlgTopRec* rec, float4* axis_tab, uint32_t* too_fine)
 {
@@ -595,17 +617,11 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 // (with the walk's records every leaf resolution is below 1024 and every index below it: the same sum by 24-bit multiply-adds)
                 const uint32_t leaf = FAST ? __umul24(__umul24((uint32_t)Lf.iz, tc.resY) + (uint32_t)Lf.iy, tc.resX) + (uint32_t)Lf.ix + tc.firstLeafIdx
                                            : (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
-                const uint2 range = FAST ? ld_off<uint2>(a.leaf_ranges, leaf * 8u) : a.leaf_ranges[leaf];
-                TLG_DIAG_HIST(range.y - range.x);
-                // (the next pair id is fetched while this triangle is tested: one dependent load less per entry)
-                uint32_t tri_next = range.x < range.y ? (FAST ? ld_off<uint32_t>(a.leaf_pairs, range.x * 8u + 4u) : a.leaf_pairs[range.x].y) : 0u;
-                for (uint32_t i = range.x; i < range.y; i++) {
-                    TLG_DIAG(6, 7);
-                    const uint32_t tri = tri_next;
-                    if (i + 1u < range.y) tri_next = FAST ? ld_off<uint32_t>(a.leaf_pairs, i * 8u + 12u) : a.leaf_pairs[i + 1u].y;
+                // one entry of a leaf cell: mailbox, then the triangle test
+                auto test_entry = [&](const uint32_t tri) {
                     mail_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
                     const mail_t tag = (mail_t)(tri >> 4);
-                    if (*slot == tag) continue;                // tested in an earlier cell: a miss, again
+                    if (*slot == tag) return;                  // tested in an earlier cell: a miss, again
                     *slot = tag;
                     TLG_DIAG(8, 9);
                     // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
@@ -639,6 +655,29 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
                     const float t = e2q * inv_det;                         // "* flag" folded into the test
                     if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
+                };
+                if (FAST) {
+                    const uint4 lr = ld_off<uint4>(a.leafrec, leaf * 16u);
+                    TLG_DIAG_HIST(lr.x);
+                    uint32_t tri_next = lr.y;
+                    for (uint32_t i = 0; i < lr.x; i++) {
+                        TLG_DIAG(6, 7);
+                        const uint32_t tri = tri_next;
+                        // (entry 1 comes with the record; later ones are fetched one entry ahead, while this triangle is tested)
+                        if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
+                        test_entry(tri);
+                    }
+                } else {
+                    const uint2 range = a.leaf_ranges[leaf];
+                    TLG_DIAG_HIST(range.y - range.x);
+                    // (the next pair id is fetched while this triangle is tested: one dependent load less per entry)
+                    uint32_t tri_next = range.x < range.y ? a.leaf_pairs[range.x].y : 0u;
+                    for (uint32_t i = range.x; i < range.y; i++) {
+                        TLG_DIAG(6, 7);
+                        const uint32_t tri = tri_next;
+                        if (i + 1u < range.y) tri_next = a.leaf_pairs[i + 1u].y;
+                        test_entry(tri);
+                    }
                 }
                 if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
                 if (FAST) { if (dda_step_fast(Lf, step_x, step_y, step_z, tc.resX, tc.resY, tc.resZ)) break; }
@@ -817,7 +856,7 @@ static TlgTraceArgs tlg_args(const TlgLaunch& t)
     TlgTraceArgs a{};
     a.grid = t.grid; a.top = t.top; a.leaf_ranges = t.leaf_ranges; a.leaf_pairs = t.leaf_pairs;
     a.v0 = t.scene->v0; a.e1 = t.scene->e1; a.e2 = t.scene->e2; a.nrm = t.scene->nrm;
-    a.toprec = t.toprec; a.axis_tab = t.axis_tab;
+    a.toprec = t.toprec; a.axis_tab = t.axis_tab; a.leafrec = t.leafrec;
     return a;
 }
 
