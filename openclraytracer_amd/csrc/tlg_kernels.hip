@@ -598,6 +598,67 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         }
         if (FAST ? rec.packed != 0u : !(tc.resX == 0 || tc.resY == 0 || tc.resZ == 0)) {
             TLG_DIAG(2, 3);
+            float cell_t = FLT_MAX;
+            uint32_t cell_tri = 0xFFFFFFFFu;
+            // one entry of a leaf cell: mailbox, then the triangle test
+            auto test_entry = [&](const uint32_t tri) {
+                mail_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
+                const mail_t tag = (mail_t)tri;                   // (the whole id: no shift; an empty slot holds ~0, no triangle)
+                if (*slot == tag) return;                  // tested in an earlier cell: a miss, again
+                *slot = tag;
+                TLG_DIAG(8, 9);
+                // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
+                // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
+                f3 edge1, edge2, tvec, qvec;
+                float e2q;
+                if (PRIMARY && a.tricam && FAST) {
+                    const uint32_t at = tri * 64u;
+                    const float4 w0 = ld_off<float4>(a.tricam, at), w1 = ld_off<float4>(a.tricam, at + 16u), w2 = ld_off<float4>(a.tricam, at + 32u);
+                    edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
+                    e2q = ld_off<float>(a.tricam, at + 48u);
+                } else if (PRIMARY && a.tricam) {
+                    const float4* p = reinterpret_cast<const float4*>(a.tricam + tri);
+                    const float4 w0 = p[0], w1 = p[1], w2 = p[2];
+                    edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
+                    e2q = p[3].x;
+                } else {
+                    const f3 vert0 = f3_from4(a.v0[tri]);
+                    edge1 = f3_from4(a.e1[tri]); edge2 = f3_from4(a.e2[tri]);
+                    tvec = f3_sub(o, vert0);
+                    qvec = f3_cross(tvec, edge1);
+                    e2q = f3_dot(edge2, qvec);
+                }
+                const f3 pvec = f3_cross(d, edge2);
+                const float det = f3_dot(edge1, pvec);
+                bool flag = fabsf(det) >= FLT_EPSILON;
+                const float inv_det = FAST ? rcp_near(det) : 1.0f / det;
+                const float u = f3_dot(tvec, pvec) * inv_det;
+                flag = flag & (u < 1.0f) & (u >= 0.0f);
+                const float v = f3_dot(d, qvec) * inv_det;
+                flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
+                const float t = e2q * inv_det;                         // "* flag" folded into the test
+                if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
+            };
+            // the entries of one leaf cell, from the walk's leaf-cell record
+            auto walk_leaf = [&](const uint32_t leaf) {
+                const uint4 lr = ld_off<uint4>(a.leafrec, leaf * 16u);
+                TLG_DIAG_HIST(lr.x);
+                uint32_t tri_next = lr.y;
+                for (uint32_t i = 0; i < lr.x; i++) {
+                    TLG_DIAG(6, 7);
+                    const uint32_t tri = tri_next;
+                    // (entry 1 comes with the record; later ones are fetched one entry ahead, while this triangle is tested)
+                    if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
+                    test_entry(tri);
+                }
+            };
+            // A leaf grid of one cell needs no DDA: its cell is processed, and whichever axis the step would take leaves the grid (:542-545).  Taken
+            // when every lane of the wave stands in such a top-level cell (11 % of the wave's top-level steps on config 4); a lane among others runs
+            // through the general code below, to the same effect.
+            const bool one_cell = FAST && __builtin_amdgcn_ballot_w64(rec.packed != (1u | (1u << 10) | (1u << 20))) == 0ull;
+            if (one_cell) {
+                walk_leaf(rec.first_leaf);
+            } else {
             // processTopLevelCell, TwoLevelGrid.h:419-545
             Dda Lf;
             if (FAST) {
@@ -609,64 +670,14 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 chi.x = clo.x + g.stepX; chi.y = clo.y + g.stepY; chi.z = clo.z + g.stepZ;
                 dda_setup(o, d, clo, chi, tc.resX, tc.resY, tc.resZ, Lf);
             }
-            float cell_t = FLT_MAX;
-            uint32_t cell_tri = 0xFFFFFFFFu;
             for (;;) {
                 TLG_DIAG(4, 5);
                 const int laxis = FAST ? 0 : dda_axis(Lf);
                 // (with the walk's records every leaf resolution is below 1024 and every index below it: the same sum by 24-bit multiply-adds)
                 const uint32_t leaf = FAST ? __umul24(__umul24((uint32_t)Lf.iz, tc.resY) + (uint32_t)Lf.iy, tc.resX) + (uint32_t)Lf.ix + tc.firstLeafIdx
                                            : (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
-                // one entry of a leaf cell: mailbox, then the triangle test
-                auto test_entry = [&](const uint32_t tri) {
-                    mail_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
-                    const mail_t tag = (mail_t)(tri >> 4);
-                    if (*slot == tag) return;                  // tested in an earlier cell: a miss, again
-                    *slot = tag;
-                    TLG_DIAG(8, 9);
-                    // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
-                    // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
-                    f3 edge1, edge2, tvec, qvec;
-                    float e2q;
-                    if (PRIMARY && a.tricam && FAST) {
-                        const uint32_t at = tri * 64u;
-                        const float4 w0 = ld_off<float4>(a.tricam, at), w1 = ld_off<float4>(a.tricam, at + 16u), w2 = ld_off<float4>(a.tricam, at + 32u);
-                        edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
-                        e2q = ld_off<float>(a.tricam, at + 48u);
-                    } else if (PRIMARY && a.tricam) {
-                        const float4* p = reinterpret_cast<const float4*>(a.tricam + tri);
-                        const float4 w0 = p[0], w1 = p[1], w2 = p[2];
-                        edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
-                        e2q = p[3].x;
-                    } else {
-                        const f3 vert0 = f3_from4(a.v0[tri]);
-                        edge1 = f3_from4(a.e1[tri]); edge2 = f3_from4(a.e2[tri]);
-                        tvec = f3_sub(o, vert0);
-                        qvec = f3_cross(tvec, edge1);
-                        e2q = f3_dot(edge2, qvec);
-                    }
-                    const f3 pvec = f3_cross(d, edge2);
-                    const float det = f3_dot(edge1, pvec);
-                    bool flag = fabsf(det) >= FLT_EPSILON;
-                    const float inv_det = FAST ? rcp_near(det) : 1.0f / det;
-                    const float u = f3_dot(tvec, pvec) * inv_det;
-                    flag = flag & (u < 1.0f) & (u >= 0.0f);
-                    const float v = f3_dot(d, qvec) * inv_det;
-                    flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
-                    const float t = e2q * inv_det;                         // "* flag" folded into the test
-                    if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
-                };
                 if (FAST) {
-                    const uint4 lr = ld_off<uint4>(a.leafrec, leaf * 16u);
-                    TLG_DIAG_HIST(lr.x);
-                    uint32_t tri_next = lr.y;
-                    for (uint32_t i = 0; i < lr.x; i++) {
-                        TLG_DIAG(6, 7);
-                        const uint32_t tri = tri_next;
-                        // (entry 1 comes with the record; later ones are fetched one entry ahead, while this triangle is tested)
-                        if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
-                        test_entry(tri);
-                    }
+                    walk_leaf(leaf);
                 } else {
                     const uint2 range = a.leaf_ranges[leaf];
                     TLG_DIAG_HIST(range.y - range.x);
@@ -685,6 +696,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     if (laxis < 0) break;
                     if (dda_advance(Lf, laxis, sg, tc.resX, tc.resY, tc.resZ)) break;   // :542-545
                 }
+            }
             }
             if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
         }
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     // (61 % of all tests on the atrium).  The reference returns from the first leaf cell in which ANY triangle is hit
     // (TwoLevelGrid.h:528-540), so whatever this ray tested before the current cell was a miss, and testing it again gives
     // the same miss: the test is skipped when the triangle sits in a 16-entry direct-mapped table of tested triangles
-    // (per lane, LDS [entry][lane]; entry = id & 15, tag = id >> 4).  Results are unchanged by construction.
+    // (per lane, LDS [entry][lane]; entry = id & 15, tag = the id).  Results are unchanged by construction.
     __shared__ mail_t s_mailbox[16][TLG_BLOCK];
     // the planes of the three axes for the walk with its own records (k_tlg_trace_records; at most TLG_AXIS_MAX of them, else a.toprec is null)
     // (dynamic: its size is the grid's -- 16 bytes per plane; the launch passes it, so that small grids leave the LDS to more waves)
