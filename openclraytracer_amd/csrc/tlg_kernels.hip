@@ -622,8 +622,8 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
                     e2q = p[3].x;
                 } else {
-                    const f3 vert0 = f3_from4(a.v0[tri]);
-                    edge1 = f3_from4(a.e1[tri]); edge2 = f3_from4(a.e2[tri]);
+                    const f3 vert0 = f3_from4(FAST ? ld_off<float4>(a.v0, tri * 16u) : a.v0[tri]);
+                    edge1 = f3_from4(FAST ? ld_off<float4>(a.e1, tri * 16u) : a.e1[tri]); edge2 = f3_from4(FAST ? ld_off<float4>(a.e2, tri * 16u) : a.e2[tri]);
                     tvec = f3_sub(o, vert0);
                     qvec = f3_cross(tvec, edge1);
                     e2q = f3_dot(edge2, qvec);
