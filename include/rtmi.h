@@ -222,8 +222,9 @@ uint32_t rt_tlg_rebuilds_without_readback(const rt_tlg* tlg);
 /* test / inspection: 1 when this build's grid is walked with the walk's own records -- per top-level cell the resolution as floats, their
  * correctly rounded reciprocals and the first leaf index, per plane index of an axis { lo, hi, 1 / (hi - lo) } -- so that the six divisions of
  * every leaf-level DDA set-up (TwoLevelGrid.h:452-468) run as short multiply-add sequences that give the IEEE quotient bit for bit; 0 when the
- * grid does not qualify (box or plane spacing beyond 2^+-30 / 2^+-20, a leaf grid finer than 1023 cells per axis, more than 512 planes, env
- * RTMI_TLG_WALK_RECORDS=0) and it is walked with the reference's divisions.  Rays with a direction component outside [2^-20, 2^20] (zero
+ * grid does not qualify (box or plane spacing beyond 2^+-30 / 2^+-20, a leaf grid finer than 1023 cells per axis, more than 512 planes, a buffer
+ * of the walk of 4 GB or more, env RTMI_TLG_WALK_RECORDS=0) and it is walked with the reference's divisions.  With the records come a
+ * 16-byte record per leaf cell (entry count, the triangles of its first two entries, its first entry) and a DDA step by lane masks.  Rays with a direction component outside [2^-20, 2^20] (zero
  * included) or an origin beyond 2^30 take that walk in any case, wave by wave.  Same contacts either way.                                    */
 int  rt_tlg_walk_records(const rt_tlg* tlg);
 /* parity read-back of one build product into host memory (`bytes` must be its exact size, see rt_tlg_info) */
