@@ -37,6 +37,9 @@ def _soup(rng, n, kind):
     if kind == 'uniform':
         c = rng.uniform(-1, 1, size=(n, 1, 3))
         return (c + rng.normal(scale=0.08, size=(n, 3, 3))).astype(np.float32)
+    if kind in ('uniform_big', 'uniform_small'):             # the same soup at another scale (exact: a power of two): coordinates of 10^6 keep the grid walk's
+        scale = np.float32(2.0 ** 20 if kind == 'uniform_big' else 2.0 ** -20)     # own records, plane spacings below 2^-20 send it back to the reference's divisions
+        return _soup(rng, n, 'uniform') * scale
     if kind == 'clustered':                                  # many coincident centres: duplicate Morton codes in both trees
         centres = rng.uniform(-1, 1, size=(8, 3))
         c = centres[rng.integers(0, 8, size=n)][:, None, :]
@@ -99,7 +102,9 @@ def _cameras(orc, osc, res, rng, tris):
                                          # around the sizes at which construct() changes its path: refit by spans from 256 triangles, one-block sorts up to 4 096
                                          (13, 'uniform', 255), (14, 'clustered', 256), (15, 'uniform', 257), (16, 'uniform', 4096), (17, 'clustered', 4097), (18, 'degenerate', 5000),
                                          # boxes far from a cube: the allocation of the search tree's key bits (key_layout)
-                                         (19, 'slab', 700), (20, 'flat', 400), (21, 'line', 300)])
+                                         (19, 'slab', 700), (20, 'flat', 400), (21, 'line', 300),
+                                         # other scales: what qualifies for the grid walk's short divisions (rt_tlg_walk_records) and what does not
+                                         (22, 'uniform_big', 300), (23, 'uniform_small', 300)])
 def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
     import oracle as orc
     from openclraytracer_amd import capi
@@ -123,7 +128,8 @@ def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
         rays = np.zeros(m, dtype=orc.RAY)
         rays['idx'] = np.arange(m)
         lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
-        rays['origin'][:, :3] = rng.uniform(lo - 1.0, hi + 1.0, size=(m, 3)).astype(np.float32)
+        margin = 1.0 if kind not in ('uniform_big', 'uniform_small') else float((hi - lo).max()) * 0.5
+        rays['origin'][:, :3] = rng.uniform(lo - margin, hi + margin, size=(m, 3)).astype(np.float32)
         rays['origin'][::5, :3] = tris.reshape(-1, 3)[rng.integers(0, len(tris) * 3, size=len(rays[::5]))]   # origins ON vertices (box planes)
         dd = rng.normal(size=(m, 3)).astype(np.float32)
         dd /= np.linalg.norm(dd, axis=1, keepdims=True).astype(np.float32)
@@ -145,10 +151,17 @@ def test_random_scene_bvh_and_grid(gpu_ctx, tmp_path, seed, kind, n):
         else:
             gg = capi.DeviceTLG(gpu_ctx, sc).build()
             assert gg.read(gg.LEAF_PAIRS).tobytes() == og.leaf_pairs.tobytes()
+            if kind == 'uniform_big':
+                assert gg.walk_records()
+            if kind == 'uniform_small':
+                assert not gg.walk_records()
             for k, cam in enumerate(_cameras(orc, osc, res, rng, tris)):
                 want, _ = og.trace_primary(cam)
                 got = gg.generate_contacts_primary(as_capi_camera(cam))
                 assert got.tobytes() == want.tobytes(), ('grid', kind, seed, k)
+            # the same ray buffer through the grid (normalised, 1000 x and 0.001 x as long, zero components: waves of every mixture)
+            want, _ = og.trace_rays(rays)
+            assert gg.generate_contacts_rays(rays.view(capi.RAY)).tobytes() == want.tobytes(), ('grid rays', kind, seed)
             gg.close()
     finally:
         gb.close(); sc.close()
