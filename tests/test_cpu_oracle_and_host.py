@@ -379,7 +379,7 @@ def test_bench_summary_line_fits_a_stdout_tail():
     keeps, and its record of the run held no parsed line); the whole record goes to --details.  Checked on round 4's committed full
     record and on its in-process rehearsal of four ranks: contract keys, the two added objects, one figure per further leg."""
     import bench
-    for src, tiled in (('r04_bench_line.json', False), ('r04_bench_group4_rehearsal.json', True)):
+    for src, tiled in (('r04_bench_line.json', False), ('r04_bench_group4_rehearsal.json', True), ('r05_bench_details.json', False), ('r05_bench_group4_rehearsal.json', True)):
         full = json.loads(open(os.path.join(ROOT, 'profiles', src)).read())
         line = bench.compact_line(full, os.path.join(ROOT, 'gpurun_out', 'bench_details.json'))
         text = json.dumps(line)
