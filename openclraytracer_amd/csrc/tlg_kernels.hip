@@ -719,6 +719,10 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
 // with the axis as the index, 16-bit mailbox tags so that nine blocks fit a CU's LDS) 3.35-3.47; eight (spills) 3.77; fetching the next
 // top-level cell / the next leaf range before the current one is worked on 3.62 / 3.63 (the copies of the DDA state cost what the
 // overlap gains) -- only the next PAIR id is fetched early (3.56 -> 3.48).
+// Round 5: with the walk's own records the kernel needs 72 VGPRs and no spill in its loops: SEVEN waves per SIMD (the plane table is dynamic LDS
+// sized by the grid, so 16 KB of mailbox + ~4 KB of planes leave room for seven blocks per CU): 2.71 -> 2.62 ms then, 2.29 at the end of the
+// round; eight waves (64 VGPRs, scalar registers spilled into lanes) 2.43, six 2.50; 16-bit mailbox tags 2.26-2.28 (noise, and a limit on the
+// triangle count); the top-level step taken early with a warming fetch of the next cell's record 2.34.  DESIGN.md section 4.6.
 #ifndef TLG_WAVES
 #define TLG_WAVES 7
 #endif
