@@ -317,7 +317,7 @@ struct TlgTraceArgs {
 // overflow, underflow, zero divisors and non-numbers: a wave takes this walk only when all of its rays have |d| > 2^-40 on every axis
 // and moderate origins, and a grid only when its box and steps are moderate (host check) -- everything else walks as in round 4.  (Bounds: |o|, |lo|, |hi| <= 2^30, |d| and hi - lo in [2^-20, 2^20], res <= 1023.)
 // The records: per top-level cell { (float)res x3, firstLeafIdx, RN(1 / (float)res) x3, res packed 10:10:10 (0: empty cell) } and per
-// plane index of an axis { lo, hi, RN(1 / (hi - lo)) } exactly as the walk computes lo and hi (glo + (float)i * step, lo + step).
+// plane index of an axis { lo, hi, RN(1 / (hi - lo)), hi - lo } exactly as the walk computes lo and hi (glo + (float)i * step, lo + step).
 __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace_records(rt_grid_data g, const rt_top_cell* __restrict__ top, uint32_t cells,
                                                                  TlgTopRec* __restrict__ rec, float4* __restrict__ axis_tab, uint32_t* __restrict__ too_fine)
 {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_trace_records(rt_grid_data g,
         // (a divisor whose significand is all ones is the one case the proofs of the sequence exclude; a width that is no ordinary number
         //  anyway: the whole grid then walks as in round 4)
         if (!(w >= 0x1p-20f && w <= 0x1p20f) || (__float_as_uint(w) & 0x7FFFFFu) == 0x7FFFFFu || !(fabsf(lo) <= 0x1p30f) || !(fabsf(hi) <= 0x1p30f)) atomicOr(too_fine, 1u);
-        axis_tab[c] = make_float4(lo, hi, 1.0f / w, 0.0f);
+        axis_tab[c] = make_float4(lo, hi, 1.0f / w, w);
     }
     if (c >= cells) return;
     const rt_top_cell t = top[c];
@@ -370,11 +370,34 @@ void launch_tlg_trace_records(hipStream_t s, const rt_grid_data& g, const rt_top
 }
 
 // a load at a 32-bit byte offset from a buffer's base (the walk with its own records: every buffer it reads is below 4 GB, host check): the
-// base stays in scalar registers and the address costs the one multiply / shift of the offset instead of 64-bit vector arithmetic per load
-template <typename T> __device__ __forceinline__ T ld_off(const void* base, uint32_t byte_off)
-{
-    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
-}
+// base stays in scalar registers and the address costs the one multiply / shift of the offset instead of 64-bit vector arithmetic per load.
+// The load goes through the CONSTANT address space (nothing the walk reads is written during the launch): where the offset is the same in
+// every lane -- made so with v_readfirstlane after a ballot, see the packet walk below -- the compiler fetches through the scalar cache into
+// scalar registers (s_load), elsewhere it is the same global_load as before.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+template <typename T> struct LdOff {
+    static __device__ __forceinline__ T at(const void* base, uint32_t byte_off)
+    {
+        typedef const __attribute__((address_space(4))) T cT;
+        return *(cT*)((unsigned long long)base + byte_off);
+    }
+};
+template <> struct LdOff<float4> {
+    static __device__ __forceinline__ float4 at(const void* base, uint32_t byte_off)
+    {
+        const f4v v = LdOff<f4v>::at(base, byte_off);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+};
+template <> struct LdOff<uint4> {
+    static __device__ __forceinline__ uint4 at(const void* base, uint32_t byte_off)
+    {
+        const u4v v = LdOff<u4v>::at(base, byte_off);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+};
+template <typename T> __device__ __forceinline__ T ld_off(const void* base, uint32_t byte_off) { return LdOff<T>::at(base, byte_off); }
 
 // x / y given r = RN(1 / y), for operands as described above
 __device__ __forceinline__ float div_by(float x, float y, float r)
@@ -499,8 +522,8 @@ __device__ __forceinline__ void dda_axis_fast(float o, float d, float a, float4 
 }
 __device__ __forceinline__ void dda_finish_fast(float p, float d, float4 plane, int res, float fres, float rres, float tmin, float tmax, float& next, float& dt, int& idx)
 {
-    const float lo = plane.x, hi = plane.y;
-    float f = div_by((p - lo) * fres, hi - lo, plane.z);
+    const float lo = plane.x;
+    float f = div_by((p - lo) * fres, plane.w, plane.z);              // plane.w = hi - lo, the subtraction done once per plane
     const float top = fres - 1;
     f = __builtin_amdgcn_fmed3f(f, 0.0f, top);                       // min(max(f, 0), top) for a finite f and top >= 0 (a -0 gives cell 0 either way)
     idx = (int)f;
@@ -559,11 +582,89 @@ __device__ __forceinline__ bool dda_step_fast(Dda& s, int sx, int sy, int sz, ui
     return ((uint32_t)s.ix >= rx) | ((uint32_t)s.iy >= ry) | ((uint32_t)s.iz >= rz);
 }
 
+// ---- the packet walk (round 5, second part) -------------------------------------------------------------------------------------------
+// The 64 rays of a wave are an 8x8 pixel block, and what they meet they mostly meet TOGETHER: on config 4 the lanes still walking stand in ONE
+// top-level cell at 79 % of the wave's top-level steps, in one leaf cell at 83 % of its leaf steps, and 91 % of the leaf entries name the same
+// triangle in every lane (counted by the diag twin, -DRTMI_TLG_DIAG).  Where that holds the cell's record, its planes, the leaf cell's record
+// and the triangle come through the SCALAR cache into scalar registers -- no vector-memory instruction, no address arithmetic, no vector
+// registers for them -- and the lanes compute exactly what they computed before, on their own rays, with scalar operands.  A wave takes this
+// walk when all of its rays qualify for the short divisions (FAST) and have the same direction signs (then near / far plane, step[] and the
+// count of cells to the far side are scalar as well); where the lanes disagree about the cell the step runs as before.
+struct UniSigns { bool px, py, pz; };      // wave-uniform: d > 0 per axis
+
+// dda_setup_fast with every property of the CELL in scalar registers: planes { lo, hi, RN(1 / (hi - lo)), hi - lo }, (float)res, RN(1 / res), res.
+// Same operations on the same values, with three exceptions that give the same results: the near / far plane is chosen by the wave's sign
+// (a >= 0 iff d > 0 for the rays that come here); t0 is one v_min3 (operands finite: it differs from the reference's two selects in the sign
+// of a zero at most, which changes no cell: p = o + d * t0 enters only (p - lo) * res / (hi - lo), truncated and clamped to a cell index);
+// the clamp to [0, res - 1] is applied to the converted integer (v_cvt_i32_f32 truncates towards zero and saturates: the same cell for every finite f).
+__device__ __forceinline__ void dda_axis_uniform(float o, float d, float a, bool pos, float lo, float hi, float& tmin, float& tmax)
+{
+    // (selects on the bit patterns: an integer select of scalar values is s_cselect_b32, a float one becomes v_cndmask)
+    const float near = __uint_as_float(pos ? __float_as_uint(lo) : __float_as_uint(hi)), far = __uint_as_float(pos ? __float_as_uint(hi) : __float_as_uint(lo));
+    tmin = (near - o) * a;
+    tmax = (far - o) * a;
+}
+__device__ __forceinline__ void dda_finish_uniform(float p, bool pos, float lo, float rcp_w, float w, int res, float fres, float rres, float tmin, float tmax,
+                                                   float& next, float& dt, int& idx)
+{
+    const float f = div_by((p - lo) * fres, w, rcp_w);
+    // (the instructions themselves: v_cvt_i32_f32 saturates, where a C conversion out of range is undefined; res - 1 is scalar)
+    asm("v_cvt_i32_f32 %0, %1\n\tv_med3_i32 %0, %0, 0, %2" : "=&v"(idx) : "v"(f), "s"(res - 1));
+    dt = div_by_res(tmax - tmin, fres, rres);
+    // d > 0: idx + 1, else res - idx  =  (idx ^ m) + c with (m, c) = (0, 1) / (~0, res + 1): both scalar
+    const int m = pos ? 0 : -1, c = pos ? 1 : res + 1;
+    next = tmin + (float)((idx ^ m) + c) * dt;
+}
+__device__ __forceinline__ void dda_setup_uniform(f3 o, f3 d, f3 a, UniSigns g, float4 px, float4 py, float4 pz, float fx, float fy, float fz,
+                                                  float rx, float ry, float rz, int resx, int resy, int resz, Dda& s)
+{
+    float txmin, txmax, tymin, tymax, tzmin, tzmax;
+    dda_axis_uniform(o.x, d.x, a.x, g.px, px.x, px.y, txmin, txmax);
+    dda_axis_uniform(o.y, d.y, a.y, g.py, py.x, py.y, tymin, tymax);
+    dda_axis_uniform(o.z, d.z, a.z, g.pz, pz.x, pz.y, tzmin, tzmax);
+    s.t0 = __builtin_fminf(txmin, __builtin_fminf(tymin, tzmin));
+    s.tmaxmax = 0.0f;                                                // (read at the top level only)
+    const bool inside = (px.x <= o.x) && (o.x <= px.y) && (py.x <= o.y) && (o.y <= py.y) && (pz.x <= o.z) && (o.z <= pz.y);
+    f3 p = o;
+    if (!inside) p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
+    dda_finish_uniform(p.x, g.px, px.x, px.z, px.w, resx, fx, rx, txmin, txmax, s.nx, s.dtx, s.ix);
+    dda_finish_uniform(p.y, g.py, py.x, py.z, py.w, resy, fy, ry, tymin, tymax, s.ny, s.dty, s.iy);
+    dda_finish_uniform(p.z, g.pz, pz.x, pz.z, pz.w, resz, fz, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
+}
+// dda_step_fast with step[] in scalar registers
+__device__ __forceinline__ bool dda_step_uniform(Dda& s, int sx, int sy, int sz, uint32_t rx, uint32_t ry, uint32_t rz)
+{
+    unsigned long long t0, t1, t2, saved;
+    asm volatile("v_cmp_le_f32_e64 %[t0], %[nx], %[ny]\n\t"
+                 "v_cmp_le_f32_e64 %[t1], %[nx], %[nz]\n\t"
+                 "v_cmp_le_f32_e64 %[t2], %[ny], %[nz]\n\t"
+                 "s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 %[t0], %[t0], %[t1]\n\t"
+                 "s_andn2_b64 %[t1], %[t2], %[t0]\n\t"
+                 "s_or_b64 %[t2], %[t0], %[t1]\n\t"
+                 "s_andn2_b64 %[t2], %[sv], %[t2]\n\t"
+                 "s_mov_b64 exec, %[t0]\n\t"
+                 "v_add_f32 %[nx], %[nx], %[dx]\n\t"
+                 "v_add_u32 %[ix], %[sx], %[ix]\n\t"
+                 "s_mov_b64 exec, %[t1]\n\t"
+                 "v_add_f32 %[ny], %[ny], %[dy]\n\t"
+                 "v_add_u32 %[iy], %[sy], %[iy]\n\t"
+                 "s_mov_b64 exec, %[t2]\n\t"
+                 "v_add_f32 %[nz], %[nz], %[dz]\n\t"
+                 "v_add_u32 %[iz], %[sz], %[iz]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [nx] "+v"(s.nx), [ny] "+v"(s.ny), [nz] "+v"(s.nz), [ix] "+v"(s.ix), [iy] "+v"(s.iy), [iz] "+v"(s.iz),
+                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(saved)
+                 : [dx] "v"(s.dtx), [dy] "v"(s.dty), [dz] "v"(s.dtz), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz)
+                 : "scc");
+    return ((uint32_t)s.ix >= rx) | ((uint32_t)s.iy >= ry) | ((uint32_t)s.iz >= rz);
+}
+
 // The walk of one ray (tlg_generate_contact, TwoLevelGrid.h:548-678).  FAST: every ray of this wave and the grid qualify for the walk's own
 // records (see k_tlg_trace_records): the leaf-level set-up takes its cell from a 32-byte record and its planes from a table in LDS, divides by
 // the sequences above, and the triangle test takes 1 / det from v_rcp_f32 + one Newton step (equal to the IEEE quotient for every operand
 // between 2^-90 and 2^90, tools/micro/div_check.hip; |det| >= FLT_EPSILON is what the test asks for anyway).  Same values, fewer instructions.
-template <int PRIMARY, int FAST>
+template <int PRIMARY, int FAST>         // FAST = 2: the packet walk (FAST = 1 and the wave's rays have the same direction signs)
 __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, const f3 d, mail_t (*s_mailbox)[TLG_BLOCK], const float4* s_axis,
                                          float& best_t, uint32_t& best_tri)
 {
@@ -572,7 +673,18 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
 
     const DdaSigns sg = DdaSigns{ d.x > 0.0f, d.y > 0.0f, d.z > 0.0f };
     const int step_x = sg.px ? 1 : -1, step_y = sg.py ? 1 : -1, step_z = sg.pz ? 1 : -1;         // step[] of :470-490 / :610-630
+    // (FAST = 2: the same values, known to be the same in every lane)
+    const UniSigns us = UniSigns{ FAST == 2 && __builtin_amdgcn_readfirstlane((int)sg.px) != 0, FAST == 2 && __builtin_amdgcn_readfirstlane((int)sg.py) != 0,
+                                  FAST == 2 && __builtin_amdgcn_readfirstlane((int)sg.pz) != 0 };
+    const int ustep_x = us.px ? 1 : -1, ustep_y = us.py ? 1 : -1, ustep_z = us.pz ? 1 : -1;
     const f3 inv_d = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };          // (what dda_axis_setup divides per cell; the compiler hoists it there as well)
+#ifdef RTMI_TLG_DIAG
+    if (FAST) {       // (86) waves all of whose rays have the same direction signs; (88) all waves taking this walk
+        const unsigned long long ax = __ballot(sg.px), ay = __ballot(sg.py), az = __ballot(sg.pz), all = __ballot(1);
+        if ((ax == 0 || ax == all) && (ay == 0 || ay == all) && (az == 0 || az == all)) TLG_DIAG(86, 87);
+        TLG_DIAG(88, 89);
+    }
+#endif
     bool done;
     Dda T;
     dda_setup(o, d, glo, ghi, g.resX, g.resY, g.resZ, T);
@@ -583,6 +695,120 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         // (at most 512 planes with the walk's records: every top-level resolution is below 512)
         const uint32_t cell = FAST ? __umul24(__umul24((uint32_t)tiz, g.resY) + (uint32_t)tiy, g.resX) + (uint32_t)tix
                                    : (uint32_t)tiz * g.resX * g.resY + (uint32_t)tiy * g.resX + (uint32_t)tix;
+#ifdef RTMI_TLG_DIAG
+        if (FAST) {       // (80) top-level steps whose active lanes all stand in ONE cell; (82) ... with all 64 lanes still walking
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
+            if (__builtin_amdgcn_ballot_w64(cell != c0) == 0ull) { TLG_DIAG(80, 81); if (__popcll(__ballot(1)) == 64) TLG_DIAG(82, 83); }
+        }
+#endif
+        float cell_t = FLT_MAX;
+        uint32_t cell_tri = 0xFFFFFFFFu;
+        // one entry of a leaf cell: mailbox, then the triangle test.  (`tri` the same in every lane -- the packet walk's leaf cells -- : the
+        // triangle comes in scalar registers; the mailbox stays the lane's own, for what a lane tested before differs from lane to lane)
+        auto test_entry = [&](const uint32_t tri) __attribute__((always_inline)) {
+#ifdef RTMI_TLG_DIAG
+            if (FAST) { const uint32_t t0_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)tri); if (__builtin_amdgcn_ballot_w64(tri != t0_) == 0ull) TLG_DIAG(90, 91); TLG_DIAG(92, 93); }
+#endif
+            mail_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
+            const mail_t tag = (mail_t)tri;                   // (the whole id: no shift; an empty slot holds ~0, no triangle)
+            if (*slot == tag) return;                  // tested in an earlier cell: a miss, again
+            *slot = tag;
+            TLG_DIAG(8, 9);
+            // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
+            // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
+            f3 edge1, edge2, tvec, qvec;
+            float e2q;
+            if (PRIMARY && FAST && (FAST == 2 || a.tricam)) {          // (the packet walk of primary rays is launched with the records only)
+                const uint32_t at = tri * 64u;
+                const float4 w0 = ld_off<float4>(a.tricam, at), w1 = ld_off<float4>(a.tricam, at + 16u), w2 = ld_off<float4>(a.tricam, at + 32u);
+                edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
+                e2q = ld_off<float>(a.tricam, at + 48u);
+            } else if (PRIMARY && a.tricam) {
+                const float4* p = reinterpret_cast<const float4*>(a.tricam + tri);
+                const float4 w0 = p[0], w1 = p[1], w2 = p[2];
+                edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
+                e2q = p[3].x;
+            } else {
+                const f3 vert0 = f3_from4(FAST ? ld_off<float4>(a.v0, tri * 16u) : a.v0[tri]);
+                edge1 = f3_from4(FAST ? ld_off<float4>(a.e1, tri * 16u) : a.e1[tri]); edge2 = f3_from4(FAST ? ld_off<float4>(a.e2, tri * 16u) : a.e2[tri]);
+                tvec = f3_sub(o, vert0);
+                qvec = f3_cross(tvec, edge1);
+                e2q = f3_dot(edge2, qvec);
+            }
+            const f3 pvec = f3_cross(d, edge2);
+            const float det = f3_dot(edge1, pvec);
+            bool flag = fabsf(det) >= FLT_EPSILON;
+            const float inv_det = FAST ? rcp_near(det) : 1.0f / det;
+            const float u = f3_dot(tvec, pvec) * inv_det;
+            flag = flag & (u < 1.0f) & (u >= 0.0f);
+            const float v = f3_dot(d, qvec) * inv_det;
+            flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
+            const float t = e2q * inv_det;                         // "* flag" folded into the test
+            if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
+        };
+        // the entries of one leaf cell, from the walk's leaf-cell record
+        auto walk_leaf = [&](const uint32_t leaf) __attribute__((always_inline)) {
+            const uint4 lr = ld_off<uint4>(a.leafrec, leaf * 16u);
+            TLG_DIAG_HIST(lr.x);
+            uint32_t tri_next = lr.y;
+            for (uint32_t i = 0; i < lr.x; i++) {
+                TLG_DIAG(6, 7);
+                const uint32_t tri = tri_next;
+                // (entry 1 comes with the record; later ones are fetched one entry ahead, while this triangle is tested)
+                if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
+                test_entry(tri);
+            }
+        };
+        bool handled = false;
+        if (FAST == 2) {
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
+            if (__builtin_amdgcn_ballot_w64(cell != c0) == 0ull) {
+                // ---- every lane still walking stands in cell c0: its record and planes in scalar registers ----
+                handled = true;
+                const float4 r0 = ld_off<float4>(a.toprec, c0 * 32u), r1 = ld_off<float4>(a.toprec, c0 * 32u + 16u);
+                const uint32_t packed = __float_as_uint(r1.w), first_leaf = __float_as_uint(r0.w);
+                if (packed != 0u) {
+                    TLG_DIAG(2, 3);
+                    const uint32_t rx = packed & 1023u, ry = (packed >> 10) & 1023u, rz = packed >> 20;
+                    const bool one = packed == (1u | (1u << 10) | (1u << 20));          // a leaf grid of one cell: no DDA (see below)
+                    Dda Lf;
+                    Lf.ix = Lf.iy = Lf.iz = 0; Lf.nx = Lf.ny = Lf.nz = 0.0f; Lf.dtx = Lf.dty = Lf.dtz = 0.0f;
+                    if (!one) {
+                        const uint32_t ux = (uint32_t)__builtin_amdgcn_readfirstlane(tix), uy = (uint32_t)__builtin_amdgcn_readfirstlane(tiy),
+                                       uz = (uint32_t)__builtin_amdgcn_readfirstlane(tiz);
+                        const float4 px = ld_off<float4>(a.axis_tab, ux * 16u), py = ld_off<float4>(a.axis_tab, (g.resX + uy) * 16u),
+                                     pz = ld_off<float4>(a.axis_tab, (g.resX + g.resY + uz) * 16u);
+                        dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
+                    }
+                    for (;;) {
+                        TLG_DIAG(4, 5);
+                        const uint32_t leaf = __umul24(__umul24((uint32_t)Lf.iz, ry) + (uint32_t)Lf.iy, rx) + (uint32_t)Lf.ix + first_leaf;
+                        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
+                        if (__builtin_amdgcn_ballot_w64(leaf != l0) == 0ull) {
+                            // ---- ... and in ONE leaf cell: its record and, entry by entry, its triangles in scalar registers ----
+#ifdef RTMI_TLG_DIAG
+                            TLG_DIAG(84, 85);
+#endif
+                            const uint4 lr = ld_off<uint4>(a.leafrec, l0 * 16u);
+                            uint32_t tri_next = lr.y;
+                            for (uint32_t i = 0; i < lr.x; i++) {
+                                TLG_DIAG(6, 7);
+                                const uint32_t tri = tri_next;
+                                if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
+                                test_entry(tri);
+                            }
+                        } else {
+                            walk_leaf(leaf);
+                        }
+                        if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
+                        if (one) break;
+                        if (dda_step_uniform(Lf, ustep_x, ustep_y, ustep_z, rx, ry, rz)) break;   // :542-545
+                    }
+                    if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
+                }
+            }
+        }
+        if (!handled) {
         rt_top_cell tc;
         TlgTopRec rec;
         if (FAST) {
@@ -598,71 +824,17 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         }
         if (FAST ? rec.packed != 0u : !(tc.resX == 0 || tc.resY == 0 || tc.resZ == 0)) {
             TLG_DIAG(2, 3);
-            float cell_t = FLT_MAX;
-            uint32_t cell_tri = 0xFFFFFFFFu;
-            // one entry of a leaf cell: mailbox, then the triangle test
-            auto test_entry = [&](const uint32_t tri) {
-                mail_t* slot = &s_mailbox[tri & 15u][threadIdx.x];
-                const mail_t tag = (mail_t)tri;                   // (the whole id: no shift; an empty slot holds ~0, no triangle)
-                if (*slot == tag) return;                  // tested in an earlier cell: a miss, again
-                *slot = tag;
-                TLG_DIAG(8, 9);
-                // triangleIntersect, Triangle.h:66-107 (edges precomputed with the same subtractions); for primary rays also
-                // what depends on the origin and the triangle alone -- tvec, qvec, edge2 . qvec -- once per camera position
-                f3 edge1, edge2, tvec, qvec;
-                float e2q;
-                if (PRIMARY && a.tricam && FAST) {
-                    const uint32_t at = tri * 64u;
-                    const float4 w0 = ld_off<float4>(a.tricam, at), w1 = ld_off<float4>(a.tricam, at + 16u), w2 = ld_off<float4>(a.tricam, at + 32u);
-                    edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
-                    e2q = ld_off<float>(a.tricam, at + 48u);
-                } else if (PRIMARY && a.tricam) {
-                    const float4* p = reinterpret_cast<const float4*>(a.tricam + tri);
-                    const float4 w0 = p[0], w1 = p[1], w2 = p[2];
-                    edge1 = f3{ w0.x, w0.y, w0.z }; edge2 = f3{ w0.w, w1.x, w1.y }; tvec = f3{ w1.z, w1.w, w2.x }; qvec = f3{ w2.y, w2.z, w2.w };
-                    e2q = p[3].x;
-                } else {
-                    const f3 vert0 = f3_from4(FAST ? ld_off<float4>(a.v0, tri * 16u) : a.v0[tri]);
-                    edge1 = f3_from4(FAST ? ld_off<float4>(a.e1, tri * 16u) : a.e1[tri]); edge2 = f3_from4(FAST ? ld_off<float4>(a.e2, tri * 16u) : a.e2[tri]);
-                    tvec = f3_sub(o, vert0);
-                    qvec = f3_cross(tvec, edge1);
-                    e2q = f3_dot(edge2, qvec);
-                }
-                const f3 pvec = f3_cross(d, edge2);
-                const float det = f3_dot(edge1, pvec);
-                bool flag = fabsf(det) >= FLT_EPSILON;
-                const float inv_det = FAST ? rcp_near(det) : 1.0f / det;
-                const float u = f3_dot(tvec, pvec) * inv_det;
-                flag = flag & (u < 1.0f) & (u >= 0.0f);
-                const float v = f3_dot(d, qvec) * inv_det;
-                flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
-                const float t = e2q * inv_det;                         // "* flag" folded into the test
-                if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
-            };
-            // the entries of one leaf cell, from the walk's leaf-cell record
-            auto walk_leaf = [&](const uint32_t leaf) {
-                const uint4 lr = ld_off<uint4>(a.leafrec, leaf * 16u);
-                TLG_DIAG_HIST(lr.x);
-                uint32_t tri_next = lr.y;
-                for (uint32_t i = 0; i < lr.x; i++) {
-                    TLG_DIAG(6, 7);
-                    const uint32_t tri = tri_next;
-                    // (entry 1 comes with the record; later ones are fetched one entry ahead, while this triangle is tested)
-                    if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
-                    test_entry(tri);
-                }
-            };
             // A leaf grid of one cell needs no DDA: its cell is processed, and whichever axis the step would take leaves the grid (:542-545).  Taken
             // when every lane of the wave stands in such a top-level cell (11 % of the wave's top-level steps on config 4); a lane among others runs
             // through the general code below, to the same effect.
-            const bool one_cell = FAST && __builtin_amdgcn_ballot_w64(rec.packed != (1u | (1u << 10) | (1u << 20))) == 0ull;
+            const bool one_cell = FAST == 1 && __builtin_amdgcn_ballot_w64(rec.packed != (1u | (1u << 10) | (1u << 20))) == 0ull;
             if (one_cell) {
                 walk_leaf(rec.first_leaf);
             } else {
             // processTopLevelCell, TwoLevelGrid.h:419-545
             Dda Lf;
             if (FAST) {
-                const float4 px = s_axis[tix], py = s_axis[g.resX + (uint32_t)tiy], pz = s_axis[g.resX + g.resY + (uint32_t)tiz];     // { lo, hi, 1 / (hi - lo) }
+                const float4 px = s_axis[tix], py = s_axis[g.resX + (uint32_t)tiy], pz = s_axis[g.resX + g.resY + (uint32_t)tiz];     // { lo, hi, 1 / (hi - lo), hi - lo }
                 dda_setup_fast(o, d, inv_d, px, py, pz, rec, Lf);
             } else {
                 f3 clo, chi;
@@ -677,6 +849,12 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 const uint32_t leaf = FAST ? __umul24(__umul24((uint32_t)Lf.iz, tc.resY) + (uint32_t)Lf.iy, tc.resX) + (uint32_t)Lf.ix + tc.firstLeafIdx
                                            : (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
                 if (FAST) {
+#ifdef RTMI_TLG_DIAG
+                    {   // (84) leaf-level steps whose active lanes all stand in ONE leaf cell
+                        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
+                        if (__builtin_amdgcn_ballot_w64(leaf != l0) == 0ull) TLG_DIAG(84, 85);
+                    }
+#endif
                     walk_leaf(leaf);
                 } else {
                     const uint2 range = a.leaf_ranges[leaf];
@@ -691,7 +869,8 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     }
                 }
                 if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
-                if (FAST) { if (dda_step_fast(Lf, step_x, step_y, step_z, tc.resX, tc.resY, tc.resZ)) break; }
+                if (FAST == 2) { if (dda_step_uniform(Lf, ustep_x, ustep_y, ustep_z, tc.resX, tc.resY, tc.resZ)) break; }
+                else if (FAST) { if (dda_step_fast(Lf, step_x, step_y, step_z, tc.resX, tc.resY, tc.resZ)) break; }
                 else {
                     if (laxis < 0) break;
                     if (dda_advance(Lf, laxis, sg, tc.resX, tc.resY, tc.resZ)) break;   // :542-545
@@ -700,9 +879,11 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
             }
             if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
         }
+        }
         // :660-676 -- the axis of the smallest next[] (chosen before the cell is processed in the reference; nothing in between changes
         // next[]), `next[axis] += dt[axis]; idx[axis] += step[axis]; if (idx[axis] == stop[axis]) break`
-        if (FAST) { if (dda_step_fast(T, step_x, step_y, step_z, g.resX, g.resY, g.resZ)) break; }
+        if (FAST == 2) { if (dda_step_uniform(T, ustep_x, ustep_y, ustep_z, g.resX, g.resY, g.resZ)) break; }
+        else if (FAST) { if (dda_step_fast(T, step_x, step_y, step_z, g.resX, g.resY, g.resZ)) break; }
         else {
             const int taxis = dda_axis(T);
             if (taxis < 0) break;
@@ -780,7 +961,12 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     uint32_t best_tri = 0xFFFFFFFFu;
     // the walk with its own records where the whole wave qualifies (wave-uniform: one of the two instances runs)
     const bool ray_ok = a.toprec != nullptr && tlg_moderate(o.x, d.x) && tlg_moderate(o.y, d.y) && tlg_moderate(o.z, d.z);
-    if (__all(ray_ok)) tlg_walk<PRIMARY, 1>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
+    if (__all(ray_ok)) {
+        // ... and the packet walk where, besides, the wave's rays have the same direction signs (all but the blocks on the image's axes)
+        const unsigned long long every = __ballot(1), bx = __ballot(d.x > 0.0f), by = __ballot(d.y > 0.0f), bz = __ballot(d.z > 0.0f);
+        if ((bx == 0ull || bx == every) && (by == 0ull || by == every) && (bz == 0ull || bz == every) && (!PRIMARY || a.tricam != nullptr)) tlg_walk<PRIMARY, 2>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
+        else tlg_walk<PRIMARY, 1>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
+    }
     else tlg_walk<PRIMARY, 0>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
 
     float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -903,6 +1089,9 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
         for (int k = 0; k < 5; k++)
             fprintf(stderr, "tlg diag %-20s wave iterations %12llu  lane iterations %14llu  lanes per wave iteration %.1f\n", nm[k], h[2 * k], h[2 * k + 1],
                     h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
+        const char* nm2[7] = { "uniform top cell", "uniform top cell, 64 lanes", "uniform leaf cell", "sign-uniform waves", "waves", "uniform triangle entry", "entries" };
+        for (int k = 0; k < 7; k++)
+            fprintf(stderr, "tlg diag %-28s wave iterations %12llu  lane iterations %14llu\n", nm2[k], h[80 + 2 * k], h[81 + 2 * k]);
         fprintf(stderr, "tlg diag leaf range sizes (lane visits):");
         for (int k = 0; k < 64; k++) fprintf(stderr, " %llu", h[16 + k]);
         fprintf(stderr, "\n");
