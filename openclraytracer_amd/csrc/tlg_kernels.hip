@@ -590,46 +590,48 @@ __device__ __forceinline__ bool dda_step_fast(Dda& s, int sx, int sy, int sz, ui
 // registers for them -- and the lanes compute exactly what they computed before, on their own rays, with scalar operands.  A wave takes this
 // walk when all of its rays qualify for the short divisions (FAST) and have the same direction signs (then near / far plane, step[] and the
 // count of cells to the far side are scalar as well); where the lanes disagree about the cell the step runs as before.
-struct UniSigns { bool px, py, pz; };      // wave-uniform: d > 0 per axis
+struct UniSigns { int mx, my, mz; };      // wave-uniform, in scalar registers: 0 where d > 0 on the axis, ~0 where d < 0
 
 // dda_setup_fast with every property of the CELL in scalar registers: planes { lo, hi, RN(1 / (hi - lo)), hi - lo }, (float)res, RN(1 / res), res.
 // Same operations on the same values, with three exceptions that give the same results: the near / far plane is chosen by the wave's sign
 // (a >= 0 iff d > 0 for the rays that come here); t0 is one v_min3 (operands finite: it differs from the reference's two selects in the sign
 // of a zero at most, which changes no cell: p = o + d * t0 enters only (p - lo) * res / (hi - lo), truncated and clamped to a cell index);
 // the clamp to [0, res - 1] is applied to the converted integer (v_cvt_i32_f32 truncates towards zero and saturates: the same cell for every finite f).
-__device__ __forceinline__ void dda_axis_uniform(float o, float d, float a, bool pos, float lo, float hi, float& tmin, float& tmax)
+__device__ __forceinline__ void dda_axis_uniform(float o, float d, float a, int neg, float lo, float hi, float& tmin, float& tmax)
 {
-    // (selects on the bit patterns: an integer select of scalar values is s_cselect_b32, a float one becomes v_cndmask)
-    const float near = __uint_as_float(pos ? __float_as_uint(lo) : __float_as_uint(hi)), far = __uint_as_float(pos ? __float_as_uint(hi) : __float_as_uint(lo));
+    // near / far plane by the wave's sign: two scalar selects (written out: the compiler turns a select between two scalar floats into v_cndmask
+    // on copies of them)
+    float near, far;
+    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(near), "=&s"(far) : "s"(neg), "s"(lo), "s"(hi) : "scc");
     tmin = (near - o) * a;
     tmax = (far - o) * a;
 }
-__device__ __forceinline__ void dda_finish_uniform(float p, bool pos, float lo, float rcp_w, float w, int res, float fres, float rres, float tmin, float tmax,
+__device__ __forceinline__ void dda_finish_uniform(float p, int neg, float lo, float rcp_w, float w, int res, float fres, float rres, float tmin, float tmax,
                                                    float& next, float& dt, int& idx)
 {
     const float f = div_by((p - lo) * fres, w, rcp_w);
     // (the instructions themselves: v_cvt_i32_f32 saturates, where a C conversion out of range is undefined; res - 1 is scalar)
     asm("v_cvt_i32_f32 %0, %1\n\tv_med3_i32 %0, %0, 0, %2" : "=&v"(idx) : "v"(f), "s"(res - 1));
     dt = div_by_res(tmax - tmin, fres, rres);
-    // d > 0: idx + 1, else res - idx  =  (idx ^ m) + c with (m, c) = (0, 1) / (~0, res + 1): both scalar
-    const int m = pos ? 0 : -1, c = pos ? 1 : res + 1;
-    next = tmin + (float)((idx ^ m) + c) * dt;
+    // d > 0: idx + 1, else res - idx  =  (idx ^ neg) + c with c = 1 / res + 1: scalar
+    const int c = 1 + (res & neg);
+    next = tmin + (float)((idx ^ neg) + c) * dt;
 }
 __device__ __forceinline__ void dda_setup_uniform(f3 o, f3 d, f3 a, UniSigns g, float4 px, float4 py, float4 pz, float fx, float fy, float fz,
                                                   float rx, float ry, float rz, int resx, int resy, int resz, Dda& s)
 {
     float txmin, txmax, tymin, tymax, tzmin, tzmax;
-    dda_axis_uniform(o.x, d.x, a.x, g.px, px.x, px.y, txmin, txmax);
-    dda_axis_uniform(o.y, d.y, a.y, g.py, py.x, py.y, tymin, tymax);
-    dda_axis_uniform(o.z, d.z, a.z, g.pz, pz.x, pz.y, tzmin, tzmax);
+    dda_axis_uniform(o.x, d.x, a.x, g.mx, px.x, px.y, txmin, txmax);
+    dda_axis_uniform(o.y, d.y, a.y, g.my, py.x, py.y, tymin, tymax);
+    dda_axis_uniform(o.z, d.z, a.z, g.mz, pz.x, pz.y, tzmin, tzmax);
     s.t0 = __builtin_fminf(txmin, __builtin_fminf(tymin, tzmin));
     s.tmaxmax = 0.0f;                                                // (read at the top level only)
     const bool inside = (px.x <= o.x) && (o.x <= px.y) && (py.x <= o.y) && (o.y <= py.y) && (pz.x <= o.z) && (o.z <= pz.y);
     f3 p = o;
     if (!inside) p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
-    dda_finish_uniform(p.x, g.px, px.x, px.z, px.w, resx, fx, rx, txmin, txmax, s.nx, s.dtx, s.ix);
-    dda_finish_uniform(p.y, g.py, py.x, py.z, py.w, resy, fy, ry, tymin, tymax, s.ny, s.dty, s.iy);
-    dda_finish_uniform(p.z, g.pz, pz.x, pz.z, pz.w, resz, fz, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
+    dda_finish_uniform(p.x, g.mx, px.x, px.z, px.w, resx, fx, rx, txmin, txmax, s.nx, s.dtx, s.ix);
+    dda_finish_uniform(p.y, g.my, py.x, py.z, py.w, resy, fy, ry, tymin, tymax, s.ny, s.dty, s.iy);
+    dda_finish_uniform(p.z, g.mz, pz.x, pz.z, pz.w, resz, fz, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
 }
 // dda_step_fast with step[] in scalar registers
 __device__ __forceinline__ bool dda_step_uniform(Dda& s, int sx, int sy, int sz, uint32_t rx, uint32_t ry, uint32_t rz)
@@ -674,9 +676,16 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
     const DdaSigns sg = DdaSigns{ d.x > 0.0f, d.y > 0.0f, d.z > 0.0f };
     const int step_x = sg.px ? 1 : -1, step_y = sg.py ? 1 : -1, step_z = sg.pz ? 1 : -1;         // step[] of :470-490 / :610-630
     // (FAST = 2: the same values, known to be the same in every lane)
-    const UniSigns us = UniSigns{ FAST == 2 && __builtin_amdgcn_readfirstlane((int)sg.px) != 0, FAST == 2 && __builtin_amdgcn_readfirstlane((int)sg.py) != 0,
-                                  FAST == 2 && __builtin_amdgcn_readfirstlane((int)sg.pz) != 0 };
-    const int ustep_x = us.px ? 1 : -1, ustep_y = us.py ? 1 : -1, ustep_z = us.pz ? 1 : -1;
+    // (from the ballots: every lane of such a wave has the same sign, so "no lane has d > 0" is the sign.  Written out: left to the compiler the
+    //  0 / ~0 of a scalar condition is made by v_cndmask in a vector register, and an "s" operand of the blocks of assembly below receives that)
+    UniSigns us = UniSigns{ 0, 0, 0 };
+    if (FAST == 2) {
+        const unsigned long long bx = __builtin_amdgcn_ballot_w64(sg.px), by = __builtin_amdgcn_ballot_w64(sg.py), bz = __builtin_amdgcn_ballot_w64(sg.pz);
+        asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(us.mx) : "s"(bx) : "scc");
+        asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(us.my) : "s"(by) : "scc");
+        asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(us.mz) : "s"(bz) : "scc");
+    }
+    const int ustep_x = 1 | us.mx, ustep_y = 1 | us.my, ustep_z = 1 | us.mz;          // 1 / -1
     const f3 inv_d = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };          // (what dda_axis_setup divides per cell; the compiler hoists it there as well)
 #ifdef RTMI_TLG_DIAG
     if (FAST) {       // (86) waves all of whose rays have the same direction signs; (88) all waves taking this walk
@@ -765,7 +774,15 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
             if (__builtin_amdgcn_ballot_w64(cell != c0) == 0ull) {
                 // ---- every lane still walking stands in cell c0: its record and planes in scalar registers ----
                 handled = true;
+                // (record and planes requested together, before the cell is known to be non-empty and to need a set-up -- nearly every cell a ray meets
+                //  does: otherwise three trips through the scalar cache in a row per cell)
+                const uint32_t ux = (uint32_t)__builtin_amdgcn_readfirstlane(tix), uy = (uint32_t)__builtin_amdgcn_readfirstlane(tiy),
+                               uz = (uint32_t)__builtin_amdgcn_readfirstlane(tiz);
                 const float4 r0 = ld_off<float4>(a.toprec, c0 * 32u), r1 = ld_off<float4>(a.toprec, c0 * 32u + 16u);
+                const float4 px = ld_off<float4>(a.axis_tab, ux * 16u), py = ld_off<float4>(a.axis_tab, (g.resX + uy) * 16u),
+                       pz = ld_off<float4>(a.axis_tab, (g.resX + g.resY + uz) * 16u);
+                // (read-only operands: the values have to be there, no copies made)
+                asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(px.x), "s"(px.w), "s"(py.x), "s"(py.w), "s"(pz.x), "s"(pz.w));
                 const uint32_t packed = __float_as_uint(r1.w), first_leaf = __float_as_uint(r0.w);
                 if (packed != 0u) {
                     TLG_DIAG(2, 3);
@@ -773,13 +790,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     const bool one = packed == (1u | (1u << 10) | (1u << 20));          // a leaf grid of one cell: no DDA (see below)
                     Dda Lf;
                     Lf.ix = Lf.iy = Lf.iz = 0; Lf.nx = Lf.ny = Lf.nz = 0.0f; Lf.dtx = Lf.dty = Lf.dtz = 0.0f;
-                    if (!one) {
-                        const uint32_t ux = (uint32_t)__builtin_amdgcn_readfirstlane(tix), uy = (uint32_t)__builtin_amdgcn_readfirstlane(tiy),
-                                       uz = (uint32_t)__builtin_amdgcn_readfirstlane(tiz);
-                        const float4 px = ld_off<float4>(a.axis_tab, ux * 16u), py = ld_off<float4>(a.axis_tab, (g.resX + uy) * 16u),
-                                     pz = ld_off<float4>(a.axis_tab, (g.resX + g.resY + uz) * 16u);
-                        dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
-                    }
+                    if (!one) dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
                     for (;;) {
                         TLG_DIAG(4, 5);
                         const uint32_t leaf = __umul24(__umul24((uint32_t)Lf.iz, ry) + (uint32_t)Lf.iy, rx) + (uint32_t)Lf.ix + first_leaf;
@@ -907,6 +918,14 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
 #ifndef TLG_WAVES
 #define TLG_WAVES 7
 #endif
+// the kernel's (only) argument read from the kernel-argument segment at the point of use (an opaque pointer: the loads can neither be merged
+// with the ones at the kernel's start nor be moved up)
+__device__ __forceinline__ const TlgTraceArgs* tlg_args_again()
+{
+    const TlgTraceArgs* p = (const TlgTraceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; kernel arguments again" : "+s"(p));
+    return p;
+}
 template <int PRIMARY>
 __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_WAVES, TLG_WAVES))) void k_tlg_trace(TlgTraceArgs a)
 {
@@ -969,22 +988,28 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     }
     else tlg_walk<PRIMARY, 0>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
 
+    // (what the store needs of the arguments -- camera, tiles, output, normals -- is read again from the kernel-argument segment here: kept in
+    //  scalar registers through the walk it costs the walk's own scalar values their registers)
+    const TlgTraceArgs& A = *tlg_args_again();
     float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t material = 0;
     if (best_tri != 0xFFFFFFFFu) {
-        const float4 n = a.nrm[best_tri];
+        const float4 n = A.nrm[best_tri];
         nt = make_float4(n.x, n.y, n.z, best_t);
-        material = __float_as_uint(a.v0[best_tri].w);
+        material = __float_as_uint(A.v0[best_tri].w);
     }
     uint32_t pixel = w, out_index = w;
     if (PRIMARY) {
-        uint32_t x, y, slot;
-        locate(x, y, slot);
-        pixel = y * a.cam.resX + x;
-        out_index = a.compact ? slot : pixel;
+        const uint32_t ordinal = w >> 12, within = w & 4095u;
+        const uint32_t tile = rt_tile_of(A.rank, ordinal, A.nranks);
+        const uint32_t ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+        const uint32_t blk = within >> 6, lp = within & 63u;
+        const uint32_t ly = ((blk >> 3) << 3) + (lp >> 3), lx = ((blk & 7u) << 3) + (lp & 7u);
+        pixel = (ty * RT_TILE + ly) * A.cam.resX + tx * RT_TILE + lx;
+        out_index = A.compact ? (ordinal << 12) + ly * RT_TILE + lx : pixel;
     }
     const uint4 head = make_uint4(pixel, material, 0u, 0u);
-    float4* dst = reinterpret_cast<float4*>(a.out + out_index);
+    float4* dst = reinterpret_cast<float4*>(A.out + out_index);
     store16_stream(dst, *reinterpret_cast<const float4*>(&head));
     store16_stream(dst + 1, nt);
 }
