@@ -34,9 +34,9 @@ static void free_tlg_buffers(rt_tlg* g)
 {
     void** ptrs[] = { (void**)&g->d_counters, (void**)&g->d_scan, (void**)&g->d_scan_scratch, (void**)&g->d_cell_ranges, (void**)&g->d_top,
                       (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written, (void**)&g->d_tricam,
-                      (void**)&g->d_toprec, (void**)&g->d_axis_tab, (void**)&g->d_leafrec };
+                      (void**)&g->d_toprec, (void**)&g->d_axis_tab, (void**)&g->d_leafrec, (void**)&g->d_axis_cam };
     for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false; g->axis_cap = 0; g->leafrec_cap = 0; g->walk_records = false;
+    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false; g->axis_cap = 0; g->leafrec_cap = 0; g->walk_records = false; g->axis_cam_cap = 0;
 }
 
 void rt_tlg_destroy(rt_tlg* g)
@@ -363,6 +363,18 @@ static void use_camera_triangles(rt_tlg* g, const rt_camera* cam, TlgLaunch& t)
     if (!g->d_tricam) {
         if (hipMalloc((void**)&g->d_tricam, (size_t)g->n * sizeof(TriCam)) != hipSuccess) { (void)hipGetLastError(); g->d_tricam = nullptr; return; }
         g->tricam_n = g->n; g->tricam_valid = false;
+    }
+    // ... and the planes of the walk's records relative to the camera (same launch, same validity)
+    if (g->walk_records) {
+        const uint32_t planes = g->grid.resX + g->grid.resY + g->grid.resZ;
+        if (planes > g->axis_cam_cap) {
+            (void)hipStreamSynchronize(g->ctx->stream);
+            if (g->d_axis_cam) { (void)hipFree(g->d_axis_cam); g->d_axis_cam = nullptr; }
+            g->axis_cam_cap = 0; g->tricam_valid = false;
+            if (hipMalloc((void**)&g->d_axis_cam, (size_t)planes * sizeof(TlgCamPlane)) != hipSuccess) { (void)hipGetLastError(); g->d_axis_cam = nullptr; }
+            else g->axis_cam_cap = planes;
+        }
+        t.axis_cam = g->d_axis_cam;
     }
     const float o[3] = { cam->viewTransform[3], cam->viewTransform[7], cam->viewTransform[11] };
     t.tricam = g->d_tricam;

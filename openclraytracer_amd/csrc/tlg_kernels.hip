@@ -299,6 +299,7 @@ struct TlgTraceArgs {
     const TlgTopRec* __restrict__ toprec;   // the walk's own records of the top-level cells and planes (null: the walk of round 4)
     const float4* __restrict__ axis_tab;    // resX + resY + resZ entries { lo, hi, RN(1 / (hi - lo)), 0 }
     const uint4* __restrict__ leafrec;      // per leaf cell { entries, triangle of entry 0, of entry 1, first entry in leaf_pairs }
+    const TlgCamPlane* __restrict__ axis_cam;   // primary rays: the planes relative to the camera position (null: axis_tab)
     uint32_t total_work;
     rt_camera cam;
     uint32_t rank, nranks, tiles_x, compact;
@@ -633,6 +634,32 @@ __device__ __forceinline__ void dda_setup_uniform(f3 o, f3 d, f3 a, UniSigns g, 
     dda_finish_uniform(p.y, g.my, py.x, py.z, py.w, resy, fy, ry, tymin, tymax, s.ny, s.dty, s.iy);
     dda_finish_uniform(p.z, g.mz, pz.x, pz.z, pz.w, resz, fz, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
 }
+// ... and for primary rays with the planes relative to the camera (TlgCamPlane): (near - o) and (far - o) come from the table -- the same
+// subtractions, done once per camera position -- and `inside` is the AND of three flags: scalar, so p = o + d * t0 is computed where it is used
+__device__ __forceinline__ void dda_setup_uniform_cam(f3 o, f3 d, f3 a, UniSigns g, const TlgCamPlane& cx, const TlgCamPlane& cy, const TlgCamPlane& cz,
+                                                      float fx, float fy, float fz, float rx, float ry, float rz, int resx, int resy, int resz, Dda& s)
+{
+    float nx, fxo, ny, fyo, nz, fzo;
+    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(nx), "=&s"(fxo) : "s"(g.mx), "s"(cx.lo_o), "s"(cx.hi_o) : "scc");
+    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(ny), "=&s"(fyo) : "s"(g.my), "s"(cy.lo_o), "s"(cy.hi_o) : "scc");
+    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(nz), "=&s"(fzo) : "s"(g.mz), "s"(cz.lo_o), "s"(cz.hi_o) : "scc");
+    const float txmin = nx * a.x, txmax = fxo * a.x, tymin = ny * a.y, tymax = fyo * a.y, tzmin = nz * a.z, tzmax = fzo * a.z;
+    s.t0 = __builtin_fminf(txmin, __builtin_fminf(tymin, tzmin));
+    s.tmaxmax = 0.0f;
+    f3 p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
+    // (a scalar condition, true in one cell per camera: a branch -- the empty statement keeps the compiler from turning it into three selects)
+    if ((cx.inside & cy.inside & cz.inside) != 0u) { asm volatile("; origin inside this cell"); p = o; }
+    dda_finish_uniform(p.x, g.mx, cx.lo, cx.rcp_w, cx.w, resx, fx, rx, txmin, txmax, s.nx, s.dtx, s.ix);
+    dda_finish_uniform(p.y, g.my, cy.lo, cy.rcp_w, cy.w, resy, fy, ry, tymin, tymax, s.ny, s.dty, s.iy);
+    dda_finish_uniform(p.z, g.mz, cz.lo, cz.rcp_w, cz.w, resz, fz, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
+}
+__device__ __forceinline__ TlgCamPlane ld_cam_plane(const TlgCamPlane* tab, uint32_t i)
+{
+    const f4v a = LdOff<f4v>::at(tab, i * 32u), b = LdOff<f4v>::at(tab, i * 32u + 16u);
+    TlgCamPlane c;
+    c.lo = a.x; c.rcp_w = a.y; c.w = a.z; c.lo_o = a.w; c.hi_o = b.x; c.inside = __float_as_uint(b.y); c.hi = b.z; c.pad = 0u;
+    return c;
+}
 // dda_step_fast with step[] in scalar registers
 __device__ __forceinline__ bool dda_step_uniform(Dda& s, int sx, int sy, int sz, uint32_t rx, uint32_t ry, uint32_t rz)
 {
@@ -779,10 +806,16 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 const uint32_t ux = (uint32_t)__builtin_amdgcn_readfirstlane(tix), uy = (uint32_t)__builtin_amdgcn_readfirstlane(tiy),
                                uz = (uint32_t)__builtin_amdgcn_readfirstlane(tiz);
                 const float4 r0 = ld_off<float4>(a.toprec, c0 * 32u), r1 = ld_off<float4>(a.toprec, c0 * 32u + 16u);
-                const float4 px = ld_off<float4>(a.axis_tab, ux * 16u), py = ld_off<float4>(a.axis_tab, (g.resX + uy) * 16u),
-                       pz = ld_off<float4>(a.axis_tab, (g.resX + g.resY + uz) * 16u);
-                // (read-only operands: the values have to be there, no copies made)
-                asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(px.x), "s"(px.w), "s"(py.x), "s"(py.w), "s"(pz.x), "s"(pz.w));
+                float4 px, py, pz;
+                TlgCamPlane cx, cy, cz;
+                if (PRIMARY) {
+                    cx = ld_cam_plane(a.axis_cam, ux); cy = ld_cam_plane(a.axis_cam, g.resX + uy); cz = ld_cam_plane(a.axis_cam, g.resX + g.resY + uz);
+                    // (read-only operands: the values have to be there, no copies made)
+                    asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(cx.lo), "s"(cx.hi_o), "s"(cy.lo), "s"(cy.hi_o), "s"(cz.lo), "s"(cz.hi_o));
+                } else {
+                    px = ld_off<float4>(a.axis_tab, ux * 16u); py = ld_off<float4>(a.axis_tab, (g.resX + uy) * 16u); pz = ld_off<float4>(a.axis_tab, (g.resX + g.resY + uz) * 16u);
+                    asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(px.x), "s"(px.w), "s"(py.x), "s"(py.w), "s"(pz.x), "s"(pz.w));
+                }
                 const uint32_t packed = __float_as_uint(r1.w), first_leaf = __float_as_uint(r0.w);
                 if (packed != 0u) {
                     TLG_DIAG(2, 3);
@@ -790,7 +823,10 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     const bool one = packed == (1u | (1u << 10) | (1u << 20));          // a leaf grid of one cell: no DDA (see below)
                     Dda Lf;
                     Lf.ix = Lf.iy = Lf.iz = 0; Lf.nx = Lf.ny = Lf.nz = 0.0f; Lf.dtx = Lf.dty = Lf.dtz = 0.0f;
-                    if (!one) dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
+                    if (!one) {
+                        if (PRIMARY) dda_setup_uniform_cam(o, d, inv_d, us, cx, cy, cz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
+                        else dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
+                    }
                     for (;;) {
                         TLG_DIAG(4, 5);
                         const uint32_t leaf = __umul24(__umul24((uint32_t)Lf.iz, ry) + (uint32_t)Lf.iy, rx) + (uint32_t)Lf.ix + first_leaf;
@@ -983,7 +1019,7 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     if (__all(ray_ok)) {
         // ... and the packet walk where, besides, the wave's rays have the same direction signs (all but the blocks on the image's axes)
         const unsigned long long every = __ballot(1), bx = __ballot(d.x > 0.0f), by = __ballot(d.y > 0.0f), bz = __ballot(d.z > 0.0f);
-        if ((bx == 0ull || bx == every) && (by == 0ull || by == every) && (bz == 0ull || bz == every) && (!PRIMARY || a.tricam != nullptr)) tlg_walk<PRIMARY, 2>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
+        if ((bx == 0ull || bx == every) && (by == 0ull || by == every) && (bz == 0ull || bz == every) && (!PRIMARY || (a.tricam != nullptr && a.axis_cam != nullptr))) tlg_walk<PRIMARY, 2>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
         else tlg_walk<PRIMARY, 1>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
     }
     else tlg_walk<PRIMARY, 0>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
@@ -1060,9 +1096,21 @@ void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pai
 // the camera-relative triangle records (TriCam) from the scene's table: the operations of the test above that involve the origin
 // and the triangle only, in its order
 __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_prepare_triangles(const float4* __restrict__ v0, const float4* __restrict__ e1, const float4* __restrict__ e2,
-                                                                     TriCam* __restrict__ out, uint32_t n, float ox, float oy, float oz)
+                                                                     TriCam* __restrict__ out, uint32_t n, float ox, float oy, float oz,
+                                                                     const float4* __restrict__ axis_tab, TlgCamPlane* __restrict__ axis_cam, uint32_t res_x, uint32_t res_y, uint32_t planes)
 {
     const uint32_t i = blockIdx.x * TLG_BLOCK + threadIdx.x;
+    // the planes relative to this origin (the packet walk): near - o / far - o of dda_axis_setup and the operands of `inside` (dda_setup), once per camera
+    if (axis_cam && i < planes) {
+        const float4 pl = axis_tab[i];
+        const float o = i < res_x ? ox : (i < res_x + res_y ? oy : oz);
+        TlgCamPlane c;
+        c.lo = pl.x; c.hi = pl.y; c.rcp_w = pl.z; c.w = pl.w;
+        c.lo_o = pl.x - o; c.hi_o = pl.y - o;
+        c.inside = (pl.x <= o) && (o <= pl.y) ? 1u : 0u;
+        c.pad = 0u;
+        axis_cam[i] = c;
+    }
     if (i >= n) return;
     const f3 vert0 = f3_from4(v0[i]), edge1 = f3_from4(e1[i]), edge2 = f3_from4(e2[i]);
     const f3 tvec = f3_sub(f3{ ox, oy, oz }, vert0);
@@ -1097,9 +1145,13 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
     a.total_work = rt_owned_tiles(tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.out = out;
     a.tricam = t.tricam;
+    const uint32_t planes = t.grid.resX + t.grid.resY + t.grid.resZ;
+    const bool cam_planes = t.tricam && t.axis_cam && t.axis_tab && t.toprec;
+    a.axis_cam = cam_planes ? t.axis_cam : nullptr;
     if (t.tricam && t.prepare_tricam && t.scene->n_tris)
-        hipLaunchKernelGGL(k_tlg_prepare_triangles, blocks_for(t.scene->n_tris), dim3(TLG_BLOCK), 0, s, t.scene->v0, t.scene->e1, t.scene->e2,
-                           const_cast<TriCam*>(t.tricam), t.scene->n_tris, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11]);
+        hipLaunchKernelGGL(k_tlg_prepare_triangles, blocks_for(t.scene->n_tris > planes ? t.scene->n_tris : planes), dim3(TLG_BLOCK), 0, s, t.scene->v0, t.scene->e1, t.scene->e2,
+                           const_cast<TriCam*>(t.tricam), t.scene->n_tris, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11],
+                           t.axis_tab, cam_planes ? t.axis_cam : nullptr, t.grid.resX, t.grid.resY, planes);
 #ifdef RTMI_TLG_DIAG
     static unsigned long long zero[96] = { 0 };
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tlg_diag), zero, sizeof zero, 0, hipMemcpyHostToDevice, s);
