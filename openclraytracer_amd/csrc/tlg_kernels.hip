@@ -400,6 +400,11 @@ template <> struct LdOff<uint4> {
 };
 template <typename T> __device__ __forceinline__ T ld_off(const void* base, uint32_t byte_off) { return LdOff<T>::at(base, byte_off); }
 
+// a * b + c on 24-bit a, b (cell indices and resolutions of the walk with its records: below 2^10 / 2^24).  Written out: the compiler, knowing
+// nothing of the operands' ranges, turns one of each pair of __umul24 + add into v_mad_u64_u32.  _s: b in a scalar register.
+__device__ __forceinline__ uint32_t mad24_s(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t mad24_v(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // x / y given r = RN(1 / y), for operands as described above
 __device__ __forceinline__ float div_by(float x, float y, float r)
 {
@@ -538,8 +543,10 @@ __device__ __forceinline__ void dda_setup_fast(f3 o, f3 d, f3 a, float4 px, floa
     dda_axis_fast(o.x, d.x, a.x, px, r.fres[0], r.rcp[0], txmin, txmax);
     dda_axis_fast(o.y, d.y, a.y, py, r.fres[1], r.rcp[1], tymin, tymax);
     dda_axis_fast(o.z, d.z, a.z, pz, r.fres[2], r.rcp[2], tzmin, tzmax);
-    s.t0 = RMIN(txmin, RMIN(tymin, tzmin));
-    s.tmaxmax = RMAX(txmax, RMAX(tymax, tzmax));
+    // (one v_min3: the operands are finite, so it differs from the reference's two selects in the sign of a zero at most, which changes no cell --
+    //  p = o + d * t0 enters only (p - lo) * res / (hi - lo), truncated and clamped to a cell index; tmaxmax is read at the top level only)
+    s.t0 = __builtin_fminf(txmin, __builtin_fminf(tymin, tzmin));
+    s.tmaxmax = 0.0f;
     const bool inside = (px.x <= o.x) && (o.x <= px.y) && (py.x <= o.y) && (o.y <= py.y) && (pz.x <= o.z) && (o.z <= pz.y);
     f3 p = o;
     if (!inside) p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
@@ -655,9 +662,11 @@ __device__ __forceinline__ void dda_setup_uniform_cam(f3 o, f3 d, f3 a, UniSigns
 }
 __device__ __forceinline__ TlgCamPlane ld_cam_plane(const TlgCamPlane* tab, uint32_t i)
 {
-    const f4v a = LdOff<f4v>::at(tab, i * 32u), b = LdOff<f4v>::at(tab, i * 32u + 16u);
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f4v a = LdOff<f4v>::at(tab, i * 32u);
+    const f2v b = LdOff<f2v>::at(tab, i * 32u + 16u);             // (hi is not read by the set-up: six words per plane)
     TlgCamPlane c;
-    c.lo = a.x; c.rcp_w = a.y; c.w = a.z; c.lo_o = a.w; c.hi_o = b.x; c.inside = __float_as_uint(b.y); c.hi = b.z; c.pad = 0u;
+    c.lo = a.x; c.rcp_w = a.y; c.w = a.z; c.lo_o = a.w; c.hi_o = b.x; c.inside = __float_as_uint(b.y); c.hi = 0.0f; c.pad = 0u;
     return c;
 }
 // dda_step_fast with step[] in scalar registers
@@ -729,7 +738,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         TLG_DIAG(0, 1);
         const int tix = T.ix, tiy = T.iy, tiz = T.iz;
         // (at most 512 planes with the walk's records: every top-level resolution is below 512)
-        const uint32_t cell = FAST ? __umul24(__umul24((uint32_t)tiz, g.resY) + (uint32_t)tiy, g.resX) + (uint32_t)tix
+        const uint32_t cell = FAST ? mad24_s(mad24_s((uint32_t)tiz, g.resY, (uint32_t)tiy), g.resX, (uint32_t)tix)
                                    : (uint32_t)tiz * g.resX * g.resY + (uint32_t)tiy * g.resX + (uint32_t)tix;
 #ifdef RTMI_TLG_DIAG
         if (FAST) {       // (80) top-level steps whose active lanes all stand in ONE cell; (82) ... with all 64 lanes still walking
@@ -829,7 +838,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     }
                     for (;;) {
                         TLG_DIAG(4, 5);
-                        const uint32_t leaf = __umul24(__umul24((uint32_t)Lf.iz, ry) + (uint32_t)Lf.iy, rx) + (uint32_t)Lf.ix + first_leaf;
+                        const uint32_t leaf = mad24_s(mad24_s((uint32_t)Lf.iz, ry, (uint32_t)Lf.iy), rx, (uint32_t)Lf.ix) + first_leaf;
                         const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
                         if (__builtin_amdgcn_ballot_w64(leaf != l0) == 0ull) {
                             // ---- ... and in ONE leaf cell: its record and, entry by entry, its triangles in scalar registers ----
@@ -893,7 +902,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 TLG_DIAG(4, 5);
                 const int laxis = FAST ? 0 : dda_axis(Lf);
                 // (with the walk's records every leaf resolution is below 1024 and every index below it: the same sum by 24-bit multiply-adds)
-                const uint32_t leaf = FAST ? __umul24(__umul24((uint32_t)Lf.iz, tc.resY) + (uint32_t)Lf.iy, tc.resX) + (uint32_t)Lf.ix + tc.firstLeafIdx
+                const uint32_t leaf = FAST ? mad24_v(mad24_v((uint32_t)Lf.iz, tc.resY, (uint32_t)Lf.iy), tc.resX, (uint32_t)Lf.ix) + tc.firstLeafIdx
                                            : (uint32_t)Lf.iz * tc.resX * tc.resY + (uint32_t)Lf.iy * tc.resX + (uint32_t)Lf.ix + tc.firstLeafIdx;
                 if (FAST) {
 #ifdef RTMI_TLG_DIAG
