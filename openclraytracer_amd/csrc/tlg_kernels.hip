@@ -9,6 +9,7 @@
 #include "device_math.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "tlg_math.h"
 
 #define TLG_BLOCK 256
@@ -698,6 +699,38 @@ __device__ __forceinline__ bool dda_step_uniform(Dda& s, int sx, int sy, int sz,
     return ((uint32_t)s.ix >= rx) | ((uint32_t)s.iy >= ry) | ((uint32_t)s.iz >= rz);
 }
 
+// The end of triangleIntersect + :528 -- `flag` and the update of the cell's closest hit -- as a chain of v_cmpx: every compare narrows exec to the
+// lanes that passed so far, the update is two moves under what is left.  The same seven ordered compares as the C expression
+//   |det| >= FLT_EPSILON & u < 1 & u >= 0 & u + v <= 1 & v >= 0 & t > 0 & t < cell_t
+// without the six scalar ANDs of their lane masks and the selects (this kernel's time follows the number of instructions it issues, scalar ones
+// included).  _s: the triangle id in a scalar register (the packet walk's leaf cells).
+#define TLG_ACCEPT_ASM(TRI_CONSTRAINT)                                                                                                          \
+    unsigned long long saved;                                                                                                                   \
+    asm volatile("s_mov_b64 %[sv], exec\n\t"                                                                                                     \
+                 "v_cmpx_ge_f32_e64 vcc, |%[det]|, %[eps]\n\t"                                                                                   \
+                 "v_cmpx_gt_f32_e32 vcc, 1.0, %[u]\n\t"                                                                                          \
+                 "v_cmpx_le_f32_e32 vcc, 0, %[u]\n\t"                                                                                            \
+                 "v_cmpx_ge_f32_e32 vcc, 1.0, %[uv]\n\t"                                                                                         \
+                 "v_cmpx_le_f32_e32 vcc, 0, %[v]\n\t"                                                                                            \
+                 "v_cmpx_lt_f32_e32 vcc, 0, %[t]\n\t"                                                                                            \
+                 "v_cmpx_gt_f32_e32 vcc, %[ct], %[t]\n\t"                                                                                        \
+                 "v_mov_b32 %[ct], %[t]\n\t"                                                                                                     \
+                 "v_mov_b32 %[ctri], %[tri]\n\t"                                                                                                 \
+                 "s_mov_b64 exec, %[sv]"                                                                                                          \
+                 : [ct] "+v"(cell_t), [ctri] "+v"(cell_tri), [sv] "=&s"(saved)                                                                    \
+                 : [det] "v"(det), [eps] "s"(eps), [u] "v"(u), [uv] "v"(uv), [v] "v"(v), [t] "v"(t), [tri] TRI_CONSTRAINT(tri)                    \
+                 : "vcc")
+__device__ __forceinline__ void tlg_accept_s(float det, float u, float v, float t, uint32_t tri, float& cell_t, uint32_t& cell_tri)
+{
+    const float eps = FLT_EPSILON, uv = u + v;
+    TLG_ACCEPT_ASM("s");
+}
+__device__ __forceinline__ void tlg_accept_v(float det, float u, float v, float t, uint32_t tri, float& cell_t, uint32_t& cell_tri)
+{
+    const float eps = FLT_EPSILON, uv = u + v;
+    TLG_ACCEPT_ASM("v");
+}
+
 // The walk of one ray (tlg_generate_contact, TwoLevelGrid.h:548-678).  FAST: every ray of this wave and the grid qualify for the walk's own
 // records (see k_tlg_trace_records): the leaf-level set-up takes its cell from a 32-byte record and its planes from a table in LDS, divides by
 // the sequences above, and the triangle test takes 1 / det from v_rcp_f32 + one Newton step (equal to the IEEE quotient for every operand
@@ -750,7 +783,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         uint32_t cell_tri = 0xFFFFFFFFu;
         // one entry of a leaf cell: mailbox, then the triangle test.  (`tri` the same in every lane -- the packet walk's leaf cells -- : the
         // triangle comes in scalar registers; the mailbox stays the lane's own, for what a lane tested before differs from lane to lane)
-        auto test_entry = [&](const uint32_t tri) __attribute__((always_inline)) {
+        auto test_entry = [&](const uint32_t tri, auto tri_is_scalar) __attribute__((always_inline)) {
 #ifdef RTMI_TLG_DIAG
             if (FAST) { const uint32_t t0_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)tri); if (__builtin_amdgcn_ballot_w64(tri != t0_) == 0ull) TLG_DIAG(90, 91); TLG_DIAG(92, 93); }
 #endif
@@ -782,14 +815,20 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
             }
             const f3 pvec = f3_cross(d, edge2);
             const float det = f3_dot(edge1, pvec);
-            bool flag = fabsf(det) >= FLT_EPSILON;
             const float inv_det = FAST ? rcp_near(det) : 1.0f / det;
             const float u = f3_dot(tvec, pvec) * inv_det;
-            flag = flag & (u < 1.0f) & (u >= 0.0f);
             const float v = f3_dot(d, qvec) * inv_det;
-            flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
             const float t = e2q * inv_det;                         // "* flag" folded into the test
-            if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
+            if (FAST) {
+                // flag = |det| >= FLT_EPSILON & u < 1 & u >= 0 & u + v <= 1 & v >= 0; if (flag & t > 0 & t < cell_t) { cell_t = t; cell_tri = tri; }   (:528)
+                if (decltype(tri_is_scalar)::value) tlg_accept_s(det, u, v, t, tri, cell_t, cell_tri);
+                else tlg_accept_v(det, u, v, t, tri, cell_t, cell_tri);
+            } else {
+                bool flag = fabsf(det) >= FLT_EPSILON;
+                flag = flag & (u < 1.0f) & (u >= 0.0f);
+                flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);
+                if (flag & (t > 0.0f) & (t < cell_t)) { cell_t = t; cell_tri = tri; }   // :528
+            }
         };
         // the entries of one leaf cell, from the walk's leaf-cell record
         auto walk_leaf = [&](const uint32_t leaf) __attribute__((always_inline)) {
@@ -801,7 +840,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 const uint32_t tri = tri_next;
                 // (entry 1 comes with the record; later ones are fetched one entry ahead, while this triangle is tested)
                 if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
-                test_entry(tri);
+                test_entry(tri, std::false_type());
             }
         };
         bool handled = false;
@@ -851,7 +890,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                                 TLG_DIAG(6, 7);
                                 const uint32_t tri = tri_next;
                                 if (i + 1u < lr.x) tri_next = i == 0u ? lr.z : ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 12u);
-                                test_entry(tri);
+                                test_entry(tri, std::true_type());
                             }
                         } else {
                             walk_leaf(leaf);
@@ -921,7 +960,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                         TLG_DIAG(6, 7);
                         const uint32_t tri = tri_next;
                         if (i + 1u < range.y) tri_next = a.leaf_pairs[i + 1u].y;
-                        test_entry(tri);
+                        test_entry(tri, std::false_type());
                     }
                 }
                 if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
