@@ -173,8 +173,8 @@ static bool enqueue_walk_records(rt_tlg* g)
     if (g->leafrec_cap != g->leaf_ranges_cap || !g->d_leafrec) {
         (void)hipStreamSynchronize(g->ctx->stream);
         if (g->d_leafrec) { (void)hipFree(g->d_leafrec); g->d_leafrec = nullptr; g->leafrec_cap = 0; }
-        if ((uint64_t)g->leaf_ranges_cap * sizeof(uint4) >= (1ull << 32)) return false;
-        if (hipMalloc((void**)&g->d_leafrec, (size_t)g->leaf_ranges_cap * sizeof(uint4)) != hipSuccess) { (void)hipGetLastError(); g->d_leafrec = nullptr; return false; }
+        if ((uint64_t)g->leaf_ranges_cap * 2u * sizeof(uint4) >= (1ull << 32)) return false;
+        if (hipMalloc((void**)&g->d_leafrec, (size_t)g->leaf_ranges_cap * 2u * sizeof(uint4)) != hipSuccess) { (void)hipGetLastError(); g->d_leafrec = nullptr; return false; }
         g->leafrec_cap = g->leaf_ranges_cap;
     }
     launch_tlg_leaf_records(g->ctx->stream, g->d_leaf_ranges, g->d_leaf_pairs, g->leaf_ranges_cap, g->leaf_cap, g->d_leafrec);
