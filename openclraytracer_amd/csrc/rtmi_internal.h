@@ -261,7 +261,8 @@ struct TlgTopRec { float fres[3]; uint32_t first_leaf; float rcp[3]; uint32_t pa
 // per plane index of an axis and camera position (tlg_kernels.hip, the packet walk of primary rays): what the leaf-level set-up takes from a
 // top-level cell's planes, with the subtractions of the origin done once per camera -- lo - o and hi - o as the walk computes them -- and
 // whether lo <= o <= hi (the walk's "origin inside the cell" is the AND of the three axes' flags)
-struct TlgCamPlane { float lo, rcp_w, w, lo_o, hi_o; uint32_t inside; float hi; uint32_t pad; };
+// (near - o, far - o) of a wave with direction sign s on the axis are the two words at byte 16 + 4 * s: { lo - o, hi - o } for d > 0, { hi - o, lo - o } for d < 0
+struct TlgCamPlane { float lo, rcp_w, w; uint32_t inside; float lo_o, hi_o, lo_o_again; uint32_t pad; };
 static_assert(sizeof(TlgCamPlane) == 32, "TlgCamPlane");
 static_assert(sizeof(TlgTopRec) == 32, "TlgTopRec");
 struct rt_tlg {
@@ -295,8 +296,6 @@ struct rt_tlg {
     float tricam_origin[3] = { 0, 0, 0 };
     bool tricam_valid = false;
     uint32_t tricam_n = 0;              // records d_tricam holds
-    TlgCamPlane* d_axis_cam = nullptr;  // the planes relative to the current camera position (packet walk of primary rays), axis_cam_cap of them
-    uint32_t axis_cam_cap = 0;
     bool frame_initialised = false;
     bool built = false;
 };
@@ -498,7 +497,9 @@ struct TlgLaunch {
     const TlgTopRec* toprec;   // the walk's records (null: none, the walk of round 4)
     const float4* axis_tab;
     const uint4* leafrec;
-    TlgCamPlane* axis_cam;     // primary rays with the records: the planes relative to the camera position, (re)computed with tricam
+    TlgCamPlane* axis_cam;     // primary rays with the records: the planes relative to the camera position, (re)computed with tricam; they live behind
+                               // the cell records in toprec's buffer (one base pointer for both in the walk), at byte cam_off
+    uint32_t cam_off;
 };
 void launch_tlg_leaf_records(hipStream_t s, const uint2* leaf_ranges, const uint2* leaf_pairs, uint32_t leaf_cells, uint32_t pairs_cap, uint4* rec);
 void launch_tlg_trace_records(hipStream_t s, const rt_grid_data& g, const rt_top_cell* top, uint32_t cells, TlgTopRec* rec, float4* axis_tab, uint32_t* too_fine);

@@ -30,13 +30,15 @@ int rt_tlg_create(rt_ctx* ctx, const rt_scene* scene, rt_tlg** out)
     return RT_SUCCESS;
 }
 
+#define TLG_AXIS_MAX_HOST 512u            // = TLG_AXIS_MAX of tlg_kernels.hip: planes the trace kernel's LDS table holds
+static_assert(sizeof(TlgCamPlane) == sizeof(TlgTopRec), "the camera planes live behind the cell records");
 static void free_tlg_buffers(rt_tlg* g)
 {
     void** ptrs[] = { (void**)&g->d_counters, (void**)&g->d_scan, (void**)&g->d_scan_scratch, (void**)&g->d_cell_ranges, (void**)&g->d_top,
                       (void**)&g->d_pairs, (void**)&g->d_leaf_pairs, (void**)&g->d_leaf_ranges, (void**)&g->d_written, (void**)&g->d_tricam,
-                      (void**)&g->d_toprec, (void**)&g->d_axis_tab, (void**)&g->d_leafrec, (void**)&g->d_axis_cam };
+                      (void**)&g->d_toprec, (void**)&g->d_axis_tab, (void**)&g->d_leafrec };
     for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false; g->axis_cap = 0; g->leafrec_cap = 0; g->walk_records = false; g->axis_cam_cap = 0;
+    g->counters_cap = 0; g->pairs_cap = 0; g->leaf_cap = 0; g->leaf_ranges_cap = 0; g->tricam_valid = false; g->axis_cap = 0; g->leafrec_cap = 0; g->walk_records = false;
 }
 
 void rt_tlg_destroy(rt_tlg* g)
@@ -127,7 +129,7 @@ int rt_tlg_initialize_frame(rt_tlg* g)
         // the walk's own records of the cells (tlg_kernels.hip, k_tlg_trace_records): without them (allocation failed, knob RTMI_TLG_WALK_RECORDS=0,
         // more planes than the kernel's table holds) the grid is walked as in round 4
         if (g->d_toprec) { (void)hipFree(g->d_toprec); g->d_toprec = nullptr; }
-        if (!ctx->tlg_no_walk_records && hipMalloc((void**)&g->d_toprec, (size_t)cells * sizeof(TlgTopRec)) != hipSuccess) { (void)hipGetLastError(); g->d_toprec = nullptr; }
+        if (!ctx->tlg_no_walk_records && hipMalloc((void**)&g->d_toprec, ((size_t)cells + TLG_AXIS_MAX_HOST) * sizeof(TlgTopRec)) != hipSuccess) { (void)hipGetLastError(); g->d_toprec = nullptr; }
     }
     {
         const uint32_t planes = g->grid.resX + g->grid.resY + g->grid.resZ;
@@ -159,13 +161,12 @@ static int read_word(rt_ctx* ctx, const uint32_t* d_src, uint32_t* out)
 
 // The last launch of a build: the walk's records from the finished top-level cells (flag word d_written[8]: a plane or a leaf grid outside
 // the bounds of the short division sequences).  false: no records for this build.
-#define TLG_AXIS_MAX_HOST 512u            // = TLG_AXIS_MAX of tlg_kernels.hip: planes the trace kernel's LDS table holds
 static bool enqueue_walk_records(rt_tlg* g)
 {
     const uint32_t planes = g->grid.resX + g->grid.resY + g->grid.resZ;
     if (!g->d_toprec || !g->d_axis_tab || planes > g->axis_cap || planes > TLG_AXIS_MAX_HOST) return false;
     // (the walk with the records addresses its buffers by 32-bit byte offsets: each of them below 4 GB)
-    if ((uint64_t)g->info.cells * sizeof(TlgTopRec) >= (1ull << 32) || (uint64_t)g->leaf_ranges_cap * sizeof(uint2) >= (1ull << 32) ||
+    if (((uint64_t)g->info.cells + TLG_AXIS_MAX_HOST) * sizeof(TlgTopRec) >= (1ull << 32) || (uint64_t)g->leaf_ranges_cap * sizeof(uint2) >= (1ull << 32) ||
         (uint64_t)g->leaf_cap * sizeof(uint2) >= (1ull << 32) || (uint64_t)g->n * sizeof(TriCam) >= (1ull << 32)) return false;
     const float* lo = g->grid.box_lo; const float* hi = g->grid.box_hi;
     for (int k = 0; k < 3; k++) if (!(std::fabs(lo[k]) <= 0x1p30f) || !(std::fabs(hi[k]) <= 0x1p30f)) return false;
@@ -364,17 +365,10 @@ static void use_camera_triangles(rt_tlg* g, const rt_camera* cam, TlgLaunch& t)
         if (hipMalloc((void**)&g->d_tricam, (size_t)g->n * sizeof(TriCam)) != hipSuccess) { (void)hipGetLastError(); g->d_tricam = nullptr; return; }
         g->tricam_n = g->n; g->tricam_valid = false;
     }
-    // ... and the planes of the walk's records relative to the camera (same launch, same validity)
+    // ... and the planes of the walk's records relative to the camera (same launch, same validity): TLG_AXIS_MAX_HOST records behind the cells'
     if (g->walk_records) {
-        const uint32_t planes = g->grid.resX + g->grid.resY + g->grid.resZ;
-        if (planes > g->axis_cam_cap) {
-            (void)hipStreamSynchronize(g->ctx->stream);
-            if (g->d_axis_cam) { (void)hipFree(g->d_axis_cam); g->d_axis_cam = nullptr; }
-            g->axis_cam_cap = 0; g->tricam_valid = false;
-            if (hipMalloc((void**)&g->d_axis_cam, (size_t)planes * sizeof(TlgCamPlane)) != hipSuccess) { (void)hipGetLastError(); g->d_axis_cam = nullptr; }
-            else g->axis_cam_cap = planes;
-        }
-        t.axis_cam = g->d_axis_cam;
+        t.axis_cam = reinterpret_cast<TlgCamPlane*>(g->d_toprec + g->info.cells);
+        t.cam_off = g->info.cells * (uint32_t)sizeof(TlgTopRec);
     }
     const float o[3] = { cam->viewTransform[3], cam->viewTransform[7], cam->viewTransform[11] };
     t.tricam = g->d_tricam;

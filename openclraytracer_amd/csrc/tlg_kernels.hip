@@ -300,7 +300,7 @@ struct TlgTraceArgs {
     const TlgTopRec* __restrict__ toprec;   // the walk's own records of the top-level cells and planes (null: the walk of round 4)
     const float4* __restrict__ axis_tab;    // resX + resY + resZ entries { lo, hi, RN(1 / (hi - lo)), 0 }
     const uint4* __restrict__ leafrec;      // per leaf cell, 32 bytes: { entries, triangle of entry 0, of entry 1, first entry in leaf_pairs } { triangles of entries 2 .. 5 }
-    const TlgCamPlane* __restrict__ axis_cam;   // primary rays: the planes relative to the camera position (null: axis_tab)
+    uint32_t cam_off;                       // primary rays: the planes relative to the camera position (TlgCamPlane) at this byte offset of toprec's buffer (0: none)
     uint32_t total_work;
     rt_camera cam;
     uint32_t rank, nranks, tiles_x, compact;
@@ -653,14 +653,19 @@ __device__ __forceinline__ void dda_setup_uniform(f3 o, f3 d, f3 a, UniSigns g, 
 }
 // ... and for primary rays with the planes relative to the camera (TlgCamPlane): (near - o) and (far - o) come from the table -- the same
 // subtractions, done once per camera position -- and `inside` is the AND of three flags: scalar, so p = o + d * t0 is computed where it is used
-__device__ __forceinline__ void dda_setup_uniform_cam(f3 o, f3 d, f3 a, UniSigns g, const TlgCamPlane& cx, const TlgCamPlane& cy, const TlgCamPlane& cz,
+// what the set-up reads of a camera plane: { lo, rcp_w, w, inside } and (near - o, far - o) -- the two words at 16 + 4 * (d < 0)
+struct CamPlaneS { float lo, rcp_w, w; uint32_t inside; float near_o, far_o; };
+__device__ __forceinline__ CamPlaneS ld_cam_plane(const void* base, uint32_t byte_off, int neg)
+{
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f4v a = LdOff<f4v>::at(base, byte_off);
+    const f2v b = LdOff<f2v>::at(base, byte_off + 16u + ((uint32_t)neg & 4u));
+    return CamPlaneS{ a.x, a.y, a.z, __float_as_uint(a.w), b.x, b.y };
+}
+__device__ __forceinline__ void dda_setup_uniform_cam(f3 o, f3 d, f3 a, UniSigns g, const CamPlaneS& cx, const CamPlaneS& cy, const CamPlaneS& cz,
                                                       float fx, float fy, float fz, float rx, float ry, float rz, int resx, int resy, int resz, Dda& s)
 {
-    float nx, fxo, ny, fyo, nz, fzo;
-    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(nx), "=&s"(fxo) : "s"(g.mx), "s"(cx.lo_o), "s"(cx.hi_o) : "scc");
-    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(ny), "=&s"(fyo) : "s"(g.my), "s"(cy.lo_o), "s"(cy.hi_o) : "scc");
-    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(nz), "=&s"(fzo) : "s"(g.mz), "s"(cz.lo_o), "s"(cz.hi_o) : "scc");
-    const float txmin = nx * a.x, txmax = fxo * a.x, tymin = ny * a.y, tymax = fyo * a.y, tzmin = nz * a.z, tzmax = fzo * a.z;
+    const float txmin = cx.near_o * a.x, txmax = cx.far_o * a.x, tymin = cy.near_o * a.y, tymax = cy.far_o * a.y, tzmin = cz.near_o * a.z, tzmax = cz.far_o * a.z;
     s.t0 = __builtin_fminf(txmin, __builtin_fminf(tymin, tzmin));
     s.tmaxmax = 0.0f;
     f3 p = f3{ o.x + d.x * s.t0, o.y + d.y * s.t0, o.z + d.z * s.t0 };
@@ -669,15 +674,6 @@ __device__ __forceinline__ void dda_setup_uniform_cam(f3 o, f3 d, f3 a, UniSigns
     dda_finish_uniform(p.x, g.mx, cx.lo, cx.rcp_w, cx.w, resx, fx, rx, txmin, txmax, s.nx, s.dtx, s.ix);
     dda_finish_uniform(p.y, g.my, cy.lo, cy.rcp_w, cy.w, resy, fy, ry, tymin, tymax, s.ny, s.dty, s.iy);
     dda_finish_uniform(p.z, g.mz, cz.lo, cz.rcp_w, cz.w, resz, fz, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
-}
-__device__ __forceinline__ TlgCamPlane ld_cam_plane(const TlgCamPlane* tab, uint32_t i)
-{
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    const f4v a = LdOff<f4v>::at(tab, i * 32u);
-    const f2v b = LdOff<f2v>::at(tab, i * 32u + 16u);             // (hi is not read by the set-up: six words per plane)
-    TlgCamPlane c;
-    c.lo = a.x; c.rcp_w = a.y; c.w = a.z; c.lo_o = a.w; c.hi_o = b.x; c.inside = __float_as_uint(b.y); c.hi = 0.0f; c.pad = 0u;
-    return c;
 }
 // dda_step_fast with step[] in scalar registers
 __device__ __forceinline__ bool dda_step_uniform(Dda& s, int sx, int sy, int sz, uint32_t rx, uint32_t ry, uint32_t rz)
@@ -852,23 +848,22 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 test_entry(tri, std::false_type());
             }
         };
-        bool handled = false;
-        if (FAST == 2) {
-            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
-            if (__builtin_amdgcn_ballot_w64(cell != c0) == 0ull) {
+        const uint32_t c0 = FAST == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cell) : 0u;
+        if (FAST == 2 && __builtin_amdgcn_ballot_w64(cell != c0) == 0ull) {
+            {
                 // ---- every lane still walking stands in cell c0: its record and planes in scalar registers ----
-                handled = true;
                 // (record and planes requested together, before the cell is known to be non-empty and to need a set-up -- nearly every cell a ray meets
                 //  does: otherwise three trips through the scalar cache in a row per cell)
                 const uint32_t ux = (uint32_t)__builtin_amdgcn_readfirstlane(tix), uy = (uint32_t)__builtin_amdgcn_readfirstlane(tiy),
                                uz = (uint32_t)__builtin_amdgcn_readfirstlane(tiz);
                 const float4 r0 = ld_off<float4>(a.toprec, c0 * 32u), r1 = ld_off<float4>(a.toprec, c0 * 32u + 16u);
                 float4 px, py, pz;
-                TlgCamPlane cx, cy, cz;
+                CamPlaneS cx, cy, cz;
                 if (PRIMARY) {
-                    cx = ld_cam_plane(a.axis_cam, ux); cy = ld_cam_plane(a.axis_cam, g.resX + uy); cz = ld_cam_plane(a.axis_cam, g.resX + g.resY + uz);
+                    cx = ld_cam_plane(a.toprec, a.cam_off + ux * 32u, us.mx); cy = ld_cam_plane(a.toprec, a.cam_off + (g.resX + uy) * 32u, us.my);
+                    cz = ld_cam_plane(a.toprec, a.cam_off + (g.resX + g.resY + uz) * 32u, us.mz);
                     // (read-only operands: the values have to be there, no copies made)
-                    asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(cx.lo), "s"(cx.hi_o), "s"(cy.lo), "s"(cy.hi_o), "s"(cz.lo), "s"(cz.hi_o));
+                    asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(cx.lo), "s"(cx.far_o), "s"(cy.lo), "s"(cy.far_o), "s"(cz.lo), "s"(cz.far_o));
                 } else {
                     px = ld_off<float4>(a.axis_tab, ux * 16u); py = ld_off<float4>(a.axis_tab, (g.resX + uy) * 16u); pz = ld_off<float4>(a.axis_tab, (g.resX + g.resY + uz) * 16u);
                     asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(px.x), "s"(px.w), "s"(py.x), "s"(py.w), "s"(pz.x), "s"(pz.w));
@@ -914,7 +909,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 }
             }
         }
-        if (!handled) {
+        else {
         rt_top_cell tc;
         TlgTopRec rec;
         if (FAST) {
@@ -1078,7 +1073,7 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     if (__all(ray_ok)) {
         // ... and the packet walk where, besides, the wave's rays have the same direction signs (all but the blocks on the image's axes)
         const unsigned long long every = __ballot(1), bx = __ballot(d.x > 0.0f), by = __ballot(d.y > 0.0f), bz = __ballot(d.z > 0.0f);
-        if ((bx == 0ull || bx == every) && (by == 0ull || by == every) && (bz == 0ull || bz == every) && (!PRIMARY || (a.tricam != nullptr && a.axis_cam != nullptr))) tlg_walk<PRIMARY, 2>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
+        if ((bx == 0ull || bx == every) && (by == 0ull || by == every) && (bz == 0ull || bz == every) && (!PRIMARY || (a.tricam != nullptr && a.cam_off != 0u))) tlg_walk<PRIMARY, 2>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
         else tlg_walk<PRIMARY, 1>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
     }
     else tlg_walk<PRIMARY, 0>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
@@ -1164,8 +1159,8 @@ __global__ __launch_bounds__(TLG_BLOCK) void k_tlg_prepare_triangles(const float
         const float4 pl = axis_tab[i];
         const float o = i < res_x ? ox : (i < res_x + res_y ? oy : oz);
         TlgCamPlane c;
-        c.lo = pl.x; c.hi = pl.y; c.rcp_w = pl.z; c.w = pl.w;
-        c.lo_o = pl.x - o; c.hi_o = pl.y - o;
+        c.lo = pl.x; c.rcp_w = pl.z; c.w = pl.w;
+        c.lo_o = pl.x - o; c.hi_o = pl.y - o; c.lo_o_again = c.lo_o;
         c.inside = (pl.x <= o) && (o <= pl.y) ? 1u : 0u;
         c.pad = 0u;
         axis_cam[i] = c;
@@ -1206,7 +1201,7 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
     a.tricam = t.tricam;
     const uint32_t planes = t.grid.resX + t.grid.resY + t.grid.resZ;
     const bool cam_planes = t.tricam && t.axis_cam && t.axis_tab && t.toprec;
-    a.axis_cam = cam_planes ? t.axis_cam : nullptr;
+    a.cam_off = cam_planes ? t.cam_off : 0u;
     if (t.tricam && t.prepare_tricam && t.scene->n_tris)
         hipLaunchKernelGGL(k_tlg_prepare_triangles, blocks_for(t.scene->n_tris > planes ? t.scene->n_tris : planes), dim3(TLG_BLOCK), 0, s, t.scene->v0, t.scene->e1, t.scene->e2,
                            const_cast<TriCam*>(t.tricam), t.scene->n_tris, cam.viewTransform[3], cam.viewTransform[7], cam.viewTransform[11],
