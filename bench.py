@@ -1240,15 +1240,24 @@ def main():
                 g4.build()
             xctx.synchronize()
             build4 = (time.perf_counter() - t1) * 1e3 / 3
-            g4.generate_contacts_primary_d(cam4, d_c); xctx.synchronize()
+            for _ in range(3):                          # (warm: camera-relative records written, clocks up)
+                g4.generate_frame_d(cam4, d_c, d_o)
+            xctx.synchronize()
+            tmx.start()
+            for _ in range(20):
+                g4.generate_frame_d(cam4, d_c, d_o)     # rt_tlg_generate_frame: the trace kernel shades what it stores, as the BVH's captured frames do
+            tmx.stop()
+            ms4 = tmx.elapsed_ms() / 20
             tmx.start()
             for _ in range(5):
                 g4.generate_contacts_primary_d(cam4, d_c)
                 capi.shade_blinn_phong_frame_d(xctx, s4, cam4, d_c, d_o)
             tmx.stop()
-            ms4 = tmx.elapsed_ms() / 5
+            ms4_two = tmx.elapsed_ms() / 5
+            g4.generate_frame_d(cam4, d_c, d_o)         # (the frame that is verified below: the fused one)
             config4 = dict(workload='Sponza-class stand-in (assets/synth, %d triangles) x 1920x1080 primary rays, Two-Level Grid (densities 2.0 / 2.0) build + trace + shade' % s4.n_tris,
                            build_ms=round(build4, 3), trace_plus_shade_ms=round(ms4, 4), mrays_per_s_grid_kept=round(npx / ms4 / 1e3, 1),
+                           trace_then_shade_two_launches_ms=round(ms4_two, 4),
                            mrays_per_s_rebuilt_every_frame=round(npx / (ms4 + build4) / 1e3, 1), grid=g4.info())
             if verified is not None and fx5 is not None and 'tlg' in fx5[key]:
                 xctx.synchronize()

@@ -212,6 +212,11 @@ int  rt_tlg_initialize_frame(rt_tlg* tlg);                                  /* i
 int  rt_tlg_construct(rt_tlg* tlg);                                         /* construct(), :207-469 */
 int  rt_tlg_generate_contacts_primary(rt_tlg* tlg, const rt_camera* cam, void* d_contacts);          /* generateContacts(Camera&), :475-513 */
 int  rt_tlg_generate_contacts_rays(rt_tlg* tlg, const void* d_rays, uint32_t ray_count, void* d_contacts);  /* generateContacts(CLBuffer&, CLBuffer&, n), :525-551 */
+/* One frame of the Demo's loop for the grid in ONE launch: generateContacts(Camera&) (:475-513) and, for every pixel, cpuShadeBlinnPhong
+ * (OpenCLRayTracerDemo.cpp:298-316, Shading.h:74-166) of the contact just found -- the trace kernel shades what it stores, as the BVH's captured
+ * frames do.  d_contacts as rt_tlg_generate_contacts_primary fills it, d_rgba as rt_shade_blinn_phong_frame fills it (float4 per pixel,
+ * misses zero): the same bytes as the two calls in a row.                                                                                      */
+int  rt_tlg_generate_frame(rt_tlg* tlg, const rt_camera* cam, void* d_contacts, void* d_rgba);
 int  rt_tlg_generate_contacts_primary_tiled(rt_tlg* tlg, const rt_camera* cam, uint32_t rank, uint32_t nranks,
                                             void* d_contacts_compact);      /* frame tiles as for the BVH (below) */
 int  rt_tlg_info_get(const rt_tlg* tlg, rt_tlg_info* out);
@@ -224,7 +229,8 @@ uint32_t rt_tlg_rebuilds_without_readback(const rt_tlg* tlg);
  * every leaf-level DDA set-up (TwoLevelGrid.h:452-468) run as short multiply-add sequences that give the IEEE quotient bit for bit; 0 when the
  * grid does not qualify (box or plane spacing beyond 2^+-30 / 2^+-20, a leaf grid finer than 1023 cells per axis, more than 512 planes, a buffer
  * of the walk of 4 GB or more, env RTMI_TLG_WALK_RECORDS=0) and it is walked with the reference's divisions.  With the records come a
- * 16-byte record per leaf cell (entry count, the triangles of its first two entries, its first entry) and a DDA step by lane masks.  Rays with a direction component outside [2^-20, 2^20] (zero
+ * 32-byte record per leaf cell (entry count, its first entry, the triangles of its first six entries), a DDA step by lane masks and, for waves
+ * whose rays share their direction signs, the packet walk (cells, planes, leaf records and triangles the lanes agree on in scalar registers).  Rays with a direction component outside [2^-20, 2^20] (zero
  * included) or an origin beyond 2^30 take that walk in any case, wave by wave.  Same contacts either way.                                    */
 int  rt_tlg_walk_records(const rt_tlg* tlg);
 /* parity read-back of one build product into host memory (`bytes` must be its exact size, see rt_tlg_info) */

@@ -43,7 +43,7 @@ SYMBOLS = [
     'rt_timer_create', 'rt_timer_start', 'rt_timer_stop',
     'rt_timer_elapsed_ms', 'rt_timer_destroy',
     'rt_tlg_create', 'rt_tlg_destroy', 'rt_tlg_set_densities', 'rt_tlg_initialize_frame', 'rt_tlg_construct',
-    'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled',
+    'rt_tlg_generate_contacts_primary', 'rt_tlg_generate_contacts_rays', 'rt_tlg_generate_contacts_primary_tiled', 'rt_tlg_generate_frame',
     'rt_comm_unique_id', 'rt_comm_create', 'rt_comm_create_group', 'rt_comm_share', 'rt_comm_destroy', 'rt_comm_rank', 'rt_comm_size', 'rt_comm_uses_rccl', 'rt_comm_rccl_ranks', 'rt_multi_frame_create_rooted', 'rt_multi_frame_root', 'rt_multi_frame_set_camera', 'rt_multi_frame_set_timing', 'rt_multi_frame_times',
     'rt_multi_frame_create', 'rt_multi_frame_render', 'rt_multi_frame_wait', 'rt_multi_frame_pixels', 'rt_multi_frame_layout', 'rt_multi_frame_destroy',
     'rt_tlg_info_get', 'rt_tlg_rebuilds_without_readback', 'rt_tlg_walk_records', 'rt_tlg_read', 'rt_tlg_pow_third', 'rt_generate_secondary_rays', 'rt_generate_primary_rays',
@@ -134,6 +134,7 @@ def load_library() -> C.CDLL:
     L.rt_tlg_initialize_frame.argtypes = [vp]
     L.rt_tlg_construct.argtypes = [vp]
     L.rt_tlg_generate_contacts_primary.argtypes = [vp, vp, vp]
+    L.rt_tlg_generate_frame.argtypes = [vp, vp, vp, vp]
     L.rt_tlg_generate_contacts_rays.argtypes = [vp, vp, u32, vp]
     L.rt_tlg_generate_contacts_primary_tiled.argtypes = [vp, vp, u32, u32, vp]
     L.rt_tlg_info_get.argtypes = [vp, vp]
@@ -513,6 +514,10 @@ class DeviceTLG:
 
     def generate_contacts_primary_d(self, cam: np.ndarray, d_contacts: int):
         self.ctx.check(self.ctx.lib.rt_tlg_generate_contacts_primary(self.h, _p(cam), C.c_void_p(d_contacts)))
+
+    def generate_frame_d(self, cam: np.ndarray, d_contacts: int, d_rgba: int):
+        """rt_tlg_generate_frame: contacts and colours of one frame in one launch"""
+        self.ctx.check(self.ctx.lib.rt_tlg_generate_frame(self.h, _p(cam), C.c_void_p(d_contacts), C.c_void_p(d_rgba)))
 
     def generate_contacts_primary_tiled_d(self, cam: np.ndarray, rank: int, nranks: int, d_contacts: int):
         self.ctx.check(self.ctx.lib.rt_tlg_generate_contacts_primary_tiled(self.h, _p(cam), rank, nranks,

@@ -516,7 +516,7 @@ void launch_tlg_emit_leaf(hipStream_t s, const rt_grid_data& g, const uint2* pai
                           const rt_top_cell* top, const DeviceScene& sc, const uint32_t* scan, const uint32_t* counters, uint2* leaf_pairs,
                           uint32_t leaf_cap, uint32_t* written_total);
 void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks, bool compact,
-                              rt_contact* out);
+                              rt_contact* out, float4* fused_rgba = nullptr);      // fused_rgba: the frame's colours as well (untiled frames)
 void launch_tlg_trace_rays(hipStream_t s, const TlgLaunch& t, const rt_ray* rays, uint32_t count, rt_contact* out);
 // secondary_kernels.hip
 void launch_secondary_flags(hipStream_t s, const rt_contact* contacts, uint32_t count, uint32_t* flags);

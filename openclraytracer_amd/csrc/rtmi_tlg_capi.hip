@@ -392,6 +392,21 @@ int rt_tlg_generate_contacts_primary(rt_tlg* g, const rt_camera* cam, void* d_co
     return RT_SUCCESS;
 }
 
+int rt_tlg_generate_frame(rt_tlg* g, const rt_camera* cam, void* d_contacts, void* d_rgba)
+{
+    if (!g) return RT_FAIL(nullptr, "tlg is null");
+    rt_ctx* ctx = g->ctx;
+    if (!g->built) return RT_FAIL(ctx, "construct must precede generateContacts");
+    if (!d_contacts || !d_rgba) return RT_FAIL(ctx, "null buffer");
+    if (rt_check_camera(ctx, cam)) return RT_ERROR;
+    RT_ENTER(ctx);
+    TlgLaunch t = make_tlg_launch(g);
+    use_camera_triangles(g, cam, t);
+    launch_tlg_trace_primary(ctx->stream, t, *cam, 0, 1, false, (rt_contact*)d_contacts, (float4*)d_rgba);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_SUCCESS;
+}
+
 int rt_tlg_generate_contacts_primary_tiled(rt_tlg* g, const rt_camera* cam, uint32_t rank, uint32_t nranks, void* d_contacts_compact)
 {
     if (!g) return RT_FAIL(nullptr, "tlg is null");

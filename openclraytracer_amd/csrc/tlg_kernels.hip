@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "tlg_math.h"
+#include "shade_math.h"
 
 #define TLG_BLOCK 256
 
@@ -306,6 +307,8 @@ struct TlgTraceArgs {
     uint32_t rank, nranks, tiles_x, compact;
     const rt_ray* __restrict__ rays;
     rt_contact* __restrict__ out;
+    float4* __restrict__ fused_rgba;        // primary, untiled: the pixel's colour as well (rt_tlg_generate_frame; null: contacts only)
+    ShadeScene fused_scene;
 };
 
 // ---- the walk's own records (round 5) ---------------------------------------------------------------------------------------------
@@ -1102,6 +1105,17 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     float4* dst = reinterpret_cast<float4*>(A.out + out_index);
     store16_stream(dst, *reinterpret_cast<const float4*>(&head));
     store16_stream(dst + 1, nt);
+    // a fused frame: what k_shade computes from the contact just written, at the pixel's own index (shade_kernels.hip; a miss is zeros)
+    if (PRIMARY && A.fused_rgba) {
+        float4 col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (best_tri != 0xFFFFFFFFu && best_t > 0.0f) {
+            rt_contact c;
+            c.pixelIndex = pixel; c.materialIndex = material; c.pad[0] = 0; c.pad[1] = 0;
+            c.normalAndDistance[0] = nt.x; c.normalAndDistance[1] = nt.y; c.normalAndDistance[2] = nt.z; c.normalAndDistance[3] = nt.w;
+            col = shade_one(A.fused_scene, A.cam, c);
+        }
+        store16_stream(A.fused_rgba + out_index, col);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1190,7 +1204,7 @@ static TlgTraceArgs tlg_args(const TlgLaunch& t)
 }
 
 void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera& cam, uint32_t rank, uint32_t nranks, bool compact,
-                              rt_contact* out)
+                              rt_contact* out, float4* fused_rgba)
 {
     TlgTraceArgs a = tlg_args(t);
     a.cam = cam; a.rank = rank; a.nranks = nranks; a.compact = compact ? 1u : 0u;
@@ -1199,6 +1213,11 @@ void launch_tlg_trace_primary(hipStream_t s, const TlgLaunch& t, const rt_camera
     a.total_work = rt_owned_tiles(tiles, rank, nranks) * RT_TILE * RT_TILE;
     a.out = out;
     a.tricam = t.tricam;
+    if (fused_rgba && !compact) {
+        a.fused_rgba = fused_rgba;
+        a.fused_scene.scene = t.scene->bytes; a.fused_scene.n_lights = t.scene->n_lights; a.fused_scene.n_spheres = t.scene->n_spheres;
+        a.fused_scene.n_materials = t.scene->n_materials;
+    }
     const uint32_t planes = t.grid.resX + t.grid.resY + t.grid.resZ;
     const bool cam_planes = t.tricam && t.axis_cam && t.axis_tab && t.toprec;
     a.cam_off = cam_planes ? t.cam_off : 0u;
