@@ -45,9 +45,13 @@ done
 # the grid walk's instruction mix: counts per class, to be priced with the per-class issue costs of tools/micro/pk_rate.hip (profiles/r05_valu_issue_costs.txt)
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE --output-format csv -d $OUT/tlg_pmc_mix -- python3 tools/tlg_config4.py > $OUT/tlg_pmc_mix.log 2>&1 || echo "config4 instruction-mix pass failed"
 timeout -k 10 300 rocprofv3 --pmc SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/tlg_pmc_cyc -- python3 tools/tlg_config4.py > $OUT/tlg_pmc_cyc.log 2>&1 || echo "config4 VALU-cycles pass failed"
+# ... and every instruction it issues, by kind (the launch time follows their total: profiles/r05_tlg_instruction_counts.json)
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH GRBM_GUI_ACTIVE --output-format csv -d $OUT/tlg_pmc_kinds -- python3 tools/tlg_config4.py > $OUT/tlg_pmc_kinds.log 2>&1 || echo "config4 instruction-kinds pass failed"
 echo "config counter passes done"
 tools/micro/pk_rate > $OUT/pk_rate.txt 2>&1 || echo "pk_rate failed"
-tools/micro/div_check > $OUT/div_check.txt 2>&1 || echo "div_check failed"
+# (the exhaustive comparison of the short division sequences takes minutes and changes only with the sequences: run when the binary was built for it,
+#  hipcc --offload-arch=gfx950 -O3 tools/micro/div_check.hip -o tools/micro/div_check; the record in profiles/ is kept otherwise)
+if [ -x tools/micro/div_check ]; then tools/micro/div_check > $OUT/div_check.txt 2>&1 || echo "div_check failed"; fi
 unset RTMI_PACKED
 python3 tools/build_profile.py heightfield --k 10 --out $OUT/build_times_heightfield_fixed.json > /dev/null 2>> $OUT/build_times.err; python3 tools/build_profile.py heightfield --k 10 --mode 2 --out $OUT/build_times_heightfield_fast.json > /dev/null 2>> $OUT/build_times.err
 python3 tools/config_report.py > $OUT/config_report.json 2> $OUT/config_report.err || echo "config report failed"

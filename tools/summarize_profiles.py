@@ -140,8 +140,34 @@ try:
     print('tlg issue floor', line['valu_issue_roof']['floor_ms'], 'priced', line['valu_issue_roof']['priced_by_class_ms'], 'of', line.get('trace_ms'))
 except Exception as e:
     print('no instruction mix of the grid walk: %s' % e)
+# every instruction the grid walk issues, by kind: the launch time of round 5's builds followed their total at 0.95-0.96 ns per million
+try:
+    f = newest(src + '/tlg_pmc_kinds/**/*counter_collection.csv')
+    by = collections.defaultdict(lambda: collections.defaultdict(float))
+    for row in csv.DictReader(open(f)):
+        if row['Kernel_Name'].split('(')[0].replace('void ', '').strip().startswith('k_tlg_trace<'):
+            by[row['Counter_Name']][int(row['Dispatch_Id'])] += float(row['Counter_Value'])
+    kinds = {}
+    for c, d in by.items():
+        vals = [d[x] for x in sorted(d)][1:] or list(d.values())
+        kinds[c] = sum(vals) / len(vals)
+    line_path = 'profiles/%s_tlg_config4_line.json' % R
+    line = json.load(open(line_path))
+    issued = sum(v for k, v in kinds.items() if k.startswith('SQ_INSTS_') and k != 'SQ_INSTS_BRANCH')
+    line['instructions_issued'] = dict(what='instructions of every kind per launch (rocprofv3 --pmc SQ_INSTS_*; branches are among the scalar ones).  Through the steps of round 5 the launch '
+                                            'time followed their TOTAL at 0.95-0.96 ns per million (profiles/r05_tlg_instruction_counts.json): the walk is bound by the rate at which its seven '
+                                            'waves per SIMD issue instructions of any kind, each wave one at a time',
+                                       per_launch_M={k[9:]: round(v / 1e6, 1) for k, v in kinds.items() if k.startswith('SQ_INSTS_')}, total_M=round(issued / 1e6, 1),
+                                       per_top_level_cell=round(issued / (1920 * 1080 / 64.0) / line['per_ray']['top_cells'], 1),
+                                       ns_per_million=(round(line['trace_ms'] * 1e6 / (issued / 1e6) / 1e3, 4) if line.get('trace_ms') else None))
+    json.dump(line, open(line_path, 'w'), indent=1)
+    print('tlg instructions issued', line['instructions_issued']['per_launch_M'], line['instructions_issued']['ns_per_million'])
+except Exception as e:
+    print('no instruction kinds of the grid walk: %s' % e)
 for f in ('pk_rate.txt', 'div_check.txt'):
     try:
+        if not os.path.exists(src + '/' + f) or 'No such file' in open(src + '/' + f).read(2000):
+            raise RuntimeError('not run in this round (the record in profiles/ is kept)')
         shutil.copy(src + '/' + f, 'profiles/%s_%s' % (R, {'pk_rate.txt': 'valu_issue_costs.txt', 'div_check.txt': 'division_sequences_check.txt'}[f]))
     except Exception as e:
         print('no %s: %s' % (f, e))
