@@ -222,11 +222,14 @@ def test_walk_records_are_in_use_and_change_no_contact(gpu_ctx, name):
                 "sc = capi.DeviceScene(ctx, open(sys.argv[1], 'rb').read()); g = capi.DeviceTLG(ctx, sc).build(); "
                 "c = g.generate_contacts_primary(np.load(sys.argv[2]).view(capi.CAMERA)); "
                 "print('RESULT', int(g.walk_records()), hashlib.sha256(c.tobytes()).hexdigest())" % ROOT)
-        r = subprocess.run([sys.executable, '-c', code, os.path.join(d, 's.bin'), os.path.join(d, 'cam.npy')],
-                           env=dict(os.environ, RTMI_TLG_WALK_RECORDS='0'), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    flag, digest = [l for l in r.stdout.splitlines() if l.startswith('RESULT')][0].split()[1:]
-    assert flag == '0' and digest == hashlib.sha256(want.tobytes()).hexdigest()
+        # ... and without the camera-relative triangle records (RTMI_TLG_TRICAM=0): the records stay in use, every wave walks lane by lane on the
+        # scene's triangle table (the packet walk of primary rays needs the camera's tables)
+        for knob, want_flag in (('RTMI_TLG_WALK_RECORDS', '0'), ('RTMI_TLG_TRICAM', '1')):
+            r = subprocess.run([sys.executable, '-c', code, os.path.join(d, 's.bin'), os.path.join(d, 'cam.npy')],
+                               env=dict(os.environ, **{knob: '0'}), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            flag, digest = [l for l in r.stdout.splitlines() if l.startswith('RESULT')][0].split()[1:]
+            assert flag == want_flag and digest == hashlib.sha256(want.tobytes()).hexdigest(), knob
 
 
 def test_walk_records_rays_at_the_edges_of_what_qualifies(gpu_ctx):
