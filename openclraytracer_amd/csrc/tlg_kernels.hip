@@ -620,10 +620,8 @@ struct UniSigns { int mx, my, mz; };      // wave-uniform, in scalar registers: 
 // the clamp to [0, res - 1] is applied to the converted integer (v_cvt_i32_f32 truncates towards zero and saturates: the same cell for every finite f).
 __device__ __forceinline__ void dda_axis_uniform(float o, float d, float a, int neg, float lo, float hi, float& tmin, float& tmax)
 {
-    // near / far plane by the wave's sign: two scalar selects (written out: the compiler turns a select between two scalar floats into v_cndmask
-    // on copies of them)
-    float near, far;
-    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %4, %3" : "=&s"(near), "=&s"(far) : "s"(neg), "s"(lo), "s"(hi) : "scc");
+    // near / far plane by the wave's sign: a constant of the walk's instance (one per direction octant)
+    const float near = neg ? hi : lo, far = neg ? lo : hi;
     tmin = (near - o) * a;
     tmax = (far - o) * a;
 }
@@ -678,8 +676,9 @@ __device__ __forceinline__ void dda_setup_uniform_cam(f3 o, f3 d, f3 a, UniSigns
     dda_finish_uniform(p.y, g.my, cy.lo, cy.rcp_w, cy.w, resy, fy, ry, tymin, tymax, s.ny, s.dty, s.iy);
     dda_finish_uniform(p.z, g.mz, cz.lo, cz.rcp_w, cz.w, resz, fz, rz, tzmin, tzmax, s.nz, s.dtz, s.iz);
 }
-// dda_step_fast with step[] in scalar registers
-__device__ __forceinline__ bool dda_step_uniform(Dda& s, int sx, int sy, int sz, uint32_t rx, uint32_t ry, uint32_t rz)
+// dda_step_fast with step[] as constants of the instruction (the packet walk is compiled once per direction octant: +1 / -1 are inline operands)
+template <int SX, int SY, int SZ>
+__device__ __forceinline__ bool dda_step_uniform(Dda& s, uint32_t rx, uint32_t ry, uint32_t rz)
 {
     unsigned long long t0, t1, t2, saved;
     asm volatile("v_cmp_le_f32_e64 %[t0], %[nx], %[ny]\n\t"
@@ -702,7 +701,7 @@ __device__ __forceinline__ bool dda_step_uniform(Dda& s, int sx, int sy, int sz,
                  "s_mov_b64 exec, %[sv]"
                  : [nx] "+v"(s.nx), [ny] "+v"(s.ny), [nz] "+v"(s.nz), [ix] "+v"(s.ix), [iy] "+v"(s.iy), [iz] "+v"(s.iz),
                    [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(saved)
-                 : [dx] "v"(s.dtx), [dy] "v"(s.dty), [dz] "v"(s.dtz), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz)
+                 : [dx] "v"(s.dtx), [dy] "v"(s.dty), [dz] "v"(s.dtz), [sx] "n"(SX), [sy] "n"(SY), [sz] "n"(SZ)
                  : "scc");
     return ((uint32_t)s.ix >= rx) | ((uint32_t)s.iy >= ry) | ((uint32_t)s.iz >= rz);
 }
@@ -743,7 +742,7 @@ __device__ __forceinline__ void tlg_accept_v(float det, float u, float v, float 
 // records (see k_tlg_trace_records): the leaf-level set-up takes its cell from a 32-byte record and its planes from a table in LDS, divides by
 // the sequences above, and the triangle test takes 1 / det from v_rcp_f32 + one Newton step (equal to the IEEE quotient for every operand
 // between 2^-90 and 2^90, tools/micro/div_check.hip; |det| >= FLT_EPSILON is what the test asks for anyway).  Same values, fewer instructions.
-template <int PRIMARY, int FAST>         // FAST = 2: the packet walk (FAST = 1 and the wave's rays have the same direction signs)
+template <int PRIMARY, int FAST, int OCT = 0>         // FAST = 2: the packet walk (FAST = 1 and the wave's rays have the same direction signs: bit k of OCT = d < 0 on axis k)
 __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, const f3 d, mail_t (*s_mailbox)[TLG_BLOCK], const float4* s_axis,
                                          float& best_t, uint32_t& best_tri)
 {
@@ -752,17 +751,10 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
 
     const DdaSigns sg = DdaSigns{ d.x > 0.0f, d.y > 0.0f, d.z > 0.0f };
     const int step_x = sg.px ? 1 : -1, step_y = sg.py ? 1 : -1, step_z = sg.pz ? 1 : -1;         // step[] of :470-490 / :610-630
-    // (FAST = 2: the same values, known to be the same in every lane)
-    // (from the ballots: every lane of such a wave has the same sign, so "no lane has d > 0" is the sign.  Written out: left to the compiler the
-    //  0 / ~0 of a scalar condition is made by v_cndmask in a vector register, and an "s" operand of the blocks of assembly below receives that)
-    UniSigns us = UniSigns{ 0, 0, 0 };
-    if (FAST == 2) {
-        const unsigned long long bx = __builtin_amdgcn_ballot_w64(sg.px), by = __builtin_amdgcn_ballot_w64(sg.py), bz = __builtin_amdgcn_ballot_w64(sg.pz);
-        asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(us.mx) : "s"(bx) : "scc");
-        asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(us.my) : "s"(by) : "scc");
-        asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(us.mz) : "s"(bz) : "scc");
-    }
-    const int ustep_x = 1 | us.mx, ustep_y = 1 | us.my, ustep_z = 1 | us.mz;          // 1 / -1
+    // FAST = 2: the signs are the instance's (the kernel picks it by the wave's ballots): 0 where d > 0 on the axis, ~0 where d < 0 -- constants, so
+    // near / far plane, step[], the count of cells to the far side and the word offsets of the camera's plane table cost neither registers nor instructions
+    const UniSigns us = UniSigns{ (OCT & 1) ? -1 : 0, (OCT & 2) ? -1 : 0, (OCT & 4) ? -1 : 0 };
+    constexpr int ustep_x = (OCT & 1) ? -1 : 1, ustep_y = (OCT & 2) ? -1 : 1, ustep_z = (OCT & 4) ? -1 : 1;          // step[]
     const f3 inv_d = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };          // (what dda_axis_setup divides per cell; the compiler hoists it there as well)
 #ifdef RTMI_TLG_DIAG
     if (FAST) {       // (86) waves all of whose rays have the same direction signs; (88) all waves taking this walk
@@ -876,15 +868,15 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     TLG_DIAG(2, 3);
                     const uint32_t rx = packed & 1023u, ry = (packed >> 10) & 1023u, rz = packed >> 20;
                     const bool one = packed == (1u | (1u << 10) | (1u << 20));          // a leaf grid of one cell: no DDA (see below)
-                    Dda Lf;
-                    Lf.ix = Lf.iy = Lf.iz = 0; Lf.nx = Lf.ny = Lf.nz = 0.0f; Lf.dtx = Lf.dty = Lf.dtz = 0.0f;
+                    Dda Lf;                                    // (not set for a leaf grid of one cell: its cell is first_leaf and no step is taken)
                     if (!one) {
                         if (PRIMARY) dda_setup_uniform_cam(o, d, inv_d, us, cx, cy, cz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
                         else dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
                     }
                     for (;;) {
                         TLG_DIAG(4, 5);
-                        const uint32_t leaf = mad24_s(mad24_s((uint32_t)Lf.iz, ry, (uint32_t)Lf.iy), rx, (uint32_t)Lf.ix) + first_leaf;
+                        uint32_t leaf = first_leaf;
+                        if (!one) leaf += mad24_s(mad24_s((uint32_t)Lf.iz, ry, (uint32_t)Lf.iy), rx, (uint32_t)Lf.ix);
                         const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
                         if (__builtin_amdgcn_ballot_w64(leaf != l0) == 0ull) {
                             // ---- ... and in ONE leaf cell: its record and, entry by entry, its triangles in scalar registers ----
@@ -906,7 +898,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                         }
                         if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
                         if (one) break;
-                        if (dda_step_uniform(Lf, ustep_x, ustep_y, ustep_z, rx, ry, rz)) break;   // :542-545
+                        if (dda_step_uniform<ustep_x, ustep_y, ustep_z>(Lf, rx, ry, rz)) break;   // :542-545
                     }
                     if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
                 }
@@ -916,10 +908,10 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         rt_top_cell tc;
         TlgTopRec rec;
         if (FAST) {
-            float4 r0 = ld_off<float4>(a.toprec, cell * 32u), r1 = ld_off<float4>(a.toprec, cell * 32u + 16u);
+            const float4 r0 = ld_off<float4>(a.toprec, cell * 32u), r1 = ld_off<float4>(a.toprec, cell * 32u + 16u);
             // (both halves and the planes are fetched BEFORE the cell is known to be non-empty -- nearly every cell a ray meets is: left to itself the
             //  compiler fetches the last word, waits, branches and only then fetches the rest: two trips to the L2 in a row per cell)
-            asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+            asm volatile("" :: "v"(r0.x), "v"(r0.w), "v"(r1.x), "v"(r1.w));          // (read-only operands: the values have to be there, no copies made)
             rec.fres[0] = r0.x; rec.fres[1] = r0.y; rec.fres[2] = r0.z; rec.first_leaf = __float_as_uint(r0.w);
             rec.rcp[0] = r1.x; rec.rcp[1] = r1.y; rec.rcp[2] = r1.z; rec.packed = __float_as_uint(r1.w);
             tc.resX = rec.packed & 1023u; tc.resY = (rec.packed >> 10) & 1023u; tc.resZ = rec.packed >> 20; tc.firstLeafIdx = rec.first_leaf;
@@ -973,7 +965,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     }
                 }
                 if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
-                if (FAST == 2) { if (dda_step_uniform(Lf, ustep_x, ustep_y, ustep_z, tc.resX, tc.resY, tc.resZ)) break; }
+                if (FAST == 2) { if (dda_step_uniform<ustep_x, ustep_y, ustep_z>(Lf, tc.resX, tc.resY, tc.resZ)) break; }
                 else if (FAST) { if (dda_step_fast(Lf, step_x, step_y, step_z, tc.resX, tc.resY, tc.resZ)) break; }
                 else {
                     if (laxis < 0) break;
@@ -986,7 +978,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         }
         // :660-676 -- the axis of the smallest next[] (chosen before the cell is processed in the reference; nothing in between changes
         // next[]), `next[axis] += dt[axis]; idx[axis] += step[axis]; if (idx[axis] == stop[axis]) break`
-        if (FAST == 2) { if (dda_step_uniform(T, ustep_x, ustep_y, ustep_z, g.resX, g.resY, g.resZ)) break; }
+        if (FAST == 2) { if (dda_step_uniform<ustep_x, ustep_y, ustep_z>(T, g.resX, g.resY, g.resZ)) break; }
         else if (FAST) { if (dda_step_fast(T, step_x, step_y, step_z, g.resX, g.resY, g.resZ)) break; }
         else {
             const int taxis = dda_axis(T);
@@ -1082,7 +1074,18 @@ __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_W
     if (__all(ray_ok)) {
         // ... and the packet walk where, besides, the wave's rays have the same direction signs (all but the blocks on the image's axes)
         const unsigned long long every = __ballot(1), bx = __ballot(d.x > 0.0f), by = __ballot(d.y > 0.0f), bz = __ballot(d.z > 0.0f);
-        if ((bx == 0ull || bx == every) && (by == 0ull || by == every) && (bz == 0ull || bz == every) && (!PRIMARY || (a.tricam != nullptr && a.cam_off != 0u))) tlg_walk<PRIMARY, 2>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
+        if ((bx == 0ull || bx == every) && (by == 0ull || by == every) && (bz == 0ull || bz == every) && (!PRIMARY || (a.tricam != nullptr && a.cam_off != 0u))) {
+            switch ((bx == 0ull ? 1u : 0u) | (by == 0ull ? 2u : 0u) | (bz == 0ull ? 4u : 0u)) {          // (a scalar value: one instance per direction octant)
+            case 0u: tlg_walk<PRIMARY, 2, 0>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            case 1u: tlg_walk<PRIMARY, 2, 1>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            case 2u: tlg_walk<PRIMARY, 2, 2>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            case 3u: tlg_walk<PRIMARY, 2, 3>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            case 4u: tlg_walk<PRIMARY, 2, 4>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            case 5u: tlg_walk<PRIMARY, 2, 5>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            case 6u: tlg_walk<PRIMARY, 2, 6>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            default: tlg_walk<PRIMARY, 2, 7>(a, o, d, s_mailbox, s_axis, best_t, best_tri); break;
+            }
+        }
         else tlg_walk<PRIMARY, 1>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
     }
     else tlg_walk<PRIMARY, 0>(a, o, d, s_mailbox, s_axis, best_t, best_tri);
