@@ -756,6 +756,8 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
     const UniSigns us = UniSigns{ (OCT & 1) ? -1 : 0, (OCT & 2) ? -1 : 0, (OCT & 4) ? -1 : 0 };
     constexpr int ustep_x = (OCT & 1) ? -1 : 1, ustep_y = (OCT & 2) ? -1 : 1, ustep_z = (OCT & 4) ? -1 : 1;          // step[]
     const f3 inv_d = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };          // (what dda_axis_setup divides per cell; the compiler hoists it there as well)
+    // where the camera's planes of the three axes start in toprec's buffer (bytes)
+    const uint32_t cam_x = a.cam_off, cam_y = a.cam_off + g.resX * 32u, cam_z = a.cam_off + (g.resX + g.resY) * 32u;
 #ifdef RTMI_TLG_DIAG
     if (FAST) {       // (86) waves all of whose rays have the same direction signs; (88) all waves taking this walk
         const unsigned long long ax = __ballot(sg.px), ay = __ballot(sg.py), az = __ballot(sg.pz), all = __ballot(1);
@@ -855,8 +857,7 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                 float4 px, py, pz;
                 CamPlaneS cx, cy, cz;
                 if (PRIMARY) {
-                    cx = ld_cam_plane(a.toprec, a.cam_off + ux * 32u, us.mx); cy = ld_cam_plane(a.toprec, a.cam_off + (g.resX + uy) * 32u, us.my);
-                    cz = ld_cam_plane(a.toprec, a.cam_off + (g.resX + g.resY + uz) * 32u, us.mz);
+                    cx = ld_cam_plane(a.toprec, cam_x + ux * 32u, us.mx); cy = ld_cam_plane(a.toprec, cam_y + uy * 32u, us.my); cz = ld_cam_plane(a.toprec, cam_z + uz * 32u, us.mz);
                     // (read-only operands: the values have to be there, no copies made)
                     asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(cx.lo), "s"(cx.far_o), "s"(cy.lo), "s"(cy.far_o), "s"(cz.lo), "s"(cz.far_o));
                 } else {
@@ -864,44 +865,47 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                     asm volatile("" :: "s"(r0.x), "s"(r0.w), "s"(r1.x), "s"(r1.w), "s"(px.x), "s"(px.w), "s"(py.x), "s"(py.w), "s"(pz.x), "s"(pz.w));
                 }
                 const uint32_t packed = __float_as_uint(r1.w), first_leaf = __float_as_uint(r0.w);
-                if (packed != 0u) {
+                // one leaf cell of this top-level cell: its entries from scalar registers where the lanes stand in the same one, else lane by lane
+                auto leaf_cell = [&](const uint32_t leaf) __attribute__((always_inline)) {
+                    const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
+                    if (__builtin_amdgcn_ballot_w64(leaf != l0) == 0ull) {
+                        // ---- ... and in ONE leaf cell: its record and, entry by entry, its triangles in scalar registers ----
+#ifdef RTMI_TLG_DIAG
+                        TLG_DIAG(84, 85);
+#endif
+                        // (up to six entries straight from the record, no loop: an entry costs its mailbox look-up and one scalar compare + branch)
+                        const uint4 lr = ld_off<uint4>(a.leafrec, l0 * 32u), lq = ld_off<uint4>(a.leafrec, l0 * 32u + 16u);
+                        if (lr.x > 0u) { test_entry(lr.y, std::true_type());
+                        if (lr.x > 1u) { test_entry(lr.z, std::true_type());
+                        if (lr.x > 2u) { test_entry(lq.x, std::true_type());
+                        if (lr.x > 3u) { test_entry(lq.y, std::true_type());
+                        if (lr.x > 4u) { test_entry(lq.z, std::true_type());
+                        if (lr.x > 5u) { test_entry(lq.w, std::true_type());
+                            for (uint32_t i = 6u; i < lr.x; i++) test_entry(ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 4u), std::true_type());
+                        } } } } } }
+                    } else {
+                        walk_leaf(leaf);
+                    }
+                };
+                if (packed == (1u | (1u << 10) | (1u << 20))) {
+                    // a leaf grid of ONE cell needs no DDA: its cell is processed, and whichever axis the step would take leaves the grid (:542-545)
+                    TLG_DIAG(2, 3);
+                    TLG_DIAG(4, 5);
+                    leaf_cell(first_leaf);
+                } else if (packed != 0u) {
                     TLG_DIAG(2, 3);
                     const uint32_t rx = packed & 1023u, ry = (packed >> 10) & 1023u, rz = packed >> 20;
-                    const bool one = packed == (1u | (1u << 10) | (1u << 20));          // a leaf grid of one cell: no DDA (see below)
-                    Dda Lf;                                    // (not set for a leaf grid of one cell: its cell is first_leaf and no step is taken)
-                    if (!one) {
-                        if (PRIMARY) dda_setup_uniform_cam(o, d, inv_d, us, cx, cy, cz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
-                        else dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
-                    }
-                    for (;;) {
+                    Dda Lf;
+                    if (PRIMARY) dda_setup_uniform_cam(o, d, inv_d, us, cx, cy, cz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
+                    else dda_setup_uniform(o, d, inv_d, us, px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, (int)rx, (int)ry, (int)rz, Lf);
+                    for (;;) {                   // processTopLevelCell, TwoLevelGrid.h:419-545
                         TLG_DIAG(4, 5);
-                        uint32_t leaf = first_leaf;
-                        if (!one) leaf += mad24_s(mad24_s((uint32_t)Lf.iz, ry, (uint32_t)Lf.iy), rx, (uint32_t)Lf.ix);
-                        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
-                        if (__builtin_amdgcn_ballot_w64(leaf != l0) == 0ull) {
-                            // ---- ... and in ONE leaf cell: its record and, entry by entry, its triangles in scalar registers ----
-#ifdef RTMI_TLG_DIAG
-                            TLG_DIAG(84, 85);
-#endif
-                            // (up to six entries straight from the record, no loop: an entry costs its mailbox look-up and one scalar compare + branch)
-                            const uint4 lr = ld_off<uint4>(a.leafrec, l0 * 32u), lq = ld_off<uint4>(a.leafrec, l0 * 32u + 16u);
-                            if (lr.x > 0u) { test_entry(lr.y, std::true_type());
-                            if (lr.x > 1u) { test_entry(lr.z, std::true_type());
-                            if (lr.x > 2u) { test_entry(lq.x, std::true_type());
-                            if (lr.x > 3u) { test_entry(lq.y, std::true_type());
-                            if (lr.x > 4u) { test_entry(lq.z, std::true_type());
-                            if (lr.x > 5u) { test_entry(lq.w, std::true_type());
-                                for (uint32_t i = 6u; i < lr.x; i++) test_entry(ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 4u), std::true_type());
-                            } } } } } }
-                        } else {
-                            walk_leaf(leaf);
-                        }
+                        leaf_cell(mad24_s(mad24_s((uint32_t)Lf.iz, ry, (uint32_t)Lf.iy), rx, (uint32_t)Lf.ix) + first_leaf);
                         if (cell_tri != 0xFFFFFFFFu) break;                       // :539-540
-                        if (one) break;
                         if (dda_step_uniform<ustep_x, ustep_y, ustep_z>(Lf, rx, ry, rz)) break;   // :542-545
                     }
-                    if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
                 }
+                if (cell_tri != 0xFFFFFFFFu) { best_t = cell_t; best_tri = cell_tri; break; }   // :668-669
             }
         }
         else {
