@@ -706,6 +706,14 @@ __device__ __forceinline__ bool dda_step_uniform(Dda& s, uint32_t rx, uint32_t r
     return ((uint32_t)s.ix >= rx) | ((uint32_t)s.iy >= ry) | ((uint32_t)s.iz >= rz);
 }
 
+// the kernel's (only) argument read from the kernel-argument segment at the point of use (an opaque pointer: the loads can neither be merged
+// with the ones at the kernel's start nor be moved up)
+__device__ __forceinline__ const TlgTraceArgs* tlg_args_again()
+{
+    const TlgTraceArgs* p = (const TlgTraceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; kernel arguments again" : "+s"(p));
+    return p;
+}
 // The end of triangleIntersect + :528 -- `flag` and the update of the cell's closest hit -- as a chain of v_cmpx: every compare narrows exec to the
 // lanes that passed so far, the update is two moves under what is left.  The same seven ordered compares as the C expression
 //   |det| >= FLT_EPSILON & u < 1 & u >= 0 & u + v <= 1 & v >= 0 & t > 0 & t < cell_t
@@ -836,6 +844,21 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
         auto walk_leaf = [&](const uint32_t leaf) __attribute__((always_inline)) {
             const uint4 lr = ld_off<uint4>(a.leafrec, leaf * 32u);
             TLG_DIAG_HIST(lr.x);
+            if (FAST == 2) {
+                // (the packet walk's lane-by-lane leaf cells: the first six entries from the record as well -- no dependent fetch of a pair per entry, and
+                //  the pair array's pointer is read again from the kernel arguments for the rare seventh entry, not held in scalar registers through the walk)
+                const uint4 lq = ld_off<uint4>(a.leafrec, leaf * 32u + 16u);
+                if (lr.x > 0u) { test_entry(lr.y, std::false_type());
+                if (lr.x > 1u) { test_entry(lr.z, std::false_type());
+                if (lr.x > 2u) { test_entry(lq.x, std::false_type());
+                if (lr.x > 3u) { test_entry(lq.y, std::false_type());
+                if (lr.x > 4u) { test_entry(lq.z, std::false_type());
+                if (lr.x > 5u) { test_entry(lq.w, std::false_type());
+                    const uint2* pairs = tlg_args_again()->leaf_pairs;
+                    for (uint32_t i = 6u; i < lr.x; i++) test_entry(ld_off<uint32_t>(pairs, (lr.w + i) * 8u + 4u), std::false_type());
+                } } } } } }
+                return;
+            }
             uint32_t tri_next = lr.y;
             for (uint32_t i = 0; i < lr.x; i++) {
                 TLG_DIAG(6, 7);
@@ -881,7 +904,8 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
                         if (lr.x > 3u) { test_entry(lq.y, std::true_type());
                         if (lr.x > 4u) { test_entry(lq.z, std::true_type());
                         if (lr.x > 5u) { test_entry(lq.w, std::true_type());
-                            for (uint32_t i = 6u; i < lr.x; i++) test_entry(ld_off<uint32_t>(a.leaf_pairs, (lr.w + i) * 8u + 4u), std::true_type());
+                            const uint2* pairs = tlg_args_again()->leaf_pairs;       // (rare: the pointer is not held in scalar registers through the walk)
+                            for (uint32_t i = 6u; i < lr.x; i++) test_entry(ld_off<uint32_t>(pairs, (lr.w + i) * 8u + 4u), std::true_type());
                         } } } } } }
                     } else {
                         walk_leaf(leaf);
@@ -1013,14 +1037,6 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
 #ifndef TLG_WAVES
 #define TLG_WAVES 7
 #endif
-// the kernel's (only) argument read from the kernel-argument segment at the point of use (an opaque pointer: the loads can neither be merged
-// with the ones at the kernel's start nor be moved up)
-__device__ __forceinline__ const TlgTraceArgs* tlg_args_again()
-{
-    const TlgTraceArgs* p = (const TlgTraceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("; kernel arguments again" : "+s"(p));
-    return p;
-}
 template <int PRIMARY>
 __global__ __launch_bounds__(TLG_BLOCK) __attribute__((amdgpu_waves_per_eu(TLG_WAVES, TLG_WAVES))) void k_tlg_trace(TlgTraceArgs a)
 {
