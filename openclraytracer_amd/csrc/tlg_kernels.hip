@@ -719,30 +719,45 @@ __device__ __forceinline__ const TlgTraceArgs* tlg_args_again()
 //   |det| >= FLT_EPSILON & u < 1 & u >= 0 & u + v <= 1 & v >= 0 & t > 0 & t < cell_t
 // without the six scalar ANDs of their lane masks and the selects (this kernel's time follows the number of instructions it issues, scalar ones
 // included).  _s: the triangle id in a scalar register (the packet walk's leaf cells).
-#define TLG_ACCEPT_ASM(TRI_CONSTRAINT)                                                                                                          \
+// (second form: v = (d . qvec) / det, t and the compares that need them stand BEHIND a branch of the wave -- a triangle most of whose tests fail fails
+//  them at |det| or u for every lane that tested it, and the wave then skips thirteen instructions.  The arithmetic inside is f3_dot's, operation for
+//  operation: x * x' + y * y' first, then + z * z', every operation rounded on its own.)
+#define TLG_ACCEPT_ASM(Q_CONSTRAINT)                                                                                                            \
     unsigned long long saved;                                                                                                                   \
+    float t1, t2;                                                                                                                               \
     asm volatile("s_mov_b64 %[sv], exec\n\t"                                                                                                     \
                  "v_cmpx_ge_f32_e64 vcc, |%[det]|, %[eps]\n\t"                                                                                   \
                  "v_cmpx_gt_f32_e32 vcc, 1.0, %[u]\n\t"                                                                                          \
                  "v_cmpx_le_f32_e32 vcc, 0, %[u]\n\t"                                                                                            \
-                 "v_cmpx_ge_f32_e32 vcc, 1.0, %[uv]\n\t"                                                                                         \
-                 "v_cmpx_le_f32_e32 vcc, 0, %[v]\n\t"                                                                                            \
-                 "v_cmpx_lt_f32_e32 vcc, 0, %[t]\n\t"                                                                                            \
-                 "v_cmpx_gt_f32_e32 vcc, %[ct], %[t]\n\t"                                                                                        \
-                 "v_mov_b32 %[ct], %[t]\n\t"                                                                                                     \
-                 "v_mov_b32 %[ctri], %[tri]\n\t"                                                                                                 \
+                 "s_cbranch_execz 1f\n\t"                                                                                                        \
+                 "v_mul_f32 %[t1], %[qx], %[dx]\n\t"                                                                                             \
+                 "v_mul_f32 %[t2], %[qy], %[dy]\n\t"                                                                                             \
+                 "v_add_f32 %[t1], %[t1], %[t2]\n\t"                                                                                             \
+                 "v_mul_f32 %[t2], %[qz], %[dz]\n\t"                                                                                             \
+                 "v_add_f32 %[t1], %[t1], %[t2]\n\t"                                                                                             \
+                 "v_mul_f32 %[t1], %[t1], %[inv]\n\t"                                                                                            \
+                 "v_add_f32 %[t2], %[u], %[t1]\n\t"                                                                                              \
+                 "v_cmpx_ge_f32_e32 vcc, 1.0, %[t2]\n\t"                                                                                         \
+                 "v_cmpx_le_f32_e32 vcc, 0, %[t1]\n\t"                                                                                           \
+                 "v_mul_f32 %[t1], %[e2q], %[inv]\n\t"                                                                                           \
+                 "v_cmpx_lt_f32_e32 vcc, 0, %[t1]\n\t"                                                                                           \
+                 "v_cmpx_gt_f32_e32 vcc, %[ct], %[t1]\n\t"                                                                                       \
+                 "v_mov_b32 %[ct], %[t1]\n\t"                                                                                                    \
+                 "v_mov_b32 %[ctri], %[tri]\n"                                                                                                   \
+                 "1:\n\t"                                                                                                                        \
                  "s_mov_b64 exec, %[sv]"                                                                                                          \
-                 : [ct] "+v"(cell_t), [ctri] "+v"(cell_tri), [sv] "=&s"(saved)                                                                    \
-                 : [det] "v"(det), [eps] "s"(eps), [u] "v"(u), [uv] "v"(uv), [v] "v"(v), [t] "v"(t), [tri] TRI_CONSTRAINT(tri)                    \
-                 : "vcc")
-__device__ __forceinline__ void tlg_accept_s(float det, float u, float v, float t, uint32_t tri, float& cell_t, uint32_t& cell_tri)
+                 : [ct] "+v"(cell_t), [ctri] "+v"(cell_tri), [sv] "=&s"(saved), [t1] "=&v"(t1), [t2] "=&v"(t2)                                    \
+                 : [det] "v"(det), [eps] "s"(eps), [u] "v"(u), [inv] "v"(inv_det), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),                   \
+                   [qx] Q_CONSTRAINT(qvec.x), [qy] Q_CONSTRAINT(qvec.y), [qz] Q_CONSTRAINT(qvec.z), [e2q] Q_CONSTRAINT(e2q), [tri] Q_CONSTRAINT(tri) \
+                 : "vcc", "scc")
+__device__ __forceinline__ void tlg_accept_s(float det, float inv_det, float u, f3 d, f3 qvec, float e2q, uint32_t tri, float& cell_t, uint32_t& cell_tri)
 {
-    const float eps = FLT_EPSILON, uv = u + v;
+    const float eps = FLT_EPSILON;
     TLG_ACCEPT_ASM("s");
 }
-__device__ __forceinline__ void tlg_accept_v(float det, float u, float v, float t, uint32_t tri, float& cell_t, uint32_t& cell_tri)
+__device__ __forceinline__ void tlg_accept_v(float det, float inv_det, float u, f3 d, f3 qvec, float e2q, uint32_t tri, float& cell_t, uint32_t& cell_tri)
 {
-    const float eps = FLT_EPSILON, uv = u + v;
+    const float eps = FLT_EPSILON;
     TLG_ACCEPT_ASM("v");
 }
 
@@ -827,13 +842,15 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
             const float det = f3_dot(edge1, pvec);
             const float inv_det = FAST ? rcp_near(det) : 1.0f / det;
             const float u = f3_dot(tvec, pvec) * inv_det;
-            const float v = f3_dot(d, qvec) * inv_det;
-            const float t = e2q * inv_det;                         // "* flag" folded into the test
             if (FAST) {
+                // v = (d . qvec) * inv_det; t = e2q * inv_det ("* flag" folded into the test);
                 // flag = |det| >= FLT_EPSILON & u < 1 & u >= 0 & u + v <= 1 & v >= 0; if (flag & t > 0 & t < cell_t) { cell_t = t; cell_tri = tri; }   (:528)
-                if (decltype(tri_is_scalar)::value) tlg_accept_s(det, u, v, t, tri, cell_t, cell_tri);
-                else tlg_accept_v(det, u, v, t, tri, cell_t, cell_tri);
+                // (for a triangle in scalar registers of a PRIMARY wave qvec and e2q are scalar; a ray buffer's are the lane's own)
+                if (decltype(tri_is_scalar)::value && PRIMARY) tlg_accept_s(det, inv_det, u, d, qvec, e2q, tri, cell_t, cell_tri);
+                else tlg_accept_v(det, inv_det, u, d, qvec, e2q, tri, cell_t, cell_tri);
             } else {
+                const float v = f3_dot(d, qvec) * inv_det;
+                const float t = e2q * inv_det;                         // "* flag" folded into the test
                 bool flag = fabsf(det) >= FLT_EPSILON;
                 flag = flag & (u < 1.0f) & (u >= 0.0f);
                 flag = flag & ((u + v) <= 1.0f) & (v >= 0.0f);

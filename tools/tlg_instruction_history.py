@@ -10,7 +10,10 @@ STEPS = [('s2c', 'packet walk, first form: record / planes / leaf record / trian
          ('s2h', 'experiment, not kept: the walk as a loop of the WAVE with the cell\'s indices carried in scalar registers (fewer vector, more scalar instructions)'),
          ('s2i', '+ the end of the triangle test as a chain of v_cmpx'),
          ('s2k', '+ 32-byte leaf records with six triangle ids, a leaf cell\'s entries without a loop'),
-         ('s2l', '+ camera planes behind the cell records (one base pointer), near / far by load offset')]
+         ('s2l', '+ camera planes behind the cell records (one base pointer), near / far by load offset'),
+         ('s2q', '+ the packet walk compiled once per direction octant (signs = constants of the instance)'),
+         ('s2r', '+ a leaf grid of one cell on its own short path, plane offsets as loop constants'),
+         ('s2s', '+ lane-by-lane leaf cells of the packet walk from the 32-byte record too')]
 KINDS = ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_SMEM', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD')
 rows = []
 for tag, what in STEPS:
@@ -20,9 +23,8 @@ for tag, what in STEPS:
         for r in csv.DictReader(open(f)):
             if 'k_tlg_trace<' in r['Kernel_Name'].split('(')[0]:
                 a = agg[r['Counter_Name']]; a[0] += 1; a[1] += float(r['Counter_Value'])
-    # (a counter is sampled once per XCD and dispatch: 8 rows per launch -- 21 launches of the tool's run: the mean over launches is the sum of the rows / launches)
-    launches = 21
-    c = {k: agg[k][1] / launches for k in KINDS if k in agg}
+    # (one row per launch and counter: 21 launches of the tool's run, 32 since the tool also times the fused frame)
+    c = {k: agg[k][1] / agg[k][0] for k in KINDS if k in agg}
     ms = [json.load(open(f))['trace_ms'] for f in sorted(glob.glob(d + '/tlg_*.json'))]
     if not c or not ms:
         continue
