@@ -1045,12 +1045,13 @@ __device__ __forceinline__ void tlg_walk(const TlgTraceArgs& a, const f3 o, cons
 // sized by the grid, so 16 KB of mailbox + ~4 KB of planes leave room for seven blocks per CU): 2.71 -> 2.62 ms then, 2.29 at the end of the
 // round; eight waves (64 VGPRs, scalar registers spilled into lanes) 2.43, six 2.50; 16-bit mailbox tags 2.26-2.28 (noise, and a limit on the
 // triangle count); the top-level step taken early with a warming fetch of the next cell's record 2.34.  DESIGN.md section 4.6.
-// Round 5, second part (the packet walk): 2.29 -> 2.03 ms at the same seven waves (71 VGPRs; the lane-per-cell half of a step sets them).  The launch
-// time followed the TOTAL number of instructions issued, scalar ones included, at 0.95-0.96 ns per million through every step
-// (profiles/r05_tlg_instruction_counts.json): 2 392 M -> 2 100 M.  Measured on the way and not kept: eight waves 2.06-2.21 (spills), six 2.27; other
+// Round 5, second part (the packet walk): 2.29 -> 1.86 ms at the same seven waves (72 VGPRs; the lane-per-cell half of a step sets them).  The launch
+// time followed the TOTAL number of instructions issued, scalar ones included, at 0.95-0.97 ns per million through the steps
+// (profiles/r05_tlg_instruction_counts.json): 2 392 M -> 1 817 M.  Measured on the way and not kept: eight waves 2.06-2.21 (spills), six 2.27; other
 // scheduler strategies (max-ilp 2.06, the default 2.00 = max-memory-clause); workgroups of 64 / 128 threads with the planes from the global table instead of
 // LDS 2.15-2.17 against 2.15 then; the walk as a loop of the wave with the cell's indices in scalar registers (fewer vector, more scalar
-// instructions: 2.27 against 2.15); a 64-entry mailbox would skip 5 % more tests (counted by the diag twin) for four times the LDS.
+// instructions: 2.27 against 2.15); a 64-entry mailbox would skip 5 % more tests (counted by the diag twin) for four times the LDS; the mailbox slots
+// of a leaf cell's entries read ahead (a second ladder of compares: 2.07 against 2.04).
 #ifndef TLG_WAVES
 #define TLG_WAVES 7
 #endif
