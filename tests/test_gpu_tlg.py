@@ -371,3 +371,39 @@ def test_packet_walk_cameras_that_move_turn_and_look_along_axes(gpu_ctx):
                     assert again.tobytes() == want.tobytes(), (round_, k, 'after the rebuild')
     finally:
         g.close(); sc.close()
+
+
+@pytest.mark.parametrize('name', ['gardenlight', 'tenryuu'])
+def test_packet_walk_of_coherent_ray_buffers(gpu_ctx, name):
+    """generateContacts(CLBuffer& rays, ..) through the grid with rays that travel together (round 5: waves of a ray buffer whose rays share their
+    direction signs take the packet walk too, with the planes of the global table and the scene's triangle table, every lane its own origin): the
+    camera's rays as Ray[] in row order and in 8x8 blocks, and a sheet of parallel rays from origins spread over a plane (the shape of shadow
+    rays).  Every contact the oracle's."""
+    import oracle as orc
+    from openclraytracer_amd import capi
+    osc, og = oracle_tlg(name)
+    _, gg = gpu_tlg(gpu_ctx, name)
+    cam = osc.demo_camera(256, 192)
+    rays = orc.generate_rays(cam)
+    want, st = og.trace_rays(rays)
+    assert st['hits'] > 100
+    assert gg.generate_contacts_rays(rays.view(capi.RAY)).tobytes() == want.tobytes()
+    # 8x8 blocks: 64 consecutive rays = one block of pixels
+    idx = np.arange(256 * 192).reshape(192 // 8, 8, 256 // 8, 8).transpose(0, 2, 1, 3).reshape(-1)
+    blocks = np.ascontiguousarray(rays[idx])
+    want_b, _ = og.trace_rays(blocks)
+    assert gg.generate_contacts_rays(blocks.view(capi.RAY)).tobytes() == want_b.tobytes()
+    # parallel rays from a sheet of origins
+    lo, hi = og.grid['lo'][0][:3], og.grid['hi'][0][:3]
+    n = 64 * 300
+    sheet = np.zeros(n, dtype=orc.RAY)
+    sheet['idx'] = np.arange(n)
+    u, v = np.meshgrid(np.linspace(0.0, 1.0, 300, dtype=np.float32), np.linspace(0.0, 1.0, 64, dtype=np.float32), indexing='ij')
+    sheet['origin'][:, 0] = (lo[0] + (hi[0] - lo[0]) * u.reshape(-1)).astype(np.float32)
+    sheet['origin'][:, 1] = np.float32(hi[1] + 0.25 * (hi[1] - lo[1]))
+    sheet['origin'][:, 2] = (lo[2] + (hi[2] - lo[2]) * v.reshape(-1)).astype(np.float32)
+    d = np.array([0.21, -0.95, 0.23], dtype=np.float32)
+    sheet['direction'][:, :3] = d / np.float32(np.linalg.norm(d))
+    want_s, st_s = og.trace_rays(sheet)
+    assert st_s['hits'] > 50
+    assert gg.generate_contacts_rays(sheet.view(capi.RAY)).tobytes() == want_s.tobytes()
