@@ -33,7 +33,7 @@ def test_scene_pack_matches_fixture(name):
     assert scene_pack.scene_header(buf)['totalNumberOfTriangles'] == probe['triangles'][name]
 
 
-def test_obj_parser_matches_reference_tinyobj_when_available():
+def test_obj_parser_matches_reference_tinyobj_when_available(tmp_path):
     """Where oracle/_ref/tinyobj_dump (the reference's own parser, built from /root/reference) exists, the
     Python restatement must equal it field by field; its dump hashes are the committed fixture."""
     import scene_pack
@@ -45,7 +45,7 @@ def test_obj_parser_matches_reference_tinyobj_when_available():
     models = {'cube': 'assets/testmodels/Cube/cube.obj', 'gardenlight': 'assets/testmodels/Gardenlight/gardenlight01.obj',
               'tenryuu': 'assets/testmodels/Tenryuu/light-cruiser-tenryuu.obj'}
     for name, obj in models.items():
-        out = '/tmp/_t_%s.bin' % name
+        out = str(tmp_path / ('%s.bin' % name))
         subprocess.check_call([dumper, os.path.join(ROOT, obj), out])
         assert sha(open(out, 'rb').read()) == g[name]['sha256']
         rs, rm = scene_pack.load_tinyobj_dump(out)
